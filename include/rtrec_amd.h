@@ -1,0 +1,179 @@
+/*
+ * include/rtrec_amd.h -- C-ABI of the MI355X-native SLIM engine (librtrec_amd.so).
+ *
+ * rtrec (the reference) is pure Python and has no FFI of its own; the interface these
+ * entry points replace is the method set of rtrec.models.internal.slim_elastic.SLIMElastic
+ * and the third-party native code it drives.  Each function cites
+ * the reference lines it stands in for.  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *  - Every pointer named d_* is a DEVICE pointer (HBM of the current HIP device).  Nothing
+ *    here allocates, frees or synchronises; the caller owns all buffers and the stream.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
+ *    enqueued on it and is stream-ordered.
+ *  - Return value: 0 on success, negative rtrec_status otherwise.  No exceptions cross the
+ *    boundary, no global mutable state, re-entrant.
+ *  - Index arrays are int32, values float32 (rtrec/utils/interactions.py:276,303 builds
+ *    float32 matrices whose scipy index dtype is int32).
+ */
+#ifndef RTREC_AMD_H
+#define RTREC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RTREC_OK = 0,
+    RTREC_ERR_INVALID_ARG = -1,   /* NULL pointer, negative size, inconsistent shapes  */
+    RTREC_ERR_UNSUPPORTED = -2,   /* parameter outside what the kernels were built for */
+    RTREC_ERR_WORKSPACE = -3,     /* workspace too small (see *_workspace_bytes)       */
+    RTREC_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after a launch    */
+} rtrec_status;
+
+/* ElasticNet hyper-parameters as they reach sklearn's Cython solver
+ * (slim_elastic.py:197-208 -> _coordinate_descent.py:653-654 -> _cd_fast.pyx:276). */
+typedef struct {
+    float    l1_reg;        /* (float)(alpha * l1_ratio * n_users)        */
+    float    l2_reg;        /* (float)(alpha * (1 - l1_ratio) * n_users)  */
+    float    tol;           /* (float)tol                                  */
+    int32_t  max_iter;
+    uint32_t seed;          /* RandomState(random_state).randint(0, 2**31-1); 43 -> 494155588 */
+    int32_t  positive;      /* positive_only                               */
+    int32_t  top_features;  /* nn_feature_selection; <= 0: every item is a feature */
+} rtrec_fit_cfg;
+
+/* Library identification; returns a static string such as "rtrec_amd 0.1 gfx950". */
+const char *rtrec_amd_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * FIT  (replaces slim_elastic.py:229-281 fit, :283-454 fit_in_parallel/_fit_items,
+ *       :510-564 partial_fit_items, :139-154 FeatureSelectionWrapper.fit, and sklearn
+ *       _cd_fast.pyx:276-561 sparse_enet_coordinate_descent)
+ * ------------------------------------------------------------------------------------- */
+
+/* Per-column sequential float32 sum of squares of a CSC matrix (norm_cols_X of
+ * _cd_fast.pyx:394-410).  d_sqnorm[n_items]. */
+int rtrec_slim_column_sqnorms(int32_t n_items, const int32_t *d_csc_ptr, const float *d_csc_val,
+                              float *d_sqnorm, void *stream);
+
+/* Bytes of scratch rtrec_slim_fit_columns needs for `n_slots` concurrently fitted targets. */
+size_t rtrec_slim_fit_workspace_bytes(int32_t n_users, int32_t n_items, int32_t n_slots,
+                                      int32_t top_features);
+
+/* One-time initialisation of a fit workspace (sets the scratch invariants the kernel keeps
+ * between targets).  Must be called once after allocation, before the first fit call. */
+int rtrec_slim_fit_workspace_init(void *d_workspace, size_t workspace_bytes,
+                                  int32_t n_users, int32_t n_items, int32_t n_slots,
+                                  int32_t top_features, void *stream);
+
+/* Fit `n_targets` item columns of the U x I interaction matrix X.
+ *   X is given twice: CSC (d_csc_*: ptr[I+1], row[nnz], val[nnz], rows ascending per column)
+ *   and CSR (d_csr_*: ptr[U+1], col[nnz], val[nnz], columns ascending per row).  Inputs are
+ *   never modified: the target column is masked by index instead of being zeroed in place
+ *   (slim_elastic.py:266/438 zero and restore it).
+ *   d_targets[n_targets]: target column ids, processed in the given order by a device-side
+ *   work queue (put long columns first for balance).
+ * Outputs, slot t = position in d_targets, `cap` entries per target:
+ *   top_features > 0 : cap >= min(top_features, I).  d_out_items[t*cap + p] is the p-th
+ *       selected feature (descending X^T y, ties -> higher id), d_out_coef the matching
+ *       coefficient -- i.e. model.sparse_coef_ INCLUDING explicit zeros (slim_elastic.py:153);
+ *       d_out_count[t] = min(top_features, I).
+ *   top_features <= 0: cap >= I.  Non-zero coefficients only, ascending item id
+ *       (sparse.csr_matrix(coef_), _coordinate_descent.py:1133-1136); d_out_count[t] = nnz.
+ *   d_out_n_iter[t] = sklearn's n_iter_.
+ * d_queue: one int32 work-queue counter, must be zero on entry (the call resets it to zero
+ * on the stream before launching). */
+int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
+                           const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                           const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
+                           const float *d_sqnorm,
+                           const int32_t *d_targets, int32_t n_targets,
+                           const rtrec_fit_cfg *cfg,
+                           int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
+                           int32_t *d_out_n_iter, int32_t cap,
+                           void *d_workspace, size_t workspace_bytes, int32_t n_slots,
+                           int32_t *d_queue, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * SCORE + TOP-K  (replaces slim_elastic.py:566-626 predict*, :628-741 recommend /
+ *       recommend_batch, :744-818 _dense/_sparse_topk_indicies and scipy's csr_matmat)
+ *
+ * W (item_similarity, I x I) is consumed in a column-tiled CSR layout: the shard's columns
+ * [col_offset, col_offset + n_cols) are cut into tiles of `tile_cols` columns; tile t holds a
+ * CSR over ALL I rows restricted to its columns:
+ *     d_tile_ptr[t * (n_items + 1) + i] .. [.. + i + 1]  -> range in d_w_col / d_w_val
+ *     d_w_col[e] = column index LOCAL to the tile (0 .. tile_cols-1), ascending per row
+ *     d_w_val[e] = float32 weight
+ * so a user row is accumulated tile by tile in LDS in exactly scipy's csr_matmat order
+ * (ascending row item, then ascending column).
+ * ------------------------------------------------------------------------------------- */
+
+typedef enum {
+    RTREC_TOPK_SPARSE = 0,   /* int ids: only non-zero sums compete (slim_elastic.py:782-818)  */
+    RTREC_TOPK_DENSE = 1,    /* str ids: every column competes        (slim_elastic.py:744-779)  */
+    RTREC_TOPK_CANDIDATES = 2 /* candidate_item_ids given: d_col_rank[c] >= 0 marks candidates,
+                                 interacted items are NOT filtered     (slim_elastic.py:661-672) */
+} rtrec_topk_mode;
+
+/* Bytes of scratch for rtrec_slim_score_topk. */
+size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k);
+
+/* Score `n_rows` user rows of the CSR matrix d_xb_* (ptr, col, val; columns ascending) against
+ * the shard and return each row's local top-k.  Job r scores CSR row d_row_ids[r] (or row r
+ * when d_row_ids is NULL), so a device-resident interaction matrix is scored in place without
+ * slicing it on the host (the reference slices: slim_elastic.py:707):
+ *   d_out_ids[n_rows*top_k]   global column ids, -1 padded
+ *   d_out_scores[n_rows*top_k] float32 scores (float64 accumulations are rounded on output),
+ *                             -inf padded;  d_out_scores64 (may be NULL) receives the float64
+ *                             values when acc_f64 != 0
+ *   d_out_aux[n_rows*top_k]   tie-break key that travels with each entry (first-touch rank in
+ *                             SPARSE mode, candidate rank in CANDIDATES mode, 0 otherwise) so
+ *                             shards can be merged with rtrec_slim_merge_topk
+ *   d_out_count[n_rows]       number of valid entries (<= top_k)
+ * Order: score descending; ties resolved exactly as the reference resolves them in SPARSE
+ * mode (stable sort over scipy's reverse-first-touch product order), by higher column id in
+ * DENSE mode and by higher candidate rank in CANDIDATES mode (numpy's unstable argsort leaves
+ * those two unspecified -- DESIGN.md D1).
+ * acc_f64 != 0 accumulates in float64 (W built by the serial SLIMElastic.fit is a float64
+ * matrix, slim_elastic.py:252). */
+int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
+                          const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
+                          int32_t n_items, int32_t n_cols, int32_t col_offset,
+                          int32_t tile_cols, int32_t n_tiles,
+                          const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
+                          const int32_t *d_col_rank,
+                          int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
+                          int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,
+                          uint32_t *d_out_aux, int32_t *d_out_count,
+                          void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Merge `n_lists` per-shard top-k lists per row (layout [n_lists][n_rows][top_k], as produced
+ * by an all-gather of rtrec_slim_score_topk outputs) into one top-k per row, using the same
+ * (score, aux, id) order.  d_in_scores64 may be NULL (then float32 scores are compared). */
+int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t top_k,
+                          const int32_t *d_in_ids, const float *d_in_scores, const double *d_in_scores64,
+                          const uint32_t *d_in_aux, const int32_t *d_in_count,
+                          int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * SIMILAR ITEMS  (replaces slim_elastic.py:820-857)
+ * W in CSC (d_wc_ptr[I+1], d_wc_row, d_wc_val).  For each query item: stored entries of its
+ * column, the item itself dropped, top_k by score descending (ties: lower row id first).
+ * Outputs [n_queries*top_k], -1 / -inf padded, and counts.
+ * ------------------------------------------------------------------------------------- */
+int rtrec_slim_similar_topk(int32_t n_queries, const int32_t *d_queries,
+                            const int32_t *d_wc_ptr, const int32_t *d_wc_row, const float *d_wc_val,
+                            int32_t top_k,
+                            int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
+                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTREC_AMD_H */

@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI in include/rtrec_amd.h (librtrec_amd.so).
+
+There is no CPU fallback: if the HIP library is missing or does not load, every product
+entry point raises.  Device buffers are torch tensors (plumbing only); the functions take
+their raw device pointers and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from . import build as _build
+
+_lib: Optional[C.CDLL] = None
+
+RTREC_OK = 0
+TOPK_SPARSE, TOPK_DENSE, TOPK_CANDIDATES = 0, 1, 2
+_STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "workspace too small",
+           -4: "kernel launch failed"}
+
+EXPORTS = [
+    "rtrec_amd_version", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
+    "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_score_workspace_bytes",
+    "rtrec_slim_score_topk", "rtrec_slim_merge_topk", "rtrec_slim_similar_topk",
+]
+
+
+class FitCfg(C.Structure):
+    _fields_ = [("l1_reg", C.c_float), ("l2_reg", C.c_float), ("tol", C.c_float), ("max_iter", C.c_int32),
+                ("seed", C.c_uint32), ("positive", C.c_int32), ("top_features", C.c_int32)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _build.LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load librtrec_amd.so (never builds implicitly on the hot path; see rtrec_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f"{path} is missing: build it with `python -m rtrec_amd.build` (hipcc, gfx950). "
+            "rtrec_amd has no CPU fallback.")
+    try:
+        L = C.CDLL(path)
+    except OSError as e:  # pragma: no cover - depends on the host
+        raise NativeLibraryError(f"cannot load {path}: {e}") from e
+    vp, i32, u64 = C.c_void_p, C.c_int32, C.c_size_t
+    L.rtrec_amd_version.restype = C.c_char_p
+    L.rtrec_amd_version.argtypes = []
+    L.rtrec_slim_column_sqnorms.restype = C.c_int
+    L.rtrec_slim_column_sqnorms.argtypes = [i32, vp, vp, vp, vp]
+    L.rtrec_slim_fit_workspace_bytes.restype = u64
+    L.rtrec_slim_fit_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.rtrec_slim_fit_workspace_init.restype = C.c_int
+    L.rtrec_slim_fit_workspace_init.argtypes = [vp, u64, i32, i32, i32, i32, vp]
+    L.rtrec_slim_fit_columns.restype = C.c_int
+    L.rtrec_slim_fit_columns.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(FitCfg),
+                                         vp, vp, vp, vp, i32, vp, u64, i32, vp, vp]
+    L.rtrec_slim_score_workspace_bytes.restype = u64
+    L.rtrec_slim_score_workspace_bytes.argtypes = [i32, i32, i32]
+    L.rtrec_slim_score_topk.restype = C.c_int
+    L.rtrec_slim_score_topk.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp,
+                                        i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, u64, vp]
+    L.rtrec_slim_merge_topk.restype = C.c_int
+    L.rtrec_slim_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rtrec_slim_similar_topk.restype = C.c_int
+    L.rtrec_slim_similar_topk.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(status: int, what: str) -> None:
+    if status != RTREC_OK:
+        raise NativeLibraryError(f"{what} failed: {_STATUS.get(status, status)} ({status})")
+
+
+def version() -> str:
+    return load().rtrec_amd_version().decode()

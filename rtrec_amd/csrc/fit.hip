@@ -1,0 +1,590 @@
+// rtrec_amd/csrc/fit.hip -- per-item-column SLIM fit: X^T y feature selection + elastic-net
+// coordinate descent, in the reference's exact float32 operation order.
+//
+// Replaces (reference): the per-column loop of SLIMElastic.fit / fit_in_parallel /
+// partial_fit_items (slim_elastic.py:261-277, 434-447, 544-560), FeatureSelectionWrapper.fit
+// (slim_elastic.py:139-154) and scikit-learn's sparse_enet_coordinate_descent
+// (sklearn/linear_model/_cd_fast.pyx:276-561, float32, selection='random').
+//
+// One wavefront fits one target column j at a time, pulled from a device work queue:
+//   1. s = X^T y over the co-occurring rows (exactly scipy csr_matvec's per-item order: rows
+//      ascending), with a touched list so only the neighbourhood of j is ever visited;
+//   2. top-K of s (descending, ties -> higher id), K = nn_feature_selection;
+//   3. coordinate descent with sklearn's xorshift32 coordinate sequence.  The dot product
+//      tmp = sum_r R[r] * x[r] is the order-sensitive step: the 64 lanes gather and multiply in
+//      parallel, then the products are folded strictly left to right (chain_add) so tmp, hence
+//      every coefficient and the sweep count, is bit-identical to the Cython loop.  Residual
+//      updates are element-wise and stay fully parallel.
+// While every coefficient is still zero (R == y) the dot product of feature p equals s[p]
+// bit for bit (same products, same order), so targets whose solution is all-zero -- the long
+// tail of a Zipf catalogue -- never touch the O(nnz) path at all.
+//
+// Scratch invariants between targets (set by rtrec_slim_fit_workspace_init): R == 0, s ==
+// kUntouched, w_all == 0, ever_flag == 0.
+#include "common.hip.h"
+#include "../../include/rtrec_amd.h"
+
+namespace rtrec {
+
+// -0.0f can never be produced by (+0) + p or by a float sum that starts at +0 under
+// round-to-nearest, so its bit pattern marks "no contribution yet".
+constexpr uint32_t kUntouched = 0x80000000u;
+
+struct FitArgs {
+    int U, I;
+    const int *cptr; const int *crow; const float *cval;
+    const int *rptr; const int *rcol; const float *rval;
+    const float *sqn;
+    const int *targets; int n_targets;
+    rtrec_fit_cfg cfg;
+    int *out_items; float *out_coef; int *out_count; int *out_niter; int cap;
+    float *R;        // [slots][U]
+    float *s;        // [slots][I]
+    int *touched;    // [slots][I]
+    float *cand_s;   // [slots][I]   K path: candidate scores; ALL path: ever_flag (as int)
+    int *cand_i;     // [slots][I]   K path: candidate ids;    ALL path: ever list
+    float *w_all;    // [slots][I]   ALL path only
+    int *queue;
+};
+
+__device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, float nrm, int positive) {
+    // _cd_fast.pyx:471-475; libc fabs() is double, so the numerator and the quotient are
+    // formed in double and rounded to float once.
+    if (positive && tmp < 0.0f) return 0.0f;
+    const double num = fabs(static_cast<double>(tmp)) - static_cast<double>(alpha);
+    const double sgn = (tmp == 0.0f) ? 0.0 : (tmp > 0.0f ? 1.0 : -1.0);
+    const float den = __fadd_rn(nrm, beta);
+    return static_cast<float>(sgn * (num > 0.0 ? num : 0.0) / static_cast<double>(den));
+}
+
+// tmp = sum over column entries [b, e) of (R[r] (+ x*w_old)) * x, strictly left to right.
+__device__ float dot_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
+                          int b, int e, float w_old) {
+    const int lane = lane_id();
+    const bool add_back = (w_old != 0.0f);
+    float tmp = 0.0f;
+    int o = b;
+    for (; o + 256 <= e; o += 256) {
+        const int r0 = crow[o + lane], r1 = crow[o + 64 + lane], r2 = crow[o + 128 + lane], r3 = crow[o + 192 + lane];
+        const float x0 = cval[o + lane], x1 = cval[o + 64 + lane], x2 = cval[o + 128 + lane], x3 = cval[o + 192 + lane];
+        float v0 = R[r0], v1 = R[r1], v2 = R[r2], v3 = R[r3];
+        if (add_back) {
+            v0 = __fadd_rn(v0, __fmul_rn(x0, w_old)); v1 = __fadd_rn(v1, __fmul_rn(x1, w_old));
+            v2 = __fadd_rn(v2, __fmul_rn(x2, w_old)); v3 = __fadd_rn(v3, __fmul_rn(x3, w_old));
+        }
+        tmp = chain_add_full(tmp, __fmul_rn(v0, x0));
+        tmp = chain_add_full(tmp, __fmul_rn(v1, x1));
+        tmp = chain_add_full(tmp, __fmul_rn(v2, x2));
+        tmp = chain_add_full(tmp, __fmul_rn(v3, x3));
+    }
+    for (; o < e; o += 64) {
+        const int n = min(64, e - o);
+        float prod = 0.0f;
+        if (lane < n) {
+            const int r = crow[o + lane];
+            const float x = cval[o + lane];
+            float v = R[r];
+            if (add_back) v = __fadd_rn(v, __fmul_rn(x, w_old));
+            prod = __fmul_rn(v, x);
+        }
+        tmp = chain_add(tmp, prod, n);
+    }
+    return tmp;
+}
+
+// R[r] <- (R[r] + x*w_old) - x*w_new over the column (element-wise, order free).
+__device__ void update_pass(const int *__restrict__ crow, const float *__restrict__ cval, float *R,
+                            int b, int e, float w_old, float w_new) {
+    const int lane = lane_id();
+    for (int o = b + lane; o < e; o += 64) {
+        const int r = crow[o];
+        const float x = cval[o];
+        float v = R[r];
+        if (w_old != 0.0f) v = __fadd_rn(v, __fmul_rn(x, w_old));
+        if (w_new != 0.0f) v = __fsub_rn(v, __fmul_rn(x, w_new));
+        R[r] = v;
+    }
+}
+
+// sum over [b, e) of x * R[r], left to right (XtA of _cd_fast.pyx:506-509).
+__device__ float xta_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, int b, int e) {
+    return dot_pass(crow, cval, R, b, e, 0.0f);   // R[r]*x == x*R[r] (one rounding, commutative)
+}
+
+template <bool ALLF>
+__device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) {
+    const int lane = lane_id();
+    const int U = a.U, I = a.I;
+    const int j = a.targets[t];
+    float *R = a.R + static_cast<size_t>(slot) * U;
+    float *s = a.s + static_cast<size_t>(slot) * I;
+    int *touched = a.touched + static_cast<size_t>(slot) * I;
+    float *cand_s = a.cand_s + static_cast<size_t>(slot) * I;
+    int *cand_i = a.cand_i + static_cast<size_t>(slot) * I;
+    float *w_all = ALLF ? a.w_all + static_cast<size_t>(slot) * I : nullptr;
+    int *ever_flag = reinterpret_cast<int *>(cand_s);   // ALL path
+    int *ever_list = cand_i;                            // ALL path
+
+    const int K = ALLF ? 0 : min(a.cfg.top_features, I);
+    int *f_id = reinterpret_cast<int *>(smem);
+    int *f_b = f_id + K;
+    int *f_e = f_b + K;
+    float *f_nrm = reinterpret_cast<float *>(f_e + K);
+    float *f_w = f_nrm + K;
+    float *f_s = f_w + K;
+    int *f_ever = reinterpret_cast<int *>(f_s + K);
+
+    const float alpha = a.cfg.l1_reg, beta = a.cfg.l2_reg;
+    const int positive = a.cfg.positive;
+    const int yb = a.cptr[j], ye = a.cptr[j + 1];
+    const int ny = ye - yb;
+
+    // ---- y . y (tolerance scale, _cd_fast.pyx:426) ----
+    float yy = 0.0f;
+    for (int o = yb; o < ye; o += 64) {
+        const int n = min(64, ye - o);
+        float prod = 0.0f;
+        if (lane < n) { const float y = a.cval[o + lane]; prod = __fmul_rn(y, y); }
+        yy = chain_add(yy, prod, n);
+    }
+    const float tol_s = __fmul_rn(a.cfg.tol, yy);
+
+    // ---- 1. s = X^T y (target column masked), touched list ----
+    int tc = 0;
+    for (int ob = yb; ob < ye; ob += 64) {
+        const int n = min(64, ye - ob);
+        int rb_l = 0, re_l = 0;
+        float y_l = 0.0f;
+        if (lane < n) {
+            const int u = a.crow[ob + lane];
+            y_l = a.cval[ob + lane];
+            rb_l = a.rptr[u];
+            re_l = a.rptr[u + 1];
+        }
+        for (int q = 0; q < n; ++q) {
+            const int rb = readlane_i(rb_l, q), re = readlane_i(re_l, q);
+            const float yv = readlane_f(y_l, q);
+            for (int o = rb; o < re; o += 64) {
+                const bool valid = (o + lane) < re;
+                int i = -1;
+                float x = 0.0f;
+                if (valid) { i = a.rcol[o + lane]; x = a.rval[o + lane]; }
+                const bool use = valid && (i != j);
+                bool first = false;
+                if (use) {
+                    const float old = s[i];
+                    first = (__float_as_uint(old) == kUntouched);
+                    s[i] = __fadd_rn(first ? 0.0f : old, __fmul_rn(x, yv));
+                }
+                const unsigned long long m = __ballot(first);
+                if (m) {
+                    if (first) touched[tc + lane_prefix(m)] = i;
+                    tc += __builtin_popcountll(m);
+                }
+            }
+        }
+    }
+
+    // ---- 2. feature selection: top-K of s, descending, ties -> higher id ----
+    int Kc = 0;
+    if (!ALLF) {
+        // compact the non-zero scores of the neighbourhood
+        int cn = 0;
+        for (int tb = 0; tb < tc; tb += 64) {
+            const int tt = tb + lane;
+            int i = -1;
+            float v = 0.0f;
+            if (tt < tc) { i = touched[tt]; v = s[i]; }
+            const bool keep = (tt < tc) && (v != 0.0f);
+            const unsigned long long m = __ballot(keep);
+            if (m) {
+                if (keep) { const int pos = cn + lane_prefix(m); cand_s[pos] = v; cand_i[pos] = i; }
+                cn += __builtin_popcountll(m);
+            }
+        }
+        const float ninf = -__builtin_huge_valf();
+        // positives, best first
+        for (; Kc < K; ++Kc) {
+            Cand<float> b; b.id = -1; b.score = ninf; b.aux = 0u;
+            int bt = -1;
+            for (int tt = lane; tt < cn; tt += 64) {
+                const float v = cand_s[tt];
+                if (!(v > 0.0f)) continue;
+                Cand<float> x; x.score = v; x.id = cand_i[tt]; x.aux = 0u;
+                if (cand_better(x, b)) { b = x; bt = tt; }
+            }
+            const Cand<float> w = wave_best(b);
+            if (w.id < 0) break;
+            if (bt >= 0 && b.id == w.id) cand_s[bt] = ninf;
+            if (lane == 0) { f_id[Kc] = w.id; f_s[Kc] = w.score; }
+        }
+        // zero scores (untouched items, the target itself, exact-zero sums): higher id first
+        for (int hi = I - 1; hi >= 0 && Kc < K; hi -= 64) {
+            const int id = hi - lane;
+            bool isz = false;
+            if (id >= 0) {
+                const float v = s[id];
+                isz = (__float_as_uint(v) == kUntouched) || (v == 0.0f);
+            }
+            const unsigned long long m = __ballot(isz);
+            if (m) {
+                const int pos = Kc + lane_prefix(m);
+                if (isz && pos < K) { f_id[pos] = id; f_s[pos] = 0.0f; }
+                Kc = min(K, Kc + __builtin_popcountll(m));
+            }
+        }
+        // negatives (only when I - #positive - #zero < K), closest to zero first
+        for (; Kc < K; ++Kc) {
+            Cand<float> b; b.id = -1; b.score = ninf; b.aux = 0u;
+            int bt = -1;
+            for (int tt = lane; tt < cn; tt += 64) {
+                const float v = cand_s[tt];
+                if (!(v < 0.0f) || v == ninf) continue;
+                Cand<float> x; x.score = v; x.id = cand_i[tt]; x.aux = 0u;
+                if (cand_better(x, b)) { b = x; bt = tt; }
+            }
+            const Cand<float> w = wave_best(b);
+            if (w.id < 0) break;
+            if (bt >= 0 && b.id == w.id) cand_s[bt] = ninf;
+            if (lane == 0) { f_id[Kc] = w.id; f_s[Kc] = w.score; }
+        }
+        for (int p = lane; p < Kc; p += 64) {
+            const int c = f_id[p];
+            f_b[p] = a.cptr[c];
+            f_e[p] = a.cptr[c + 1];
+            f_nrm[p] = (c == j) ? 0.0f : a.sqn[c];
+            f_w[p] = 0.0f;
+            f_ever[p] = 0;
+        }
+    }
+    const int nf = ALLF ? I : Kc;
+
+    // ---- 3. coordinate descent (_cd_fast.pyx:428-548) ----
+    bool dirty = false;            // false while every w is still 0, i.e. R == y
+    int n_ever = 0;                // ALL path: features whose w was ever non-zero
+    float gap = __fadd_rn(a.cfg.tol, 1.0f);
+    uint32_t rng = a.cfg.seed;
+    int n_iter = 0;
+    const int max_iter = a.cfg.max_iter;
+    const bool skip_cd = (ny == 0) || (nf == 0);   // y == 0: all coefficients stay 0, max_iter sweeps
+    if (skip_cd) n_iter = max_iter > 0 ? max_iter - 1 : 0;
+
+    auto s_value = [&](int p) -> float {
+        const float v = s[p];
+        return (__float_as_uint(v) == kUntouched) ? 0.0f : v;
+    };
+
+    for (n_iter = skip_cd ? n_iter : 0; !skip_cd && n_iter < max_iter; ++n_iter) {
+        float w_max = 0.0f, d_w_max = 0.0f;
+        for (int f = 0; f < nf; ++f) {
+            const int p = static_cast<int>(rand_int(static_cast<uint32_t>(nf), rng));
+            float nrm;
+            int b, e;
+            float w_old;
+            if (ALLF) {
+                nrm = (p == j) ? 0.0f : a.sqn[p];
+                if (nrm == 0.0f) continue;
+                b = a.cptr[p]; e = a.cptr[p + 1];
+                w_old = w_all[p];
+            } else {
+                nrm = f_nrm[p];
+                if (nrm == 0.0f) continue;
+                b = f_b[p]; e = f_e[p];
+                w_old = f_w[p];
+            }
+            float tmp;
+            if (!dirty) tmp = ALLF ? s_value(p) : f_s[p];
+            else tmp = dot_pass(a.crow, a.cval, R, b, e, w_old);
+            const float w_new = cd_update(tmp, alpha, beta, nrm, positive);
+            if (w_old != 0.0f || w_new != 0.0f) {
+                if (!dirty) {   // materialise R = y
+                    for (int o = yb + lane; o < ye; o += 64) R[a.crow[o]] = a.cval[o];
+                    dirty = true;
+                }
+                update_pass(a.crow, a.cval, R, b, e, w_old, w_new);
+                if (ALLF) {
+                    if (ever_flag[p] == 0) { if (lane == 0) { ever_flag[p] = 1; ever_list[n_ever] = p; } n_ever++; }
+                    if (lane == 0) w_all[p] = w_new;
+                } else {
+                    if (lane == 0) { f_w[p] = w_new; f_ever[p] = 1; }
+                }
+            }
+            const float d = fabsf(__fsub_rn(w_new, w_old));
+            d_w_max = d > d_w_max ? d : d_w_max;
+            const float aw = fabsf(w_new);
+            w_max = aw > w_max ? aw : w_max;
+        }
+
+        if (w_max == 0.0f || __fdiv_rn(d_w_max, w_max) < a.cfg.tol || n_iter == max_iter - 1) {
+            // dual norm of XtA = X^T R - beta w
+            float dn = 0.0f;
+            bool dn_init = false;
+            auto dn_take = [&](float xta) {
+                const float v = positive ? xta : fabsf(xta);
+                if (!dn_init) { dn = v; dn_init = true; } else if (v > dn) dn = v;
+            };
+            if (ALLF) {
+                if (!dirty) {
+                    // XtA[p] = s[p] for every feature (0 for untouched ones and the target)
+                    float mx = 0.0f;   // I >= 1 and the target itself contributes exactly 0
+                    for (int tb = 0; tb < tc; tb += 64) {
+                        float v = 0.0f;
+                        if (tb + lane < tc) { v = s[touched[tb + lane]]; v = positive ? v : fabsf(v); }
+                        const float m = wave_max(v);
+                        mx = m > mx ? m : mx;
+                    }
+                    dn = mx; dn_init = true;
+                } else {
+                    for (int p = 0; p < I; ++p) {
+                        float xta = 0.0f;
+                        const int b = a.cptr[p], e = a.cptr[p + 1];
+                        if (p != j && b != e) {
+                            xta = xta_pass(a.crow, a.cval, R, b, e);
+                            xta = __fsub_rn(xta, __fmul_rn(beta, w_all[p]));
+                        }
+                        dn_take(xta);
+                    }
+                }
+            } else {
+                for (int p = 0; p < nf; ++p) {
+                    float xta = 0.0f;
+                    if (f_nrm[p] != 0.0f) {
+                        if (!dirty) xta = f_s[p];
+                        else {
+                            xta = xta_pass(a.crow, a.cval, R, f_b[p], f_e[p]);
+                            xta = __fsub_rn(xta, __fmul_rn(beta, f_w[p]));
+                        }
+                    }
+                    dn_take(xta);
+                }
+            }
+            // R.R, R.y, w.w, |w|_1 in ascending index order (canonical order)
+            float R_norm2, Ry, w_norm2 = 0.0f, l1 = 0.0f;
+            if (!dirty) { R_norm2 = yy; Ry = yy; }
+            else {
+                R_norm2 = 0.0f;
+                for (int o = 0; o < U; o += 64) {
+                    float prod = 0.0f;
+                    if (o + lane < U) { const float v = R[o + lane]; prod = __fmul_rn(v, v); }
+                    if (__ballot(prod != 0.0f)) R_norm2 = chain_add(R_norm2, prod, min(64, U - o));
+                }
+                Ry = 0.0f;
+                for (int o = yb; o < ye; o += 64) {
+                    const int n = min(64, ye - o);
+                    float prod = 0.0f;
+                    if (lane < n) prod = __fmul_rn(R[a.crow[o + lane]], a.cval[o + lane]);
+                    Ry = chain_add(Ry, prod, n);
+                }
+                for (int o = 0; o < nf; o += 64) {
+                    float wv = 0.0f;
+                    if (o + lane < nf) wv = ALLF ? w_all[o + lane] : f_w[o + lane];
+                    if (__ballot(wv != 0.0f)) {
+                        const int n = min(64, nf - o);
+                        w_norm2 = chain_add(w_norm2, __fmul_rn(wv, wv), n);
+                        l1 = chain_add(l1, fabsf(wv), n);
+                    }
+                }
+            }
+            float cst;
+            if (dn > alpha) {
+                cst = __fdiv_rn(alpha, dn);
+                const float A_norm2 = __fmul_rn(R_norm2, __fmul_rn(cst, cst));
+                gap = static_cast<float>(0.5 * static_cast<double>(__fadd_rn(R_norm2, A_norm2)));
+            } else {
+                cst = 1.0f;
+                gap = R_norm2;
+            }
+            const float t12 = __fsub_rn(__fmul_rn(alpha, l1), __fmul_rn(cst, Ry));
+            const double t3 = 0.5 * static_cast<double>(beta) * static_cast<double>(__fadd_rn(1.0f, __fmul_rn(cst, cst))) *
+                              static_cast<double>(w_norm2);
+            gap = static_cast<float>(static_cast<double>(gap) + (static_cast<double>(t12) + t3));
+            if (gap < tol_s) break;
+        }
+    }
+    const int n_iter_out = (n_iter < max_iter ? n_iter : max_iter - 1) + 1;
+
+    // ---- outputs ----
+    int *oi = a.out_items + static_cast<size_t>(t) * a.cap;
+    float *oc = a.out_coef + static_cast<size_t>(t) * a.cap;
+    if (ALLF) {
+        int cnt = 0;
+        // non-zero coefficients ascending by id; n_ever is small, so rank the ever-list
+        for (int k = lane; k < n_ever; k += 64) {
+            const int p = ever_list[k];
+            const float wv = w_all[p];
+            if (wv != 0.0f) {
+                int rank = 0;
+                for (int q = 0; q < n_ever; ++q) {
+                    const int pq = ever_list[q];
+                    if (pq < p && w_all[pq] != 0.0f) rank++;
+                }
+                oi[rank] = p; oc[rank] = wv;
+            }
+        }
+        for (int k = 0; k < n_ever; k += 64) {
+            bool nz = false;
+            if (k + lane < n_ever) nz = (w_all[ever_list[k + lane]] != 0.0f);
+            cnt += __builtin_popcountll(__ballot(nz));
+        }
+        if (lane == 0) a.out_count[t] = cnt;
+    } else {
+        for (int p = lane; p < Kc; p += 64) { oi[p] = f_id[p]; oc[p] = f_w[p]; }
+        if (lane == 0) a.out_count[t] = Kc;
+    }
+    if (lane == 0) a.out_niter[t] = n_iter_out;
+
+    // ---- restore the scratch invariants ----
+    if (dirty) {
+        for (int o = yb + lane; o < ye; o += 64) R[a.crow[o]] = 0.0f;
+        if (ALLF) {
+            for (int k = 0; k < n_ever; ++k) {
+                const int p = ever_list[k];
+                for (int o = a.cptr[p] + lane; o < a.cptr[p + 1]; o += 64) R[a.crow[o]] = 0.0f;
+            }
+        } else {
+            for (int p = 0; p < Kc; ++p) {
+                if (f_ever[p] == 0) continue;
+                for (int o = f_b[p] + lane; o < f_e[p]; o += 64) R[a.crow[o]] = 0.0f;
+            }
+        }
+    }
+    if (ALLF) {
+        for (int k = lane; k < n_ever; k += 64) { const int p = ever_list[k]; w_all[p] = 0.0f; ever_flag[p] = 0; }
+    }
+    for (int tt = lane; tt < tc; tt += 64) s[touched[tt]] = __uint_as_float(kUntouched);
+}
+
+template <bool ALLF>
+__global__ __launch_bounds__(64) void fit_columns_kernel(FitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int slot = blockIdx.x;
+    for (;;) {
+        int t = 0;
+        if (lane_id() == 0) t = atomicAdd(a.queue, 1);
+        t = readfirst_i(t);
+        if (t >= a.n_targets) return;
+        fit_one<ALLF>(a, t, slot, smem);
+    }
+}
+
+__global__ __launch_bounds__(64) void column_sqnorms_kernel(int n_items, const int *cptr, const float *cval, float *sqn) {
+    const int lane = lane_id();
+    for (int c = blockIdx.x; c < n_items; c += gridDim.x) {
+        const int b = cptr[c], e = cptr[c + 1];
+        float acc = 0.0f;
+        for (int o = b; o < e; o += 64) {
+            const int n = min(64, e - o);
+            float prod = 0.0f;
+            if (lane < n) { const float x = cval[o + lane]; prod = __fmul_rn(x, x); }
+            acc = chain_add(acc, prod, n);
+        }
+        if (lane == 0) sqn[c] = acc;
+    }
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, size_t n, uint32_t v) {
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<size_t>(gridDim.x) * blockDim.x)
+        p[i] = v;
+}
+
+}  // namespace rtrec
+
+using namespace rtrec;
+
+namespace {
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+struct FitWs { size_t R, s, touched, cand_s, cand_i, w_all, total; };
+FitWs fit_ws_layout(int U, int I, int slots, int top_features) {
+    FitWs w;
+    size_t o = 0;
+    const size_t sl = static_cast<size_t>(slots);
+    w.R = o;       o = align_up(o + sl * U * 4, 256);
+    w.s = o;       o = align_up(o + sl * I * 4, 256);
+    w.touched = o; o = align_up(o + sl * I * 4, 256);
+    w.cand_s = o;  o = align_up(o + sl * I * 4, 256);
+    w.cand_i = o;  o = align_up(o + sl * I * 4, 256);
+    w.w_all = o;   if (top_features <= 0) o = align_up(o + sl * I * 4, 256);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" const char *rtrec_amd_version(void) { return "rtrec_amd 0.1 gfx950"; }
+
+extern "C" int rtrec_slim_column_sqnorms(int32_t n_items, const int32_t *d_csc_ptr, const float *d_csc_val,
+                                         float *d_sqnorm, void *stream) {
+    if (n_items < 0 || !d_csc_ptr || !d_sqnorm) return RTREC_ERR_INVALID_ARG;
+    if (n_items == 0) return RTREC_OK;
+    const int grid = n_items < 8192 ? n_items : 8192;
+    hipLaunchKernelGGL(column_sqnorms_kernel, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream),
+                       n_items, d_csc_ptr, d_csc_val, d_sqnorm);
+    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+}
+
+extern "C" size_t rtrec_slim_fit_workspace_bytes(int32_t n_users, int32_t n_items, int32_t n_slots, int32_t top_features) {
+    if (n_users <= 0 || n_items <= 0 || n_slots <= 0) return 0;
+    return fit_ws_layout(n_users, n_items, n_slots, top_features).total;
+}
+
+extern "C" int rtrec_slim_fit_workspace_init(void *d_workspace, size_t workspace_bytes, int32_t n_users, int32_t n_items,
+                                             int32_t n_slots, int32_t top_features, void *stream) {
+    if (!d_workspace || n_users <= 0 || n_items <= 0 || n_slots <= 0) return RTREC_ERR_INVALID_ARG;
+    const FitWs L = fit_ws_layout(n_users, n_items, n_slots, top_features);
+    if (workspace_bytes < L.total) return RTREC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned char *ws = static_cast<unsigned char *>(d_workspace);
+    if (hipMemsetAsync(ws, 0, L.total, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    const size_t n = static_cast<size_t>(n_slots) * n_items;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<uint32_t *>(ws + L.s), n, kUntouched);
+    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+}
+
+extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
+                                      const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                                      const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
+                                      const float *d_sqnorm,
+                                      const int32_t *d_targets, int32_t n_targets,
+                                      const rtrec_fit_cfg *cfg,
+                                      int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
+                                      int32_t *d_out_n_iter, int32_t cap,
+                                      void *d_workspace, size_t workspace_bytes, int32_t n_slots,
+                                      int32_t *d_queue, void *stream) {
+    if (n_users <= 0 || n_items <= 0 || n_targets < 0 || !cfg || n_slots <= 0) return RTREC_ERR_INVALID_ARG;
+    if (n_targets == 0) return RTREC_OK;
+    if (!d_csc_ptr || !d_csr_ptr || !d_sqnorm || !d_targets || !d_out_items || !d_out_coef || !d_out_count ||
+        !d_out_n_iter || !d_workspace || !d_queue)
+        return RTREC_ERR_INVALID_ARG;
+    const bool allf = cfg->top_features <= 0;
+    const int K = allf ? n_items : (cfg->top_features < n_items ? cfg->top_features : n_items);
+    if (cap < K) return RTREC_ERR_INVALID_ARG;
+    if (!allf && K > 4096) return RTREC_ERR_UNSUPPORTED;   // 7 LDS arrays of K entries per wave
+    if (cfg->max_iter <= 0) return RTREC_ERR_INVALID_ARG;
+    const FitWs L = fit_ws_layout(n_users, n_items, n_slots, cfg->top_features);
+    if (workspace_bytes < L.total) return RTREC_ERR_WORKSPACE;
+
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned char *ws = static_cast<unsigned char *>(d_workspace);
+    FitArgs a{};
+    a.U = n_users; a.I = n_items;
+    a.cptr = d_csc_ptr; a.crow = d_csc_row; a.cval = d_csc_val;
+    a.rptr = d_csr_ptr; a.rcol = d_csr_col; a.rval = d_csr_val;
+    a.sqn = d_sqnorm; a.targets = d_targets; a.n_targets = n_targets; a.cfg = *cfg;
+    a.out_items = d_out_items; a.out_coef = d_out_coef; a.out_count = d_out_count; a.out_niter = d_out_n_iter; a.cap = cap;
+    a.R = reinterpret_cast<float *>(ws + L.R);
+    a.s = reinterpret_cast<float *>(ws + L.s);
+    a.touched = reinterpret_cast<int *>(ws + L.touched);
+    a.cand_s = reinterpret_cast<float *>(ws + L.cand_s);
+    a.cand_i = reinterpret_cast<int *>(ws + L.cand_i);
+    a.w_all = allf ? reinterpret_cast<float *>(ws + L.w_all) : nullptr;
+    a.queue = d_queue;
+    if (hipMemsetAsync(d_queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    const int grid = n_slots < n_targets ? n_slots : n_targets;
+    if (allf) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true>), dim3(grid), dim3(64), 16, st, a);
+    } else {
+        const size_t lds = static_cast<size_t>(K) * 7 * 4 + 16;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), lds, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+}

@@ -1,0 +1,393 @@
+"""Device engine: owns the HBM-resident matrices and drives the HIP kernels through the C-ABI.
+
+Data layout in HBM (per GPU)
+  X   : the U x I interaction matrix, replicated on every GPU, in BOTH orientations
+        (CSC for the coordinate-descent column sweeps, CSR for X^T y and for scoring);
+        int32 indices, float32 values -- 16 B per interaction in total.
+  W   : this GPU's column shard [col_lo, col_hi) of the I x I item-item matrix, in the
+        column-tiled CSR layout described in include/rtrec_amd.h (6 B per stored weight).
+Nothing here computes on the host: numpy is used only to marshal index arrays.
+
+Multi-GPU (one process per GPU, torch.distributed / RCCL): fit has no collective (each rank
+fits the target columns it owns), scoring ends with one all-gather of the per-shard top-k
+followed by the merge kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import _native
+
+DEFAULT_TILE_COLS = 8192
+MAX_SLOTS = 2048
+
+
+def sklearn_seed(random_state: Optional[int]) -> int:
+    """The xorshift seed sklearn draws per ElasticNet.fit: check_random_state(rs).randint(0, 2**31-1)
+    (sklearn/linear_model/_cd_fast.pyx:367).  random_state=43 -> 494155588."""
+    return int(np.random.RandomState(random_state).randint(0, 2147483647))
+
+
+def shard_bounds(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Item-column shard [lo, hi) owned by `rank` (contiguous blocks of ceil(I / G) columns)."""
+    per = -(-n_items // world_size) if n_items > 0 else 0
+    lo = min(n_items, rank * per)
+    hi = min(n_items, lo + per)
+    return lo, hi
+
+
+@dataclass
+class TiledW:
+    """Host-side description of one shard of W in the kernel's tiled layout."""
+    n_items: int
+    col_lo: int
+    n_cols: int
+    tile_cols: int
+    n_tiles: int
+    tile_ptr: np.ndarray  # int32 [n_tiles * (n_items + 1)]
+    w_col: np.ndarray     # uint16 [nnz]
+    w_val: np.ndarray     # float32 [nnz]
+
+
+def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int) -> TiledW:
+    """Cut columns [col_lo, col_hi) of W (CSC, I x I) into tiles; per tile a CSR over all rows."""
+    n_items = W_csc.shape[0]
+    n_cols = col_hi - col_lo
+    n_tiles = max(1, -(-n_cols // tile_cols))
+    indptr = np.asarray(W_csc.indptr, dtype=np.int64)
+    s, e = int(indptr[col_lo]), int(indptr[col_hi])
+    rows = np.asarray(W_csc.indices[s:e], dtype=np.int64)
+    vals = np.asarray(W_csc.data[s:e], dtype=np.float32)
+    counts = np.diff(indptr[col_lo:col_hi + 1])
+    kloc = np.repeat(np.arange(n_cols, dtype=np.int64), counts)
+    tile = kloc // tile_cols
+    order = np.lexsort((kloc, rows, tile))
+    key = (tile * n_items + rows)[order]
+    cnt = np.bincount(key, minlength=n_tiles * n_items)
+    starts = np.zeros(n_tiles * n_items + 1, dtype=np.int64)
+    np.cumsum(cnt, out=starts[1:])
+    if starts[-1] >= 2 ** 31:
+        raise ValueError("W shard has more than 2**31 stored weights")
+    tile_ptr = np.empty(n_tiles * (n_items + 1), dtype=np.int32)
+    for t in range(n_tiles):
+        tile_ptr[t * (n_items + 1):(t + 1) * (n_items + 1)] = starts[t * n_items:t * n_items + n_items + 1]
+    w_col = (kloc[order] % tile_cols).astype(np.uint16)
+    return TiledW(n_items, col_lo, n_cols, tile_cols, n_tiles, tile_ptr, w_col, np.ascontiguousarray(vals[order]))
+
+
+class HipBackend:
+    """Thin marshalling layer over librtrec_amd.so; all arrays are torch CUDA tensors."""
+
+    def __init__(self, device: Any = None):
+        import torch
+        if not torch.cuda.is_available():
+            raise _native.NativeLibraryError("rtrec_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                                             "there is no CPU fallback")
+        self.torch = torch
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.lib = _native.load()
+
+    # -- helpers -------------------------------------------------------------------------
+    def to_dev(self, a: np.ndarray):
+        t = self.torch.from_numpy(np.ascontiguousarray(a))
+        return t.to(self.device, non_blocking=False)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=dtype, device=self.device)
+
+    def zeros(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def stream(self) -> C.c_void_p:
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    @staticmethod
+    def ptr(t) -> C.c_void_p:
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+class SlimEngine:
+    """Fit / score / similar-items on one GPU (one shard of W)."""
+
+    def __init__(self, device: Any = None, rank: int = 0, world_size: int = 1, process_group: Any = None,
+                 tile_cols: Optional[int] = None, backend: Any = None):
+        self.rank, self.world_size, self.group = rank, world_size, process_group
+        self.tile_cols = int(tile_cols or DEFAULT_TILE_COLS)
+        self.be = backend if backend is not None else HipBackend(device)
+        self.n_users = 0
+        self.n_items = 0
+        self._X: Dict[str, Any] = {}
+        self._W: Dict[str, Any] = {}
+        self._fit_ws: Dict[Tuple[int, int, int, int], Any] = {}
+        self._score_ws = None
+        self.last_fit_stats: Dict[str, Any] = {}
+
+    # ------------------------------------------------------------------------------ X
+    def set_interactions(self, X_csc: sp.csc_matrix, X_csr: Optional[sp.csr_matrix] = None,
+                         need_csc: bool = True) -> None:
+        """Upload X (U x I).  Both orientations must have sorted indices (scipy canonical form)."""
+        be = self.be
+        if X_csr is None:
+            X_csr = X_csc.tocsr()
+        if not X_csr.has_sorted_indices:
+            X_csr = X_csr.sorted_indices()
+        self.n_users, self.n_items = X_csr.shape
+        if X_csr.nnz >= 2 ** 31:
+            raise ValueError("more than 2**31 interactions per GPU are not supported")
+        X: Dict[str, Any] = {}
+        X["rptr"] = be.to_dev(np.asarray(X_csr.indptr, dtype=np.int32))
+        X["rcol"] = be.to_dev(np.asarray(X_csr.indices, dtype=np.int32))
+        X["rval"] = be.to_dev(np.asarray(X_csr.data, dtype=np.float32))
+        if need_csc:
+            if X_csc is None:
+                X_csc = X_csr.tocsc()
+            if not X_csc.has_sorted_indices:
+                X_csc = X_csc.sorted_indices()
+            X["cptr"] = be.to_dev(np.asarray(X_csc.indptr, dtype=np.int32))
+            X["crow"] = be.to_dev(np.asarray(X_csc.indices, dtype=np.int32))
+            X["cval"] = be.to_dev(np.asarray(X_csc.data, dtype=np.float32))
+            X["col_nnz"] = np.diff(np.asarray(X_csc.indptr, dtype=np.int64))
+        self._X = X
+
+    # ------------------------------------------------------------------------------ fit
+    def owned_columns(self, columns: np.ndarray) -> np.ndarray:
+        lo, hi = shard_bounds(self.n_items, self.world_size, self.rank)
+        columns = np.asarray(columns, dtype=np.int64)
+        return columns[(columns >= lo) & (columns < hi)]
+
+    def fit_columns(self, targets: Sequence[int], alpha: float = 0.1, l1_ratio: float = 0.1,
+                    positive: bool = True, max_iter: int = 100, tol: float = 1e-4, random_state: Optional[int] = 43,
+                    nn_feature_selection: Optional[int] = None, n_slots: Optional[int] = None
+                    ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """Fit the given target columns on this GPU.
+
+        Returns (targets_in_processing_order, items[n, cap], coef[n, cap], count[n], n_iter[n]);
+        row t describes model.sparse_coef_ of target t (see rtrec_slim_fit_columns).
+        """
+        be, X = self.be, self._X
+        if "cptr" not in X:
+            raise RuntimeError("set_interactions() with the CSC orientation must be called before fit_columns()")
+        U, I = self.n_users, self.n_items
+        targets = np.asarray(targets, dtype=np.int64)
+        # longest columns first: the device work queue then ends on short jobs
+        order = np.argsort(-X["col_nnz"][targets], kind="stable")
+        targets = targets[order]
+        K = int(nn_feature_selection) if nn_feature_selection is not None else 0
+        if nn_feature_selection is not None and K <= 0:
+            raise AssertionError(f"n_neighbors must be a positive integer: {K}")
+        cap = min(K, I) if K > 0 else I
+        cfg = _native.FitCfg(np.float32(alpha * l1_ratio * U), np.float32(alpha * (1.0 - l1_ratio) * U),
+                             np.float32(tol), int(max_iter), sklearn_seed(random_state), int(bool(positive)), K)
+        torch = be.torch
+        if "sqn" not in X:
+            X["sqn"] = be.empty((I,), torch.float32)
+            _native.check(be.lib.rtrec_slim_column_sqnorms(I, be.ptr(X["cptr"]), be.ptr(X["cval"]), be.ptr(X["sqn"]),
+                                                           be.stream()), "rtrec_slim_column_sqnorms")
+        n = len(targets)
+        slots = int(n_slots or min(MAX_SLOTS, max(1, n)))
+        # keep the per-slot scratch (R: U floats, s/touched/cand: I each) within ~8 GiB
+        per_slot = 4 * (U + (5 if K <= 0 else 4) * I)
+        slots = max(1, min(slots, int((8 << 30) // max(per_slot, 1))))
+        ws_key = (U, I, slots, K if K > 0 else 0)
+        if ws_key not in self._fit_ws:
+            self._fit_ws.clear()
+            nbytes = int(be.lib.rtrec_slim_fit_workspace_bytes(U, I, slots, K))
+            ws = be.empty((nbytes,), torch.uint8)
+            _native.check(be.lib.rtrec_slim_fit_workspace_init(be.ptr(ws), nbytes, U, I, slots, K, be.stream()),
+                          "rtrec_slim_fit_workspace_init")
+            self._fit_ws[ws_key] = (ws, nbytes, be.zeros((1,), torch.int32))
+        ws, nbytes, queue = self._fit_ws[ws_key]
+
+        # chunk so that the output block stays below ~1 GiB (matters for K=None, cap = I)
+        chunk = max(1, min(n, int((1 << 30) // max(cap * 8, 1)))) if n else 1
+        items_out = np.empty((n, cap), dtype=np.int32)
+        coef_out = np.empty((n, cap), dtype=np.float32)
+        count_out = np.empty((n,), dtype=np.int32)
+        niter_out = np.empty((n,), dtype=np.int32)
+        for s in range(0, n, chunk):
+            tg = targets[s:s + chunk]
+            m = len(tg)
+            d_t = be.to_dev(tg.astype(np.int32))
+            d_items = be.empty((m, cap), torch.int32)
+            d_coef = be.empty((m, cap), torch.float32)
+            d_count = be.empty((m,), torch.int32)
+            d_niter = be.empty((m,), torch.int32)
+            _native.check(be.lib.rtrec_slim_fit_columns(
+                U, I, be.ptr(X["cptr"]), be.ptr(X["crow"]), be.ptr(X["cval"]),
+                be.ptr(X["rptr"]), be.ptr(X["rcol"]), be.ptr(X["rval"]), be.ptr(X["sqn"]),
+                be.ptr(d_t), m, C.byref(cfg), be.ptr(d_items), be.ptr(d_coef), be.ptr(d_count), be.ptr(d_niter),
+                cap, be.ptr(ws), nbytes, slots, be.ptr(queue), be.stream()), "rtrec_slim_fit_columns")
+            items_out[s:s + m] = d_items.cpu().numpy()
+            coef_out[s:s + m] = d_coef.cpu().numpy()
+            count_out[s:s + m] = d_count.cpu().numpy()
+            niter_out[s:s + m] = d_niter.cpu().numpy()
+        self.last_fit_stats = {"n_targets": n, "slots": slots, "cap": cap}
+        return targets, items_out, coef_out, count_out, niter_out
+
+    # ------------------------------------------------------------------------------ W
+    def set_weights(self, W_csc: sp.csc_matrix, acc_f64: bool = False) -> None:
+        """Upload this rank's column shard of W (I x I, CSC with sorted indices)."""
+        be = self.be
+        n_items = W_csc.shape[1]
+        lo, hi = shard_bounds(n_items, self.world_size, self.rank)
+        W_csc = W_csc if W_csc.has_sorted_indices else W_csc.sorted_indices()
+        W: Dict[str, Any] = {"n_items": n_items, "col_lo": lo, "n_cols": hi - lo, "acc_f64": bool(acc_f64)}
+        if hi > lo:
+            # the exact-tie pass keeps a float accumulator AND a first-touch word per column in LDS
+            tile = self.tile_cols
+            while tile > 256 and tile * ((8 if acc_f64 else 4) + 4) + 2048 > 160 * 1024:
+                tile //= 2
+            T = build_tiled_w(W_csc, lo, hi, tile)
+            W.update(tile_cols=T.tile_cols, n_tiles=T.n_tiles, tile_ptr=be.to_dev(T.tile_ptr),
+                     w_col=be.to_dev(T.w_col.view(np.int16)), w_val=be.to_dev(T.w_val), nnz=int(T.w_val.shape[0]))
+        # CSC copy for similar_items (whole matrix is small: <= K entries per column)
+        W["cptr"] = be.to_dev(np.asarray(W_csc.indptr, dtype=np.int32))
+        W["crow"] = be.to_dev(np.asarray(W_csc.indices, dtype=np.int32))
+        W["cval"] = be.to_dev(np.asarray(W_csc.data, dtype=np.float32))
+        self._W = W
+
+    # ------------------------------------------------------------------------------ score
+    def _local_topk(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
+                    d_col_rank):
+        be, W = self.be, self._W
+        torch = be.torch
+        ids = be.empty((n_rows, top_k), torch.int32)
+        sc = be.empty((n_rows, top_k), torch.float32)
+        aux = be.empty((n_rows, top_k), torch.int32)
+        cnt = be.empty((n_rows,), torch.int32)
+        sc64 = be.empty((n_rows, top_k), torch.float64) if W["acc_f64"] else None
+        if W["n_cols"] == 0:
+            ids.fill_(-1); sc.fill_(float("-inf")); aux.zero_(); cnt.zero_()
+            if sc64 is not None:
+                sc64.fill_(float("-inf"))
+            return ids, sc, sc64, aux, cnt
+        need = int(be.lib.rtrec_slim_score_workspace_bytes(n_rows, W["n_tiles"], top_k))
+        if self._score_ws is None or self._score_ws.numel() < need:
+            self._score_ws = be.empty((need,), torch.uint8)
+        ws = self._score_ws
+        _native.check(be.lib.rtrec_slim_score_topk(
+            n_rows, be.ptr(d_row_ids), be.ptr(xb[0]), be.ptr(xb[1]), be.ptr(xb[2]),
+            W["n_items"], W["n_cols"], W["col_lo"], W["tile_cols"], W["n_tiles"],
+            be.ptr(W["tile_ptr"]), be.ptr(W["w_col"]), be.ptr(W["w_val"]), be.ptr(d_col_rank),
+            top_k, int(bool(filter_interacted)), int(mode), int(W["acc_f64"]),
+            be.ptr(ids), be.ptr(sc), be.ptr(sc64), be.ptr(aux), be.ptr(cnt),
+            be.ptr(ws), ws.numel(), be.stream()), "rtrec_slim_score_topk")
+        return ids, sc, sc64, aux, cnt
+
+    def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
+                          mode: int, col_rank: Optional[np.ndarray] = None, xb=None):
+        """Device tensors (ids, scores, counts) of the GLOBAL top-k for the given rows of X
+        (or of the CSR batch `xb` = (ptr, col, val) device tensors)."""
+        be = self.be
+        if not self._W:
+            raise RuntimeError("Model must be fitted before calling batch_recommend.")
+        if xb is None:
+            xb = (self._X["rptr"], self._X["rcol"], self._X["rval"])
+        d_rows = be.to_dev(np.asarray(row_ids, dtype=np.int32)) if row_ids is not None else None
+        d_rank = be.to_dev(np.asarray(col_rank, dtype=np.int32)) if col_rank is not None else None
+        ids, sc, sc64, aux, cnt = self._local_topk(d_rows, n_rows, xb, top_k, filter_interacted, mode, d_rank)
+        if self.world_size == 1:
+            return ids, sc, cnt
+        import torch.distributed as dist
+        torch = be.torch
+        G = self.world_size
+
+        def gather(t):
+            out = be.empty((G,) + tuple(t.shape), t.dtype)
+            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
+            return out
+        g_ids, g_sc, g_aux, g_cnt = gather(ids), gather(sc), gather(aux), gather(cnt)
+        g_sc64 = gather(sc64) if sc64 is not None else None
+        o_ids = be.empty((n_rows, top_k), torch.int32)
+        o_sc = be.empty((n_rows, top_k), torch.float32)
+        o_cnt = be.empty((n_rows,), torch.int32)
+        _native.check(be.lib.rtrec_slim_merge_topk(n_rows, G, top_k, be.ptr(g_ids), be.ptr(g_sc), be.ptr(g_sc64),
+                                                   be.ptr(g_aux), be.ptr(g_cnt), be.ptr(o_ids), be.ptr(o_sc),
+                                                   be.ptr(o_cnt), be.stream()), "rtrec_slim_merge_topk")
+        return o_ids, o_sc, o_cnt
+
+    def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
+                       mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None
+                       ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Top-k for rows of the resident X.  Returns numpy (ids[B,k], scores[B,k], counts[B])."""
+        row_ids = np.asarray(row_ids, dtype=np.int32)
+        if len(row_ids) == 0:
+            return (np.empty((0, top_k), np.int32), np.empty((0, top_k), np.float32), np.empty((0,), np.int32))
+        ids, sc, cnt = self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank)
+        return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+
+    def recommend_csr(self, Xb: sp.csr_matrix, top_k: int = 10, filter_interacted: bool = True,
+                      mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None
+                      ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Top-k for the rows of a host CSR batch (the SLIMElastic.recommend_batch boundary)."""
+        be = self.be
+        B = Xb.shape[0]
+        if B == 0:
+            return (np.empty((0, top_k), np.int32), np.empty((0, top_k), np.float32), np.empty((0,), np.int32))
+        if not Xb.has_sorted_indices:
+            Xb = Xb.sorted_indices()
+        xb = (be.to_dev(np.asarray(Xb.indptr, dtype=np.int32)), be.to_dev(np.asarray(Xb.indices, dtype=np.int32)),
+              be.to_dev(np.asarray(Xb.data, dtype=np.float32)))
+        ids, sc, cnt = self.score_topk_device(None, B, top_k, filter_interacted, mode, col_rank, xb=xb)
+        return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+
+    # ------------------------------------------------------------------------------ similar
+    def similar_items(self, queries: Sequence[int], top_k: int = 10) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        be, W = self.be, self._W
+        if not W:
+            raise RuntimeError("Model must be fitted before calling similar_items.")
+        torch = be.torch
+        q = np.asarray(queries, dtype=np.int32)
+        n = len(q)
+        if n == 0:
+            return (np.empty((0, top_k), np.int32), np.empty((0, top_k), np.float32), np.empty((0,), np.int32))
+        d_q = be.to_dev(q)
+        ids = be.empty((n, top_k), torch.int32)
+        sc = be.empty((n, top_k), torch.float32)
+        cnt = be.empty((n,), torch.int32)
+        _native.check(be.lib.rtrec_slim_similar_topk(n, be.ptr(d_q), be.ptr(W["cptr"]), be.ptr(W["crow"]),
+                                                     be.ptr(W["cval"]), top_k, be.ptr(ids), be.ptr(sc), be.ptr(cnt),
+                                                     be.stream()), "rtrec_slim_similar_topk")
+        return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+
+
+def coefficients_to_updates(targets: np.ndarray, items: np.ndarray, coef: np.ndarray, count: np.ndarray
+                            ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """Flatten fit_columns output to COO triples (row item i, column target j, value), explicit
+    zeros included, ready for merge_coefficients()."""
+    n, cap = items.shape
+    mask = np.arange(cap)[None, :] < count[:, None]
+    rows = items[mask].astype(np.int64)
+    cols = np.repeat(targets.astype(np.int64), count)
+    return rows, cols, coef[mask]
+
+
+def merge_coefficients(W_old: Optional[sp.csc_matrix], n_items: int, rows: np.ndarray, cols: np.ndarray,
+                       vals: np.ndarray, dtype=np.float32) -> sp.csc_matrix:
+    """The LIL write-back of slim_elastic.py:271-274 / 371-374 / 554-557 as one vectorised merge:
+    start from the old matrix (resized to n_items), then for every fitted (i, j): a non-zero value
+    overwrites W[i, j], an explicit zero deletes it; entries of column j that the new solution does
+    not mention survive."""
+    if W_old is not None and W_old.nnz:
+        Wo = W_old.tocoo()
+        o_rows, o_cols, o_vals = Wo.row.astype(np.int64), Wo.col.astype(np.int64), Wo.data.astype(dtype)
+        o_key = o_cols * n_items + o_rows
+        n_key = cols * n_items + rows
+        keep = ~np.isin(o_key, n_key)
+        rows_all = np.concatenate([o_rows[keep], rows])
+        cols_all = np.concatenate([o_cols[keep], cols])
+        vals_all = np.concatenate([o_vals[keep], vals.astype(dtype)])
+    else:
+        rows_all, cols_all, vals_all = rows, cols, vals.astype(dtype)
+    nz = vals_all != 0
+    W = sp.csc_matrix((vals_all[nz], (rows_all[nz], cols_all[nz])), shape=(n_items, n_items), dtype=dtype)
+    W.sort_indices()
+    return W

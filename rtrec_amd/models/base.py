@@ -1,0 +1,266 @@
+"""Model boundary: raw ids in, raw ids out.
+
+Public surface of rtrec.models.base.BaseModel (/root/reference/rtrec/models/base.py:21-423):
+feature registration (:36-70), add_interactions (:72-94), fit (:107-115), recommend (:135-173),
+recommend_batch (:188-269), similar_items (:320-340), get_users_by_items (:342-362),
+save/load/loads (:376-405) and the abstract hooks a concrete model fills in.  Batches are
+ingested through the columnar store in one vectorised call when the batch is well formed; a
+malformed interaction falls back to the reference's per-tuple "log a warning and skip it".
+"""
+from __future__ import annotations
+
+import logging
+import pickle
+from abc import ABC, abstractmethod
+from io import BytesIO
+from typing import Any, Iterable, List, Optional, Tuple, Union
+
+import numpy as np
+
+from ..utils.features import FeatureStore
+from ..utils.identifiers import Identifier
+from ..utils.interactions import UserItemInteractions
+
+FileLike = Union[BytesIO, Any]
+
+
+class BaseModel(ABC):
+    def __init__(self, **kwargs: Any):
+        self.interactions = UserItemInteractions(**kwargs)
+        self.user_ids = Identifier(**kwargs)
+        self.item_ids = Identifier(**kwargs)
+        self.feature_store = FeatureStore()
+
+    # ------------------------------------------------------------ features
+    def register_user_feature(self, user: Any, user_tags: List[str]) -> int:
+        user_id = self.user_ids.identify(user)
+        self.feature_store.put_user_features(user_id, user_tags)
+        return user_id
+
+    def clear_user_features(self, user_ids: Optional[List[int]] = None) -> None:
+        self.feature_store.clear_user_features(user_ids)
+
+    def register_item_feature(self, item: Any, item_tags: List[str]) -> int:
+        item_id = self.item_ids.identify(item)
+        self.feature_store.put_item_features(item_id, item_tags)
+        return item_id
+
+    def clear_item_features(self, item_ids: Optional[List[int]] = None) -> None:
+        self.feature_store.clear_item_features(item_ids)
+
+    # ------------------------------------------------------------ ingest
+    def _ingest(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool
+                ) -> Tuple[np.ndarray, np.ndarray]:
+        """Identify and store a batch.  Returns the internal (user_ids, item_ids) that were stored."""
+        rows = interactions if isinstance(interactions, list) else list(interactions)
+        if not rows:
+            return np.empty(0, np.int64), np.empty(0, np.int64)
+        try:
+            users, items, tstamps, ratings = zip(*rows)
+            ts = np.asarray(tstamps, dtype=np.float64)
+            dl = np.asarray(ratings, dtype=np.float64)
+            if ts.shape != (len(rows),) or dl.shape != (len(rows),):
+                raise ValueError("malformed interaction batch")
+            clean = self._batch_is_homogeneous(users, self.user_ids) and self._batch_is_homogeneous(items, self.item_ids)
+        except Exception:
+            clean = False
+        if clean:
+            uid = self.user_ids.identify_many(users)
+            iid = self.item_ids.identify_many(items)
+            self.interactions.add_interactions_batch(uid, iid, ts, dl, upsert=update_interaction)
+            return uid, iid
+        # per-interaction path with the reference's swallow-and-warn convention (base.py:86-94)
+        u_out: List[int] = []
+        i_out: List[int] = []
+        for row in rows:
+            try:
+                user, item, tstamp, rating = row
+                user_id = self.user_ids.identify(user)
+                item_id = self.item_ids.identify(item)
+                self.interactions.add_interaction(user_id, item_id, tstamp, rating, upsert=update_interaction)
+                u_out.append(user_id)
+                i_out.append(item_id)
+            except Exception as e:
+                logging.warning(f"Error processing interaction: {e}")
+                continue
+        return np.asarray(u_out, dtype=np.int64), np.asarray(i_out, dtype=np.int64)
+
+    @staticmethod
+    def _batch_is_homogeneous(objs: Tuple[Any, ...], ident: Identifier) -> bool:
+        """True when identify() cannot raise for any element of the batch."""
+        all_int = all(isinstance(o, (int, np.integer)) for o in objs)
+        if ident.force_identify:
+            return True
+        if all_int:
+            return ident.pass_through is not False and all(o >= 0 for o in objs)
+        none_int = not any(isinstance(o, (int, np.integer)) for o in objs)
+        return none_int and ident.pass_through is not True
+
+    def add_interactions(self, interactions: Iterable[Tuple[Any, Any, float, float]],
+                         update_interaction: bool = False, record_interactions: bool = False) -> None:
+        uid, iid = self._ingest(interactions, update_interaction)
+        if record_interactions:
+            self._record_batch(uid, iid)
+
+    def _record_batch(self, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
+        for u, i in zip(user_ids.tolist(), item_ids.tolist()):
+            self._record_interactions(u, i, 0.0, 0.0)
+
+    @abstractmethod
+    def _record_interactions(self, user_id: int, item_id: int, tstamp: float, rating: float) -> None:
+        raise NotImplementedError("_record_interactions method must be implemented in the derived class")
+
+    def fit(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool = False,
+            progress_bar: bool = True) -> "BaseModel":
+        self.add_interactions(interactions, update_interaction=update_interaction, record_interactions=True)
+        return self._fit_recorded(progress_bar=progress_bar)
+
+    @abstractmethod
+    def _fit_recorded(self, parallel: bool = False, progress_bar: bool = True) -> "BaseModel":
+        raise NotImplementedError("_fit_recorded method must be implemented in the derived class")
+
+    @abstractmethod
+    def bulk_fit(self, parallel: bool = True, progress_bar: bool = True) -> "BaseModel":
+        raise NotImplementedError("bulk_fit method must be implemented in the derived class")
+
+    # ------------------------------------------------------------ recommend
+    def _candidate_ids(self, candidate_items: Optional[List[Any]]) -> Optional[List[int]]:
+        if candidate_items is None:
+            return None
+        out = []
+        for item in candidate_items:
+            item_id = self.item_ids.get_id(item)
+            if item_id is None:
+                continue
+            if self.item_ids.pass_through and item_id > self.interactions.max_item_id:
+                continue
+            out.append(item_id)
+        return out or None
+
+    def _known_user_id(self, user: Any) -> Optional[int]:
+        user_id = self.user_ids.get_id(user)
+        if user_id is not None and self.user_ids.pass_through and user_id > self.interactions.max_user_id:
+            return None   # an integer id the store has never seen is a cold-start user
+        return user_id
+
+    def recommend(self, user: Any, candidate_items: Optional[List[Any]] = None, user_tags: Optional[List[str]] = None,
+                  top_k: int = 10, filter_interacted: bool = True) -> List[Any]:
+        candidate_item_ids = self._candidate_ids(candidate_items)
+        user_id = self._known_user_id(user)
+        if user_id is None:
+            hot = self.interactions.get_hot_items(top_k, filter_interacted=False)
+            if candidate_item_ids is not None:
+                hot = [i for i in hot if i in candidate_item_ids]
+            return hot
+        rec = self._recommend(user_id, candidate_item_ids=candidate_item_ids, user_tags=user_tags, top_k=top_k,
+                              filter_interacted=filter_interacted)
+        return [self.item_ids.get(i) for i in rec]
+
+    @abstractmethod
+    def _recommend(self, user_id: int, candidate_item_ids: Optional[List[int]] = None,
+                   user_tags: Optional[List[str]] = None, top_k: int = 10, filter_interacted: bool = True) -> List[int]:
+        raise NotImplementedError("_recommend method must be implemented in the derived class")
+
+    def recommend_batch(self, users: List[Any], candidate_items: Optional[List[Any]] = None,
+                        users_tags: Optional[List[List[str]]] = None, top_k: int = 10,
+                        filter_interacted: bool = True) -> List[List[Any]]:
+        hot_pos: List[int] = []
+        hot_ids: List[int] = []
+        cold_pos: List[int] = []
+        cold_ids: List[Optional[int]] = []
+        for pos, user in enumerate(users):
+            uid = self._known_user_id(user)
+            if uid is None:
+                cold_pos.append(pos)
+                cold_ids.append(self.handle_unknown_user(user))
+            else:
+                hot_pos.append(pos)
+                hot_ids.append(uid)
+        candidate_item_ids = self._candidate_ids(candidate_items)
+
+        def to_items(rows: List[List[int]]) -> List[List[Any]]:
+            return [[self.item_ids.get(i) for i in row] for row in rows]
+
+        if not cold_ids:
+            return to_items(self._recommend_hot_batch(hot_ids, candidate_item_ids=candidate_item_ids,
+                                                      users_tags=users_tags, top_k=top_k,
+                                                      filter_interacted=filter_interacted))
+        results: List[List[Any]] = [[] for _ in users]
+        cold_tags = [users_tags[p] for p in cold_pos] if users_tags else None
+        cold = to_items(self._recommend_cold_batch(cold_ids, candidate_item_ids=candidate_item_ids,
+                                                   users_tags=cold_tags, top_k=top_k))
+        for p, row in zip(cold_pos, cold):
+            results[p] = row
+        if hot_ids:
+            hot_tags = [users_tags[p] for p in hot_pos] if users_tags else None
+            hot = to_items(self._recommend_hot_batch(hot_ids, candidate_item_ids=candidate_item_ids,
+                                                     users_tags=hot_tags, top_k=top_k,
+                                                     filter_interacted=filter_interacted))
+            for p, row in zip(hot_pos, hot):
+                results[p] = row
+        return results
+
+    def handle_unknown_user(self, user: Any) -> Optional[int]:
+        return None
+
+    def _recommend_cold_batch(self, user_ids: List[Optional[int]], candidate_item_ids: Optional[List[int]] = None,
+                              users_tags: Optional[List[List[str]]] = None, top_k: int = 10) -> List[List[int]]:
+        hot = self.interactions.get_hot_items(top_k, filter_interacted=False)
+        if candidate_item_ids is not None:
+            hot = [i for i in hot if i in candidate_item_ids]
+        return [hot for _ in user_ids]
+
+    def _recommend_hot_batch(self, user_ids: List[int], candidate_item_ids: Optional[List[int]] = None,
+                             users_tags: Optional[List[List[str]]] = None, top_k: int = 10,
+                             filter_interacted: bool = True) -> List[List[int]]:
+        if users_tags:
+            assert len(user_ids) == len(users_tags), (
+                f"Number of user tags must match the number of users. Got {len(user_ids)} users and "
+                f"{len(users_tags)} user tags.")
+            return [self._recommend(u, candidate_item_ids=candidate_item_ids, user_tags=t, top_k=top_k,
+                                    filter_interacted=filter_interacted) for u, t in zip(user_ids, users_tags)]
+        return [self._recommend(u, candidate_item_ids=candidate_item_ids, top_k=top_k,
+                                filter_interacted=filter_interacted) for u in user_ids]
+
+    # ------------------------------------------------------------ item-to-item, lookups
+    def similar_items(self, query_item: Any, query_item_tags: Optional[List[str]] = None, top_k: int = 10,
+                      ret_scores: bool = False) -> List[Tuple[Any, float]] | List[Any]:
+        query_item_id = self.item_ids.identify(query_item)   # like the reference, registers unseen items
+        if query_item_id is None:
+            return []
+        pairs = self._similar_items(query_item_id, query_item_tags=query_item_tags, top_k=top_k)
+        if ret_scores:
+            return [(self.item_ids.get(i), s) for i, s in pairs]
+        return [self.item_ids.get(i) for i, _ in pairs]
+
+    def get_users_by_items(self, items: List[Any]) -> List[Any]:
+        item_ids = [i for i in (self.item_ids.get_id(item) for item in items) if i is not None]
+        if not item_ids:
+            return []
+        return [self.user_ids.get(u) for u in self.interactions.get_users_by_items(item_ids)]
+
+    @abstractmethod
+    def _similar_items(self, query_item_id: int, query_item_tags: Optional[List[str]] = None, top_k: int = 10
+                       ) -> List[Tuple[int, float]]:
+        raise NotImplementedError("_similar_items method must be implemented in the derived class")
+
+    # ------------------------------------------------------------ persistence
+    def save(self, f: FileLike) -> int:
+        return f.write(pickle.dumps(self._serialize(), protocol=pickle.HIGHEST_PROTOCOL))
+
+    @classmethod
+    def load(cls, f: FileLike) -> "BaseModel":
+        return cls._deserialize(pickle.loads(f.read()))
+
+    @classmethod
+    def loads(cls, data: bytes) -> "BaseModel":
+        return cls.load(BytesIO(data))
+
+    @abstractmethod
+    def _serialize(self) -> dict:
+        raise NotImplementedError("_serialize method must be implemented in the derived class")
+
+    @classmethod
+    @abstractmethod
+    def _deserialize(cls, data: dict) -> "BaseModel":
+        raise NotImplementedError("_deserialize method must be implemented in the derived class")

@@ -1,0 +1,269 @@
+"""SLIMElastic: the operator boundary of the SLIM path, served by the MI355X engine.
+
+Mirrors the method set of rtrec.models.internal.slim_elastic.SLIMElastic
+(/root/reference/rtrec/models/internal/slim_elastic.py:156-857) -- same constructor config, same
+arguments, same return types, same error messages -- so callers written against the reference
+(rtrec.models.SLIM, HybridSlimFM) switch by import.  Where the reference loops over item columns
+calling scikit-learn's ElasticNet and over users calling scipy/numpy/sorted(), this class uploads
+the matrices once and calls the HIP kernels (rtrec_amd/csrc) through rtrec_amd.engine.
+
+`item_similarity` stays a host scipy.sparse.csc_matrix (public attribute, pickled, read by
+HybridSlimFM); the GPU keeps its own tiled copy that is rebuilt whenever the attribute changes.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import scipy.sparse as sp
+from numpy import ndarray
+
+from ... import _native
+from ...engine import SlimEngine, coefficients_to_updates, merge_coefficients
+
+
+def _default_engine() -> SlimEngine:
+    """One engine per process: cuda:LOCAL_RANK, sharded over the default process group if any."""
+    import os
+    import torch
+    rank, world, group = 0, 1, None
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+    except Exception:   # pragma: no cover
+        pass
+    dev = None
+    if torch.cuda.is_available():
+        dev = f"cuda:{int(os.environ.get('LOCAL_RANK', torch.cuda.current_device()))}"
+    return SlimEngine(device=dev, rank=rank, world_size=world, process_group=group)
+
+
+class SLIMElastic:
+    """Sparse linear method: one elastic-net regression per item column, W = item_similarity."""
+
+    def __init__(self, config: dict = {}, engine: Optional[SlimEngine] = None):
+        self.optim_name = config.get("optim", "cd")
+        self.eta0 = config.get("eta0", 0.001)
+        self.alpha = config.get("alpha", 0.1)
+        self.l1_ratio = config.get("l1_ratio", 0.1)
+        self.positive_only = config.get("positive_only", True)
+        self.max_iter = config.get("max_iter", 100)
+        self.tol = config.get("tol", 1e-4)
+        self.random_state = config.get("random_state", 43)
+        self.nn_feature_selection = config.get("nn_feature_selection", None)
+        self._item_similarity: Optional[sp.csc_matrix] = None
+        self._engine = engine
+        self._w_on_device: Optional[int] = None      # id() of the matrix the GPU copy was built from
+        self.n_iter_: Optional[np.ndarray] = None    # sweeps per fitted column of the last fit
+
+    # ---------------------------------------------------------------- state
+    @property
+    def item_similarity(self) -> Optional[sp.csc_matrix]:
+        return self._item_similarity
+
+    @item_similarity.setter
+    def item_similarity(self, W: Optional[sp.csc_matrix]) -> None:
+        self._item_similarity = W
+        self._w_on_device = None
+
+    @property
+    def engine(self) -> SlimEngine:
+        if self._engine is None:
+            self._engine = _default_engine()
+        return self._engine
+
+    def __getstate__(self) -> Dict[str, Any]:
+        state = dict(self.__dict__)
+        state["_engine"] = None
+        state["_w_on_device"] = None
+        return state
+
+    def _check_optim(self) -> None:
+        if self.optim_name == "cd":
+            return
+        if self.optim_name == "sgd":
+            raise NotImplementedError("optim='sgd' (scikit-learn SGDRegressor) is not implemented on the GPU path; "
+                                      "use optim='cd'")
+        raise ValueError(f"Invalid Optimizer name: {self.optim_name}")
+
+    # ---------------------------------------------------------------- fit
+    def _fit_targets(self, X_csc: sp.csc_matrix, targets: np.ndarray, W_old: Optional[sp.csc_matrix],
+                     dtype) -> sp.csc_matrix:
+        """Fit `targets` on the GPU(s) and write the coefficients back like the reference's LIL loop."""
+        self._check_optim()
+        eng = self.engine
+        n_items = X_csc.shape[1]
+        eng.set_interactions(X_csc)
+        mine = eng.owned_columns(targets)
+        tg, items, coef, count, n_iter = eng.fit_columns(
+            mine, alpha=self.alpha, l1_ratio=self.l1_ratio, positive=self.positive_only, max_iter=self.max_iter,
+            tol=self.tol, random_state=self.random_state, nn_feature_selection=self.nn_feature_selection)
+        rows, cols, vals = coefficients_to_updates(tg, items, coef, count)
+        self.n_iter_ = n_iter
+        if eng.world_size > 1:
+            import torch.distributed as dist
+            parts: List[Any] = [None] * eng.world_size
+            dist.all_gather_object(parts, (rows, cols, vals), group=eng.group)
+            rows = np.concatenate([p[0] for p in parts])
+            cols = np.concatenate([p[1] for p in parts])
+            vals = np.concatenate([p[2] for p in parts])
+        if W_old is not None and W_old.shape[0] != n_items:
+            W_old = W_old.copy()
+            W_old.resize((n_items, n_items))
+        return merge_coefficients(W_old, n_items, rows, cols, vals, dtype=dtype)
+
+    @staticmethod
+    def _as_csc(interaction_matrix: Any, err: str) -> sp.csc_matrix:
+        if isinstance(interaction_matrix, sp.csc_matrix):
+            return interaction_matrix
+        if isinstance(interaction_matrix, sp.csr_matrix):
+            return interaction_matrix.tocsc()
+        raise ValueError(err)
+
+    def fit(self, interaction_matrix: sp.csc_matrix | sp.csr_matrix, parallel: bool = False,
+            progress_bar: bool = False) -> "SLIMElastic":
+        """Fit every item column.  Serial mode starts from an empty float64 matrix, `parallel`
+        merges into the existing float32 one (slim_elastic.py:252 vs :322-327)."""
+        if isinstance(interaction_matrix, sp.csc_matrix) and parallel:
+            return self.fit_in_parallel(interaction_matrix, progress_bar=progress_bar)
+        if isinstance(interaction_matrix, sp.csr_matrix) and parallel:
+            logging.warning("Multiprocessing is only supported for CSC format. Fitting in single process.")
+        X = self._as_csc(interaction_matrix,
+                         "Interaction matrix must be a scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
+        self.item_similarity = self._fit_targets(X, np.arange(X.shape[1]), None, np.float64)
+        return self
+
+    def fit_in_parallel(self, interaction_matrix: sp.csc_matrix, item_ids: Optional[ndarray] = None,
+                        progress_bar: bool = False, chunk_size: int = 100, num_workers: Optional[int] = None
+                        ) -> "SLIMElastic":
+        """Reference: process pool over item chunks (slim_elastic.py:283-386).  Here the item
+        columns are the GPU work queue; chunk_size / num_workers are accepted and ignored."""
+        if not isinstance(interaction_matrix, sp.csc_matrix):
+            raise ValueError("Interaction matrix must be in CSC format for parallel processing.")
+        n_items = interaction_matrix.shape[1]
+        targets = np.arange(n_items) if item_ids is None else np.asarray(item_ids, dtype=np.int64)
+        W_old = self.item_similarity
+        dtype = np.float32 if W_old is None else W_old.dtype
+        self.item_similarity = self._fit_targets(interaction_matrix, targets, W_old, dtype)
+        return self
+
+    def partial_fit(self, interaction_matrix: sp.csr_matrix, user_ids: List[int], parallel: bool = False,
+                    progress_bar: bool = False) -> "SLIMElastic":
+        """Refit the items the given users interacted with (slim_elastic.py:495-508)."""
+        X = interaction_matrix.tocsr()
+        items = np.unique(np.concatenate([X.indices[X.indptr[u]:X.indptr[u + 1]] for u in user_ids])
+                          if len(user_ids) else np.empty(0, np.int64))
+        return self.partial_fit_items(interaction_matrix, items.tolist(), progress_bar=progress_bar)
+
+    def partial_fit_items(self, interaction_matrix: sp.csc_matrix | sp.csr_matrix, updated_items: List[int],
+                          parallel: bool = False, progress_bar: bool = False) -> "SLIMElastic":
+        """Refit only `updated_items`, keeping every other column of W (slim_elastic.py:510-564)."""
+        if isinstance(interaction_matrix, sp.csc_matrix) and parallel:
+            return self.fit_in_parallel(interaction_matrix, item_ids=np.array(updated_items), progress_bar=progress_bar)
+        X = self._as_csc(interaction_matrix,
+                         "Interaction matrix must be a scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
+        W_old = self.item_similarity
+        dtype = np.float32 if W_old is None else W_old.dtype
+        self.item_similarity = self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), W_old, dtype)
+        return self
+
+    # ---------------------------------------------------------------- score
+    def _sync_weights(self) -> None:
+        W = self._item_similarity
+        if self._w_on_device != id(W):
+            Wc = W if isinstance(W, sp.csc_matrix) else sp.csc_matrix(W)
+            self.engine.set_weights(Wc, acc_f64=(Wc.dtype == np.float64))
+            self._w_on_device = id(W)
+
+    def _topk(self, Xb: sp.csr_matrix, candidate_item_ids: Optional[List[int]], top_k: int, filter_interacted: bool,
+              dense_output: bool, row_ids: Optional[Sequence[int]] = None):
+        """(ids[B,k], scores[B,k], counts[B]) for the rows of Xb (or rows `row_ids` of the resident X)."""
+        self._sync_weights()
+        n_items = self._item_similarity.shape[1]
+        col_rank = None
+        if candidate_item_ids is not None:
+            mode = _native.TOPK_CANDIDATES
+            col_rank = np.full(n_items, -1, dtype=np.int32)
+            col_rank[np.asarray(candidate_item_ids, dtype=np.int64)] = np.arange(len(candidate_item_ids), dtype=np.int32)
+            top_k = min(top_k, len(candidate_item_ids))
+        else:
+            mode = _native.TOPK_DENSE if dense_output else _native.TOPK_SPARSE
+            top_k = min(top_k, n_items)
+        if top_k <= 0:
+            B = Xb.shape[0] if row_ids is None else len(row_ids)
+            return np.empty((B, 0), np.int32), np.empty((B, 0), np.float32), np.zeros(B, np.int32)
+        if row_ids is not None:
+            return self.engine.recommend_rows(row_ids, top_k, filter_interacted, mode, col_rank)
+        if Xb.shape[1] != n_items:   # the reference would fail inside scipy on a shape mismatch
+            Xb = Xb.copy()
+            Xb.resize((Xb.shape[0], n_items))
+        return self.engine.recommend_csr(Xb, top_k, filter_interacted, mode, col_rank)
+
+    def recommend(self, user_id: int, interaction_matrix: sp.csr_matrix,
+                  candidate_item_ids: Optional[List[int]] = None, top_k: int = 10, filter_interacted: bool = True,
+                  dense_output: bool = True, ret_scores: bool = False) -> List[int] | Tuple[List[int], ndarray]:
+        if self.item_similarity is None:
+            raise RuntimeError("Model must be fitted before calling predict.")
+        out = self.recommend_batch([user_id], interaction_matrix, candidate_item_ids, top_k, filter_interacted,
+                                   dense_output, ret_scores)
+        return out[0]
+
+    def recommend_batch(self, user_ids: List[int], interaction_matrix: sp.csr_matrix,
+                        candidate_item_ids: Optional[List[int]] = None, top_k: int = 10,
+                        filter_interacted: bool = True, dense_output: bool = True, ret_scores: bool = False
+                        ) -> List[List[int]] | List[Tuple[List[int], ndarray]]:
+        if self.item_similarity is None:
+            raise RuntimeError("Model must be fitted before calling batch_recommend.")
+        if len(user_ids) == 0:
+            return []
+        Xb = interaction_matrix[user_ids, :]
+        ids, scores, counts = self._topk(Xb, candidate_item_ids, top_k, filter_interacted, dense_output)
+        return self._format(ids, scores, counts, ret_scores)
+
+    @staticmethod
+    def _format(ids: ndarray, scores: ndarray, counts: ndarray, ret_scores: bool):
+        out: List[Any] = []
+        for r in range(ids.shape[0]):
+            c = int(counts[r])
+            if ret_scores:
+                out.append((ids[r, :c].tolist(), scores[r, :c].copy()))
+            else:
+                out.append(ids[r, :c].tolist())
+        return out
+
+    # ---------------------------------------------------------------- predict (dense / sparse score rows)
+    def _not_fitted(self, what: str) -> None:
+        if self.item_similarity is None:
+            raise RuntimeError(f"Model must be fitted before calling {what}.")
+
+    def predict(self, user_id: int, interaction_matrix: sp.csr_matrix, dense_output: bool = True):
+        self._not_fitted("predict")
+        raise NotImplementedError("score-vector export (predict*) is not part of the GPU path yet; "
+                                  "use recommend()/recommend_batch()")
+
+    def predict_selected(self, user_id: int, item_ids: List[int], interaction_matrix: sp.csr_matrix,
+                         dense_output: bool = True):
+        self._not_fitted("predict_selected")
+        raise NotImplementedError("score-vector export (predict*) is not part of the GPU path yet")
+
+    def predict_all(self, interaction_matrix: sp.csr_matrix, dense_output: bool = True):
+        self._not_fitted("predict_all")
+        raise NotImplementedError("score-vector export (predict*) is not part of the GPU path yet")
+
+    # ---------------------------------------------------------------- item-to-item
+    def similar_items(self, item_id: int, top_k: int = 10, ret_ndarrays: bool = False
+                      ) -> List[Tuple[int, float]] | Tuple[ndarray, ndarray]:
+        if self.item_similarity is None:
+            raise RuntimeError("Model must be fitted before calling similar_items.")
+        n_items = self.item_similarity.shape[1]
+        if not 0 <= item_id < n_items or top_k <= 0:
+            ids, sc = np.empty(0, np.int32), np.empty(0, np.float32)
+        else:
+            self._sync_weights()
+            i, s, c = self.engine.similar_items([item_id], top_k)
+            ids, sc = i[0, :int(c[0])], s[0, :int(c[0])]
+        if ret_ndarrays:
+            return ids, sc
+        return list(zip(ids.tolist(), sc.tolist()))

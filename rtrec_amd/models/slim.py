@@ -1,0 +1,100 @@
+"""SLIM model: the drop-in for rtrec.models.SLIM (/root/reference/rtrec/models/slim.py:21-149).
+
+Same constructor kwargs (fan out to the interaction store, both Identifiers and SLIMElastic;
+unknown keys ignored), same fit / bulk_fit / recommend / recommend_batch / similar_items
+behaviour, same pickle payload keys.  The interaction matrix is kept resident in HBM between
+calls and scored in place by row id instead of being rebuilt and sliced per request.
+"""
+from __future__ import annotations
+
+from typing import Any, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+from .base import BaseModel
+from .internal.slim_elastic import SLIMElastic
+
+
+class SLIM(BaseModel):
+    def __init__(self, **kwargs: Any):
+        super().__init__(**kwargs)
+        self.model = SLIMElastic(kwargs)
+        self.recorded_item_ids: set = set()
+        self._x_on_device: Optional[Tuple[int, float]] = None   # (store version, max_timestamp) of the GPU copy
+
+    # ------------------------------------------------------------ fit
+    def fit(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool = False,
+            progress_bar: bool = True) -> "SLIM":
+        """Ingest a mini-batch and refit exactly the items it touched (slim.py:29-43): the matrix
+        handed to the solver has ONLY those items' columns populated."""
+        _, iid = self._ingest(interactions, update_interaction)
+        item_ids = np.unique(iid).tolist()
+        interaction_matrix = self.interactions.to_csc(item_ids)
+        self.model.partial_fit_items(interaction_matrix, item_ids, progress_bar=progress_bar)
+        self._x_on_device = None
+        return self
+
+    def _record_interactions(self, user_id: int, item_id: int, tstamp: float, rating: float) -> None:
+        self.recorded_item_ids.add(item_id)
+
+    def _record_batch(self, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
+        self.recorded_item_ids.update(np.unique(item_ids).tolist())
+
+    def _fit_recorded(self, parallel: bool = False, progress_bar: bool = True) -> "SLIM":
+        item_ids = sorted(self.recorded_item_ids)
+        interaction_matrix = self.interactions.to_csc(item_ids)
+        self.model.partial_fit_items(interaction_matrix, item_ids, parallel=parallel, progress_bar=progress_bar)
+        self.recorded_item_ids.clear()
+        self._x_on_device = None
+        return self
+
+    def bulk_fit(self, parallel: bool = False, progress_bar: bool = True) -> "SLIM":
+        interaction_matrix = self.interactions.to_csc()
+        self.model.fit(interaction_matrix, parallel=parallel, progress_bar=progress_bar)
+        self._x_on_device = None
+        return self
+
+    # ------------------------------------------------------------ recommend
+    def _sync_interactions(self) -> None:
+        """Make the GPU copy of X (CSR, decayed to the current max_timestamp) current."""
+        stamp = (self.interactions.version, self.interactions.max_timestamp)
+        if self._x_on_device != stamp:
+            self.model.engine.set_interactions(None, self.interactions.to_csr(), need_csc=False)
+            self._x_on_device = stamp
+
+    def _recommend(self, user_id: int, candidate_item_ids: Optional[List[int]] = None,
+                   user_tags: Optional[List[str]] = None, top_k: int = 10, filter_interacted: bool = True) -> List[int]:
+        return self._recommend_hot_batch([user_id], candidate_item_ids=candidate_item_ids, top_k=top_k,
+                                         filter_interacted=filter_interacted)[0]
+
+    def _recommend_hot_batch(self, user_ids: List[int], candidate_item_ids: Optional[List[int]] = None,
+                             users_tags: Optional[List[List[str]]] = None, top_k: int = 10,
+                             filter_interacted: bool = True) -> List[List[int]]:
+        if self.model.item_similarity is None:
+            raise RuntimeError("Model must be fitted before calling batch_recommend.")
+        if len(user_ids) == 0:
+            return []
+        self._sync_interactions()
+        dense_output = not self.item_ids.pass_through
+        ids, scores, counts = self.model._topk(None, candidate_item_ids, top_k, filter_interacted, dense_output,
+                                               row_ids=user_ids)
+        return self.model._format(ids, scores, counts, ret_scores=False)
+
+    def _similar_items(self, query_item_id: int, query_item_tags: Optional[List[str]] = None, top_k: int = 10
+                       ) -> List[Tuple[int, float]]:
+        return self.model.similar_items(query_item_id, top_k=top_k, ret_ndarrays=False)  # type: ignore
+
+    # ------------------------------------------------------------ persistence (slim.py:117-149)
+    def _serialize(self) -> dict:
+        return {"model": self.model, "interactions": self.interactions, "user_ids": self.user_ids,
+                "item_ids": self.item_ids, "feature_store": self.feature_store}
+
+    @classmethod
+    def _deserialize(cls, data: dict) -> "SLIM":
+        instance = cls()
+        instance.model = data["model"]
+        instance.interactions = data["interactions"]
+        instance.user_ids = data["user_ids"]
+        instance.item_ids = data["item_ids"]
+        instance.feature_store = data["feature_store"]
+        return instance

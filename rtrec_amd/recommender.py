@@ -1,0 +1,114 @@
+"""DataFrame facade: the drop-in for rtrec.recommender.Recommender
+(/root/reference/rtrec/recommender.py:20-223).
+
+Same methods, arguments, mini-batching and the same printed wall-clock / "Throughput: N
+samples/sec" figure (interactions divided by ingest + fit time, recommender.py:81,126) that
+BASELINE.md quotes.  Mini-batches are cut from the DataFrame columns as arrays rather than
+through itertuples().
+"""
+from __future__ import annotations
+
+import math
+import time
+from typing import Any, Dict, Iterable, Iterator, List, Optional, Tuple
+
+import pandas as pd
+
+from .models.base import BaseModel
+from .utils.metrics import compute_scores
+
+_COLUMNS = ["user", "item", "tstamp", "rating"]
+
+
+class Recommender:
+    def __init__(self, model: BaseModel, use_generator: bool = True):
+        self.model = model
+        self.use_generator = use_generator
+
+    def get_model(self) -> BaseModel:
+        return self.model
+
+    def partial_fit(self, user_interactions: Iterable[Tuple[int, int, int, float]],
+                    update_interaction: bool = False) -> "Recommender":
+        t0 = time.time()
+        self.model.fit(user_interactions, update_interaction=update_interaction, progress_bar=False)
+        print(f"Fit completed in {time.time() - t0:.2f} seconds")
+        return self
+
+    def _register_tags(self, user_tags, item_tags) -> None:
+        for user, tags in (user_tags or {}).items():
+            self.model.register_user_feature(user, tags)
+        for item, tags in (item_tags or {}).items():
+            self.model.register_item_feature(item, tags)
+
+    def _ingest_frame(self, train_data: pd.DataFrame, batch_size: int, update_interaction: bool, record: bool,
+                      assume_sorted: bool) -> None:
+        frame = train_data[_COLUMNS]
+        if not assume_sorted:
+            frame = frame.sort_values("tstamp", ascending=True)
+        for batch in Recommender.generate_batches(frame, batch_size, as_generator=self.use_generator):
+            self.model.add_interactions(batch, update_interaction=update_interaction, record_interactions=record)
+
+    def fit(self, train_data: pd.DataFrame, user_tags: Optional[Dict[Any, List[str]]] = None,
+            item_tags: Optional[Dict[Any, List[str]]] = None, batch_size: int = 1_000,
+            update_interaction: bool = False, parallel: bool = False, assume_sorted: bool = True) -> "Recommender":
+        """Incremental fit: ingest in mini-batches, then refit the items that were touched."""
+        t0 = time.time()
+        self._register_tags(user_tags, item_tags)
+        self._ingest_frame(train_data, batch_size, update_interaction, True, assume_sorted)
+        self.model._fit_recorded(parallel=parallel, progress_bar=True)
+        dt = time.time() - t0
+        print(f"Fit completed in {dt:.2f} seconds")
+        print(f"Throughput: {len(train_data) / dt:.2f} samples/sec")
+        return self
+
+    def bulk_fit(self, train_data: pd.DataFrame, user_tags: Optional[Dict[Any, List[str]]] = None,
+                 item_tags: Optional[Dict[Any, List[str]]] = None, batch_size: int = 1_000,
+                 update_interaction: bool = False, parallel: bool = True, assume_sorted: bool = True) -> "Recommender":
+        """Ingest everything, then fit every item column."""
+        t0 = time.time()
+        self._register_tags(user_tags, item_tags)
+        self._ingest_frame(train_data, batch_size, update_interaction, False, assume_sorted)
+        self.model.bulk_fit(parallel=parallel, progress_bar=True)
+        dt = time.time() - t0
+        print(f"Fit completed in {dt:.2f} seconds")
+        print(f"Throughput: {len(train_data) / dt:.2f} samples/sec")
+        return self
+
+    def recommend(self, user: Any, candidate_items: Optional[List[Any]] = None, user_tags: Optional[List[str]] = None,
+                  top_k: int = 10, filter_interacted: bool = True) -> List[Any]:
+        return self.model.recommend(user, candidate_items, user_tags, top_k, filter_interacted)
+
+    def recommend_batch(self, users: List[Any], candidate_items: Optional[List[Any]] = None,
+                        users_tags: Optional[List[List[str]]] = None, top_k: int = 10,
+                        filter_interacted: bool = True) -> List[List[Any]]:
+        return self.model.recommend_batch(users, candidate_items, users_tags, top_k, filter_interacted)
+
+    def similar_items(self, query_items: List[Any], query_item_tags: Optional[List[str]] = None, top_k: int = 10,
+                      ret_scores: bool = False):
+        return [self.model.similar_items(item, query_item_tags, top_k, ret_scores) for item in query_items]
+
+    def evaluate(self, test_data: pd.DataFrame, user_tags: Optional[Dict[Any, List[str]]] = None,
+                 recommend_size: int = 10, batch_size=100, filter_interacted: bool = True) -> Dict[str, float]:
+        """Average ranking metrics over the users of test_data (columns user, item)."""
+        truth = test_data.groupby("user")["item"].apply(list).to_dict()
+        users = list(truth.keys())
+
+        def pairs() -> Iterator[Tuple[List[Any], List[Any]]]:
+            for s in range(0, len(users), batch_size):
+                chunk = users[s:s + batch_size]
+                tags = [user_tags.get(u, []) for u in chunk] if user_tags else None
+                recs = self.recommend_batch(chunk, users_tags=tags, top_k=recommend_size,
+                                            filter_interacted=filter_interacted)
+                for u, rec in zip(chunk, recs):
+                    yield rec, truth[u]
+        return compute_scores(pairs(), recommend_size)
+
+    @staticmethod
+    def generate_batches(df: pd.DataFrame, batch_size: int = 1_000, as_generator: bool = False
+                         ) -> Iterator[Iterable[Tuple[int, int, int, float]]]:
+        """Mini-batches of (user, item, tstamp, rating) tuples in row order."""
+        cols = [df[c].tolist() for c in df.columns[:4]]
+        for s in range(0, len(df), batch_size):
+            batch = list(zip(*(c[s:s + batch_size] for c in cols)))
+            yield iter(batch) if as_generator else batch

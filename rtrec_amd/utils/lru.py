@@ -1,0 +1,81 @@
+"""Capacity-bounded recency set with hit counts (cold-start "hot items").
+
+Behaviour follows rtrec.utils.lru.LRUFreqSet (/root/reference/rtrec/utils/lru.py:11-123):
+adding an existing key bumps its count and makes it most recent; adding a new key at capacity
+first evicts the least recently added/bumped key; get_freq_items() lists keys by count,
+descending, ties in recency order (Python's stable sort over the recency-ordered dict).
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from collections.abc import MutableSet
+from typing import Any, Iterable, Iterator, List, Optional
+
+
+class LRUFreqSet(MutableSet):
+    def __init__(self, capacity: int):
+        if capacity <= 0:
+            raise ValueError("Capacity must be greater than 0.")
+        self.capacity = capacity
+        self.data: "OrderedDict[Any, int]" = OrderedDict()   # key -> hit count, oldest first
+
+    def add(self, value: Any) -> None:
+        hits = self.data.pop(value, None)
+        if hits is None:
+            if len(self.data) >= self.capacity:
+                self.data.popitem(last=False)
+            hits = 0
+        self.data[value] = hits + 1
+
+    def add_many(self, values: Iterable[Any]) -> None:
+        """Same end state as calling add() for each value in order."""
+        values = list(values)
+        fresh = {v for v in values if v not in self.data}
+        if len(self.data) + len(fresh) > self.capacity:
+            for v in values:        # evictions depend on the exact interleaving
+                self.add(v)
+            return
+        hits: dict = {}
+        for v in values:
+            hits[v] = hits.get(v, 0) + 1
+        # final recency order = order of LAST occurrence
+        seen = set()
+        last_order = []
+        for v in reversed(values):
+            if v not in seen:
+                seen.add(v)
+                last_order.append(v)
+        for v in reversed(last_order):
+            self.data[v] = self.data.pop(v, 0) + hits[v]
+
+    def discard(self, value: Any) -> None:
+        if value not in self.data:
+            raise KeyError(value)
+        del self.data[value]
+
+    def __contains__(self, key: Any) -> bool:
+        return key in self.data
+
+    def __iter__(self) -> Iterator[Any]:
+        return iter(self.data)
+
+    def __len__(self) -> int:
+        return len(self.data)
+
+    def __repr__(self) -> str:
+        return f"LRUFreqSet(capacity={self.capacity}, size={len(self.data)})"
+
+    def get_freq_items(self, n: Optional[int] = None, exclude_items: List[Any] = []) -> Iterator[Any]:
+        ranked = sorted(self.data.items(), key=lambda kv: kv[1], reverse=True)
+        if len(exclude_items) == 0:
+            for key, _ in (ranked if n is None else ranked[:n]):
+                yield key
+            return
+        emitted = 0
+        for key, _ in ranked:
+            if key in exclude_items:
+                continue
+            if n is not None and emitted >= n:
+                return
+            emitted += 1
+            yield key

@@ -1,0 +1,29 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import slim_oracle
+    slim_oracle.lib()
+    return slim_oracle
+
+
+@pytest.fixture(scope="session")
+def engine():
+    """One SlimEngine on cuda:0 for the whole GPU session."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from rtrec_amd.engine import SlimEngine
+    return SlimEngine(device="cuda:0")

@@ -1,0 +1,183 @@
+"""GPU parity: HIP kernels (through the C-ABI) vs the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact for everything -- coefficient bits, sweep counts, selected features, score bits
+and top-k ids (the kernels reproduce the reference's float32 operation order).
+"""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from rtrec_amd import _native
+from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients
+from rtrec_amd.synth import interaction_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_w(oracle, X_csc, cols, **kw):
+    ptr, idx, val, nit = oracle.fit_columns(X_csc, cols, **kw)
+    rows = idx.astype(np.int64)
+    cc = np.repeat(np.asarray(cols, dtype=np.int64), np.diff(ptr))
+    return merge_coefficients(None, X_csc.shape[1], rows, cc, val), (ptr, idx, val, nit)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("U,I,draws,K,positive,float_ratings", [
+    (600, 200, 12000, None, True, True),
+    (600, 200, 12000, 8, True, True),
+    (600, 200, 12000, 8, False, True),
+    (3000, 800, 90000, 50, True, True),
+    (3000, 800, 90000, 50, True, False),     # integer ratings: ties everywhere, same tie rule both sides
+    (400, 30, 3000, 50, True, True),         # K > I
+])
+def test_fit_columns_bit_exact(engine, oracle, U, I, draws, K, positive, float_ratings):
+    X = interaction_matrix(U, I, draws, seed=11, float_ratings=float_ratings)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    cols = np.arange(I)
+    tg, items, coef, count, n_iter = engine.fit_columns(cols, positive=positive, nn_feature_selection=K)
+    ptr, idx, val, nit = oracle.fit_columns(Xc, tg, positive=positive, nn_feature_selection=K)
+    assert np.array_equal(n_iter, nit), f"n_iter differs on {np.flatnonzero(n_iter != nit)[:10]}"
+    assert np.array_equal(count, np.diff(ptr))
+    for t in range(len(tg)):
+        c = count[t]
+        got_i, got_v = items[t, :c], coef[t, :c]
+        if K is not None:   # kernel emits selection order, oracle ascending ids
+            o = np.argsort(got_i, kind="stable")
+            got_i, got_v = got_i[o], got_v[o]
+        assert np.array_equal(got_i, idx[ptr[t]:ptr[t + 1]]), f"feature set differs for column {tg[t]}"
+        assert np.array_equal(bits(got_v), bits(val[ptr[t]:ptr[t + 1]])), f"coefficient bits differ for column {tg[t]}"
+
+
+def test_fit_subset_of_columns_and_empty_column(engine, oracle):
+    X = interaction_matrix(500, 120, 6000, seed=5).tolil()
+    X[:, 7] = 0          # an item nobody interacted with
+    X = X.tocsr()
+    X.eliminate_zeros()
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    cols = np.array([7, 3, 119, 0, 64])
+    for K in (None, 10):
+        tg, items, coef, count, n_iter = engine.fit_columns(cols, nn_feature_selection=K)
+        ptr, idx, val, nit = oracle.fit_columns(Xc, tg, nn_feature_selection=K)
+        assert np.array_equal(n_iter, nit)
+        assert n_iter[list(tg).index(7)] == 100      # y == 0 never meets gap < tol: all max_iter sweeps
+        rows, cc, vals = coefficients_to_updates(tg, items, coef, count)
+        W = merge_coefficients(None, 120, rows, cc, vals)
+        Wo = merge_coefficients(None, 120, idx.astype(np.int64), np.repeat(tg, np.diff(ptr)), val)
+        assert (W != Wo).nnz == 0 and np.array_equal(bits(W.data), bits(Wo.data))
+
+
+def make_model(oracle, U=1500, I=700, draws=40000, K=20, seed=3):
+    X = interaction_matrix(U, I, draws, seed=seed)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    W, _ = oracle_w(oracle, Xc, np.arange(I), nn_feature_selection=K)
+    return X, W
+
+
+@pytest.mark.parametrize("tile_cols", [256, 8192])
+@pytest.mark.parametrize("mode,filt", [("sparse", True), ("sparse", False), ("dense", True), ("dense", False)])
+@pytest.mark.parametrize("f64", [False, True])
+def test_score_topk_bit_exact(oracle, mode, filt, f64, tile_cols):
+    X, W = make_model(oracle)
+    eng = SlimEngine(device="cuda:0", tile_cols=tile_cols)
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W.astype(np.float64) if f64 else W, acc_f64=f64)
+    rows = np.arange(0, X.shape[0], 3)
+    m = _native.TOPK_DENSE if mode == "dense" else _native.TOPK_SPARSE
+    ids, sc, cnt = eng.recommend_rows(rows, top_k=10, filter_interacted=filt, mode=m)
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], W.tocsr(), top_k=10, filter_interacted=filt,
+                                                dense=(mode == "dense"), use_f64=f64)
+    assert np.array_equal(cnt, o_cnt)
+    assert np.array_equal(ids, o_ids)
+    assert np.array_equal(bits(sc), bits(o_sc))
+
+
+def test_score_exact_ties_follow_reference_order(oracle):
+    """Duplicate W columns give exactly equal scores; the sparse path must order them like
+    Python's stable sorted() over scipy's reverse-first-touch product order."""
+    rng = np.random.default_rng(0)
+    I = 600
+    base = sp.random(I, 40, density=0.08, random_state=1, format="csc", dtype=np.float32)
+    pick = rng.integers(0, 40, size=I)
+    W = sp.csc_matrix(base[:, pick])          # every column is a copy of one of 40 -> many exact ties
+    W.sort_indices()
+    X = interaction_matrix(300, I, 6000, seed=9)
+    for tile in (256, 1024):
+        eng = SlimEngine(device="cuda:0", tile_cols=tile)
+        eng.set_interactions(None, X, need_csc=False)
+        eng.set_weights(W)
+        rows = np.arange(X.shape[0])
+        for filt in (True, False):
+            ids, sc, cnt = eng.recommend_rows(rows, top_k=10, filter_interacted=filt, mode=_native.TOPK_SPARSE)
+            o_ids, o_sc, o_cnt = oracle.recommend_batch(X, W.tocsr(), top_k=10, filter_interacted=filt)
+            assert np.array_equal(cnt, o_cnt)
+            assert np.array_equal(ids, o_ids)
+            assert np.array_equal(bits(sc), bits(o_sc))
+
+
+def test_candidate_mode(oracle):
+    X, W = make_model(oracle, U=400, I=300, draws=8000, K=10)
+    eng = SlimEngine(device="cuda:0", tile_cols=256)
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    cands = [5, 17, 250, 3, 99, 100, 101, 42]
+    rank = np.full(300, -1, np.int32)
+    rank[cands] = np.arange(len(cands))
+    rows = np.arange(50)
+    ids, sc, cnt = eng.recommend_rows(rows, top_k=5, filter_interacted=True, mode=_native.TOPK_CANDIDATES, col_rank=rank)
+    S = (X[rows] @ W.tocsr()[:, cands]).toarray().astype(np.float32)
+    for r in range(len(rows)):
+        order = sorted(range(len(cands)), key=lambda c: (-S[r, c], -c))[:5]     # stable-argsort tie rule
+        assert ids[r].tolist() == [cands[c] for c in order]
+        assert cnt[r] == 5
+
+
+def test_similar_items(engine, oracle):
+    X, W = make_model(oracle, U=800, I=300, draws=15000, K=30)
+    engine.set_weights(W)
+    q = np.arange(300)
+    ids, sc, cnt = engine.similar_items(q, top_k=7)
+    for j in q:
+        oi, ov = oracle.similar_items(W, int(j), top_k=7)
+        assert cnt[j] == len(oi)
+        assert np.array_equal(ids[j, :cnt[j]], oi)
+        assert np.array_equal(bits(sc[j, :cnt[j]]), bits(ov))
+
+
+def test_merge_topk_equals_unsharded(oracle):
+    """Column-sharded scoring + merge kernel == single-shard result (the multi-GPU data path,
+    run here as two engines on one GPU)."""
+    import torch
+    X, W = make_model(oracle, U=500, I=640, draws=12000, K=15)
+    rows = np.arange(0, 500, 2)
+    full = SlimEngine(device="cuda:0", tile_cols=256)
+    full.set_interactions(None, X, need_csc=False)
+    full.set_weights(W)
+    ids, sc, cnt = full.recommend_rows(rows, top_k=10)
+    parts = []
+    for r in range(2):
+        e = SlimEngine(device="cuda:0", rank=r, world_size=2, tile_cols=256)
+        e.world_size_for_merge = 2
+        e.set_interactions(None, X, need_csc=False)
+        e.set_weights(W)
+        d_rows = e.be.to_dev(rows.astype(np.int32))
+        xb = (e._X["rptr"], e._X["rcol"], e._X["rval"])
+        parts.append(e._local_topk(d_rows, len(rows), xb, 10, True, _native.TOPK_SPARSE, None))
+    be = full.be
+    g = [torch.stack([p[k] for p in parts]).contiguous() for k in (0, 1, 3, 4)]
+    o_ids = be.empty((len(rows), 10), torch.int32)
+    o_sc = be.empty((len(rows), 10), torch.float32)
+    o_cnt = be.empty((len(rows),), torch.int32)
+    _native.check(be.lib.rtrec_slim_merge_topk(len(rows), 2, 10, be.ptr(g[0]), be.ptr(g[1]), None, be.ptr(g[2]),
+                                               be.ptr(g[3]), be.ptr(o_ids), be.ptr(o_sc), be.ptr(o_cnt), be.stream()),
+                  "merge")
+    assert np.array_equal(o_ids.cpu().numpy(), ids)
+    assert np.array_equal(bits(o_sc.cpu().numpy()), bits(sc))
+    assert np.array_equal(o_cnt.cpu().numpy(), cnt)
