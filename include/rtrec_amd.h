@@ -50,6 +50,10 @@ typedef struct {
 /* Library identification; returns a static string such as "rtrec_amd 0.1 gfx950". */
 const char *rtrec_amd_version(void);
 
+/* hipGetErrorString() of the HIP error behind the calling thread's most recent
+ * RTREC_ERR_LAUNCH (diagnostics only). */
+const char *rtrec_amd_last_error(void);
+
 /* ---------------------------------------------------------------------------------------
  * FIT  (replaces slim_elastic.py:229-281 fit, :283-454 fit_in_parallel/_fit_items,
  *       :510-564 partial_fit_items, :139-154 FeatureSelectionWrapper.fit, and sklearn

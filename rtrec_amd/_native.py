@@ -20,7 +20,7 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
            -4: "kernel launch failed"}
 
 EXPORTS = [
-    "rtrec_amd_version", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
+    "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
     "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_merge_topk", "rtrec_slim_similar_topk",
 ]
@@ -44,6 +44,9 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: librtrec_amd.so must bind to the HIP runtime torch ships and initialises
+    # (device pointers and streams come from it); loading ours first pulls in a second runtime.
+    import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise NativeLibraryError(
@@ -56,6 +59,8 @@ def load() -> C.CDLL:
     vp, i32, u64 = C.c_void_p, C.c_int32, C.c_size_t
     L.rtrec_amd_version.restype = C.c_char_p
     L.rtrec_amd_version.argtypes = []
+    L.rtrec_amd_last_error.restype = C.c_char_p
+    L.rtrec_amd_last_error.argtypes = []
     L.rtrec_slim_column_sqnorms.restype = C.c_int
     L.rtrec_slim_column_sqnorms.argtypes = [i32, vp, vp, vp, vp]
     L.rtrec_slim_fit_workspace_bytes.restype = u64
@@ -68,8 +73,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_score_workspace_bytes.restype = u64
     L.rtrec_slim_score_workspace_bytes.argtypes = [i32, i32, i32]
     L.rtrec_slim_score_topk.restype = C.c_int
-    L.rtrec_slim_score_topk.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp,
-                                        i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, u64, vp]
+    L.rtrec_slim_score_topk.argtypes = ([i32] + [vp] * 4 + [i32] * 5 + [vp] * 4 + [i32] * 4 + [vp] * 5
+                                        + [vp, u64, vp])
     L.rtrec_slim_merge_topk.restype = C.c_int
     L.rtrec_slim_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtrec_slim_similar_topk.restype = C.c_int
@@ -80,7 +85,8 @@ def load() -> C.CDLL:
 
 def check(status: int, what: str) -> None:
     if status != RTREC_OK:
-        raise NativeLibraryError(f"{what} failed: {_STATUS.get(status, status)} ({status})")
+        detail = load().rtrec_amd_last_error().decode() if status == -4 else ""
+        raise NativeLibraryError(f"{what} failed: {_STATUS.get(status, status)} ({status}) {detail}")
 
 
 def version() -> str:

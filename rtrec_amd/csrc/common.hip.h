@@ -138,4 +138,15 @@ __device__ __forceinline__ uint32_t rand_int(uint32_t end, uint32_t &state) {
     return (state % 2147483648u) % end;
 }
 
+// Host side: status of the launches issued since the entry point cleared the error state.
+inline int &last_hip_error() {
+    static thread_local int e = 0;
+    return e;
+}
+inline int launch_status() {
+    const hipError_t e = hipGetLastError();
+    last_hip_error() = static_cast<int>(e);
+    return e == hipSuccess ? 0 : -4;
+}
+
 }  // namespace rtrec

@@ -306,9 +306,11 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                     if (ever_flag[p] == 0) { if (lane == 0) { ever_flag[p] = 1; ever_list[n_ever] = p; } n_ever++; }
                     if (lane == 0) w_all[p] = w_new;
                 } else {
-                    if (lane == 0) { f_w[p] = w_new; f_ever[p] = 1; }
+                    if (lane == 0) f_ever[p] = 1;
                 }
             }
+            // always store: the sign of a zero coefficient follows the last update (w = -1 * 0 / d)
+            if (!ALLF && lane == 0) f_w[p] = w_new;
             const float d = fabsf(__fsub_rn(w_new, w_old));
             d_w_max = d > d_w_max ? d : d_w_max;
             const float aw = fabsf(w_new);
@@ -512,14 +514,19 @@ FitWs fit_ws_layout(int U, int I, int slots, int top_features) {
 
 extern "C" const char *rtrec_amd_version(void) { return "rtrec_amd 0.1 gfx950"; }
 
+extern "C" const char *rtrec_amd_last_error(void) {
+    return hipGetErrorString(static_cast<hipError_t>(rtrec::last_hip_error()));
+}
+
 extern "C" int rtrec_slim_column_sqnorms(int32_t n_items, const int32_t *d_csc_ptr, const float *d_csc_val,
                                          float *d_sqnorm, void *stream) {
     if (n_items < 0 || !d_csc_ptr || !d_sqnorm) return RTREC_ERR_INVALID_ARG;
     if (n_items == 0) return RTREC_OK;
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     const int grid = n_items < 8192 ? n_items : 8192;
     hipLaunchKernelGGL(column_sqnorms_kernel, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream),
                        n_items, d_csc_ptr, d_csc_val, d_sqnorm);
-    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+    return rtrec::launch_status();
 }
 
 extern "C" size_t rtrec_slim_fit_workspace_bytes(int32_t n_users, int32_t n_items, int32_t n_slots, int32_t top_features) {
@@ -532,12 +539,13 @@ extern "C" int rtrec_slim_fit_workspace_init(void *d_workspace, size_t workspace
     if (!d_workspace || n_users <= 0 || n_items <= 0 || n_slots <= 0) return RTREC_ERR_INVALID_ARG;
     const FitWs L = fit_ws_layout(n_users, n_items, n_slots, top_features);
     if (workspace_bytes < L.total) return RTREC_ERR_WORKSPACE;
+    (void)hipGetLastError();
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned char *ws = static_cast<unsigned char *>(d_workspace);
     if (hipMemsetAsync(ws, 0, L.total, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const size_t n = static_cast<size_t>(n_slots) * n_items;
     hipLaunchKernelGGL(fill_u32_kernel, dim3(2048), dim3(256), 0, st, reinterpret_cast<uint32_t *>(ws + L.s), n, kUntouched);
-    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+    return rtrec::launch_status();
 }
 
 extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
@@ -578,6 +586,7 @@ extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
     a.cand_i = reinterpret_cast<int *>(ws + L.cand_i);
     a.w_all = allf ? reinterpret_cast<float *>(ws + L.w_all) : nullptr;
     a.queue = d_queue;
+    (void)hipGetLastError();
     if (hipMemsetAsync(d_queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const int grid = n_slots < n_targets ? n_slots : n_targets;
     if (allf) {
@@ -586,5 +595,5 @@ extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
         const size_t lds = static_cast<size_t>(K) * 7 * 4 + 16;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), lds, st, a);
     }
-    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+    return rtrec::launch_status();
 }

@@ -258,21 +258,15 @@ __global__ __launch_bounds__(64) void score_tiles_kernel(ScoreArgs a) {
     score_tile_job<ACC, false>(a, row, tile, smem);
 }
 
-// Exact-tie pass: persistent waves pull (flagged row, tile) jobs from a device queue.
+// Exact-tie pass: block b re-scores (flagged row b / n_tiles, tile b % n_tiles); blocks beyond
+// the flagged count exit at once (the count only exists on the device).
 template <typename ACC>
 __global__ __launch_bounds__(64) void score_tiles_ft_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_flag = *a.row_list_len;
-    const long long total = static_cast<long long>(n_flag) * a.n_tiles;
-    for (;;) {
-        int w = 0;
-        if (lane_id() == 0) w = atomicAdd(a.queue, 1);
-        w = readfirst_i(w);
-        if (w >= total) return;
-        const int row = a.row_list[w / a.n_tiles];
-        const int tile = w % a.n_tiles;
-        score_tile_job<ACC, true>(a, row, tile, smem);
-    }
+    const int f = blockIdx.x / a.n_tiles;
+    if (f >= n_flag) return;
+    score_tile_job<ACC, true>(a, a.row_list[f], blockIdx.x % a.n_tiles, smem);
 }
 
 struct MergeArgs {
@@ -416,7 +410,18 @@ __global__ __launch_bounds__(64) void similar_topk_kernel(int n_queries, const i
 // ------------------------------------------------------------------------------------------
 using namespace rtrec;
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
+// RTREC_AMD_DEBUG=1: synchronise after every launch and report the stage (diagnostics only).
+inline void debug_stage(hipStream_t st, const char *what) {
+    static const bool on = std::getenv("RTREC_AMD_DEBUG") != nullptr;
+    if (!on) return;
+    const hipError_t e = hipStreamSynchronize(st);
+    std::fprintf(stderr, "[rtrec_amd] %s: %s\n", what, hipGetErrorString(e));
+    std::fflush(stderr);
+}
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ScoreWs {
@@ -455,6 +460,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     a.row_list = flag_list;
     a.row_list_len = flag_len;
     a.queue = queue;
+    (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (hipMemsetAsync(flag_len, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     if (hipMemsetAsync(queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
 
@@ -463,7 +469,9 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
     const long long per_xcd = (total + 7) / 8;
     const unsigned grid = static_cast<unsigned>(per_xcd * 8);
+    debug_stage(st, "score: begin");
     hipLaunchKernelGGL(HIP_KERNEL_NAME(score_tiles_kernel<ACC>), dim3(grid), dim3(64), lds_fast, st, a);
+    debug_stage(st, "score_tiles_kernel");
 
     MergeArgs m{};
     m.n_rows = a.n_rows; m.n_lists = a.n_tiles; m.kk = a.kk; m.top_k = top_k;
@@ -476,21 +484,24 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     m.flag_list = flag_list; m.flag_len = flag_len;
     m.row_list = nullptr; m.row_list_len = nullptr;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, m);
+    debug_stage(st, "merge_topk_kernel");
 
     if (sparse) {
         // exact tie order for the flagged rows only
         ScoreArgs f = a;
         f.kk = top_k;
-        const unsigned ft_grid = static_cast<unsigned>(total < 1024 ? total : 1024);
+        const unsigned ft_grid = static_cast<unsigned>(total);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_tiles_ft_kernel<ACC>), dim3(ft_grid), dim3(64), lds_ft, st, f);
+        debug_stage(st, "score_tiles_ft_kernel");
         MergeArgs mf = m;
         mf.kk = top_k;
         mf.list_stride = top_k; mf.row_stride = static_cast<long long>(a.n_tiles) * top_k;
         mf.detect_ties = 0;
         mf.row_list = flag_list; mf.row_list_len = flag_len;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, mf);
+        debug_stage(st, "merge_topk_kernel (exact ties)");
     }
-    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+    return rtrec::launch_status();
 }
 }  // namespace
 
@@ -553,6 +564,7 @@ extern "C" int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t to
     m.out_id = d_out_ids; m.out_score = d_out_scores; m.out_score64 = nullptr; m.out_aux = nullptr; m.out_cnt = d_out_count;
     m.detect_ties = 0; m.flag_list = nullptr; m.flag_len = nullptr; m.row_list = nullptr; m.row_list_len = nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
     if (d_in_scores64) {
         m.in_score = d_in_scores64;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<double>), dim3(n_rows), dim3(64), 0, st, m);
@@ -560,7 +572,7 @@ extern "C" int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t to
         m.in_score = d_in_scores;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<float>), dim3(n_rows), dim3(64), 0, st, m);
     }
-    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+    return rtrec::launch_status();
 }
 
 extern "C" int rtrec_slim_similar_topk(int32_t n_queries, const int32_t *d_queries,
@@ -571,7 +583,8 @@ extern "C" int rtrec_slim_similar_topk(int32_t n_queries, const int32_t *d_queri
     if (n_queries < 0 || top_k <= 0) return RTREC_ERR_INVALID_ARG;
     if (n_queries == 0) return RTREC_OK;
     if (!d_queries || !d_wc_ptr || !d_out_ids || !d_out_scores || !d_out_count) return RTREC_ERR_INVALID_ARG;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(similar_topk_kernel, dim3(n_queries), dim3(64), 0, static_cast<hipStream_t>(stream),
                        n_queries, d_queries, d_wc_ptr, d_wc_row, d_wc_val, top_k, d_out_ids, d_out_scores, d_out_count);
-    return hipGetLastError() == hipSuccess ? RTREC_OK : RTREC_ERR_LAUNCH;
+    return rtrec::launch_status();
 }
