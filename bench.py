@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- SLIM hot path on MI355X: fit W, then score every user (top-10) K times.
+
+Contract (one JSON line on rank 0):
+  metric  users-scored/sec at top-10 (BASELINE.json's score metric); the fit half of the metric
+          (interactions/sec) is reported in the `fit` object of the same line.
+  step    one pass of the fused SpMV + interacted filter + top-k path over ALL users of the
+          workload, inputs (X in CSR, W tiles) already resident in HBM.
+  N > 1   W is sharded by item column over the ranks (each rank also fits only its own columns);
+          every rank scores all users against its shard, the per-shard top-k lists are
+          all-gathered over RCCL and merged -> total work is fixed: "scaling": "strong".
+  roofline  algorithmic bytes of score_tiles_kernel (user row ids+vals,
+          gathered W row ids+vals, top-k output; 8 B per entry) / its mean launch time measured
+          with HIP events on the launch stream, against the 8 TB/s HBM peak.
+  cpu_baseline  the C oracle (bit-checked restatement of the reference's scipy/sklearn path)
+          timed single-threaded on this host on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: synthetic 100k users x 50k items, 5M interactions
+    "c2": dict(U=100_000, I=50_000, draws=5_000_000, K=50,
+               desc="synthetic 100k users x 50k items, 5M interaction draws (Zipf users 0.6 / items 0.85), "
+                    "SLIM nn_feature_selection=50, fit + recommend top-10 for all users"),
+    # BASELINE.json configs[2] shape (MovieLens-20M): 138,493 x 26,744
+    "c3": dict(U=138_493, I=26_744, draws=26_000_000, K=50,
+               desc="MovieLens-20M-shaped synthetic 138,493 users x 26,744 items, ~20M interactions, K=50"),
+    "small": dict(U=20_000, I=5_000, draws=500_000, K=50, desc="small plumbing workload 20k x 5k, 500k draws, K=50"),
+}
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--tile-cols", type=int, default=8192)
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from rtrec_amd import _native
+    from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients, shard_bounds
+    from rtrec_amd.synth import interaction_matrix
+
+    wl = WORKLOADS[args.workload]
+    U, I, K, top_k = wl["U"], wl["I"], wl["K"], args.top_k
+    t0 = time.time()
+    X = interaction_matrix(U, I, wl["draws"], seed=20251003, float_ratings=True)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    nnz = int(X.nnz)
+    if rank == 0:
+        log(f"[bench] workload {args.workload}: {U} x {I}, nnz={nnz} generated in {time.time() - t0:.1f}s")
+
+    eng = SlimEngine(device=f"cuda:{local_rank}", rank=rank, world_size=world, tile_cols=args.tile_cols)
+    eng.set_interactions(Xc, X)
+
+    # ------------------------------------------------------------------ fit (each rank: its own columns)
+    lo, hi = shard_bounds(I, world, rank)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    tg, items, coef, count, n_iter = eng.fit_columns(np.arange(lo, hi), nn_feature_selection=K)
+    torch.cuda.synchronize()
+    fit_local = time.time() - t0
+    rows, cols, vals = coefficients_to_updates(tg, items, coef, count)
+    if world > 1:
+        parts = [None] * world
+        dist.all_gather_object(parts, (rows, cols, vals))
+        rows = np.concatenate([p[0] for p in parts])
+        cols = np.concatenate([p[1] for p in parts])
+        vals = np.concatenate([p[2] for p in parts])
+        t = torch.tensor([fit_local], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        fit_s = float(t.item())
+    else:
+        fit_s = fit_local
+    W = merge_coefficients(None, I, rows, cols, vals)
+    eng.set_weights(W)
+    if rank == 0:
+        log(f"[bench] fit: {fit_s:.2f}s ({nnz / fit_s:,.0f} interactions/s), W nnz={W.nnz}, "
+            f"sweeps mean={n_iter.mean():.1f} max={n_iter.max()}")
+
+    # ------------------------------------------------------------------ score: K timed steps
+    row_ids = np.arange(U, dtype=np.int32)
+    d_rows = eng.be.to_dev(row_ids)
+    xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
+
+    def step():
+        d_rank = None
+        ids, sc, sc64, aux, cnt = eng._local_topk(d_rows, U, xb, top_k, True, _native.TOPK_SPARSE, d_rank)
+        if world == 1:
+            return ids, sc, cnt
+        G = world
+        outs = []
+        for t_ in (ids, sc, aux, cnt):
+            o = eng.be.empty((G,) + tuple(t_.shape), t_.dtype)
+            dist.all_gather_into_tensor(o, t_.contiguous())
+            outs.append(o)
+        o_ids = eng.be.empty((U, top_k), torch.int32)
+        o_sc = eng.be.empty((U, top_k), torch.float32)
+        o_cnt = eng.be.empty((U,), torch.int32)
+        be = eng.be
+        _native.check(be.lib.rtrec_slim_merge_topk(U, G, top_k, be.ptr(outs[0]), be.ptr(outs[1]), None,
+                                                   be.ptr(outs[2]), be.ptr(outs[3]), be.ptr(o_ids), be.ptr(o_sc),
+                                                   be.ptr(o_cnt), be.stream()), "merge")
+        return o_ids, o_sc, o_cnt
+
+    for _ in range(args.warmup):
+        out = step()
+    lib = eng.be.lib
+    tot_ms, n_launch = C.c_double(0), C.c_int64(0)
+    torch.cuda.synchronize()
+    lib.rtrec_amd_score_timer(1, None, None)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    lib.rtrec_amd_score_timer(0, C.byref(tot_ms), C.byref(n_launch))
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = U * args.steps / dt
+
+    # ------------------------------------------------------------------ roofline of score_tiles_kernel (this rank)
+    Wr = W.tocsr()
+    shard_row_nnz = np.diff(Wr[:, lo:hi].tocsr().indptr).astype(np.float64) if hi > lo else np.zeros(I)
+    users_per_item = np.diff(Xc.indptr).astype(np.float64)
+    gathered_entries = float((users_per_item * shard_row_nnz).sum())
+    algo_bytes = 8.0 * nnz + 8.0 * gathered_entries + 8.0 * top_k * U + 4.0 * (U + 1)
+    kern_ms = tot_ms.value / max(n_launch.value, 1)
+    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+
+    lay = eng._layout(True) or {"tile_cols": None, "n_tiles": 0, "n_cols": 0}
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    line = {
+        "metric": "users-scored/sec top-10 (SLIM recommend, int ids, filter_interacted) + fit interactions/sec in `fit`",
+        "value": value, "unit": "users/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {wl['desc']}", "n_users": U, "n_items": I, "nnz": nnz,
+                   "nn_feature_selection": K, "top_k": top_k, "tile_cols": lay["tile_cols"], "n_tiles": lay["n_tiles"],
+                   "active_columns": lay["n_cols"],
+                   "parallelism": f"item-column shard x{world}" if world > 1 else "single GPU"},
+        "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
+                "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean())},
+        "roofline": {"kernel": "score_sparse_kernel<float,false>", "bound": "hbm", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                     "kernel_ms_avg": kern_ms, "launches": int(n_launch.value)},
+    }
+
+    # ------------------------------------------------------------------ cpu_baseline (oracle, 1 thread, bounded sample)
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import slim_oracle as so
+        so.lib()
+        rng = np.random.default_rng(7)
+        sample = rng.permutation(U)
+        n, done, spent = 64, 0, 0.0
+        ok = True
+        ids_gpu = out[0].cpu().numpy()
+        while spent < args.cpu_seconds and done < U:
+            rows_s = np.sort(sample[done:done + n])
+            t1 = time.perf_counter()
+            o_ids, _, _ = so.recommend_batch(X[rows_s], Wr, top_k=top_k)
+            spent += time.perf_counter() - t1
+            ok = ok and np.array_equal(o_ids, ids_gpu[rows_s])
+            done += len(rows_s)
+            n = min(n * 2, 8192)
+        line["cpu_baseline"] = {"value": done / spent, "unit": "users/s", "cores": 1, "kind": "port",
+                                "sample": f"{done} random users of the same workload scored with the C oracle in "
+                                          f"{spent:.1f}s (top-k ids identical to the GPU: {ok})"}
+        # fit leg: random columns until the budget is spent
+        perm = rng.permutation(I)
+        spent_f, nnz_f, ncol_f = 0.0, 0, 0
+        col_nnz = np.diff(Xc.indptr)
+        while spent_f < args.cpu_seconds and ncol_f < I:
+            c = perm[ncol_f:ncol_f + 1]
+            t1 = time.perf_counter()
+            so.fit_columns(Xc, c, nn_feature_selection=K)
+            spent_f += time.perf_counter() - t1
+            nnz_f += int(col_nnz[c[0]])
+            ncol_f += 1
+        line["fit"]["cpu_baseline"] = {"value": nnz_f / spent_f, "unit": "interactions/s", "cores": 1, "kind": "port",
+                                       "sample": f"{ncol_f} random item columns ({nnz_f} interactions) fitted with the "
+                                                 f"C oracle in {spent_f:.1f}s"}
+    print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

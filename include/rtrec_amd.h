@@ -115,6 +115,11 @@ int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
  *     d_w_val[e] = float32 weight
  * so a user row is accumulated tile by tile in LDS in exactly scipy's csr_matmat order
  * (ascending row item, then ascending column).
+ * The layout may be COMPACTED to the columns that hold at least one weight (only those can
+ * score != 0, i.e. only those can be recommended in SPARSE mode): then d_col_ids[n_cols] maps a
+ * layout column to its global item id (ascending) and d_col_map[n_items] maps a global item id
+ * to its layout column or -1; pass both NULL for the plain layout whose column c is item
+ * col_offset + c.
  * ------------------------------------------------------------------------------------- */
 
 typedef enum {
@@ -123,6 +128,12 @@ typedef enum {
     RTREC_TOPK_CANDIDATES = 2 /* candidate_item_ids given: d_col_rank[c] >= 0 marks candidates,
                                  interacted items are NOT filtered     (slim_elastic.py:661-672) */
 } rtrec_topk_mode;
+
+/* Measurement hook: HIP events on the launch stream around score_tiles_kernel (the dominant
+ * kernel of rtrec_slim_score_topk).  enable > 0 starts (and zeroes) the accumulation, 0 stops it,
+ * < 0 zeroes it; on return *total_ms / *launches hold the kernel time and count collected so
+ * far (either may be NULL).  Not thread-safe; used by bench.py only. */
+int rtrec_amd_score_timer(int32_t enable, double *total_ms, int64_t *launches);
 
 /* Bytes of scratch for rtrec_slim_score_topk. */
 size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k);
@@ -148,6 +159,7 @@ size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t
 int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                           const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
                           int32_t n_items, int32_t n_cols, int32_t col_offset,
+                          const int32_t *d_col_ids, const int32_t *d_col_map,
                           int32_t tile_cols, int32_t n_tiles,
                           const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
                           const int32_t *d_col_rank,

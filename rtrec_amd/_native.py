@@ -20,7 +20,7 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
            -4: "kernel launch failed"}
 
 EXPORTS = [
-    "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
+    "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_amd_score_timer", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
     "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_merge_topk", "rtrec_slim_similar_topk",
 ]
@@ -61,6 +61,8 @@ def load() -> C.CDLL:
     L.rtrec_amd_version.argtypes = []
     L.rtrec_amd_last_error.restype = C.c_char_p
     L.rtrec_amd_last_error.argtypes = []
+    L.rtrec_amd_score_timer.restype = C.c_int
+    L.rtrec_amd_score_timer.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.rtrec_slim_column_sqnorms.restype = C.c_int
     L.rtrec_slim_column_sqnorms.argtypes = [i32, vp, vp, vp, vp]
     L.rtrec_slim_fit_workspace_bytes.restype = u64
@@ -73,8 +75,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_score_workspace_bytes.restype = u64
     L.rtrec_slim_score_workspace_bytes.argtypes = [i32, i32, i32]
     L.rtrec_slim_score_topk.restype = C.c_int
-    L.rtrec_slim_score_topk.argtypes = ([i32] + [vp] * 4 + [i32] * 5 + [vp] * 4 + [i32] * 4 + [vp] * 5
-                                        + [vp, u64, vp])
+    L.rtrec_slim_score_topk.argtypes = ([i32] + [vp] * 4 + [i32] * 3 + [vp] * 2 + [i32] * 2 + [vp] * 4
+                                        + [i32] * 4 + [vp] * 5 + [vp, u64, vp])
     L.rtrec_slim_merge_topk.restype = C.c_int
     L.rtrec_slim_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtrec_slim_similar_topk.restype = C.c_int

@@ -27,35 +27,67 @@ struct ScoreArgs {
     const int *xb_ptr;
     const int *xb_col;
     const float *xb_val;
-    int n_items;
-    int n_cols;
-    int col_offset;
+    int n_items;          // rows of W
+    int n_cols;           // columns of this layout (shard width, or number of active columns)
+    int col_offset;       // global id of local column 0 when col_ids == nullptr
+    const int *col_ids;   // optional: local column -> global item id (ascending)
+    const int *col_map;   // optional: global item id -> local column or -1
     int tile_cols;
     int n_tiles;
     const int *tile_ptr;
     const uint16_t *w_col;
     const float *w_val;
     const int *col_rank;
-    int kk;      // candidates kept per tile (top_k or top_k + 1)
+    int kk;               // entries kept per (row, tile): top_k, or top_k + 1 when ties are detected
+    int top_k;
     int filter;
     int mode;
-    // per (row, tile) candidate lists
-    void *cand_score;  // ACC[n_rows * n_tiles * kk]
+    // per (row, tile) candidate lists, used when n_tiles > 1
+    void *cand_score;     // ACC[n_rows * n_tiles * kk]
     int *cand_id;
     uint32_t *cand_aux;
-    int *cand_cnt;     // [n_rows * n_tiles]
-    // FT pass: list of rows to re-score and its length (device)
+    int *cand_cnt;        // [n_rows * n_tiles]
+    // final outputs, written directly when n_tiles == 1
+    int direct;
+    int *out_id;
+    float *out_score;
+    double *out_score64;
+    uint32_t *out_aux;
+    int *out_cnt;
+    int detect_ties;
+    int *flag_list;
+    int *flag_len;
+    // exact-tie pass: rows to re-score
     const int *row_list;
     const int *row_list_len;
     int *queue;
 };
 
-constexpr int kListCap = 1024;  // LDS candidate list entries (uint16 column ids)
+constexpr int kListCap = 512;    // threshold-candidate list (uint16 columns)
+constexpr int kTouchCap = 1536;  // touched-column list of the sparse kernel (uint16 columns)
+constexpr int kResCap = 64;      // top_k + 1 <= 64
+
+__host__ __device__ constexpr size_t score_lds_bytes(int tile_cols, int acc_bytes, bool ft, bool touched) {
+    return static_cast<size_t>(tile_cols) * (acc_bytes + (ft ? 4 : 0)) + (touched ? kTouchCap * 2 : 0) + kListCap * 2 +
+           kResCap * (8 + 4 + 4);
+}
 
 template <typename ACC>
 __device__ __forceinline__ void lds_add(ACC *p, ACC v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+template <typename ACC>
+__device__ __forceinline__ ACC lds_add_rtn(ACC *p, ACC v) {
+    return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// "No contribution yet" marker of the sparse kernel's accumulators: -0.0.  (-0) + p == p for
+// every p != 0, a float sum that left -0 never returns to it under round-to-nearest, and
+// -0 == 0 compares as a zero score (excluded in SPARSE mode exactly like scipy's `!= 0`).
+__device__ __forceinline__ float untouched_value(float) { return __uint_as_float(0x80000000u); }
+__device__ __forceinline__ double untouched_value(double) { return __longlong_as_double(static_cast<long long>(0x8000000000000000ull)); }
+__device__ __forceinline__ bool is_untouched(float v) { return __float_as_uint(v) == 0x80000000u; }
+__device__ __forceinline__ bool is_untouched(double v) { return static_cast<unsigned long long>(__double_as_longlong(v)) == 0x8000000000000000ull; }
 
 // Key of an accumulator for selection: invalid columns map to -inf.
 template <typename ACC>
@@ -63,30 +95,209 @@ __device__ __forceinline__ ACC sel_key(ACC v, bool zero_is_valid) {
     return (!zero_is_valid && v == ACC(0)) ? NegInf<ACC>::value() : v;
 }
 
-template <typename ACC, bool FT>
-__device__ void score_tile_job(const ScoreArgs &a, int row, int tile, unsigned char *smem) {
+struct IdxAll {    // every column of the tile
+    __device__ __forceinline__ int operator()(int t) const { return t; }
+};
+struct IdxList {   // columns named by a uint16 list in LDS
+    const uint16_t *l;
+    __device__ __forceinline__ int operator()(int t) const { return l[t]; }
+};
+
+template <typename ACC>
+struct TileLds {
+    ACC *acc;
+    uint32_t *ft;
+    uint16_t *tlist;
+    uint16_t *clist;
+    ACC *res_s;
+    int *res_i;
+    uint32_t *res_a;
+};
+
+template <typename ACC>
+__device__ __forceinline__ TileLds<ACC> carve_lds(unsigned char *smem, int S, bool ft, bool touched) {
+    TileLds<ACC> L;
+    unsigned char *p = smem;
+    L.res_s = reinterpret_cast<ACC *>(p);          p += kResCap * 8;
+    L.acc = reinterpret_cast<ACC *>(p);            p += static_cast<size_t>(S) * sizeof(ACC);
+    L.ft = reinterpret_cast<uint32_t *>(p);        if (ft) p += static_cast<size_t>(S) * 4;
+    L.res_i = reinterpret_cast<int *>(p);          p += kResCap * 4;
+    L.res_a = reinterpret_cast<uint32_t *>(p);     p += kResCap * 4;
+    L.tlist = reinterpret_cast<uint16_t *>(p);     if (touched) p += kTouchCap * 2;
+    L.clist = reinterpret_cast<uint16_t *>(p);
+    return L;
+}
+
+__device__ __forceinline__ int global_col(const ScoreArgs &a, int local) {
+    return a.col_ids ? a.col_ids[local] : a.col_offset + local;
+}
+
+// Top-kk of the columns idx(0..n_idx) of one tile by (score, aux, global id), written sorted to
+// L.res_*; returns the number of entries.  All 64 lanes must call it.
+template <typename ACC, bool FT, typename IDX>
+__device__ int select_topk(const ScoreArgs &a, const TileLds<ACC> &L, IDX idx, int n_idx, int t0, bool zero_valid) {
     const int lane = lane_id();
-    const int S = a.tile_cols;
-    ACC *acc = reinterpret_cast<ACC *>(smem);
-    uint32_t *ft = reinterpret_cast<uint32_t *>(smem + static_cast<size_t>(S) * sizeof(ACC));
-    uint16_t *clist = reinterpret_cast<uint16_t *>(smem + static_cast<size_t>(S) * (sizeof(ACC) + (FT ? 4 : 0)));
     const ACC ninf = NegInf<ACC>::value();
+    const ACC *acc = L.acc;
 
-    const int t0 = tile * S;                                   // first shard-local column of the tile
-    const int ncol = min(S, a.n_cols - t0);                    // valid columns in this tile
-    const int xrow = a.row_ids ? a.row_ids[row] : row;
-    const int a0 = a.xb_ptr[xrow];
-    const int n_a = a.xb_ptr[xrow + 1] - a0;
-    const bool zero_valid = (a.mode != RTREC_TOPK_SPARSE);
+    auto make_cand = [&](int c) {
+        Cand<ACC> x;
+        x.score = acc[c];
+        x.id = global_col(a, t0 + c);
+        x.aux = FT ? L.ft[c] : (a.mode == RTREC_TOPK_CANDIDATES ? static_cast<uint32_t>(a.col_rank[x.id]) : 0u);
+        return x;
+    };
+    auto rank_and_store = [&](bool have, const Cand<ACC> &mine, int n_lanes) {
+        int rank = 0;
+        for (int t = 0; t < n_lanes; ++t) {
+            const Cand<ACC> o = cand_readlane<ACC>(mine, t);
+            rank += cand_better(o, mine) ? 1 : 0;
+        }
+        if (have && rank < a.kk) { L.res_s[rank] = mine.score; L.res_i[rank] = mine.id; L.res_a[rank] = mine.aux; }
+        return min(static_cast<int>(__builtin_popcountll(__ballot(have))), a.kk);
+    };
 
-    // ---- init accumulators (S is a multiple of 256) ----
-    for (int c = lane * 4; c < S; c += 256) {
-        acc[c + 0] = ACC(0); acc[c + 1] = ACC(0); acc[c + 2] = ACC(0); acc[c + 3] = ACC(0);
-        if (FT) { ft[c + 0] = 0xffffffffu; ft[c + 1] = 0xffffffffu; ft[c + 2] = 0xffffffffu; ft[c + 3] = 0xffffffffu; }
+    if (n_idx <= 64) {
+        Cand<ACC> mine; mine.id = -1; mine.score = ninf; mine.aux = 0u;
+        bool have = false;
+        if (lane < n_idx) {
+            const int c = idx(lane);
+            if (sel_key(acc[c], zero_valid) != ninf) { mine = make_cand(c); have = true; }
+        }
+        return rank_and_store(have, mine, n_idx);
     }
 
-    // ---- accumulate: rows of W for the user's items, ascending item order ----
+    // pass 1: per-lane best key, then tau = kk-th largest lane best (lower bound of the answer)
+    ACC best = ninf;
+    for (int t = lane; t < n_idx; t += 64) {
+        const ACC k = sel_key(acc[idx(t)], zero_valid);
+        best = k > best ? k : best;
+    }
+    ACC tau = ninf;
+    {
+        ACC cur = best;
+        for (int r = 0; r < a.kk; ++r) {
+            const ACC m = wave_max(cur);
+            tau = m;
+            if (m == ninf) break;
+            const unsigned long long eq = __ballot(cur == m);
+            if (lane == __builtin_ctzll(eq)) cur = ninf;
+        }
+    }
+    // pass 2: collect the columns with key >= tau
+    int cnt = 0;
+    for (int tb = 0; tb < n_idx; tb += 64) {
+        const int t = tb + lane;
+        int c = 0;
+        bool hit = false;
+        if (t < n_idx) {
+            c = idx(t);
+            const ACC k = sel_key(acc[c], zero_valid);
+            hit = (k != ninf) && (k >= tau);
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            const int pos = cnt + lane_prefix(m);
+            if (hit && pos < kListCap) L.clist[pos] = static_cast<uint16_t>(c);
+            cnt += __builtin_popcountll(m);
+        }
+    }
+    if (cnt <= 64) {
+        Cand<ACC> mine; mine.id = -1; mine.score = ninf; mine.aux = 0u;
+        const bool have = lane < cnt;
+        if (have) mine = make_cand(L.clist[lane]);
+        return rank_and_store(have, mine, cnt);
+    }
+    int n_out = 0;
+    if (cnt <= kListCap) {
+        for (int r = 0; r < a.kk; ++r) {
+            Cand<ACC> b; b.id = -1; b.score = ninf; b.aux = 0u;
+            int bt = -1;
+            for (int t = lane; t < cnt; t += 64) {
+                const uint16_t c = L.clist[t];
+                if (c == 0xffffu) continue;
+                const Cand<ACC> x = make_cand(c);
+                if (cand_better(x, b)) { b = x; bt = t; }
+            }
+            const Cand<ACC> w = wave_best(b);
+            if (w.id < 0) break;
+            if (b.id == w.id && bt >= 0) L.clist[bt] = 0xffffu;
+            if (lane == 0) { L.res_s[r] = w.score; L.res_i[r] = w.id; L.res_a[r] = w.aux; }
+            n_out = r + 1;
+        }
+        return n_out;
+    }
+    // more threshold candidates than the list holds (mass ties): successive scans, each bounded
+    // above by the previously emitted candidate
+    Cand<ACC> last; last.id = -1; last.score = ninf; last.aux = 0u;
+    for (int r = 0; r < a.kk; ++r) {
+        Cand<ACC> b; b.id = -1; b.score = ninf; b.aux = 0u;
+        for (int t = lane; t < n_idx; t += 64) {
+            const int c = idx(t);
+            if (sel_key(acc[c], zero_valid) == ninf) continue;
+            const Cand<ACC> x = make_cand(c);
+            if (last.id >= 0 && !cand_better(last, x)) continue;   // strictly below `last`
+            if (cand_better(x, b)) b = x;
+        }
+        const Cand<ACC> w = wave_best(b);
+        if (w.id < 0) break;
+        last = w;
+        if (lane == 0) { L.res_s[r] = w.score; L.res_i[r] = w.id; L.res_a[r] = w.aux; }
+        n_out = r + 1;
+    }
+    return n_out;
+}
+
+// Write the tile's sorted result (L.res_*, n_out entries) either as the row's final answer
+// (single-tile layouts) or as this tile's candidate list for the merge kernel.
+template <typename ACC>
+__device__ void emit_result(const ScoreArgs &a, const TileLds<ACC> &L, int row, int tile, int n_out) {
+    const int lane = lane_id();
+    if (a.direct) {
+        const int n_fin = min(n_out, a.top_k);
+        if (lane < a.top_k) {
+            const long long o = static_cast<long long>(row) * a.top_k + lane;
+            const bool ok = lane < n_fin;
+            const ACC sc = ok ? L.res_s[lane] : NegInf<ACC>::value();
+            a.out_id[o] = ok ? L.res_i[lane] : -1;
+            a.out_score[o] = static_cast<float>(sc);
+            if (a.out_score64) a.out_score64[o] = static_cast<double>(sc);
+            if (a.out_aux) a.out_aux[o] = ok ? L.res_a[lane] : 0u;
+        }
+        bool tie = false;
+        if (a.detect_ties && lane + 1 < n_out) tie = (L.res_s[lane] == L.res_s[lane + 1]);
+        const unsigned long long any_tie = __ballot(tie);
+        if (lane == 0) {
+            a.out_cnt[row] = n_fin;
+            if (any_tie) a.flag_list[atomicAdd(a.flag_len, 1)] = row;
+        }
+    } else {
+        const size_t base = (static_cast<size_t>(row) * a.n_tiles + tile) * a.kk;
+        if (lane < n_out) {
+            reinterpret_cast<ACC *>(a.cand_score)[base + lane] = L.res_s[lane];
+            a.cand_id[base + lane] = L.res_i[lane];
+            a.cand_aux[base + lane] = L.res_a[lane];
+        }
+        if (lane == 0) a.cand_cnt[static_cast<size_t>(row) * a.n_tiles + tile] = n_out;
+    }
+}
+
+// ---- accumulate the W rows of one user's items into the tile, ascending item order ----------
+// TOUCH: returning atomics detect the first contribution to a column and append it to tlist.
+template <typename ACC, bool FT, bool TOUCH>
+__device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds<ACC> &L, int a0, int n_a, int tile) {
+    const int lane = lane_id();
+    ACC *acc = L.acc;
     const int *tp = a.tile_ptr + static_cast<size_t>(tile) * (a.n_items + 1);
+    int tcnt = 0;
+    auto push = [&](bool first, int c) {
+        const unsigned long long m = __ballot(first);
+        if (m) {
+            const int pos = tcnt + lane_prefix(m);
+            if (first && pos < kTouchCap) L.tlist[pos] = static_cast<uint16_t>(c);
+            tcnt += __builtin_popcountll(m);
+        }
+    };
     for (int base = 0; base < n_a; base += 64) {
         const int p = base + lane;
         float x = 0.0f;
@@ -106,167 +317,137 @@ __device__ void score_tile_job(const ScoreArgs &a, int row, int tile, unsigned c
             const int ss = readlane_i(s, q), ee = readlane_i(e, q);
             const ACC xx = static_cast<ACC>(readlane_f(x, q));
             const uint32_t pos = static_cast<uint32_t>(base + q);
-            int o = ss + lane;
-            // 4 independent loads in flight per lane on long rows
-            for (; o + 192 < ee; o += 256) {
+            int ob = ss;
+            for (; ob + 256 <= ee; ob += 256) {   // 4 independent loads in flight per lane
+                const int o = ob + lane;
                 const int c0 = a.w_col[o], c1 = a.w_col[o + 64], c2 = a.w_col[o + 128], c3 = a.w_col[o + 192];
                 const float v0 = a.w_val[o], v1 = a.w_val[o + 64], v2 = a.w_val[o + 128], v3 = a.w_val[o + 192];
-                lds_add(&acc[c0], xx * static_cast<ACC>(v0));
-                lds_add(&acc[c1], xx * static_cast<ACC>(v1));
-                lds_add(&acc[c2], xx * static_cast<ACC>(v2));
-                lds_add(&acc[c3], xx * static_cast<ACC>(v3));
-                if (FT) { atomicMin(&ft[c0], pos); atomicMin(&ft[c1], pos); atomicMin(&ft[c2], pos); atomicMin(&ft[c3], pos); }
+                if (TOUCH) {
+                    const ACC o0 = lds_add_rtn(&acc[c0], xx * static_cast<ACC>(v0));
+                    const ACC o1 = lds_add_rtn(&acc[c1], xx * static_cast<ACC>(v1));
+                    const ACC o2 = lds_add_rtn(&acc[c2], xx * static_cast<ACC>(v2));
+                    const ACC o3 = lds_add_rtn(&acc[c3], xx * static_cast<ACC>(v3));
+                    push(is_untouched(o0), c0); push(is_untouched(o1), c1);
+                    push(is_untouched(o2), c2); push(is_untouched(o3), c3);
+                } else {
+                    lds_add(&acc[c0], xx * static_cast<ACC>(v0));
+                    lds_add(&acc[c1], xx * static_cast<ACC>(v1));
+                    lds_add(&acc[c2], xx * static_cast<ACC>(v2));
+                    lds_add(&acc[c3], xx * static_cast<ACC>(v3));
+                }
+                if (FT) { atomicMin(&L.ft[c0], pos); atomicMin(&L.ft[c1], pos); atomicMin(&L.ft[c2], pos); atomicMin(&L.ft[c3], pos); }
             }
-            for (; o < ee; o += 64) {
-                const int c = a.w_col[o];
-                const float v = a.w_val[o];
-                lds_add(&acc[c], xx * static_cast<ACC>(v));
-                if (FT) atomicMin(&ft[c], pos);
-            }
-        }
-    }
-
-    // ---- invalidate: tile padding, interacted items, non-candidates ----
-    for (int c = ncol + lane; c < S; c += 64) acc[c] = ninf;
-    if (a.mode == RTREC_TOPK_CANDIDATES) {
-        for (int c = lane; c < ncol; c += 64)
-            if (a.col_rank[a.col_offset + t0 + c] < 0) acc[c] = ninf;
-    } else if (a.filter) {
-        const int lo = a.col_offset + t0, hi = lo + ncol;
-        for (int p = lane; p < n_a; p += 64) {
-            const int item = a.xb_col[a0 + p];
-            if (item >= lo && item < hi) acc[item - lo] = ninf;
-        }
-    }
-
-    // ---- pass 1: per-lane best key ----
-    ACC best = ninf;
-    for (int c = lane * 4; c < S; c += 256) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const ACC k = sel_key(acc[c + j], zero_valid);
-            best = k > best ? k : best;
-        }
-    }
-    // tau = kk-th largest lane best (a lower bound of the kk-th largest key overall)
-    ACC tau = ninf;
-    {
-        ACC cur = best;
-        for (int r = 0; r < a.kk; ++r) {
-            const ACC m = wave_max(cur);
-            tau = m;
-            if (m == ninf) break;
-            const unsigned long long eq = __ballot(cur == m);
-            if (lane == __builtin_ctzll(eq)) cur = ninf;
-        }
-    }
-
-    // ---- pass 2: collect columns with key >= tau ----
-    int cnt = 0;
-    for (int c = lane * 4; c < S; c += 256) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const ACC k = sel_key(acc[c + j], zero_valid);
-            const bool hit = (k != ninf) && (k >= tau);
-            const unsigned long long m = __ballot(hit);
-            if (m) {
-                const int pos = cnt + lane_prefix(m);
-                if (hit && pos < kListCap) clist[pos] = static_cast<uint16_t>(c + j);
-                cnt += __builtin_popcountll(m);
+            for (; ob < ee; ob += 64) {
+                const int o = ob + lane;
+                const bool in = o < ee;
+                int c = 0;
+                bool first = false;
+                if (in) {
+                    c = a.w_col[o];
+                    const ACC prod = xx * static_cast<ACC>(a.w_val[o]);
+                    if (TOUCH) first = is_untouched(lds_add_rtn(&acc[c], prod));
+                    else lds_add(&acc[c], prod);
+                    if (FT) atomicMin(&L.ft[c], pos);
+                }
+                if (TOUCH) push(first, c);
             }
         }
     }
-
-    ACC *out_s = reinterpret_cast<ACC *>(a.cand_score) + (static_cast<size_t>(row) * a.n_tiles + tile) * a.kk;
-    int *out_i = a.cand_id + (static_cast<size_t>(row) * a.n_tiles + tile) * a.kk;
-    uint32_t *out_a = a.cand_aux + (static_cast<size_t>(row) * a.n_tiles + tile) * a.kk;
-    const int gbase = a.col_offset + t0;
-
-    auto make_cand = [&](int c) {
-        Cand<ACC> x;
-        x.score = acc[c];
-        x.id = gbase + c;
-        x.aux = FT ? ft[c] : (a.mode == RTREC_TOPK_CANDIDATES ? static_cast<uint32_t>(a.col_rank[gbase + c]) : 0u);
-        return x;
-    };
-
-    int n_out = 0;
-    if (cnt <= 64) {
-        // one candidate per lane, rank by counting
-        Cand<ACC> mine;
-        mine.id = -1; mine.score = ninf; mine.aux = 0u;
-        if (lane < cnt) mine = make_cand(clist[lane]);
-        int rank = 0;
-        for (int t = 0; t < cnt; ++t) {
-            const Cand<ACC> o = cand_readlane<ACC>(mine, t);
-            rank += cand_better(o, mine) ? 1 : 0;
-        }
-        if (lane < cnt && rank < a.kk) {
-            out_s[rank] = mine.score; out_i[rank] = mine.id; out_a[rank] = mine.aux;
-        }
-        n_out = min(cnt, a.kk);
-    } else if (cnt <= kListCap) {
-        for (int r = 0; r < a.kk; ++r) {
-            Cand<ACC> b; b.id = -1; b.score = ninf; b.aux = 0u;
-            int bt = -1;
-            for (int t = lane; t < cnt; t += 64) {
-                const uint16_t c = clist[t];
-                if (c == 0xffffu) continue;
-                const Cand<ACC> x = make_cand(c);
-                if (cand_better(x, b)) { b = x; bt = t; }
-            }
-            const Cand<ACC> w = wave_best(b);
-            if (w.id < 0) break;
-            if (b.id == w.id && bt >= 0) clist[bt] = 0xffffu;
-            if (lane == 0) { out_s[r] = w.score; out_i[r] = w.id; out_a[r] = w.aux; }
-            n_out = r + 1;
-        }
-    } else {
-        // more exact-threshold candidates than the list holds: successive full scans, each
-        // bounded above by the previously emitted candidate
-        Cand<ACC> last; last.id = -1; last.score = ninf; last.aux = 0u;
-        for (int r = 0; r < a.kk; ++r) {
-            Cand<ACC> b; b.id = -1; b.score = ninf; b.aux = 0u;
-            for (int c = lane; c < ncol; c += 64) {
-                if (sel_key(acc[c], zero_valid) == ninf) continue;
-                const Cand<ACC> x = make_cand(c);
-                if (last.id >= 0 && !cand_better(last, x)) continue;   // x must be strictly below last
-                if (cand_better(x, b)) b = x;
-            }
-            const Cand<ACC> w = wave_best(b);
-            if (w.id < 0) break;
-            last = w;
-            if (lane == 0) { out_s[r] = w.score; out_i[r] = w.id; out_a[r] = w.aux; }
-            n_out = r + 1;
-        }
-    }
-    if (lane == 0) a.cand_cnt[static_cast<size_t>(row) * a.n_tiles + tile] = n_out;
+    return tcnt;
 }
 
-// Fast pass: one (row, tile) job per workgroup.  Work items are ordered tile-major and dealt
-// to the 8 XCDs in contiguous ranges (blocks b and b+8 share an XCD and its L2), so an XCD
-// streams one tile's slice of W at a time out of its own L2.
+// ---- DENSE / CANDIDATES modes: one (row, tile) job per workgroup, full-tile scan --------------
 template <typename ACC>
-__global__ __launch_bounds__(64) void score_tiles_kernel(ScoreArgs a) {
+__global__ __launch_bounds__(64) void score_tiles_dense_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
     const long long per_xcd = (total + 7) / 8;
+    // tile-major work list dealt to the 8 XCDs in contiguous ranges (blocks b and b+8 share an
+    // XCD and its L2), so an XCD streams one tile's slice of W at a time
     const long long w = static_cast<long long>(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     if (blockIdx.x / 8 >= per_xcd || w >= total) return;
     const int tile = static_cast<int>(w / a.n_rows);
     const int row = static_cast<int>(w % a.n_rows);
-    score_tile_job<ACC, false>(a, row, tile, smem);
+
+    const int lane = lane_id();
+    const int S = a.tile_cols;
+    const TileLds<ACC> L = carve_lds<ACC>(smem, S, false, false);
+    const ACC ninf = NegInf<ACC>::value();
+    const int t0 = tile * S;
+    const int ncol = min(S, a.n_cols - t0);
+    const int xrow = a.row_ids ? a.row_ids[row] : row;
+    const int a0 = a.xb_ptr[xrow];
+    const int n_a = a.xb_ptr[xrow + 1] - a0;
+
+    for (int c = lane * 4; c < S; c += 256) { L.acc[c] = ACC(0); L.acc[c + 1] = ACC(0); L.acc[c + 2] = ACC(0); L.acc[c + 3] = ACC(0); }
+    accumulate_tile<ACC, false, false>(a, L, a0, n_a, tile);
+
+    if (a.mode == RTREC_TOPK_CANDIDATES) {
+        for (int c = lane; c < ncol; c += 64)
+            if (a.col_rank[global_col(a, t0 + c)] < 0) L.acc[c] = ninf;
+    } else if (a.filter) {
+        for (int p = lane; p < n_a; p += 64) {
+            const int item = a.xb_col[a0 + p];
+            const int lc = (a.col_map ? (item < a.n_items ? a.col_map[item] : -1) : item - a.col_offset) - t0;
+            if (lc >= 0 && lc < ncol) L.acc[lc] = ninf;
+        }
+    }
+    const int n_out = select_topk<ACC, false>(a, L, IdxAll{}, ncol, t0, /*zero_valid=*/true);
+    emit_result<ACC>(a, L, row, tile, n_out);
 }
 
-// Exact-tie pass: block b re-scores (flagged row b / n_tiles, tile b % n_tiles); blocks beyond
-// the flagged count exit at once (the count only exists on the device).
-template <typename ACC>
-__global__ __launch_bounds__(64) void score_tiles_ft_kernel(ScoreArgs a) {
+// ---- SPARSE mode: persistent waves, accumulators stay in LDS across jobs ----------------------
+// Between jobs every accumulator holds the "untouched" marker; a job only visits, selects from
+// and resets the columns it touched, so its cost follows the user's W rows, not the tile width.
+template <typename ACC, bool FT>
+__global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int n_flag = *a.row_list_len;
-    const int f = blockIdx.x / a.n_tiles;
-    if (f >= n_flag) return;
-    score_tile_job<ACC, true>(a, a.row_list[f], blockIdx.x % a.n_tiles, smem);
+    const int lane = lane_id();
+    const int S = a.tile_cols;
+    const TileLds<ACC> L = carve_lds<ACC>(smem, S, FT, true);
+    const ACC ninf = NegInf<ACC>::value();
+    const ACC unt = untouched_value(ACC(0));
+    for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
+
+    const int n_rows = FT ? *a.row_list_len : a.n_rows;
+    const int total = n_rows * a.n_tiles;
+    for (;;) {
+        int w = 0;
+        if (lane == 0) w = atomicAdd(a.queue, 1);
+        w = readfirst_i(w);
+        if (w >= total) break;
+        const int tile = w / n_rows;             // tile-major: concurrent waves share a W tile in L2
+        const int row = FT ? a.row_list[w % n_rows] : (w % n_rows);
+        const int t0 = tile * S;
+        const int ncol = min(S, a.n_cols - t0);
+        const int xrow = a.row_ids ? a.row_ids[row] : row;
+        const int a0 = a.xb_ptr[xrow];
+        const int n_a = a.xb_ptr[xrow + 1] - a0;
+
+        const int tcnt = accumulate_tile<ACC, FT, true>(a, L, a0, n_a, tile);
+        const bool overflow = tcnt > kTouchCap;
+
+        if (a.filter && tcnt > 0) {   // interacted items that received a score leave the race
+            for (int p = lane; p < n_a; p += 64) {
+                const int item = a.xb_col[a0 + p];
+                const int lc = (a.col_map ? (item < a.n_items ? a.col_map[item] : -1) : item - a.col_offset) - t0;
+                if (lc >= 0 && lc < ncol && !is_untouched(L.acc[lc])) L.acc[lc] = ninf;
+            }
+        }
+        int n_out = 0;
+        if (tcnt > 0) {
+            if (!overflow) n_out = select_topk<ACC, FT>(a, L, IdxList{L.tlist}, tcnt, t0, /*zero_valid=*/false);
+            else n_out = select_topk<ACC, FT>(a, L, IdxAll{}, ncol, t0, /*zero_valid=*/false);
+        }
+        emit_result<ACC>(a, L, row, tile, n_out);
+
+        // restore the invariant
+        if (!overflow) {
+            for (int t = lane; t < tcnt; t += 64) { const int c = L.tlist[t]; L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
+        } else {
+            for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
+        }
+    }
 }
 
 struct MergeArgs {
@@ -424,23 +605,53 @@ inline void debug_stage(hipStream_t st, const char *what) {
 }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Optional HIP-event bracket around score_tiles_kernel (bench.py's roofline leg).
+struct KernelTimer {
+    bool enabled = false;
+    hipEvent_t start = nullptr, stop = nullptr;
+    double total_ms = 0.0;
+    long long launches = 0;
+    bool pending = false;
+};
+KernelTimer &score_timer() {
+    static KernelTimer t;
+    return t;
+}
+void timer_collect(KernelTimer &t) {
+    if (!t.pending) return;
+    float ms = 0.0f;
+    if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+        t.total_ms += ms;
+        t.launches += 1;
+    }
+    t.pending = false;
+}
+
 struct ScoreWs {
-    size_t cand_score, cand_id, cand_aux, cand_cnt, flag_list, flag_len, queue, tmp_id, tmp_score, tmp_aux, tmp_cnt, total;
+    size_t cand_score, cand_id, cand_aux, cand_cnt, flag_list, flag_len, queue, total;
 };
 ScoreWs score_ws_layout(int n_rows, int n_tiles, int top_k) {
     ScoreWs w;
     const size_t kk = static_cast<size_t>(top_k) + 1;
-    const size_t n = static_cast<size_t>(n_rows) * n_tiles * kk;
+    const size_t n = n_tiles > 1 ? static_cast<size_t>(n_rows) * n_tiles * kk : 0;
     size_t o = 0;
     w.cand_score = o; o = align_up(o + n * sizeof(double), 256);
     w.cand_id = o;    o = align_up(o + n * sizeof(int), 256);
     w.cand_aux = o;   o = align_up(o + n * sizeof(uint32_t), 256);
-    w.cand_cnt = o;   o = align_up(o + static_cast<size_t>(n_rows) * n_tiles * sizeof(int), 256);
+    w.cand_cnt = o;   o = align_up(o + (n_tiles > 1 ? static_cast<size_t>(n_rows) * n_tiles * sizeof(int) : 0), 256);
     w.flag_list = o;  o = align_up(o + static_cast<size_t>(n_rows) * sizeof(int), 256);
     w.flag_len = o;   o = align_up(o + 256, 256);
     w.queue = o;      o = align_up(o + 256, 256);
     w.total = o;
     return w;
+}
+
+// Persistent grid: as many single-wave workgroups as the LDS footprint lets a CU hold.
+unsigned persistent_grid(size_t lds_bytes, long long jobs) {
+    int per_cu = static_cast<int>((160u * 1024u) / (lds_bytes > 0 ? lds_bytes : 1));
+    per_cu = per_cu < 1 ? 1 : (per_cu > 16 ? 16 : per_cu);
+    const long long g = 256ll * per_cu;
+    return static_cast<unsigned>(jobs < g ? (jobs > 0 ? jobs : 1) : g);
 }
 
 template <typename ACC>
@@ -449,6 +660,8 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
                unsigned char *ws, const ScoreWs &L, hipStream_t st) {
     ScoreArgs a = base;
     const bool sparse = (a.mode == RTREC_TOPK_SPARSE);
+    const bool single = (a.n_tiles == 1);
+    a.top_k = top_k;
     a.kk = sparse ? top_k + 1 : top_k;
     a.cand_score = ws + L.cand_score;
     a.cand_id = reinterpret_cast<int *>(ws + L.cand_id);
@@ -456,22 +669,34 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     a.cand_cnt = reinterpret_cast<int *>(ws + L.cand_cnt);
     int *flag_list = reinterpret_cast<int *>(ws + L.flag_list);
     int *flag_len = reinterpret_cast<int *>(ws + L.flag_len);
-    int *queue = reinterpret_cast<int *>(ws + L.queue);
-    a.row_list = flag_list;
-    a.row_list_len = flag_len;
+    int *queue = reinterpret_cast<int *>(ws + L.queue);   // [0]: fast pass, [1]: exact-tie pass
+    a.direct = single ? 1 : 0;
+    a.out_id = d_out_ids; a.out_score = d_out_scores; a.out_score64 = d_out_scores64; a.out_aux = d_out_aux;
+    a.out_cnt = d_out_count;
+    a.detect_ties = sparse ? 1 : 0;
+    a.flag_list = flag_list; a.flag_len = flag_len;
+    a.row_list = flag_list; a.row_list_len = flag_len;
     a.queue = queue;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
     if (hipMemsetAsync(flag_len, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
-    if (hipMemsetAsync(queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    if (hipMemsetAsync(queue, 0, 8, st) != hipSuccess) return RTREC_ERR_LAUNCH;
 
-    const size_t lds_fast = static_cast<size_t>(a.tile_cols) * acc_bytes + kListCap * 2;
-    const size_t lds_ft = static_cast<size_t>(a.tile_cols) * (acc_bytes + 4) + kListCap * 2;
     const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
-    const long long per_xcd = (total + 7) / 8;
-    const unsigned grid = static_cast<unsigned>(per_xcd * 8);
+    KernelTimer &tm = score_timer();
     debug_stage(st, "score: begin");
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(score_tiles_kernel<ACC>), dim3(grid), dim3(64), lds_fast, st, a);
-    debug_stage(st, "score_tiles_kernel");
+    if (tm.enabled) { timer_collect(tm); (void)hipEventRecord(tm.start, st); }
+    if (sparse) {
+        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, false>), dim3(persistent_grid(lds, total)), dim3(64),
+                           lds, st, a);
+    } else {
+        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, false);
+        const long long per_xcd = (total + 7) / 8;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_tiles_dense_kernel<ACC>), dim3(static_cast<unsigned>(per_xcd * 8)),
+                           dim3(64), lds, st, a);
+    }
+    if (tm.enabled) { (void)hipEventRecord(tm.stop, st); tm.pending = true; }
+    debug_stage(st, "score tiles");
 
     MergeArgs m{};
     m.n_rows = a.n_rows; m.n_lists = a.n_tiles; m.kk = a.kk; m.top_k = top_k;
@@ -483,27 +708,47 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     m.detect_ties = sparse ? 1 : 0;
     m.flag_list = flag_list; m.flag_len = flag_len;
     m.row_list = nullptr; m.row_list_len = nullptr;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, m);
-    debug_stage(st, "merge_topk_kernel");
+    if (!single) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, m);
+        debug_stage(st, "merge_topk_kernel");
+    }
 
     if (sparse) {
-        // exact tie order for the flagged rows only
+        // exact reference tie order for the flagged rows only (first-touch tracking on)
         ScoreArgs f = a;
         f.kk = top_k;
-        const unsigned ft_grid = static_cast<unsigned>(total);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_tiles_ft_kernel<ACC>), dim3(ft_grid), dim3(64), lds_ft, st, f);
-        debug_stage(st, "score_tiles_ft_kernel");
-        MergeArgs mf = m;
-        mf.kk = top_k;
-        mf.list_stride = top_k; mf.row_stride = static_cast<long long>(a.n_tiles) * top_k;
-        mf.detect_ties = 0;
-        mf.row_list = flag_list; mf.row_list_len = flag_len;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, mf);
-        debug_stage(st, "merge_topk_kernel (exact ties)");
+        f.detect_ties = 0;
+        f.queue = queue + 1;
+        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, true, true);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, true>), dim3(persistent_grid(lds, total)), dim3(64),
+                           lds, st, f);
+        debug_stage(st, "score_sparse_kernel (exact ties)");
+        if (!single) {
+            MergeArgs mf = m;
+            mf.kk = top_k;
+            mf.list_stride = top_k; mf.row_stride = static_cast<long long>(a.n_tiles) * top_k;
+            mf.detect_ties = 0;
+            mf.row_list = flag_list; mf.row_list_len = flag_len;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, mf);
+            debug_stage(st, "merge_topk_kernel (exact ties)");
+        }
     }
     return rtrec::launch_status();
 }
 }  // namespace
+
+extern "C" int rtrec_amd_score_timer(int32_t enable, double *total_ms, int64_t *launches) {
+    KernelTimer &t = score_timer();
+    if (enable && !t.start) {
+        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return RTREC_ERR_LAUNCH;
+    }
+    timer_collect(t);
+    if (total_ms) *total_ms = t.total_ms;
+    if (launches) *launches = t.launches;
+    if (enable < 0 || (enable && !t.enabled)) { t.total_ms = 0.0; t.launches = 0; }
+    t.enabled = enable > 0;
+    return RTREC_OK;
+}
 
 extern "C" size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k) {
     if (n_rows < 0 || n_tiles <= 0 || top_k <= 0) return 0;
@@ -513,6 +758,7 @@ extern "C" size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_til
 extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                                      const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
                                      int32_t n_items, int32_t n_cols, int32_t col_offset,
+                                     const int32_t *d_col_ids, const int32_t *d_col_map,
                                      int32_t tile_cols, int32_t n_tiles,
                                      const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
                                      const int32_t *d_col_rank,
@@ -525,18 +771,20 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     if (!d_xb_ptr || !d_tile_ptr || !d_out_ids || !d_out_scores || !d_out_count || !d_workspace) return RTREC_ERR_INVALID_ARG;
     if (mode < 0 || mode > 2) return RTREC_ERR_INVALID_ARG;
     if (mode == RTREC_TOPK_CANDIDATES && !d_col_rank) return RTREC_ERR_INVALID_ARG;
+    if ((d_col_ids == nullptr) != (d_col_map == nullptr)) return RTREC_ERR_INVALID_ARG;
     if (tile_cols < 256 || tile_cols > 65536 || (tile_cols % 256) != 0) return RTREC_ERR_UNSUPPORTED;
     if (n_tiles != (n_cols + tile_cols - 1) / tile_cols) return RTREC_ERR_INVALID_ARG;
     const int acc_bytes = acc_f64 ? 8 : 4;
-    // the first-touch instantiation needs tile_cols * (acc + 4) + list bytes of LDS (160 KiB / CU)
-    if (static_cast<size_t>(tile_cols) * (acc_bytes + 4) + kListCap * 2 > 160u * 1024u) return RTREC_ERR_UNSUPPORTED;
-    if (top_k + 1 > 64 || static_cast<long long>(n_tiles) * (top_k + 1) > 1024) return RTREC_ERR_UNSUPPORTED;
+    // the exact-tie instantiation keeps an accumulator AND a first-touch word per column in LDS
+    if (score_lds_bytes(tile_cols, acc_bytes, true, true) > 160u * 1024u) return RTREC_ERR_UNSUPPORTED;
+    if (top_k + 1 > kResCap || static_cast<long long>(n_tiles) * (top_k + 1) > 1024) return RTREC_ERR_UNSUPPORTED;
+    if (static_cast<long long>(n_rows) * n_tiles >= (1ll << 31)) return RTREC_ERR_UNSUPPORTED;
     const ScoreWs L = score_ws_layout(n_rows, n_tiles, top_k);
     if (workspace_bytes < L.total) return RTREC_ERR_WORKSPACE;
 
     ScoreArgs a{};
     a.n_rows = n_rows; a.row_ids = d_row_ids; a.xb_ptr = d_xb_ptr; a.xb_col = d_xb_col; a.xb_val = d_xb_val;
-    a.n_items = n_items; a.n_cols = n_cols; a.col_offset = col_offset;
+    a.n_items = n_items; a.n_cols = n_cols; a.col_offset = col_offset; a.col_ids = d_col_ids; a.col_map = d_col_map;
     a.tile_cols = tile_cols; a.n_tiles = n_tiles;
     a.tile_ptr = d_tile_ptr; a.w_col = d_w_col; a.w_val = d_w_val; a.col_rank = d_col_rank;
     a.filter = filter_interacted; a.mode = mode;

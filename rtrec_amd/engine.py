@@ -46,25 +46,39 @@ class TiledW:
     """Host-side description of one shard of W in the kernel's tiled layout."""
     n_items: int
     col_lo: int
-    n_cols: int
+    n_cols: int           # layout columns (shard width, or number of active columns when compacted)
     tile_cols: int
     n_tiles: int
     tile_ptr: np.ndarray  # int32 [n_tiles * (n_items + 1)]
     w_col: np.ndarray     # uint16 [nnz]
     w_val: np.ndarray     # float32 [nnz]
+    col_ids: Optional[np.ndarray] = None   # int32 [n_cols]: layout column -> global item id
+    col_map: Optional[np.ndarray] = None   # int32 [n_items]: global item id -> layout column or -1
 
 
-def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int) -> TiledW:
-    """Cut columns [col_lo, col_hi) of W (CSC, I x I) into tiles; per tile a CSR over all rows."""
+def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int, compact: bool = False) -> TiledW:
+    """Cut columns [col_lo, col_hi) of W (CSC, I x I) into tiles; per tile a CSR over all rows.
+    compact=True keeps only the columns that store at least one weight (the only ones that can
+    be recommended in SPARSE mode), in ascending id order."""
     n_items = W_csc.shape[0]
-    n_cols = col_hi - col_lo
-    n_tiles = max(1, -(-n_cols // tile_cols))
     indptr = np.asarray(W_csc.indptr, dtype=np.int64)
     s, e = int(indptr[col_lo]), int(indptr[col_hi])
     rows = np.asarray(W_csc.indices[s:e], dtype=np.int64)
     vals = np.asarray(W_csc.data[s:e], dtype=np.float32)
     counts = np.diff(indptr[col_lo:col_hi + 1])
-    kloc = np.repeat(np.arange(n_cols, dtype=np.int64), counts)
+    col_ids = col_map = None
+    if compact:
+        active = np.flatnonzero(counts > 0)
+        n_cols = int(active.shape[0])
+        col_ids = (active + col_lo).astype(np.int32)
+        col_map = np.full(n_items, -1, dtype=np.int32)
+        col_map[col_ids] = np.arange(n_cols, dtype=np.int32)
+        kloc = np.repeat(np.arange(n_cols, dtype=np.int64), counts[active])
+    else:
+        n_cols = col_hi - col_lo
+        kloc = np.repeat(np.arange(n_cols, dtype=np.int64), counts)
+    tile_cols = max(256, min(int(tile_cols), -(-max(n_cols, 1) // 256) * 256))
+    n_tiles = max(1, -(-n_cols // tile_cols))
     tile = kloc // tile_cols
     order = np.lexsort((kloc, rows, tile))
     key = (tile * n_items + rows)[order]
@@ -77,7 +91,8 @@ def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int
     for t in range(n_tiles):
         tile_ptr[t * (n_items + 1):(t + 1) * (n_items + 1)] = starts[t * n_items:t * n_items + n_items + 1]
     w_col = (kloc[order] % tile_cols).astype(np.uint16)
-    return TiledW(n_items, col_lo, n_cols, tile_cols, n_tiles, tile_ptr, w_col, np.ascontiguousarray(vals[order]))
+    return TiledW(n_items, col_lo, n_cols, tile_cols, n_tiles, tile_ptr, w_col, np.ascontiguousarray(vals[order]),
+                  col_ids, col_map)
 
 
 class HipBackend:
@@ -234,25 +249,39 @@ class SlimEngine:
 
     # ------------------------------------------------------------------------------ W
     def set_weights(self, W_csc: sp.csc_matrix, acc_f64: bool = False) -> None:
-        """Upload this rank's column shard of W (I x I, CSC with sorted indices)."""
+        """Register W (I x I, CSC).  The tiled layouts of this rank's column shard are built and
+        uploaded on first use: a compacted one (columns with at least one weight) for SPARSE mode,
+        a plain one for DENSE / CANDIDATES mode."""
         be = self.be
         n_items = W_csc.shape[1]
         lo, hi = shard_bounds(n_items, self.world_size, self.rank)
         W_csc = W_csc if W_csc.has_sorted_indices else W_csc.sorted_indices()
-        W: Dict[str, Any] = {"n_items": n_items, "col_lo": lo, "n_cols": hi - lo, "acc_f64": bool(acc_f64)}
-        if hi > lo:
-            # the exact-tie pass keeps a float accumulator AND a first-touch word per column in LDS
-            tile = self.tile_cols
-            while tile > 256 and tile * ((8 if acc_f64 else 4) + 4) + 2048 > 160 * 1024:
-                tile //= 2
-            T = build_tiled_w(W_csc, lo, hi, tile)
-            W.update(tile_cols=T.tile_cols, n_tiles=T.n_tiles, tile_ptr=be.to_dev(T.tile_ptr),
-                     w_col=be.to_dev(T.w_col.view(np.int16)), w_val=be.to_dev(T.w_val), nnz=int(T.w_val.shape[0]))
+        W: Dict[str, Any] = {"n_items": n_items, "col_lo": lo, "col_hi": hi, "acc_f64": bool(acc_f64),
+                             "host": W_csc, "layouts": {}}
         # CSC copy for similar_items (whole matrix is small: <= K entries per column)
         W["cptr"] = be.to_dev(np.asarray(W_csc.indptr, dtype=np.int32))
         W["crow"] = be.to_dev(np.asarray(W_csc.indices, dtype=np.int32))
         W["cval"] = be.to_dev(np.asarray(W_csc.data, dtype=np.float32))
         self._W = W
+
+    def _layout(self, compact: bool) -> Optional[Dict[str, Any]]:
+        W, be = self._W, self.be
+        if compact not in W["layouts"]:
+            lay = None
+            if W["col_hi"] > W["col_lo"]:
+                # the exact-tie pass keeps an accumulator AND a first-touch word per column in LDS
+                tile = self.tile_cols
+                while tile > 256 and tile * ((8 if W["acc_f64"] else 4) + 4) + 8192 > 160 * 1024:
+                    tile //= 2
+                T = build_tiled_w(W["host"], W["col_lo"], W["col_hi"], tile, compact=compact)
+                if T.n_cols > 0:
+                    lay = dict(n_cols=T.n_cols, tile_cols=T.tile_cols, n_tiles=T.n_tiles, nnz=int(T.w_val.shape[0]),
+                               tile_ptr=be.to_dev(T.tile_ptr), w_col=be.to_dev(T.w_col.view(np.int16)),
+                               w_val=be.to_dev(T.w_val),
+                               col_ids=be.to_dev(T.col_ids) if T.col_ids is not None else None,
+                               col_map=be.to_dev(T.col_map) if T.col_map is not None else None)
+            W["layouts"][compact] = lay
+        return W["layouts"][compact]
 
     # ------------------------------------------------------------------------------ score
     def _local_topk(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
@@ -264,19 +293,21 @@ class SlimEngine:
         aux = be.empty((n_rows, top_k), torch.int32)
         cnt = be.empty((n_rows,), torch.int32)
         sc64 = be.empty((n_rows, top_k), torch.float64) if W["acc_f64"] else None
-        if W["n_cols"] == 0:
+        lay = self._layout(compact=(mode == _native.TOPK_SPARSE))
+        if lay is None:
             ids.fill_(-1); sc.fill_(float("-inf")); aux.zero_(); cnt.zero_()
             if sc64 is not None:
                 sc64.fill_(float("-inf"))
             return ids, sc, sc64, aux, cnt
-        need = int(be.lib.rtrec_slim_score_workspace_bytes(n_rows, W["n_tiles"], top_k))
+        need = int(be.lib.rtrec_slim_score_workspace_bytes(n_rows, lay["n_tiles"], top_k))
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = be.empty((need,), torch.uint8)
         ws = self._score_ws
         _native.check(be.lib.rtrec_slim_score_topk(
             n_rows, be.ptr(d_row_ids), be.ptr(xb[0]), be.ptr(xb[1]), be.ptr(xb[2]),
-            W["n_items"], W["n_cols"], W["col_lo"], W["tile_cols"], W["n_tiles"],
-            be.ptr(W["tile_ptr"]), be.ptr(W["w_col"]), be.ptr(W["w_val"]), be.ptr(d_col_rank),
+            W["n_items"], lay["n_cols"], W["col_lo"], be.ptr(lay["col_ids"]), be.ptr(lay["col_map"]),
+            lay["tile_cols"], lay["n_tiles"],
+            be.ptr(lay["tile_ptr"]), be.ptr(lay["w_col"]), be.ptr(lay["w_val"]), be.ptr(d_col_rank),
             top_k, int(bool(filter_interacted)), int(mode), int(W["acc_f64"]),
             be.ptr(ids), be.ptr(sc), be.ptr(sc64), be.ptr(aux), be.ptr(cnt),
             be.ptr(ws), ws.numel(), be.stream()), "rtrec_slim_score_topk")
