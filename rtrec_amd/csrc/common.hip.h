@@ -36,6 +36,9 @@ __device__ __forceinline__ float readfirst_f(float v) {
 }
 __device__ __forceinline__ int readfirst_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+__device__ __forceinline__ float readlane_t(float v, int lane) { return readlane_f(v, lane); }
+__device__ __forceinline__ double readlane_t(double v, int lane) { return readlane_d(v, lane); }
+
 // Exclusive count of set bits of `mask` below this lane.
 __device__ __forceinline__ int lane_prefix(unsigned long long mask) {
     return static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<unsigned int>(mask >> 32),

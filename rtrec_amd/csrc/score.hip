@@ -61,11 +61,15 @@ struct ScoreArgs {
     const int *row_list;
     const int *row_list_len;
     int *queue;
+    int ablate;           // diagnostics: bit0 skip accumulate, bit1 skip select, bit2 skip reset, bit3 skip filter
 };
 
 constexpr int kListCap = 512;    // threshold-candidate list (uint16 columns)
 constexpr int kTouchCap = 1536;  // touched-column list of the sparse kernel (uint16 columns)
 constexpr int kResCap = 64;      // top_k + 1 <= 64
+constexpr int kQueueChunk = 8;   // jobs claimed per work-queue atomic
+constexpr int kRowGroup = 8;     // W rows whose first loads are issued together
+constexpr int kStreamDepth = 8;  // 64-entry chunks of a long W row requested per round trip
 
 __host__ __device__ constexpr size_t score_lds_bytes(int tile_cols, int acc_bytes, bool ft, bool touched) {
     return static_cast<size_t>(tile_cols) * (acc_bytes + (ft ? 4 : 0)) + (touched ? kTouchCap * 2 : 0) + kListCap * 2 +
@@ -96,9 +100,11 @@ __device__ __forceinline__ ACC sel_key(ACC v, bool zero_is_valid) {
 }
 
 struct IdxAll {    // every column of the tile
+    static constexpr bool kAll = true;
     __device__ __forceinline__ int operator()(int t) const { return t; }
 };
 struct IdxList {   // columns named by a uint16 list in LDS
+    static constexpr bool kAll = false;
     const uint16_t *l;
     __device__ __forceinline__ int operator()(int t) const { return l[t]; }
 };
@@ -135,7 +141,7 @@ __device__ __forceinline__ int global_col(const ScoreArgs &a, int local) {
 // Top-kk of the columns idx(0..n_idx) of one tile by (score, aux, global id), written sorted to
 // L.res_*; returns the number of entries.  All 64 lanes must call it.
 template <typename ACC, bool FT, typename IDX>
-__device__ int select_topk(const ScoreArgs &a, const TileLds<ACC> &L, IDX idx, int n_idx, int t0, bool zero_valid) {
+__device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC> &L, IDX idx, int n_idx, int t0, bool zero_valid) {
     const int lane = lane_id();
     const ACC ninf = NegInf<ACC>::value();
     const ACC *acc = L.acc;
@@ -169,23 +175,55 @@ __device__ int select_topk(const ScoreArgs &a, const TileLds<ACC> &L, IDX idx, i
 
     // pass 1: per-lane best key, then tau = kk-th largest lane best (lower bound of the answer)
     ACC best = ninf;
-    for (int t = lane; t < n_idx; t += 64) {
-        const ACC k = sel_key(acc[idx(t)], zero_valid);
-        best = k > best ? k : best;
+    if (IDX::kAll) {   // whole tile: 4 columns per lane and step (columns >= n_idx hold invalid keys)
+        for (int c = lane * 4; c < n_idx; c += 256) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const ACC k = sel_key(acc[c + j], zero_valid);
+                best = k > best ? k : best;
+            }
+        }
+    } else {
+        for (int t = lane; t < n_idx; t += 64) {
+            const ACC k = sel_key(acc[idx(t)], zero_valid);
+            best = k > best ? k : best;
+        }
     }
+    // rank of this lane's best among the 64 lane bests (ties broken by lane id): pure VALU
+    // (v_readlane + compare), no cross-lane LDS traffic
     ACC tau = ninf;
     {
-        ACC cur = best;
-        for (int r = 0; r < a.kk; ++r) {
-            const ACC m = wave_max(cur);
-            tau = m;
-            if (m == ninf) break;
-            const unsigned long long eq = __ballot(cur == m);
-            if (lane == __builtin_ctzll(eq)) cur = ninf;
+        int rank = 0;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            const ACC o = readlane_t(best, t);
+            rank += (o > best || (o == best && t < lane)) ? 1 : 0;
         }
+        const unsigned long long at = __ballot(rank == a.kk - 1);
+        if (at) tau = readlane_t(best, __builtin_ctzll(at));
     }
     // pass 2: collect the columns with key >= tau
     int cnt = 0;
+    if (IDX::kAll) {
+        for (int c0 = lane * 4; c0 < n_idx + 256; c0 += 256) {   // uniform trip count
+            if (c0 - lane * 4 >= n_idx) break;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                bool hit = false;
+                if (c < n_idx) {
+                    const ACC k = sel_key(acc[c], zero_valid);
+                    hit = (k != ninf) && (k >= tau);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    const int pos = cnt + lane_prefix(m);
+                    if (hit && pos < kListCap) L.clist[pos] = static_cast<uint16_t>(c);
+                    cnt += __builtin_popcountll(m);
+                }
+            }
+        }
+    } else
     for (int tb = 0; tb < n_idx; tb += 64) {
         const int t = tb + lane;
         int c = 0;
@@ -251,7 +289,7 @@ __device__ int select_topk(const ScoreArgs &a, const TileLds<ACC> &L, IDX idx, i
 // Write the tile's sorted result (L.res_*, n_out entries) either as the row's final answer
 // (single-tile layouts) or as this tile's candidate list for the merge kernel.
 template <typename ACC>
-__device__ void emit_result(const ScoreArgs &a, const TileLds<ACC> &L, int row, int tile, int n_out) {
+__device__ __forceinline__ void emit_result(const ScoreArgs &a, const TileLds<ACC> &L, int row, int tile, int n_out) {
     const int lane = lane_id();
     if (a.direct) {
         const int n_fin = min(n_out, a.top_k);
@@ -283,19 +321,29 @@ __device__ void emit_result(const ScoreArgs &a, const TileLds<ACC> &L, int row, 
 }
 
 // ---- accumulate the W rows of one user's items into the tile, ascending item order ----------
-// TOUCH: returning atomics detect the first contribution to a column and append it to tlist.
+// The accumulators are updated with plain LDS read-modify-write, not atomics: one wave owns the
+// tile, its LDS operations execute in program order, and a W row never repeats a column, so the
+// lanes of one instruction never collide.  (ds_add_f32 measures ~190 cycles per wave-instruction
+// per CU on gfx950, a read+write pair ~14: tools/microbench/lds_atomic_rate.hip.)
+// TOUCH: the value read back tells whether this is the first contribution to the column; such
+// columns are appended to tlist.  FT: the first-touch position of the column is recorded.
 template <typename ACC, bool FT, bool TOUCH>
 __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds<ACC> &L, int a0, int n_a, int tile) {
     const int lane = lane_id();
     ACC *acc = L.acc;
     const int *tp = a.tile_ptr + static_cast<size_t>(tile) * (a.n_items + 1);
     int tcnt = 0;
+    // Once a user is known to touch most of the tile (a long W row, or the list is full) the
+    // touched list is pointless: stop maintaining it and let the caller scan / reset the whole tile.
+    bool track = TOUCH;
     auto push = [&](bool first, int c) {
+        if (!track) return;
         const unsigned long long m = __ballot(first);
         if (m) {
             const int pos = tcnt + lane_prefix(m);
             if (first && pos < kTouchCap) L.tlist[pos] = static_cast<uint16_t>(c);
             tcnt += __builtin_popcountll(m);
+            if (tcnt > kTouchCap) track = false;
         }
     };
     for (int base = 0; base < n_a; base += 64) {
@@ -311,45 +359,76 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
             }
         }
         unsigned long long live = __ballot(e > s);
+        if (TOUCH && track && __ballot(e - s >= kTouchCap / 4)) { track = false; tcnt = kTouchCap + 1; }
         while (live) {
-            const int q = __builtin_ctzll(live);
-            live &= live - 1;
-            const int ss = readlane_i(s, q), ee = readlane_i(e, q);
-            const ACC xx = static_cast<ACC>(readlane_f(x, q));
-            const uint32_t pos = static_cast<uint32_t>(base + q);
-            int ob = ss;
-            for (; ob + 256 <= ee; ob += 256) {   // 4 independent loads in flight per lane
-                const int o = ob + lane;
-                const int c0 = a.w_col[o], c1 = a.w_col[o + 64], c2 = a.w_col[o + 128], c3 = a.w_col[o + 192];
-                const float v0 = a.w_val[o], v1 = a.w_val[o + 64], v2 = a.w_val[o + 128], v3 = a.w_val[o + 192];
-                if (TOUCH) {
-                    const ACC o0 = lds_add_rtn(&acc[c0], xx * static_cast<ACC>(v0));
-                    const ACC o1 = lds_add_rtn(&acc[c1], xx * static_cast<ACC>(v1));
-                    const ACC o2 = lds_add_rtn(&acc[c2], xx * static_cast<ACC>(v2));
-                    const ACC o3 = lds_add_rtn(&acc[c3], xx * static_cast<ACC>(v3));
-                    push(is_untouched(o0), c0); push(is_untouched(o1), c1);
-                    push(is_untouched(o2), c2); push(is_untouched(o3), c3);
-                } else {
-                    lds_add(&acc[c0], xx * static_cast<ACC>(v0));
-                    lds_add(&acc[c1], xx * static_cast<ACC>(v1));
-                    lds_add(&acc[c2], xx * static_cast<ACC>(v2));
-                    lds_add(&acc[c3], xx * static_cast<ACC>(v3));
+            // Take the next kRowGroup non-empty rows (ascending item order) and issue the loads of
+            // their first 64 entries together, so one memory round trip serves the whole group;
+            // the accumulator updates are then issued row by row (scipy's accumulation order).
+            int ss[kRowGroup], ee[kRowGroup], cc[kRowGroup];
+            float vv[kRowGroup];
+            ACC xx[kRowGroup];
+            uint32_t ps[kRowGroup];
+#pragma unroll
+            for (int j = 0; j < kRowGroup; ++j) {
+                ss[j] = 0; ee[j] = 0; xx[j] = ACC(0); ps[j] = 0u;
+                if (live) {
+                    const int q = __builtin_ctzll(live);
+                    live &= live - 1;
+                    ss[j] = readlane_i(s, q);
+                    ee[j] = readlane_i(e, q);
+                    xx[j] = static_cast<ACC>(readlane_f(x, q));
+                    ps[j] = static_cast<uint32_t>(base + q);
                 }
-                if (FT) { atomicMin(&L.ft[c0], pos); atomicMin(&L.ft[c1], pos); atomicMin(&L.ft[c2], pos); atomicMin(&L.ft[c3], pos); }
+                cc[j] = -1; vv[j] = 0.0f;
+                if (ss[j] + lane < ee[j]) { cc[j] = a.w_col[ss[j] + lane]; vv[j] = a.w_val[ss[j] + lane]; }
             }
-            for (; ob < ee; ob += 64) {
-                const int o = ob + lane;
-                const bool in = o < ee;
-                int c = 0;
+#pragma unroll
+            for (int j = 0; j < kRowGroup; ++j) {
+                if (ee[j] == ss[j]) continue;   // group not full
                 bool first = false;
-                if (in) {
-                    c = a.w_col[o];
-                    const ACC prod = xx * static_cast<ACC>(a.w_val[o]);
-                    if (TOUCH) first = is_untouched(lds_add_rtn(&acc[c], prod));
-                    else lds_add(&acc[c], prod);
-                    if (FT) atomicMin(&L.ft[c], pos);
+                if (cc[j] >= 0) {
+                    const ACC old = acc[cc[j]];
+                    first = is_untouched(old);
+                    acc[cc[j]] = old + xx[j] * static_cast<ACC>(vv[j]);
+                    if (FT && first) L.ft[cc[j]] = ps[j];
                 }
-                if (TOUCH) push(first, c);
+                if (TOUCH) push(first, cc[j]);
+                // the rest of a long row: kStreamDepth x 64 entries are requested before the first
+                // of them is consumed; the columns of one row are distinct, so the updates of a
+                // batch are issued as reads, then adds, then writes
+                const int eej = ee[j];
+                const ACC xj = xx[j];
+                const uint32_t pos = ps[j];
+                for (int ob = ss[j] + 64; ob < eej; ob += 64 * kStreamDepth) {
+                    int c[kStreamDepth];
+                    float v[kStreamDepth];
+                    ACC old[kStreamDepth];
+#pragma unroll
+                    for (int u = 0; u < kStreamDepth; ++u) {
+                        const int o = ob + u * 64 + lane;
+                        c[u] = -1; v[u] = 0.0f;
+                        if (o < eej) { c[u] = a.w_col[o]; v[u] = a.w_val[o]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < kStreamDepth; ++u) {
+                        old[u] = ACC(0);
+                        if (c[u] >= 0) old[u] = acc[c[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kStreamDepth; ++u) {
+                        if (c[u] >= 0) {
+                            acc[c[u]] = old[u] + xj * static_cast<ACC>(v[u]);
+                            if (FT && is_untouched(old[u])) L.ft[c[u]] = pos;
+                        }
+                    }
+                    if (TOUCH) {
+#pragma unroll
+                        for (int u = 0; u < kStreamDepth; ++u) {
+                            if (ob + u * 64 >= eej) break;
+                            push(c[u] >= 0 && is_untouched(old[u]), c[u]);
+                        }
+                    }
+                }
             }
         }
     }
@@ -411,11 +490,17 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
 
     const int n_rows = FT ? *a.row_list_len : a.n_rows;
     const int total = n_rows * a.n_tiles;
+    // jobs are claimed kQueueChunk at a time: one device-scope counter serves only ~90 claims/us
+    int w_next = 0, w_end = 0;
     for (;;) {
-        int w = 0;
-        if (lane == 0) w = atomicAdd(a.queue, 1);
-        w = readfirst_i(w);
-        if (w >= total) break;
+        if (w_next >= w_end) {
+            int w0 = 0;
+            if (lane == 0) w0 = atomicAdd(a.queue, kQueueChunk);
+            w_next = readfirst_i(w0);
+            if (w_next >= total) break;
+            w_end = min(w_next + kQueueChunk, total);
+        }
+        const int w = w_next++;
         const int tile = w / n_rows;             // tile-major: concurrent waves share a W tile in L2
         const int row = FT ? a.row_list[w % n_rows] : (w % n_rows);
         const int t0 = tile * S;
@@ -424,10 +509,10 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
         const int a0 = a.xb_ptr[xrow];
         const int n_a = a.xb_ptr[xrow + 1] - a0;
 
-        const int tcnt = accumulate_tile<ACC, FT, true>(a, L, a0, n_a, tile);
+        const int tcnt = (a.ablate & 1) ? 0 : accumulate_tile<ACC, FT, true>(a, L, a0, n_a, tile);
         const bool overflow = tcnt > kTouchCap;
 
-        if (a.filter && tcnt > 0) {   // interacted items that received a score leave the race
+        if (a.filter && tcnt > 0 && !(a.ablate & 8)) {   // interacted items that received a score leave the race
             for (int p = lane; p < n_a; p += 64) {
                 const int item = a.xb_col[a0 + p];
                 const int lc = (a.col_map ? (item < a.n_items ? a.col_map[item] : -1) : item - a.col_offset) - t0;
@@ -435,17 +520,21 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
             }
         }
         int n_out = 0;
-        if (tcnt > 0) {
+        if (tcnt > 0 && !(a.ablate & 2)) {
             if (!overflow) n_out = select_topk<ACC, FT>(a, L, IdxList{L.tlist}, tcnt, t0, /*zero_valid=*/false);
             else n_out = select_topk<ACC, FT>(a, L, IdxAll{}, ncol, t0, /*zero_valid=*/false);
         }
         emit_result<ACC>(a, L, row, tile, n_out);
 
         // restore the invariant
-        if (!overflow) {
+        if (a.ablate & 4) {
+        } else if (!overflow) {
             for (int t = lane; t < tcnt; t += 64) { const int c = L.tlist[t]; L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
         } else {
-            for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
+            for (int c = lane * 4; c < S; c += 256) {
+                L.acc[c] = unt; L.acc[c + 1] = unt; L.acc[c + 2] = unt; L.acc[c + 3] = unt;
+                if (FT) { L.ft[c] = 0xffffffffu; L.ft[c + 1] = 0xffffffffu; L.ft[c + 2] = 0xffffffffu; L.ft[c + 3] = 0xffffffffu; }
+            }
         }
     }
 }
@@ -788,6 +877,7 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     a.tile_cols = tile_cols; a.n_tiles = n_tiles;
     a.tile_ptr = d_tile_ptr; a.w_col = d_w_col; a.w_val = d_w_val; a.col_rank = d_col_rank;
     a.filter = filter_interacted; a.mode = mode;
+    { const char *ab = std::getenv("RTREC_AMD_ABLATE"); a.ablate = ab ? std::atoi(ab) : 0; }
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned char *ws = static_cast<unsigned char *>(d_workspace);
     if (acc_f64)
