@@ -127,7 +127,7 @@ def main() -> None:
         G = world
         outs = []
         for t_ in (ids, sc, aux, cnt):
-            o = eng.be.empty((G,) + tuple(t_.shape), t_.dtype)
+            o = eng.be.empty((G * t_.shape[0],) + tuple(t_.shape[1:]), t_.dtype)
             dist.all_gather_into_tensor(o, t_.contiguous())
             outs.append(o)
         o_ids = eng.be.empty((U, top_k), torch.int32)

@@ -128,6 +128,55 @@ class HipBackend:
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
 
+    # -- the C-ABI, one method per entry point (tests substitute a CPU stand-in with the same
+    #    methods to exercise the multi-process orchestration without a GPU) -------------------
+    def column_sqnorms(self, n_items, cptr, cval, out):
+        _native.check(self.lib.rtrec_slim_column_sqnorms(n_items, self.ptr(cptr), self.ptr(cval), self.ptr(out),
+                                                         self.stream()), "rtrec_slim_column_sqnorms")
+
+    def fit_workspace(self, n_users, n_items, slots, top_features):
+        nbytes = int(self.lib.rtrec_slim_fit_workspace_bytes(n_users, n_items, slots, top_features))
+        ws = self.empty((nbytes,), self.torch.uint8)
+        _native.check(self.lib.rtrec_slim_fit_workspace_init(self.ptr(ws), nbytes, n_users, n_items, slots,
+                                                             top_features, self.stream()),
+                      "rtrec_slim_fit_workspace_init")
+        return ws, self.zeros((1,), self.torch.int32)
+
+    def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
+                    ws, queue, slots):
+        _native.check(self.lib.rtrec_slim_fit_columns(
+            n_users, n_items, self.ptr(X["cptr"]), self.ptr(X["crow"]), self.ptr(X["cval"]),
+            self.ptr(X["rptr"]), self.ptr(X["rcol"]), self.ptr(X["rval"]), self.ptr(X["sqn"]),
+            self.ptr(targets), int(targets.shape[0]), C.byref(cfg), self.ptr(out_items), self.ptr(out_coef),
+            self.ptr(out_count), self.ptr(out_niter), cap, self.ptr(ws), ws.numel(), slots, self.ptr(queue),
+            self.stream()), "rtrec_slim_fit_columns")
+
+    def score_workspace_bytes(self, n_rows, n_tiles, top_k):
+        return int(self.lib.rtrec_slim_score_workspace_bytes(n_rows, n_tiles, top_k))
+
+    def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
+                   acc_f64, ids, sc, sc64, aux, cnt, ws):
+        _native.check(self.lib.rtrec_slim_score_topk(
+            n_rows, self.ptr(row_ids), self.ptr(xb[0]), self.ptr(xb[1]), self.ptr(xb[2]),
+            n_items, lay["n_cols"], col_lo, self.ptr(lay["col_ids"]), self.ptr(lay["col_map"]),
+            lay["tile_cols"], lay["n_tiles"],
+            self.ptr(lay["tile_ptr"]), self.ptr(lay["w_col"]), self.ptr(lay["w_val"]), self.ptr(col_rank),
+            top_k, int(bool(filter_interacted)), int(mode), int(acc_f64),
+            self.ptr(ids), self.ptr(sc), self.ptr(sc64), self.ptr(aux), self.ptr(cnt),
+            self.ptr(ws), ws.numel(), self.stream()), "rtrec_slim_score_topk")
+
+    def merge_topk(self, n_rows, n_lists, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt):
+        _native.check(self.lib.rtrec_slim_merge_topk(n_rows, n_lists, top_k, self.ptr(g_ids), self.ptr(g_sc),
+                                                     self.ptr(g_sc64), self.ptr(g_aux), self.ptr(g_cnt),
+                                                     self.ptr(o_ids), self.ptr(o_sc), self.ptr(o_cnt),
+                                                     self.stream()), "rtrec_slim_merge_topk")
+
+    def similar_topk(self, queries, W, top_k, ids, sc, cnt):
+        _native.check(self.lib.rtrec_slim_similar_topk(int(queries.shape[0]), self.ptr(queries), self.ptr(W["cptr"]),
+                                                       self.ptr(W["crow"]), self.ptr(W["cval"]), top_k,
+                                                       self.ptr(ids), self.ptr(sc), self.ptr(cnt), self.stream()),
+                      "rtrec_slim_similar_topk")
+
 
 class SlimEngine:
     """Fit / score / similar-items on one GPU (one shard of W)."""
@@ -204,8 +253,7 @@ class SlimEngine:
         torch = be.torch
         if "sqn" not in X:
             X["sqn"] = be.empty((I,), torch.float32)
-            _native.check(be.lib.rtrec_slim_column_sqnorms(I, be.ptr(X["cptr"]), be.ptr(X["cval"]), be.ptr(X["sqn"]),
-                                                           be.stream()), "rtrec_slim_column_sqnorms")
+            be.column_sqnorms(I, X["cptr"], X["cval"], X["sqn"])
         n = len(targets)
         slots = int(n_slots or min(MAX_SLOTS, max(1, n)))
         # keep the per-slot scratch (R: U floats, s/touched/cand: I each) within ~8 GiB
@@ -214,12 +262,8 @@ class SlimEngine:
         ws_key = (U, I, slots, K if K > 0 else 0)
         if ws_key not in self._fit_ws:
             self._fit_ws.clear()
-            nbytes = int(be.lib.rtrec_slim_fit_workspace_bytes(U, I, slots, K))
-            ws = be.empty((nbytes,), torch.uint8)
-            _native.check(be.lib.rtrec_slim_fit_workspace_init(be.ptr(ws), nbytes, U, I, slots, K, be.stream()),
-                          "rtrec_slim_fit_workspace_init")
-            self._fit_ws[ws_key] = (ws, nbytes, be.zeros((1,), torch.int32))
-        ws, nbytes, queue = self._fit_ws[ws_key]
+            self._fit_ws[ws_key] = be.fit_workspace(U, I, slots, K)
+        ws, queue = self._fit_ws[ws_key]
 
         # chunk so that the output block stays below ~1 GiB (matters for K=None, cap = I)
         chunk = max(1, min(n, int((1 << 30) // max(cap * 8, 1)))) if n else 1
@@ -235,11 +279,7 @@ class SlimEngine:
             d_coef = be.empty((m, cap), torch.float32)
             d_count = be.empty((m,), torch.int32)
             d_niter = be.empty((m,), torch.int32)
-            _native.check(be.lib.rtrec_slim_fit_columns(
-                U, I, be.ptr(X["cptr"]), be.ptr(X["crow"]), be.ptr(X["cval"]),
-                be.ptr(X["rptr"]), be.ptr(X["rcol"]), be.ptr(X["rval"]), be.ptr(X["sqn"]),
-                be.ptr(d_t), m, C.byref(cfg), be.ptr(d_items), be.ptr(d_coef), be.ptr(d_count), be.ptr(d_niter),
-                cap, be.ptr(ws), nbytes, slots, be.ptr(queue), be.stream()), "rtrec_slim_fit_columns")
+            be.fit_columns(U, I, X, d_t, cfg, d_items, d_coef, d_count, d_niter, cap, ws, queue, slots)
             items_out[s:s + m] = d_items.cpu().numpy()
             coef_out[s:s + m] = d_coef.cpu().numpy()
             count_out[s:s + m] = d_count.cpu().numpy()
@@ -299,18 +339,11 @@ class SlimEngine:
             if sc64 is not None:
                 sc64.fill_(float("-inf"))
             return ids, sc, sc64, aux, cnt
-        need = int(be.lib.rtrec_slim_score_workspace_bytes(n_rows, lay["n_tiles"], top_k))
+        need = be.score_workspace_bytes(n_rows, lay["n_tiles"], top_k)
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = be.empty((need,), torch.uint8)
-        ws = self._score_ws
-        _native.check(be.lib.rtrec_slim_score_topk(
-            n_rows, be.ptr(d_row_ids), be.ptr(xb[0]), be.ptr(xb[1]), be.ptr(xb[2]),
-            W["n_items"], lay["n_cols"], W["col_lo"], be.ptr(lay["col_ids"]), be.ptr(lay["col_map"]),
-            lay["tile_cols"], lay["n_tiles"],
-            be.ptr(lay["tile_ptr"]), be.ptr(lay["w_col"]), be.ptr(lay["w_val"]), be.ptr(d_col_rank),
-            top_k, int(bool(filter_interacted)), int(mode), int(W["acc_f64"]),
-            be.ptr(ids), be.ptr(sc), be.ptr(sc64), be.ptr(aux), be.ptr(cnt),
-            be.ptr(ws), ws.numel(), be.stream()), "rtrec_slim_score_topk")
+        be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
+                      mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws)
         return ids, sc, sc64, aux, cnt
 
     def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
@@ -331,18 +364,16 @@ class SlimEngine:
         torch = be.torch
         G = self.world_size
 
-        def gather(t):
-            out = be.empty((G,) + tuple(t.shape), t.dtype)
+        def gather(t):   # one fused all-gather per array: [G * n_rows, ...] viewed as [G, n_rows, ...]
+            out = be.empty((G * t.shape[0],) + tuple(t.shape[1:]), t.dtype)
             dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-            return out
+            return out.view((G,) + tuple(t.shape))
         g_ids, g_sc, g_aux, g_cnt = gather(ids), gather(sc), gather(aux), gather(cnt)
         g_sc64 = gather(sc64) if sc64 is not None else None
         o_ids = be.empty((n_rows, top_k), torch.int32)
         o_sc = be.empty((n_rows, top_k), torch.float32)
         o_cnt = be.empty((n_rows,), torch.int32)
-        _native.check(be.lib.rtrec_slim_merge_topk(n_rows, G, top_k, be.ptr(g_ids), be.ptr(g_sc), be.ptr(g_sc64),
-                                                   be.ptr(g_aux), be.ptr(g_cnt), be.ptr(o_ids), be.ptr(o_sc),
-                                                   be.ptr(o_cnt), be.stream()), "rtrec_slim_merge_topk")
+        be.merge_topk(n_rows, G, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt)
         return o_ids, o_sc, o_cnt
 
     def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
@@ -384,9 +415,7 @@ class SlimEngine:
         ids = be.empty((n, top_k), torch.int32)
         sc = be.empty((n, top_k), torch.float32)
         cnt = be.empty((n,), torch.int32)
-        _native.check(be.lib.rtrec_slim_similar_topk(n, be.ptr(d_q), be.ptr(W["cptr"]), be.ptr(W["crow"]),
-                                                     be.ptr(W["cval"]), top_k, be.ptr(ids), be.ptr(sc), be.ptr(cnt),
-                                                     be.stream()), "rtrec_slim_similar_topk")
+        be.similar_topk(d_q, W, top_k, ids, sc, cnt)
         return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
 
 

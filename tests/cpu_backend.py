@@ -1,0 +1,113 @@
+"""CPU stand-in for rtrec_amd.engine.HipBackend, built on the oracle.  TEST-ONLY.
+
+Lets the multi-process orchestration of SlimEngine / SLIMElastic (column sharding, the
+all-gather of per-shard top-k, the coefficient gather) run under gloo on a machine without a
+GPU.  It is never importable from the product package; the product path has no CPU fallback.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from oracle import slim_oracle as so
+
+
+class OracleBackend:
+    def __init__(self):
+        self.torch = torch
+        self.device = torch.device("cpu")
+
+    def to_dev(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a).copy())
+
+    def empty(self, shape, dtype):
+        return torch.empty(shape, dtype=dtype)
+
+    def zeros(self, shape, dtype):
+        return torch.zeros(shape, dtype=dtype)
+
+    def synchronize(self):
+        pass
+
+    # ---- ops -------------------------------------------------------------------------
+    def column_sqnorms(self, n_items, cptr, cval, out):
+        out.zero_()
+
+    def fit_workspace(self, n_users, n_items, slots, top_features):
+        return torch.zeros(1, dtype=torch.uint8), torch.zeros(1, dtype=torch.int32)
+
+    def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
+                    ws, queue, slots):
+        Xc = sp.csc_matrix((X["cval"].numpy(), X["crow"].numpy(), X["cptr"].numpy()), shape=(n_users, n_items))
+        tg = targets.numpy()
+        L = so.lib()
+        import ctypes as C
+        for t, j in enumerate(tg):
+            idx = np.empty(n_items, np.int32)
+            val = np.empty(n_items, np.float32)
+            nit, gap = C.c_int32(0), C.c_float(0)
+            n = L.slim_oracle_fit_column(
+                n_users, n_items, np.ascontiguousarray(Xc.data, np.float32), np.ascontiguousarray(Xc.indices, np.int32),
+                np.ascontiguousarray(Xc.indptr, np.int32), int(j),
+                # undo the scaling the engine applied: the oracle takes alpha / l1_ratio
+                *self._alpha_l1(cfg, n_users), float(cfg.tol), int(cfg.max_iter), int(cfg.seed), int(cfg.positive),
+                int(cfg.top_features), idx, val, C.byref(nit), C.byref(gap))
+            out_items[t, :n] = torch.from_numpy(idx[:n])
+            out_coef[t, :n] = torch.from_numpy(val[:n])
+            out_count[t] = n
+            out_niter[t] = nit.value
+
+    @staticmethod
+    def _alpha_l1(cfg, n_users):
+        a, b = float(cfg.l1_reg) / n_users, float(cfg.l2_reg) / n_users   # alpha*l1, alpha*(1-l1)
+        alpha = a + b
+        return alpha, (a / alpha if alpha else 0.0)
+
+    def score_workspace_bytes(self, n_rows, n_tiles, top_k):
+        return 1
+
+    def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
+                   acc_f64, ids, sc, sc64, aux, cnt, ws):
+        # rebuild this shard's W (n_items x n_items, only the shard's columns populated)
+        S, T = lay["tile_cols"], lay["n_tiles"]
+        tp = lay["tile_ptr"].numpy().reshape(T, n_items + 1)
+        wc = lay["w_col"].numpy().view(np.uint16).astype(np.int64)
+        wv = lay["w_val"].numpy()
+        rows, cols = [], []
+        for t in range(T):
+            cnt_t = np.diff(tp[t])
+            rows.append(np.repeat(np.arange(n_items), cnt_t))
+            loc = wc[tp[t, 0]:tp[t, -1]] + t * S
+            cols.append(lay["col_ids"].numpy()[loc] if lay["col_ids"] is not None else loc + col_lo)
+        Wr = sp.csr_matrix((wv, (np.concatenate(rows), np.concatenate(cols))), shape=(n_items, n_items))
+        ptr, col, val = (t.numpy() for t in xb)
+        Xall = sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, n_items))
+        rsel = row_ids.numpy() if row_ids is not None else np.arange(n_rows)
+        o_ids, o_sc, o_cnt = so.recommend_batch(Xall[rsel], Wr, top_k=top_k, filter_interacted=filter_interacted,
+                                                dense=(mode == 1), use_f64=bool(acc_f64))
+        ids.copy_(torch.from_numpy(o_ids)); sc.copy_(torch.from_numpy(o_sc)); cnt.copy_(torch.from_numpy(o_cnt))
+        aux.zero_()
+        if sc64 is not None:
+            sc64.copy_(torch.from_numpy(o_sc.astype(np.float64)))
+
+    def merge_topk(self, n_rows, n_lists, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt):
+        gi, gs, ga, gc = g_ids.numpy(), g_sc.numpy(), g_aux.numpy().view(np.uint32), g_cnt.numpy()
+        for r in range(n_rows):
+            cand = [(gs[l, r, k], ga[l, r, k], gi[l, r, k]) for l in range(n_lists) for k in range(gc[l, r])]
+            cand.sort(key=lambda c: (-c[0], -int(c[1]), -int(c[2])))
+            cand = cand[:top_k]
+            o_cnt[r] = len(cand)
+            for k in range(top_k):
+                o_ids[r, k] = int(cand[k][2]) if k < len(cand) else -1
+                o_sc[r, k] = float(cand[k][0]) if k < len(cand) else float("-inf")
+
+    def similar_topk(self, queries, W, top_k, ids, sc, cnt):
+        n_items = W["cptr"].shape[0] - 1
+        Wc = sp.csc_matrix((W["cval"].numpy(), W["crow"].numpy(), W["cptr"].numpy()), shape=(n_items, n_items))
+        ids.fill_(-1); sc.fill_(float("-inf"))
+        for q, j in enumerate(queries.numpy()):
+            oi, ov = so.similar_items(Wc, int(j), top_k=top_k)
+            ids[q, :len(oi)] = torch.from_numpy(oi)
+            sc[q, :len(oi)] = torch.from_numpy(ov)
+            cnt[q] = len(oi)

@@ -1,0 +1,124 @@
+"""Drop-in API on the real GPU path: rtrec_amd.SLIM / Recommender vs golden outputs of the
+reference (tests/golden/, tools/gen_golden.py)."""
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_csc(z, prefix):
+    return sp.csc_matrix((z[f"{prefix}_data"], z[f"{prefix}_indices"], z[f"{prefix}_indptr"]),
+                         shape=tuple(z[f"{prefix}_shape"]))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def same_matrix(A, B):
+    A, B = A.tocsc(), B.tocsc()
+    A.sort_indices(); B.sort_indices()
+    return (A.shape == B.shape and np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+            and np.array_equal(bits(A.data), bits(B.data)))
+
+
+def test_reference_unit_test_scenarios():
+    from rtrec_amd import SLIM
+    api = json.load(open(os.path.join(G, "api.json")))
+    m = SLIM()
+    m.fit([tuple(x) for x in api["similar_items"]["interactions"]])
+    assert m.similar_items("item_1", top_k=5) == ["item_4", "item_3"] == api["similar_items"]["similar_item_1"]
+    got = m.similar_items("item_1", top_k=5, ret_scores=True)
+    ref = api["similar_items"]["similar_item_1_scores"]
+    assert [a for a, _ in got] == [a for a, _ in ref]
+    assert np.array_equal(bits([b for _, b in got]), bits([b for _, b in ref]))
+    assert m.recommend("user_2", top_k=5) == api["similar_items"]["recommend_user_2"]
+
+    m = SLIM()
+    inter = [tuple(x) for x in api["fit_and_recommend"]["interactions"]]
+    m.fit(inter)
+    m.fit(iter(inter))            # generator input, additive re-ingest
+    assert m.recommend("user_1", top_k=5) == ["item_4", "item_2"] == api["fit_and_recommend"]["recommend_user_1"]
+    assert m.interactions.get_user_item_rating(0, 0) == api["fit_and_recommend"]["rating_u1_i1"]
+
+    m = SLIM()
+    m.fit([tuple(x) for x in api["recommend_batch"]["interactions"]])
+    users = ["user_1", "user_2", "user_3"]
+    ref = api["recommend_batch"]
+    assert m.recommend_batch(users, top_k=2) == ref["top2"]
+    assert m.recommend_batch(users, candidate_items=["item_1", "item_2", "item_3"], top_k=2) == ref["cands"]
+    assert m.recommend_batch(["user_1"], top_k=3, filter_interacted=False) == ref["nofilter_u1"]
+    assert m.recommend_batch(["user_1", "nobody"], top_k=2) == ref["cold"]
+    assert m.recommend_batch([], top_k=2) == []
+
+    m = SLIM()
+    m.fit([tuple(x) for x in api["int_ids"]["interactions"]])
+    assert m.recommend_batch([1, 2, 3, 4], top_k=3) == api["int_ids"]["top3"]
+    assert m.recommend_batch([1, 2, 3, 4], top_k=3, filter_interacted=False) == api["int_ids"]["nofilter"]
+    assert m.recommend(99, top_k=3) == api["int_ids"]["cold_99"]
+    assert m.similar_items(10, top_k=3) == api["int_ids"]["similar_10"]
+    buf = io.BytesIO()
+    m.save(buf)
+    m2 = SLIM.loads(buf.getvalue())
+    assert m2.recommend_batch([1, 2, 3, 4], top_k=3) == api["int_ids"]["top3"]
+
+
+@pytest.mark.parametrize("name,kw", [("k5", {"nn_feature_selection": 5}), ("all", {})])
+def test_incremental_fit_sequence_on_gpu(name, kw):
+    from rtrec_amd import SLIM
+    z = np.load(os.path.join(G, "partial_fit.npz"))
+    u, i, v, ts = z["u"], z["i"], z["v"], z["ts"]
+    m = SLIM(min_value=0, max_value=15, **kw)
+    for label, key, upsert in (("A", "A", False), ("B", "B", False), ("C_add", "C", False), ("C_upsert", "C", True)):
+        a, b = z[key]
+        batch = [(int(x), int(y), float(t), float(r)) for x, y, t, r in zip(u[a:b], i[a:b], ts[a:b], v[a:b])]
+        m.fit(batch, update_interaction=upsert, progress_bar=False)
+        assert same_matrix(m.model.item_similarity, load_csc(z, f"W_{name}_{label}")), f"{name} after {label}"
+    users = z[f"rec_users_{name}"].tolist()
+    assert m.recommend_batch(users, top_k=5) == [[x for x in row.tolist() if x >= 0] for row in z[f"rec_{name}"]]
+
+
+def test_slimelastic_matches_reference_models_and_scores():
+    from rtrec_amd.models.internal.slim_elastic import SLIMElastic
+    z = np.load(os.path.join(G, "models.npz"))
+    zs = np.load(os.path.join(G, "scoring.npz"))
+    X = load_csc(z, "X")
+    assert same_matrix(SLIMElastic({}).fit(X.copy()).item_similarity, load_csc(z, "W_serial_all"))
+    assert same_matrix(SLIMElastic({"nn_feature_selection": 8}).fit(X.copy(), parallel=True).item_similarity,
+                       load_csc(z, "W_parallel_k8"))
+    assert same_matrix(SLIMElastic({"nn_feature_selection": 8, "positive_only": False})
+                       .partial_fit_items(X.copy(), list(range(60))).item_similarity, load_csc(z, "W_nonpos_k8"))
+    X2 = load_csc(z, "X2")
+    m = SLIMElastic({"nn_feature_selection": 50}).partial_fit_items(X2.copy(), list(range(400)))
+    assert same_matrix(m.item_similarity, load_csc(z, "W2_k50"))
+    users = zs["users"].tolist()
+    Xr = X2.tocsr()
+    for wname in ("f32", "f64"):
+        if wname == "f64":
+            m.item_similarity = sp.csc_matrix(m.item_similarity, dtype=np.float64)
+        for filt in (True, False):
+            out = m.recommend_batch(users, Xr, top_k=10, filter_interacted=filt, dense_output=False, ret_scores=True)
+            key = f"{wname}_sparse_{'filter' if filt else 'nofilter'}"
+            for r, (ids, sc) in enumerate(out):
+                ref = [x for x in zs[f"ids_{key}"][r].tolist() if x >= 0]
+                assert ids == ref
+                assert np.array_equal(bits(sc), bits(zs[f"scores_{key}"][r, :len(ref)]))
+    m.item_similarity = load_csc(z, "W2_k50")
+    out = m.recommend_batch(users, Xr, candidate_item_ids=zs["cands"].tolist(), top_k=5, ret_scores=True)
+    for r, (ids, sc) in enumerate(out):
+        g = zs["scores_cands"][r]
+        n = next((k for k in range(4) if g[k] == g[k + 1]), 5)       # untied prefix (D1)
+        assert ids[:n] == zs["ids_cands"][r, :n].tolist()
+        assert np.array_equal(bits(sc[:n]), bits(g[:n]))
+    for j in range(0, 400, 7):
+        ids, sc = m.similar_items(j, top_k=6, ret_ndarrays=True)
+        g = zs["similar_scores"][j]
+        fin = int(np.sum(np.isfinite(g)))
+        n = next((k for k in range(fin - 1) if g[k] == g[k + 1]), fin)
+        assert ids[:n].tolist() == zs["similar_ids"][j, :n].tolist()

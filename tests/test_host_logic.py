@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference interface: store, ids, LRU, metrics, W write-back, layouts.
+
+Expected values are either golden vectors produced by the real reference (tests/golden/, see
+tools/gen_golden.py) or the expectations of the reference's own unit tests restated
+(/root/reference/tests/utils/test_interactions.py, test_lru.py, test_metrics.py).
+"""
+import json
+import os
+import time
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from rtrec_amd.engine import build_tiled_w, coefficients_to_updates, merge_coefficients, shard_bounds, sklearn_seed
+from rtrec_amd.utils.identifiers import Identifier, IdentifierError
+from rtrec_amd.utils.interactions import UserItemInteractions
+from rtrec_amd.utils.lru import LRUFreqSet
+from rtrec_amd.utils import metrics
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_csc(z, prefix):
+    return sp.csc_matrix((z[f"{prefix}_data"], z[f"{prefix}_indices"], z[f"{prefix}_indptr"]),
+                         shape=tuple(z[f"{prefix}_shape"]))
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+# ------------------------------------------------------------------ interaction store
+@pytest.mark.parametrize("name,kw,upsert", [("plain", {}, False), ("decay7", {"decay_in_days": 7}, False),
+                                            ("decay7_upsert", {"decay_in_days": 7}, True),
+                                            ("clip", {"min_value": -1, "max_value": 4}, False)])
+@pytest.mark.parametrize("batch", [1, 7, 400])
+def test_store_matches_reference(name, kw, upsert, batch):
+    d = json.load(open(os.path.join(G, "store.json")))
+    ev, ref = d["events"], d[name]
+    s = UserItemInteractions(**kw)
+    for a in range(0, len(ev["u"]), batch):   # batched ingest must equal one-by-one ingest
+        s.add_interactions_batch(ev["u"][a:a + batch], ev["i"][a:a + batch], ev["ts"][a:a + batch],
+                                 ev["r"][a:a + batch], upsert=upsert)
+    assert list(s.shape) == ref["shape"]
+    assert s.max_timestamp == ref["max_timestamp"]
+    # float32 matrices: identical up to 1 ulp (numpy's vectorised pow vs libm pow)
+    for got, exp in ((s.to_csr().toarray(), ref["csr"]), (s.to_csc([1, 3, 5, 24]).toarray(), ref["csc_sel"]),
+                     (s.to_csr([0, 2, 29]).toarray(), ref["csr_sel"])):
+        exp = np.asarray(exp, dtype=np.float32)
+        assert got.dtype == np.float32 and got.shape == exp.shape
+        assert np.array_equal(got != 0, exp != 0)
+        assert np.max(np.abs(bits(got).astype(np.int64) - bits(exp).astype(np.int64))) <= 1
+    assert s.get_hot_items(10, filter_interacted=False) == ref["hot"]
+    assert s.get_user_item_rating(3, 4) == pytest.approx(ref["rating_3_4"], rel=1e-12)
+    assert sorted(s.get_user_items(5)) == ref["user_items_5"]
+
+
+def test_decay_rates_match_reference():
+    d = json.load(open(os.path.join(G, "store.json")))["decay_rate"]
+    for days, rate in d.items():
+        assert UserItemInteractions(decay_in_days=int(days)).decay_rate == rate
+    assert UserItemInteractions(decay_in_days=7).decay_rate == 0.9009789742057221
+
+
+def test_store_reference_unit_expectations():
+    s = UserItemInteractions(min_value=-5, max_value=10)
+    t = time.time()
+    s.add_interaction(1, 10, t, 5.0)
+    assert s.get_user_item_rating(1, 10) == 5.0
+    s.add_interaction(1, 10, t, 3.0)
+    assert s.get_user_item_rating(1, 10) == 8.0
+    s.add_interaction(1, 10, t, 5.0)
+    assert s.get_user_item_rating(1, 10) == 10.0          # clipped
+    s.add_interaction(1, 20, t, -2.0)
+    s.add_interaction(2, 15, t, 3.0)
+    s.add_interaction(3, 9, t, 3.0)
+    assert set(s.get_all_non_interacted_items(1)) == {15, 9}
+    assert set(s.get_all_non_negative_items(1)) == {10, 15, 9}
+    assert set(s.get_all_users()) == {1, 2, 3}
+    assert set(s.get_user_items(1)) == {10, 20}
+    assert s.get_user_items(99) == [] and s.get_user_item_rating(99, 10) == 0.0
+    assert s.has_interaction(1, 20) and not s.has_interaction(1, 21)
+    assert set(s.get_users_by_items([10, 9])) == {1, 3}
+    s.add_interaction(1, 10, t, -10.0)
+    assert s.get_user_item_rating(1, 10) == 0.0 and 10 in s.get_user_items(1)
+
+
+def test_decay_half_life():
+    s = UserItemInteractions(min_value=-5, max_value=10, decay_in_days=7)
+    now = time.time()
+    s.add_interaction(1, 10, now - 7 * 86400, 5.0)
+    s.add_interaction(2, 10, now, 5.0)          # advances max_timestamp
+    r = s.get_user_item_rating(1, 10)
+    assert abs(r - 2.5) < 0.1
+    assert abs(r - 5.0 * s.decay_rate ** ((s.max_timestamp - (now - 7 * 86400)) / 86400.0)) < 1e-9
+
+
+def test_to_csc_exact_small():
+    s = UserItemInteractions(min_value=-5, max_value=10, decay_in_days=None)
+    s.add_interaction(0, 0, tstamp=12345, delta=5)
+    s.add_interaction(0, 2, tstamp=12345, delta=3)
+    s.add_interaction(1, 1, tstamp=12345, delta=2)
+    s.add_interaction(2, 2, tstamp=12345, delta=4)
+    assert np.array_equal(s.to_csc().toarray(), np.array([[5, 0, 3], [0, 2, 0], [0, 0, 4]], dtype=np.float32))
+    assert np.array_equal(s.to_csc([2]).toarray(), np.array([[0, 0, 3], [0, 0, 0], [0, 0, 4]], dtype=np.float32))
+    assert np.array_equal(s.to_coo(select_users=[0], select_items=[2]).toarray(),
+                          np.array([[0, 0, 3], [0, 0, 0], [0, 0, 0]], dtype=np.float32))
+    assert s.to_csr(include_weights=False).dtype == np.int32
+
+
+# ------------------------------------------------------------------ identifiers / LRU
+def test_identifier_semantics():
+    ids = Identifier(name="user")
+    assert ids.identify(7) == 7 and ids.pass_through is True and ids.get(7) == 7 and ids.get_id(9) == 9
+    with pytest.raises(ValueError, match="Mixed types"):
+        ids.identify("x")
+    s = Identifier(name="item")
+    assert [s.identify(x) for x in ("a", "b", "a")] == [0, 1, 0] and s.pass_through is False
+    assert s.get(1) == "b" and s.get_id("b") == 1 and s.get_id("zz") is None and s[0] == "a"
+    with pytest.raises(ValueError):
+        s.identify(3)
+    with pytest.raises(ValueError):
+        s.get_id(3)
+    with pytest.raises(IdentifierError):
+        s.get(5)
+    assert s.get_or_default(5, "d") == "d"
+    f = Identifier(force_identify=True)
+    assert f.identify(100) == 0 and f.identify(np.int64(5)) == 1 and f.get(0) == 100
+    assert Identifier().identify_many(np.array([4, 2, 9])).tolist() == [4, 2, 9]
+    assert Identifier().identify_many(["q", "r", "q"]).tolist() == [0, 1, 0]
+
+
+def test_lru_freq_set():
+    l = LRUFreqSet(capacity=3)
+    for v in (1, 2, 3, 1, 4):        # 2 is evicted (least recently used), 1 was refreshed
+        l.add(v)
+    assert list(l) == [3, 1, 4] and 2 not in l and len(l) == 3
+    assert list(l.get_freq_items()) == [1, 3, 4] and list(l.get_freq_items(1)) == [1]
+    assert list(l.get_freq_items(2, exclude_items=[1])) == [3, 4]
+    with pytest.raises(KeyError):
+        l.discard(99)
+    with pytest.raises(ValueError):
+        LRUFreqSet(0)
+    rng = np.random.default_rng(0)
+    seq = rng.integers(0, 40, 500).tolist()
+    for cap in (5, 64):
+        a, b = LRUFreqSet(cap), LRUFreqSet(cap)
+        for v in seq:
+            a.add(v)
+        for s in range(0, 500, 37):
+            b.add_many(seq[s:s + 37])
+        assert list(a.data.items()) == list(b.data.items())
+
+
+# ------------------------------------------------------------------ metrics (reference formulas)
+def test_metrics_known_values():
+    ranked, truth = [1, 2, 3, 4, 5], [2, 5, 9]
+    assert metrics.precision(ranked, truth, 5) == pytest.approx(0.4)
+    assert metrics.recall(ranked, truth, 5) == pytest.approx(2 / 3)
+    assert metrics.hit(ranked, truth, 5) == 1.0 and metrics.true_positives(ranked, truth, 5) == 2
+    assert metrics.reciprocal_rank(ranked, truth, 5) == 0.5
+    from math import log2
+    dcg = 1 / log2(3) + 1 / log2(6)
+    idcg = 1 / log2(2) + 1 / log2(3) + 1 / log2(4)
+    assert metrics.ndcg(ranked, truth, 5) == pytest.approx(dcg / idcg)
+    assert metrics.average_precision(ranked, truth, 5) == pytest.approx((1 / 2 + 2 / 5) / 3)
+    assert metrics.auc(ranked, truth, 5) == pytest.approx((1 + 1 + 0) / 6)    # misses 3,4 after hit 2; none after 5
+    assert metrics.precision([], [], 5) == 1.0 and metrics.f1_score([], [], 5) == 1.0 and metrics.auc([1], [], 5) == 0.0
+    out = metrics.compute_scores([(ranked, truth), ([7], [7])], 5)
+    assert out["tp"] == 3 and out["hit_rate"] == 1.0 and out["mrr"] == pytest.approx(0.75)
+    assert metrics.compute_scores([], 5)["ndcg"] == 0.0
+
+
+# ------------------------------------------------------------------ W write-back and layouts
+def test_merge_coefficients_stale_entry_semantics():
+    """non-zero overwrites, explicit zero deletes, unmentioned entries survive."""
+    W0 = sp.csc_matrix(np.array([[0, .5, 0], [.25, 0, .75], [.125, 0, 0]], dtype=np.float32))
+    rows = np.array([0, 1, 2]); cols = np.array([0, 0, 1]); vals = np.array([0.9, 0.0, 0.3], dtype=np.float32)
+    W = merge_coefficients(W0, 3, rows, cols, vals).toarray()
+    assert np.array_equal(W, np.array([[.9, .5, 0], [0, 0, .75], [.125, .3, 0]], dtype=np.float32))
+    W4 = merge_coefficients(W0, 3, rows, cols, vals, dtype=np.float64)
+    assert W4.dtype == np.float64 and W4.has_sorted_indices
+    t, it, co, cnt = np.array([2, 0]), np.array([[1, 0, 9], [2, 9, 9]]), np.array([[.1, .2, 9], [.3, 9, 9]], np.float32), np.array([2, 1])
+    r, c, v = coefficients_to_updates(t, it, co, cnt)
+    assert r.tolist() == [1, 0, 2] and c.tolist() == [2, 2, 0] and np.allclose(v, [.1, .2, .3])
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_tiled_layout_roundtrip(compact):
+    W = sp.random(300, 300, density=0.02, random_state=3, format="csc", dtype=np.float32)
+    W.sort_indices()
+    for lo, hi in ((0, 300), (150, 300)):
+        T = build_tiled_w(W, lo, hi, 256, compact=compact)
+        rows, cols, vals = [], [], []
+        tp = T.tile_ptr.reshape(T.n_tiles, T.n_items + 1)
+        for t in range(T.n_tiles):
+            for i in range(T.n_items):
+                seg = slice(tp[t, i], tp[t, i + 1])
+                loc = T.w_col[seg].astype(np.int64) + t * T.tile_cols
+                assert np.all(np.diff(loc) > 0)          # ascending columns inside a row
+                rows += [i] * len(loc)
+                cols += (T.col_ids[loc] if compact else loc + lo).tolist()
+                vals += T.w_val[seg].tolist()
+        R = sp.csc_matrix((vals, (rows, cols)), shape=(300, 300), dtype=np.float32)
+        assert (R != W[:, lo:hi].tocsc().__class__(sp.hstack([sp.csc_matrix((300, lo)), W[:, lo:hi]]))).nnz == 0
+        if compact:
+            assert np.array_equal(np.flatnonzero(T.col_map >= 0), T.col_ids)
+            assert T.n_cols == int(np.count_nonzero(np.diff(W.indptr[lo:hi + 1])))
+
+
+def test_shard_bounds_and_seed():
+    assert [shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [shard_bounds(3, 8, r) for r in range(8)][:4] == [(0, 1), (1, 2), (2, 3), (3, 3)]
+    assert sklearn_seed(43) == 494155588

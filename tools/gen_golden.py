@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container: imports rtrec from /root/reference (read-only) plus the
+scikit-learn 1.7.2 / scipy 1.15.3 / numpy 2.2.6 it drives, feeds it seeded synthetic inputs and
+stores inputs + outputs as small .npz / .json fixtures.  Nothing here (nor the reference) ships
+to the GPU box; the tests read only the fixtures.
+
+    python tools/gen_golden.py
+
+Inputs use float ("decayed") ratings so that X^T y has no exact ties: numpy's default argsort is
+unstable, so the reference's own choice among tied features is platform-defined.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+import warnings
+
+import numpy as np
+import scipy.sparse as sp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+from ref_import import import_reference  # noqa: E402
+
+import_reference()
+from rtrec.models import SLIM as RefSLIM  # noqa: E402
+from rtrec.models.internal.slim_elastic import SLIMElastic as RefSLIMElastic  # noqa: E402
+from rtrec.utils.interactions import UserItemInteractions as RefStore  # noqa: E402
+from sklearn.exceptions import ConvergenceWarning  # noqa: E402
+from sklearn.linear_model import ElasticNet  # noqa: E402
+
+from rtrec_amd.synth import interaction_matrix  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+warnings.simplefilter("ignore", ConvergenceWarning)
+T0 = 1_700_000_000.0
+
+
+def csc_parts(M, prefix):
+    M = M.tocsc()
+    M.sort_indices()
+    return {f"{prefix}_data": M.data, f"{prefix}_indices": M.indices.astype(np.int32),
+            f"{prefix}_indptr": M.indptr.astype(np.int32), f"{prefix}_shape": np.array(M.shape),
+            f"{prefix}_dtype": np.array(str(M.dtype))}
+
+
+def pad_lists(lists, k, fill):
+    out = np.full((len(lists), k), fill, dtype=np.float64 if isinstance(fill, float) else np.int64)
+    for r, l in enumerate(lists):
+        out[r, :len(l)] = l
+    return out
+
+
+# ------------------------------------------------------------------ G2: RNG + per-column CD known answers
+def gen_rng():
+    from sklearn.utils import check_random_state
+    d = {}
+    for rs in (43, 0, 1, 7, 12345):
+        seed = int(check_random_state(rs).randint(0, 2147483647))
+        st, draws = seed, []
+        for _ in range(12):
+            st ^= (st << 13) & 0xFFFFFFFF
+            st ^= st >> 17
+            st ^= (st << 5) & 0xFFFFFFFF
+            draws.append(st % 2147483648)
+        d[str(rs)] = {"seed": seed, "mod50": [x % 50 for x in draws], "mod3707": [x % 3707 for x in draws]}
+    json.dump(d, open(os.path.join(OUT, "rng.json"), "w"), indent=1)
+
+
+def gen_cd_columns():
+    X = interaction_matrix(300, 40, 2600, seed=101).tocsc()
+    X.sort_indices()
+    out = csc_parts(X, "X")
+    for name, kw in {"default": {}, "nonpositive": {"positive": False}, "loose": {"tol": 1e-2, "max_iter": 5},
+                     "strong": {"alpha": 0.5, "l1_ratio": 0.5}}.items():
+        coefs, iters = [], []
+        for j in range(X.shape[1]):
+            Xj = X.copy()
+            y = Xj[:, j].toarray().ravel()
+            Xj.data[Xj.indptr[j]:Xj.indptr[j + 1]] = 0
+            m = ElasticNet(alpha=kw.get("alpha", 0.1), l1_ratio=kw.get("l1_ratio", 0.1), fit_intercept=False,
+                           precompute=True, max_iter=kw.get("max_iter", 100), copy_X=False, tol=kw.get("tol", 1e-4),
+                           positive=kw.get("positive", True), random_state=43, selection="random")
+            m.fit(Xj, y)
+            coefs.append(m.coef_.astype(np.float32))
+            iters.append(m.n_iter_)
+        out[f"{name}_coef"] = np.stack(coefs)
+        out[f"{name}_n_iter"] = np.array(iters)
+    np.savez_compressed(os.path.join(OUT, "cd_columns.npz"), **out)
+
+
+# ------------------------------------------------------------------ G3: whole-model W through SLIMElastic
+def gen_models():
+    X = interaction_matrix(200, 60, 1800, seed=202).tocsc()
+    X.sort_indices()
+    out = csc_parts(X, "X")
+    cases = {"serial_all": ({}, "fit"), "serial_k8": ({"nn_feature_selection": 8}, "fit"),
+             "partial_all": ({}, "partial"), "partial_k8": ({"nn_feature_selection": 8}, "partial"),
+             "partial_k100": ({"nn_feature_selection": 100}, "partial"),   # K > I
+             "parallel_k8": ({"nn_feature_selection": 8}, "parallel"),
+             "nonpos_k8": ({"nn_feature_selection": 8, "positive_only": False}, "partial")}
+    for name, (cfg, how) in cases.items():
+        m = RefSLIMElastic(cfg)
+        if how == "fit":
+            m.fit(X.copy())
+        elif how == "parallel":
+            m.fit_in_parallel(X.copy())
+        else:
+            m.partial_fit_items(X.copy(), list(range(X.shape[1])))
+        out.update(csc_parts(m.item_similarity, f"W_{name}"))
+    # a mid-size model with K=50 (the headline setting)
+    X2 = interaction_matrix(1200, 400, 30000, seed=203).tocsc()
+    X2.sort_indices()
+    out.update(csc_parts(X2, "X2"))
+    m = RefSLIMElastic({"nn_feature_selection": 50}).partial_fit_items(X2.copy(), list(range(400)))
+    out.update(csc_parts(m.item_similarity, "W2_k50"))
+    np.savez_compressed(os.path.join(OUT, "models.npz"), **out)
+    return X, X2, m
+
+
+# ------------------------------------------------------------------ G4: incremental fits through SLIM (facts 6, 7)
+def gen_partial():
+    rng = np.random.default_rng(5)
+    X = interaction_matrix(150, 50, 1500, seed=303).tocoo()
+    order = rng.permutation(X.nnz)
+    u, i, v = X.row[order], X.col[order], X.data[order]
+    ts = T0 + np.arange(X.nnz, dtype=np.float64) * 37.0
+    A = slice(0, 900)
+    B = slice(900, 1300)
+    C = slice(700, 1000)       # re-sends part of A: additive updates / upserts
+    out = {"u": u.astype(np.int64), "i": i.astype(np.int64), "v": v.astype(np.float64), "ts": ts,
+           "A": np.array([0, 900]), "B": np.array([900, 1300]), "C": np.array([700, 1000])}
+    for name, kw in {"k5": {"nn_feature_selection": 5}, "all": {}, "k5_decay": {"nn_feature_selection": 5, "decay_in_days": 30}}.items():
+        model = RefSLIM(min_value=0, max_value=15, **kw)
+        steps = [("A", A, False), ("B", B, False), ("C_add", C, False), ("C_upsert", C, True)]
+        for label, sl, upsert in steps:
+            batch = [(int(a), int(b), float(t), float(r)) for a, b, t, r in zip(u[sl], i[sl], ts[sl], v[sl])]
+            model.fit(batch, update_interaction=upsert, progress_bar=False)
+            out.update(csc_parts(model.model.item_similarity, f"W_{name}_{label}"))
+        users = list(range(0, 150, 7))
+        recs = model.recommend_batch(users, top_k=5)
+        out[f"rec_{name}"] = pad_lists(recs, 5, -1)
+        out[f"rec_users_{name}"] = np.array(users)
+    np.savez_compressed(os.path.join(OUT, "partial_fit.npz"), **out)
+
+
+# ------------------------------------------------------------------ G5 / G6: scoring, top-k, similar items
+def gen_scoring(X2, model):
+    Xr = X2.tocsr()
+    Xr.sort_indices()
+    out = {}
+    users = list(range(0, 1200, 5))
+    out["users"] = np.array(users)
+    W32 = model.item_similarity
+    W64 = sp.csc_matrix(W32, dtype=np.float64)
+    for wname, W in (("f32", W32), ("f64", W64)):
+        model.item_similarity = W
+        for dense in (False, True):
+            for filt in (True, False):
+                res = model.recommend_batch(users, Xr, top_k=10, filter_interacted=filt, dense_output=dense, ret_scores=True)
+                key = f"{wname}_{'dense' if dense else 'sparse'}_{'filter' if filt else 'nofilter'}"
+                out[f"ids_{key}"] = pad_lists([r[0] for r in res], 10, -1)
+                out[f"scores_{key}"] = pad_lists([np.asarray(r[1], dtype=np.float64).tolist() for r in res], 10, float("-inf"))
+    model.item_similarity = W32
+    cands = [3, 399, 17, 250, 251, 252, 8, 120, 77, 301, 5, 64]
+    res = model.recommend_batch(users, Xr, candidate_item_ids=cands, top_k=5, ret_scores=True)
+    out["cands"] = np.array(cands)
+    out["ids_cands"] = pad_lists([r[0] for r in res], 5, -1)
+    out["scores_cands"] = pad_lists([np.asarray(r[1], dtype=np.float64).tolist() for r in res], 5, float("-inf"))
+    sim_i, sim_s = [], []
+    for j in range(400):
+        a, b = model.similar_items(j, top_k=6, ret_ndarrays=True)
+        sim_i.append(a.tolist())
+        sim_s.append(b.astype(np.float64).tolist())
+    out["similar_ids"] = pad_lists(sim_i, 6, -1)
+    out["similar_scores"] = pad_lists(sim_s, 6, float("-inf"))
+    np.savez_compressed(os.path.join(OUT, "scoring.npz"), **out)
+
+
+# ------------------------------------------------------------------ G7: interaction store / decay
+def gen_store():
+    d = {"decay_rate": {}}
+    for days in (7, 180, 365):
+        d["decay_rate"][str(days)] = RefStore(decay_in_days=days).decay_rate
+    rng = np.random.default_rng(11)
+    n = 400
+    u = rng.integers(0, 30, n)
+    i = rng.integers(0, 25, n)
+    ts = T0 + np.sort(rng.random(n)) * 40 * 86400
+    r = rng.integers(-3, 6, n).astype(float)
+    d["events"] = {"u": u.tolist(), "i": i.tolist(), "ts": ts.tolist(), "r": r.tolist()}
+    for name, kw, upsert in (("plain", {}, False), ("decay7", {"decay_in_days": 7}, False),
+                             ("decay7_upsert", {"decay_in_days": 7}, True), ("clip", {"min_value": -1, "max_value": 4}, False)):
+        s = RefStore(**kw)
+        for a, b, t, x in zip(u, i, ts, r):
+            s.add_interaction(int(a), int(b), float(t), float(x), upsert=upsert)
+        d[name] = {"csr": s.to_csr().toarray().astype(np.float64).tolist(),
+                   "csc_sel": s.to_csc([1, 3, 5, 24]).toarray().astype(np.float64).tolist(),
+                   "csr_sel": s.to_csr([0, 2, 29]).toarray().astype(np.float64).tolist(),
+                   "max_timestamp": s.max_timestamp, "shape": list(s.shape),
+                   "hot": s.get_hot_items(10, filter_interacted=False),
+                   "rating_3_4": s.get_user_item_rating(3, 4), "user_items_5": sorted(s.get_user_items(5))}
+    json.dump(d, open(os.path.join(OUT, "store.json"), "w"))
+
+
+# ------------------------------------------------------------------ G1: the reference's own API scenarios
+def gen_api():
+    t = T0
+    scenarios = {
+        "similar_items": [('user_1', 'item_1', t, 5.0), ('user_1', 'item_3', t, 4.0), ('user_1', 'item_4', t, 3.0),
+                          ('user_2', 'item_1', t, 3.0), ('user_2', 'item_2', t, -2.0), ('user_2', 'item_4', t, 3.0),
+                          ('user_3', 'item_1', t, 4.0), ('user_3', 'item_3', t, 2.0), ('user_3', 'item_4', t, 4.0)],
+        "fit_and_recommend": [('user_1', 'item_1', t, 5.0), ('user_2', 'item_2', t, -2.0), ('user_2', 'item_1', t, 3.0),
+                              ('user_2', 'item_4', t, 3.0), ('user_1', 'item_3', t, 4.0)],
+        "recommend_batch": [('user_1', 'item_1', t, 5.0), ('user_1', 'item_3', t, 4.0), ('user_2', 'item_2', t, 3.0),
+                            ('user_2', 'item_4', t, 4.0), ('user_3', 'item_1', t, 2.0), ('user_3', 'item_2', t, 3.0)],
+        "int_ids": [(1, 10, t, 5.0), (1, 30, t, 4.0), (2, 20, t, 3.0), (2, 40, t, 4.0), (3, 10, t, 2.0), (3, 20, t, 3.0),
+                    (4, 10, t, 1.5), (4, 40, t, 2.5), (4, 30, t, 0.5)],
+    }
+    out = {}
+    m = RefSLIM(); m.fit(scenarios["similar_items"], progress_bar=False)
+    out["similar_items"] = {"interactions": scenarios["similar_items"],
+                            "similar_item_1": m.similar_items('item_1', top_k=5),
+                            "similar_item_1_scores": [[a, float(b)] for a, b in m.similar_items('item_1', top_k=5, ret_scores=True)],
+                            "recommend_user_2": m.recommend('user_2', top_k=5)}
+    m = RefSLIM(); m.fit(scenarios["fit_and_recommend"], progress_bar=False); m.fit(iter(scenarios["fit_and_recommend"]), progress_bar=False)
+    out["fit_and_recommend"] = {"interactions": scenarios["fit_and_recommend"], "recommend_user_1": m.recommend('user_1', top_k=5),
+                                "rating_u1_i1": m.interactions.get_user_item_rating(0, 0)}
+    m = RefSLIM(); m.fit(scenarios["recommend_batch"], progress_bar=False)
+    users = ['user_1', 'user_2', 'user_3']
+    out["recommend_batch"] = {"interactions": scenarios["recommend_batch"],
+                              "top2": m.recommend_batch(users, top_k=2),
+                              "cands": m.recommend_batch(users, candidate_items=['item_1', 'item_2', 'item_3'], top_k=2),
+                              "nofilter_u1": m.recommend_batch(['user_1'], top_k=3, filter_interacted=False),
+                              "cold": m.recommend_batch(['user_1', 'nobody'], top_k=2)}
+    m = RefSLIM(); m.fit(scenarios["int_ids"], progress_bar=False)
+    out["int_ids"] = {"interactions": scenarios["int_ids"],
+                      "top3": m.recommend_batch([1, 2, 3, 4], top_k=3),
+                      "nofilter": m.recommend_batch([1, 2, 3, 4], top_k=3, filter_interacted=False),
+                      "cold_99": m.recommend(99, top_k=3),
+                      "similar_10": m.similar_items(10, top_k=3)}
+    json.dump(out, open(os.path.join(OUT, "api.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    gen_rng()
+    gen_cd_columns()
+    X, X2, model = gen_models()
+    gen_partial()
+    gen_scoring(X2, model)
+    gen_store()
+    gen_api()
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
