@@ -52,7 +52,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--tile-cols", type=int, default=8192)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -164,6 +164,15 @@ def main() -> None:
     ms_per_step = dt / args.steps * 1e3
     value = U * args.steps / dt
 
+    # host-buffer boundary (SLIMElastic.recommend_batch hands over a scipy CSR): upload the user
+    # rows over PCIe, score, download ids + scores.  Reported beside `value`, never as `value`.
+    pcie_users_per_s = None
+    if world == 1:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.recommend_csr(X, top_k=top_k, filter_interacted=True, mode=_native.TOPK_SPARSE)
+        pcie_users_per_s = U / (time.perf_counter() - t1)
+
     # ------------------------------------------------------------------ roofline of score_tiles_kernel (this rank)
     Wr = W.tocsr()
     shard_row_nnz = np.diff(Wr[:, lo:hi].tocsr().indptr).astype(np.float64) if hi > lo else np.zeros(I)
@@ -188,6 +197,7 @@ def main() -> None:
                    "nn_feature_selection": K, "top_k": top_k, "tile_cols": lay["tile_cols"], "n_tiles": lay["n_tiles"],
                    "active_columns": lay["n_cols"],
                    "parallelism": f"item-column shard x{world}" if world > 1 else "single GPU"},
+        "pcie_inclusive_users_per_sec": pcie_users_per_s,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean())},
         "roofline": {"kernel": "score_sparse_kernel<float,false>", "bound": "hbm", "achieved": achieved,

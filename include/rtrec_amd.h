@@ -120,6 +120,10 @@ int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
  * layout column to its global item id (ascending) and d_col_map[n_items] maps a global item id
  * to its layout column or -1; pass both NULL for the plain layout whose column c is item
  * col_offset + c.
+ * Well-filled row segments may be stored DENSE instead: d_dense_idx[t * n_items + i] >= 0 names
+ * a block of tile_cols floats in d_dense_val (zero where W[i, c] is not stored) and the CSR range
+ * of that (tile, row) is then empty; pass both NULL when no segment is dense.  Adding x * 0 never
+ * changes an accumulator, so results are identical; dense blocks are updated 4 columns per lane.
  * ------------------------------------------------------------------------------------- */
 
 typedef enum {
@@ -162,6 +166,7 @@ int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                           const int32_t *d_col_ids, const int32_t *d_col_map,
                           int32_t tile_cols, int32_t n_tiles,
                           const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
+                          const int32_t *d_dense_idx, const float *d_dense_val,
                           const int32_t *d_col_rank,
                           int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
                           int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,

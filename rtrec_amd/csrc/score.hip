@@ -37,6 +37,8 @@ struct ScoreArgs {
     const int *tile_ptr;
     const uint16_t *w_col;
     const float *w_val;
+    const int *dense_idx;  // optional: [n_tiles * n_items] dense block of (tile, row) or -1
+    const float *dense_val; // optional: [n_dense * tile_cols]
     const int *col_rank;
     int kk;               // entries kept per (row, tile): top_k, or top_k + 1 when ties are detected
     int top_k;
@@ -349,33 +351,35 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
     for (int base = 0; base < n_a; base += 64) {
         const int p = base + lane;
         float x = 0.0f;
-        int s = 0, e = 0;
+        int s = 0, e = 0, d = -1;
         if (p < n_a) {
             const int item = a.xb_col[a0 + p];
             x = a.xb_val[a0 + p];
             if (item < a.n_items) {   // items newer than W have no row yet
                 s = tp[item];
                 e = tp[item + 1];
+                if (a.dense_idx) d = a.dense_idx[static_cast<size_t>(tile) * a.n_items + item];
             }
         }
-        unsigned long long live = __ballot(e > s);
-        if (TOUCH && track && __ballot(e - s >= kTouchCap / 4)) { track = false; tcnt = kTouchCap + 1; }
+        unsigned long long live = __ballot(e > s || d >= 0);
+        if (TOUCH && track && __ballot(e - s >= kTouchCap / 4 || d >= 0)) { track = false; tcnt = kTouchCap + 1; }
         while (live) {
             // Take the next kRowGroup non-empty rows (ascending item order) and issue the loads of
             // their first 64 entries together, so one memory round trip serves the whole group;
             // the accumulator updates are then issued row by row (scipy's accumulation order).
-            int ss[kRowGroup], ee[kRowGroup], cc[kRowGroup];
+            int ss[kRowGroup], ee[kRowGroup], cc[kRowGroup], dd[kRowGroup];
             float vv[kRowGroup];
             ACC xx[kRowGroup];
             uint32_t ps[kRowGroup];
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
-                ss[j] = 0; ee[j] = 0; xx[j] = ACC(0); ps[j] = 0u;
+                ss[j] = 0; ee[j] = 0; dd[j] = -1; xx[j] = ACC(0); ps[j] = 0u;
                 if (live) {
                     const int q = __builtin_ctzll(live);
                     live &= live - 1;
                     ss[j] = readlane_i(s, q);
                     ee[j] = readlane_i(e, q);
+                    dd[j] = readlane_i(d, q);
                     xx[j] = static_cast<ACC>(readlane_f(x, q));
                     ps[j] = static_cast<uint32_t>(base + q);
                 }
@@ -384,6 +388,33 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
             }
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
+                if (dd[j] >= 0) {
+                    // dense block: 4 consecutive accumulators per lane and step.  x * 0 is +-0 and
+                    // never changes a sum, so the zero padding is inert.
+                    const float *dv = a.dense_val + static_cast<size_t>(dd[j]) * a.tile_cols;
+                    const ACC xj = xx[j];
+                    for (int c = lane * 4; c < a.tile_cols; c += 256) {
+                        const float4 w4 = *reinterpret_cast<const float4 *>(dv + c);
+                        ACC o0 = acc[c], o1 = acc[c + 1], o2 = acc[c + 2], o3 = acc[c + 3];
+                        if (FT) {
+                            if (w4.x != 0.0f && is_untouched(o0)) L.ft[c] = ps[j];
+                            if (w4.y != 0.0f && is_untouched(o1)) L.ft[c + 1] = ps[j];
+                            if (w4.z != 0.0f && is_untouched(o2)) L.ft[c + 2] = ps[j];
+                            if (w4.w != 0.0f && is_untouched(o3)) L.ft[c + 3] = ps[j];
+                            // a padded zero must not make the column look touched
+                            if (w4.x != 0.0f) acc[c] = o0 + xj * static_cast<ACC>(w4.x);
+                            if (w4.y != 0.0f) acc[c + 1] = o1 + xj * static_cast<ACC>(w4.y);
+                            if (w4.z != 0.0f) acc[c + 2] = o2 + xj * static_cast<ACC>(w4.z);
+                            if (w4.w != 0.0f) acc[c + 3] = o3 + xj * static_cast<ACC>(w4.w);
+                        } else {
+                            acc[c] = o0 + xj * static_cast<ACC>(w4.x);
+                            acc[c + 1] = o1 + xj * static_cast<ACC>(w4.y);
+                            acc[c + 2] = o2 + xj * static_cast<ACC>(w4.z);
+                            acc[c + 3] = o3 + xj * static_cast<ACC>(w4.w);
+                        }
+                    }
+                    continue;
+                }
                 if (ee[j] == ss[j]) continue;   // group not full
                 bool first = false;
                 if (cc[j] >= 0) {
@@ -850,6 +881,7 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                                      const int32_t *d_col_ids, const int32_t *d_col_map,
                                      int32_t tile_cols, int32_t n_tiles,
                                      const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
+                                     const int32_t *d_dense_idx, const float *d_dense_val,
                                      const int32_t *d_col_rank,
                                      int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
                                      int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,
@@ -861,6 +893,7 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     if (mode < 0 || mode > 2) return RTREC_ERR_INVALID_ARG;
     if (mode == RTREC_TOPK_CANDIDATES && !d_col_rank) return RTREC_ERR_INVALID_ARG;
     if ((d_col_ids == nullptr) != (d_col_map == nullptr)) return RTREC_ERR_INVALID_ARG;
+    if ((d_dense_idx == nullptr) != (d_dense_val == nullptr)) return RTREC_ERR_INVALID_ARG;
     if (tile_cols < 256 || tile_cols > 65536 || (tile_cols % 256) != 0) return RTREC_ERR_UNSUPPORTED;
     if (n_tiles != (n_cols + tile_cols - 1) / tile_cols) return RTREC_ERR_INVALID_ARG;
     const int acc_bytes = acc_f64 ? 8 : 4;
@@ -876,6 +909,7 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     a.n_items = n_items; a.n_cols = n_cols; a.col_offset = col_offset; a.col_ids = d_col_ids; a.col_map = d_col_map;
     a.tile_cols = tile_cols; a.n_tiles = n_tiles;
     a.tile_ptr = d_tile_ptr; a.w_col = d_w_col; a.w_val = d_w_val; a.col_rank = d_col_rank;
+    a.dense_idx = d_dense_idx; a.dense_val = d_dense_val;
     a.filter = filter_interacted; a.mode = mode;
     { const char *ab = std::getenv("RTREC_AMD_ABLATE"); a.ablate = ab ? std::atoi(ab) : 0; }
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -24,6 +24,7 @@ import scipy.sparse as sp
 from . import _native
 
 DEFAULT_TILE_COLS = 8192
+DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
 MAX_SLOTS = 2048
 
 
@@ -54,9 +55,12 @@ class TiledW:
     w_val: np.ndarray     # float32 [nnz]
     col_ids: Optional[np.ndarray] = None   # int32 [n_cols]: layout column -> global item id
     col_map: Optional[np.ndarray] = None   # int32 [n_items]: global item id -> layout column or -1
+    dense_idx: Optional[np.ndarray] = None  # int32 [n_tiles * n_items]: dense block of (tile, row) or -1
+    dense_val: Optional[np.ndarray] = None  # float32 [n_dense * tile_cols]: zero-padded dense rows
 
 
-def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int, compact: bool = False) -> TiledW:
+def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int, compact: bool = False,
+                  dense_fill: Optional[float] = None) -> TiledW:
     """Cut columns [col_lo, col_hi) of W (CSC, I x I) into tiles; per tile a CSR over all rows.
     compact=True keeps only the columns that store at least one weight (the only ones that can
     be recommended in SPARSE mode), in ascending id order."""
@@ -83,6 +87,20 @@ def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int
     order = np.lexsort((kloc, rows, tile))
     key = (tile * n_items + rows)[order]
     cnt = np.bincount(key, minlength=n_tiles * n_items)
+    # (tile, row) segments that fill at least `dense_fill` of the tile are stored as zero-padded
+    # dense vectors: the kernel then updates 4 accumulators per lane and instruction
+    dense_idx = dense_val = None
+    kl, vl = kloc[order], vals[order]
+    if dense_fill is not None:
+        dense_keys = np.flatnonzero(cnt >= max(64, int(dense_fill * tile_cols)))
+        if dense_keys.size:
+            dense_idx = np.full(n_tiles * n_items, -1, dtype=np.int32)
+            dense_idx[dense_keys] = np.arange(dense_keys.size, dtype=np.int32)
+            is_dense = dense_idx[key] >= 0
+            dense_val = np.zeros(dense_keys.size * tile_cols, dtype=np.float32)
+            dense_val[dense_idx[key[is_dense]].astype(np.int64) * tile_cols + kl[is_dense] % tile_cols] = vl[is_dense]
+            key, kl, vl = key[~is_dense], kl[~is_dense], vl[~is_dense]
+            cnt = np.bincount(key, minlength=n_tiles * n_items)
     starts = np.zeros(n_tiles * n_items + 1, dtype=np.int64)
     np.cumsum(cnt, out=starts[1:])
     if starts[-1] >= 2 ** 31:
@@ -90,9 +108,9 @@ def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int
     tile_ptr = np.empty(n_tiles * (n_items + 1), dtype=np.int32)
     for t in range(n_tiles):
         tile_ptr[t * (n_items + 1):(t + 1) * (n_items + 1)] = starts[t * n_items:t * n_items + n_items + 1]
-    w_col = (kloc[order] % tile_cols).astype(np.uint16)
-    return TiledW(n_items, col_lo, n_cols, tile_cols, n_tiles, tile_ptr, w_col, np.ascontiguousarray(vals[order]),
-                  col_ids, col_map)
+    w_col = (kl % tile_cols).astype(np.uint16)
+    return TiledW(n_items, col_lo, n_cols, tile_cols, n_tiles, tile_ptr, w_col, np.ascontiguousarray(vl),
+                  col_ids, col_map, dense_idx, dense_val)
 
 
 class HipBackend:
@@ -160,7 +178,8 @@ class HipBackend:
             n_rows, self.ptr(row_ids), self.ptr(xb[0]), self.ptr(xb[1]), self.ptr(xb[2]),
             n_items, lay["n_cols"], col_lo, self.ptr(lay["col_ids"]), self.ptr(lay["col_map"]),
             lay["tile_cols"], lay["n_tiles"],
-            self.ptr(lay["tile_ptr"]), self.ptr(lay["w_col"]), self.ptr(lay["w_val"]), self.ptr(col_rank),
+            self.ptr(lay["tile_ptr"]), self.ptr(lay["w_col"]), self.ptr(lay["w_val"]),
+            self.ptr(lay.get("dense_idx")), self.ptr(lay.get("dense_val")), self.ptr(col_rank),
             top_k, int(bool(filter_interacted)), int(mode), int(acc_f64),
             self.ptr(ids), self.ptr(sc), self.ptr(sc64), self.ptr(aux), self.ptr(cnt),
             self.ptr(ws), ws.numel(), self.stream()), "rtrec_slim_score_topk")
@@ -313,9 +332,13 @@ class SlimEngine:
                 tile = self.tile_cols
                 while tile > 256 and tile * ((8 if W["acc_f64"] else 4) + 4) + 8192 > 160 * 1024:
                     tile //= 2
-                T = build_tiled_w(W["host"], W["col_lo"], W["col_hi"], tile, compact=compact)
+                T = build_tiled_w(W["host"], W["col_lo"], W["col_hi"], tile, compact=compact,
+                                  dense_fill=DENSE_ROW_FILL if compact else None)
                 if T.n_cols > 0:
                     lay = dict(n_cols=T.n_cols, tile_cols=T.tile_cols, n_tiles=T.n_tiles, nnz=int(T.w_val.shape[0]),
+                               dense_idx=be.to_dev(T.dense_idx) if T.dense_idx is not None else None,
+                               dense_val=be.to_dev(T.dense_val) if T.dense_val is not None else None,
+                               n_dense=0 if T.dense_idx is None else int(T.dense_val.shape[0] // T.tile_cols),
                                tile_ptr=be.to_dev(T.tile_ptr), w_col=be.to_dev(T.w_col.view(np.int16)),
                                w_val=be.to_dev(T.w_val),
                                col_ids=be.to_dev(T.col_ids) if T.col_ids is not None else None,

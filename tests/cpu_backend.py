@@ -80,7 +80,18 @@ class OracleBackend:
             rows.append(np.repeat(np.arange(n_items), cnt_t))
             loc = wc[tp[t, 0]:tp[t, -1]] + t * S
             cols.append(lay["col_ids"].numpy()[loc] if lay["col_ids"] is not None else loc + col_lo)
-        Wr = sp.csr_matrix((wv, (np.concatenate(rows), np.concatenate(cols))), shape=(n_items, n_items))
+        vals = [wv]
+        if lay.get("dense_idx") is not None:
+            di = lay["dense_idx"].numpy().reshape(T, n_items)
+            dv = lay["dense_val"].numpy().reshape(-1, S)
+            for t, i in zip(*np.nonzero(di >= 0)):
+                blk = dv[di[t, i]]
+                nz = np.flatnonzero(blk)
+                loc = nz + t * S
+                rows.append(np.full(len(nz), i))
+                cols.append(lay["col_ids"].numpy()[loc] if lay["col_ids"] is not None else loc + col_lo)
+                vals.append(blk[nz])
+        Wr = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n_items, n_items))
         ptr, col, val = (t.numpy() for t in xb)
         Xall = sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, n_items))
         rsel = row_ids.numpy() if row_ids is not None else np.arange(n_rows)
