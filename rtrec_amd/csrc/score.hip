@@ -424,41 +424,45 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                     if (FT && first) L.ft[cc[j]] = ps[j];
                 }
                 if (TOUCH) push(first, cc[j]);
-                // the rest of a long row: kStreamDepth x 64 entries are requested before the first
-                // of them is consumed; the columns of one row are distinct, so the updates of a
-                // batch are issued as reads, then adds, then writes
+                // the rest of a long row.  Full batches of kStreamDepth x 64 entries are branch-free:
+                // all loads are issued before the first is consumed, and since the columns of one
+                // row are distinct the updates go out as reads, then adds, then writes.
                 const int eej = ee[j];
                 const ACC xj = xx[j];
                 const uint32_t pos = ps[j];
-                for (int ob = ss[j] + 64; ob < eej; ob += 64 * kStreamDepth) {
+                int ob = ss[j] + 64;
+                for (; ob + 64 * kStreamDepth <= eej; ob += 64 * kStreamDepth) {
+                    const uint16_t *pc = a.w_col + ob + lane;
+                    const float *pv = a.w_val + ob + lane;
                     int c[kStreamDepth];
                     float v[kStreamDepth];
                     ACC old[kStreamDepth];
 #pragma unroll
-                    for (int u = 0; u < kStreamDepth; ++u) {
-                        const int o = ob + u * 64 + lane;
-                        c[u] = -1; v[u] = 0.0f;
-                        if (o < eej) { c[u] = a.w_col[o]; v[u] = a.w_val[o]; }
-                    }
+                    for (int u = 0; u < kStreamDepth; ++u) { c[u] = pc[u * 64]; v[u] = pv[u * 64]; }
+#pragma unroll
+                    for (int u = 0; u < kStreamDepth; ++u) old[u] = acc[c[u]];
 #pragma unroll
                     for (int u = 0; u < kStreamDepth; ++u) {
-                        old[u] = ACC(0);
-                        if (c[u] >= 0) old[u] = acc[c[u]];
+                        acc[c[u]] = old[u] + xj * static_cast<ACC>(v[u]);
+                        if (FT && is_untouched(old[u])) L.ft[c[u]] = pos;
                     }
+                    if (TOUCH && track) {
 #pragma unroll
-                    for (int u = 0; u < kStreamDepth; ++u) {
-                        if (c[u] >= 0) {
-                            acc[c[u]] = old[u] + xj * static_cast<ACC>(v[u]);
-                            if (FT && is_untouched(old[u])) L.ft[c[u]] = pos;
-                        }
+                        for (int u = 0; u < kStreamDepth; ++u) push(is_untouched(old[u]), c[u]);
                     }
-                    if (TOUCH) {
-#pragma unroll
-                        for (int u = 0; u < kStreamDepth; ++u) {
-                            if (ob + u * 64 >= eej) break;
-                            push(c[u] >= 0 && is_untouched(old[u]), c[u]);
-                        }
+                }
+                for (; ob < eej; ob += 64) {   // ragged tail, one masked chunk at a time
+                    const int o = ob + lane;
+                    int c = 0;
+                    bool f2 = false;
+                    if (o < eej) {
+                        c = a.w_col[o];
+                        const ACC old = acc[c];
+                        f2 = is_untouched(old);
+                        acc[c] = old + xj * static_cast<ACC>(a.w_val[o]);
+                        if (FT && f2) L.ft[c] = pos;
                     }
+                    if (TOUCH) push(f2, c);
                 }
             }
         }
