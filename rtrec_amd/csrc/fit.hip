@@ -24,7 +24,13 @@
 #include "common.hip.h"
 #include "../../include/rtrec_amd.h"
 
+#include <cstdlib>
+
 namespace rtrec {
+
+#ifndef FIT_WAVES_PER_SIMD
+#define FIT_WAVES_PER_SIMD 5
+#endif
 
 // -0.0f can never be produced by (+0) + p or by a float sum that starts at +0 under
 // round-to-nearest, so its bit pattern marks "no contribution yet".
@@ -58,24 +64,51 @@ __device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, f
 }
 
 // tmp = sum over column entries [b, e) of (R[r] (+ x*w_old)) * x, strictly left to right.
+// Software-pipelined over batches of 4 x 64 entries: while batch k is folded (256 dependent adds),
+// the R gathers of batch k+1 and the index/value loads of batch k+2 are already in flight, so the
+// wave is bound by the fold itself instead of by two dependent memory round trips per batch.
 __device__ float dot_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
                           int b, int e, float w_old) {
     const int lane = lane_id();
     const bool add_back = (w_old != 0.0f);
     float tmp = 0.0f;
+    const int n_full = (e - b) >> 8;              // batches of 256 entries
     int o = b;
-    for (; o + 256 <= e; o += 256) {
-        const int r0 = crow[o + lane], r1 = crow[o + 64 + lane], r2 = crow[o + 128 + lane], r3 = crow[o + 192 + lane];
-        const float x0 = cval[o + lane], x1 = cval[o + 64 + lane], x2 = cval[o + 128 + lane], x3 = cval[o + 192 + lane];
-        float v0 = R[r0], v1 = R[r1], v2 = R[r2], v3 = R[r3];
-        if (add_back) {
-            v0 = __fadd_rn(v0, __fmul_rn(x0, w_old)); v1 = __fadd_rn(v1, __fmul_rn(x1, w_old));
-            v2 = __fadd_rn(v2, __fmul_rn(x2, w_old)); v3 = __fadd_rn(v3, __fmul_rn(x3, w_old));
+    if (n_full > 0) {
+        int ra[4], rb[4];
+        float xa[4], xb[4], va[4];
+        // prologue: indices of batch 0 -> gathers of batch 0; indices of batch 1
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ra[u] = crow[o + u * 64 + lane]; xa[u] = cval[o + u * 64 + lane]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) va[u] = R[ra[u]];
+        if (n_full > 1) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { rb[u] = crow[o + 256 + u * 64 + lane]; xb[u] = cval[o + 256 + u * 64 + lane]; }
         }
-        tmp = chain_add_full(tmp, __fmul_rn(v0, x0));
-        tmp = chain_add_full(tmp, __fmul_rn(v1, x1));
-        tmp = chain_add_full(tmp, __fmul_rn(v2, x2));
-        tmp = chain_add_full(tmp, __fmul_rn(v3, x3));
+        for (int k = 0; k < n_full; ++k) {
+            float vn[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            int rc[4] = {0, 0, 0, 0};
+            float xc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (k + 1 < n_full) {              // gathers of batch k+1 (its indices arrived during batch k-1)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vn[u] = R[rb[u]];
+            }
+            if (k + 2 < n_full) {              // indices of batch k+2
+                const int o2 = o + 512;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { rc[u] = crow[o2 + u * 64 + lane]; xc[u] = cval[o2 + u * 64 + lane]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float v = va[u];
+                if (add_back) v = __fadd_rn(v, __fmul_rn(xa[u], w_old));
+                tmp = chain_add_full(tmp, __fmul_rn(v, xa[u]));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { va[u] = vn[u]; xa[u] = xb[u]; rb[u] = rc[u]; xb[u] = xc[u]; }
+            o += 256;
+        }
     }
     for (; o < e; o += 64) {
         const int n = min(64, e - o);
@@ -92,11 +125,27 @@ __device__ float dot_pass(const int *__restrict__ crow, const float *__restrict_
     return tmp;
 }
 
-// R[r] <- (R[r] + x*w_old) - x*w_new over the column (element-wise, order free).
+// R[r] <- (R[r] + x*w_old) - x*w_new over the column (element-wise, order free; 4 x 64 entries
+// per step so that four gathers are in flight per lane).
 __device__ void update_pass(const int *__restrict__ crow, const float *__restrict__ cval, float *R,
                             int b, int e, float w_old, float w_new) {
     const int lane = lane_id();
-    for (int o = b + lane; o < e; o += 64) {
+    int o = b;
+    for (; o + 256 <= e; o += 256) {
+        int r[4];
+        float x[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { r[u] = crow[o + u * 64 + lane]; x[u] = cval[o + u * 64 + lane]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = R[r[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (w_old != 0.0f) v[u] = __fadd_rn(v[u], __fmul_rn(x[u], w_old));
+            if (w_new != 0.0f) v[u] = __fsub_rn(v[u], __fmul_rn(x[u], w_new));
+            R[r[u]] = v[u];
+        }
+    }
+    for (o += lane; o < e; o += 64) {
         const int r = crow[o];
         const float x = cval[o];
         float v = R[r];
@@ -111,33 +160,38 @@ __device__ float xta_pass(const int *__restrict__ crow, const float *__restrict_
     return dot_pass(crow, cval, R, b, e, 0.0f);   // R[r]*x == x*R[r] (one rounding, commutative)
 }
 
+// LDS arrays describing the selected features of the current target (K path).
+struct FeatLds {
+    int *f_id, *f_b, *f_e, *f_ever;
+    float *f_nrm, *f_w, *f_s;
+};
+__device__ __forceinline__ FeatLds carve_feat(unsigned char *smem, int K) {
+    FeatLds F;
+    F.f_id = reinterpret_cast<int *>(smem);
+    F.f_b = F.f_id + K;
+    F.f_e = F.f_b + K;
+    F.f_nrm = reinterpret_cast<float *>(F.f_e + K);
+    F.f_w = F.f_nrm + K;
+    F.f_s = F.f_w + K;
+    F.f_ever = reinterpret_cast<int *>(F.f_s + K);
+    return F;
+}
+
+struct Prep {
+    float yy, tol_s;
+    int tc, Kc;
+};
+
+// Steps 0-2 for target j, executed by ONE wave: y.y, s = X^T y with its touched list, and (K path)
+// the top-K feature selection written to the LDS feature arrays.
 template <bool ALLF>
-__device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) {
+__device__ __forceinline__ Prep prep_target(const FitArgs &a, int j, int K, float *s, int *touched, float *cand_s,
+                                            int *cand_i, const FeatLds &F) {
     const int lane = lane_id();
-    const int U = a.U, I = a.I;
-    const int j = a.targets[t];
-    float *R = a.R + static_cast<size_t>(slot) * U;
-    float *s = a.s + static_cast<size_t>(slot) * I;
-    int *touched = a.touched + static_cast<size_t>(slot) * I;
-    float *cand_s = a.cand_s + static_cast<size_t>(slot) * I;
-    int *cand_i = a.cand_i + static_cast<size_t>(slot) * I;
-    float *w_all = ALLF ? a.w_all + static_cast<size_t>(slot) * I : nullptr;
-    int *ever_flag = reinterpret_cast<int *>(cand_s);   // ALL path
-    int *ever_list = cand_i;                            // ALL path
-
-    const int K = ALLF ? 0 : min(a.cfg.top_features, I);
-    int *f_id = reinterpret_cast<int *>(smem);
-    int *f_b = f_id + K;
-    int *f_e = f_b + K;
-    float *f_nrm = reinterpret_cast<float *>(f_e + K);
-    float *f_w = f_nrm + K;
-    float *f_s = f_w + K;
-    int *f_ever = reinterpret_cast<int *>(f_s + K);
-
-    const float alpha = a.cfg.l1_reg, beta = a.cfg.l2_reg;
-    const int positive = a.cfg.positive;
+    const int I = a.I;
+    int *f_id = F.f_id, *f_b = F.f_b, *f_e = F.f_e, *f_ever = F.f_ever;
+    float *f_nrm = F.f_nrm, *f_w = F.f_w, *f_s = F.f_s;
     const int yb = a.cptr[j], ye = a.cptr[j + 1];
-    const int ny = ye - yb;
 
     // ---- y . y (tolerance scale, _cd_fast.pyx:426) ----
     float yy = 0.0f;
@@ -257,6 +311,38 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
             f_ever[p] = 0;
         }
     }
+    Prep P;
+    P.yy = yy; P.tol_s = tol_s; P.tc = tc; P.Kc = Kc;
+    return P;
+}
+
+template <bool ALLF>
+__device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) {
+    const int lane = lane_id();
+    const int U = a.U, I = a.I;
+    const int j = a.targets[t];
+    float *R = a.R + static_cast<size_t>(slot) * U;
+    float *s = a.s + static_cast<size_t>(slot) * I;
+    int *touched = a.touched + static_cast<size_t>(slot) * I;
+    float *cand_s = a.cand_s + static_cast<size_t>(slot) * I;
+    int *cand_i = a.cand_i + static_cast<size_t>(slot) * I;
+    float *w_all = ALLF ? a.w_all + static_cast<size_t>(slot) * I : nullptr;
+    int *ever_flag = reinterpret_cast<int *>(cand_s);   // ALL path
+    int *ever_list = cand_i;                            // ALL path
+
+    const int K = ALLF ? 0 : min(a.cfg.top_features, I);
+    const FeatLds F = carve_feat(smem, K);
+    int *f_id = F.f_id, *f_b = F.f_b, *f_e = F.f_e, *f_ever = F.f_ever;
+    float *f_nrm = F.f_nrm, *f_w = F.f_w, *f_s = F.f_s;
+
+    const float alpha = a.cfg.l1_reg, beta = a.cfg.l2_reg;
+    const int positive = a.cfg.positive;
+    const int yb = a.cptr[j], ye = a.cptr[j + 1];
+    const int ny = ye - yb;
+
+    const Prep P = prep_target<ALLF>(a, j, K, s, touched, cand_s, cand_i, F);
+    const float yy = P.yy, tol_s = P.tol_s;
+    const int tc = P.tc, Kc = P.Kc;
     const int nf = ALLF ? I : Kc;
 
     // ---- 3. coordinate descent (_cd_fast.pyx:428-548) ----
@@ -457,7 +543,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
 }
 
 template <bool ALLF>
-__global__ __launch_bounds__(64) void fit_columns_kernel(FitArgs a) {
+__global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(FitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int slot = blockIdx.x;
     for (;;) {

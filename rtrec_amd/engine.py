@@ -15,6 +15,7 @@ followed by the merge kernel.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
 
@@ -25,7 +26,7 @@ from . import _native
 
 DEFAULT_TILE_COLS = 8192
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
-MAX_SLOTS = 2048
+MAX_SLOTS = 5120   # 5 single-wave workgroups per SIMD (fit kernel: <= 96 VGPRs)
 
 
 def sklearn_seed(random_state: Optional[int]) -> int:
@@ -274,10 +275,10 @@ class SlimEngine:
             X["sqn"] = be.empty((I,), torch.float32)
             be.column_sqnorms(I, X["cptr"], X["cval"], X["sqn"])
         n = len(targets)
-        slots = int(n_slots or min(MAX_SLOTS, max(1, n)))
-        # keep the per-slot scratch (R: U floats, s/touched/cand: I each) within ~8 GiB
+        slots = int(n_slots or min(int(os.environ.get("RTREC_AMD_FIT_SLOTS", MAX_SLOTS)), max(1, n)))
+        # keep the per-slot scratch (R: U floats, s/touched/cand: I each) within ~24 GiB of the 288 GB
         per_slot = 4 * (U + (5 if K <= 0 else 4) * I)
-        slots = max(1, min(slots, int((8 << 30) // max(per_slot, 1))))
+        slots = max(1, min(slots, int((24 << 30) // max(per_slot, 1))))
         ws_key = (U, I, slots, K if K > 0 else 0)
         if ws_key not in self._fit_ws:
             self._fit_ws.clear()
