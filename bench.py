@@ -38,6 +38,9 @@ WORKLOADS = {
     # BASELINE.json configs[2] shape (MovieLens-20M): 138,493 x 26,744
     "c3": dict(U=138_493, I=26_744, draws=26_000_000, K=50,
                desc="MovieLens-20M-shaped synthetic 138,493 users x 26,744 items, ~20M interactions, K=50"),
+    # BASELINE.json configs[3] shape: 1M users x 500k items, 100M interactions (bulk part)
+    "c4": dict(U=1_000_000, I=500_000, draws=100_000_000, K=50,
+               desc="synthetic 1M users x 500k items, 100M interaction draws, K=50 (bulk fit + score; 8-GPU shard config)"),
     "small": dict(U=20_000, I=5_000, draws=500_000, K=50, desc="small plumbing workload 20k x 5k, 500k draws, K=50"),
 }
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -66,9 +69,17 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
         log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    # RTREC_BENCH_SAME_GPU=1 (functional test only): every rank drives cuda:0 and the collectives
+    # run over gloo, so the sharded path can be exercised on a single-GPU box.
+    same_gpu = os.environ.get("RTREC_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if same_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
     from rtrec_amd import _native
     from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients, shard_bounds
