@@ -28,6 +28,8 @@
 
 namespace rtrec {
 
+constexpr int kRowUnroll = 8;   // 64-item chunks of one user row updated together in the X^T y step
+
 #ifndef FIT_WAVES_PER_SIMD
 #define FIT_WAVES_PER_SIMD 5
 #endif
@@ -162,9 +164,10 @@ __device__ float xta_pass(const int *__restrict__ crow, const float *__restrict_
 
 // LDS arrays describing the selected features of the current target (K path).
 struct FeatLds {
-    int *f_id, *f_b, *f_e, *f_ever;
+    int *f_id, *f_b, *f_e, *f_ever, *hist;
     float *f_nrm, *f_w, *f_s;
 };
+__host__ __device__ constexpr size_t feat_lds_bytes(int K) { return static_cast<size_t>(K) * 7 * 4 + 256 * 4 + 16; }
 __device__ __forceinline__ FeatLds carve_feat(unsigned char *smem, int K) {
     FeatLds F;
     F.f_id = reinterpret_cast<int *>(smem);
@@ -174,6 +177,7 @@ __device__ __forceinline__ FeatLds carve_feat(unsigned char *smem, int K) {
     F.f_w = F.f_nrm + K;
     F.f_s = F.f_w + K;
     F.f_ever = reinterpret_cast<int *>(F.f_s + K);
+    F.hist = F.f_ever + K;
     return F;
 }
 
@@ -218,22 +222,33 @@ __device__ __forceinline__ Prep prep_target(const FitArgs &a, int j, int K, floa
         for (int q = 0; q < n; ++q) {
             const int rb = readlane_i(rb_l, q), re = readlane_i(re_l, q);
             const float yv = readlane_f(y_l, q);
-            for (int o = rb; o < re; o += 64) {
-                const bool valid = (o + lane) < re;
-                int i = -1;
-                float x = 0.0f;
-                if (valid) { i = a.rcol[o + lane]; x = a.rval[o + lane]; }
-                const bool use = valid && (i != j);
-                bool first = false;
-                if (use) {
-                    const float old = s[i];
-                    first = (__float_as_uint(old) == kUntouched);
-                    s[i] = __fadd_rn(first ? 0.0f : old, __fmul_rn(x, yv));
+            // Items of one row are distinct, so the s updates of a row are independent: 8 x 64 of them
+            // are gathered together (rows themselves stay strictly sequential = csr_matvec order).
+            for (int o = rb; o < re; o += 64 * kRowUnroll) {
+                int it[kRowUnroll];
+                float xv[kRowUnroll], old[kRowUnroll];
+#pragma unroll
+                for (int k = 0; k < kRowUnroll; ++k) {
+                    const int oo = o + k * 64 + lane;
+                    it[k] = -1; xv[k] = 0.0f;
+                    if (oo < re) { it[k] = a.rcol[oo]; xv[k] = a.rval[oo]; }
+                    if (it[k] == j) it[k] = -1;
                 }
-                const unsigned long long m = __ballot(first);
-                if (m) {
-                    if (first) touched[tc + lane_prefix(m)] = i;
-                    tc += __builtin_popcountll(m);
+#pragma unroll
+                for (int k = 0; k < kRowUnroll; ++k) { old[k] = 0.0f; if (it[k] >= 0) old[k] = s[it[k]]; }
+#pragma unroll
+                for (int k = 0; k < kRowUnroll; ++k) {
+                    if (o + k * 64 >= re) break;
+                    bool first = false;
+                    if (it[k] >= 0) {
+                        first = (__float_as_uint(old[k]) == kUntouched);
+                        s[it[k]] = __fadd_rn(first ? 0.0f : old[k], __fmul_rn(xv[k], yv));
+                    }
+                    const unsigned long long m = __ballot(first);
+                    if (m) {
+                        if (first) touched[tc + lane_prefix(m)] = it[k];
+                        tc += __builtin_popcountll(m);
+                    }
                 }
             }
         }
@@ -257,21 +272,98 @@ __device__ __forceinline__ Prep prep_target(const FitArgs &a, int j, int K, floa
             }
         }
         const float ninf = -__builtin_huge_valf();
-        // positives, best first
-        for (; Kc < K; ++Kc) {
-            Cand<float> b; b.id = -1; b.score = ninf; b.aux = 0u;
-            int bt = -1;
-            for (int tt = lane; tt < cn; tt += 64) {
-                const float v = cand_s[tt];
-                if (!(v > 0.0f)) continue;
-                Cand<float> x; x.score = v; x.id = cand_i[tt]; x.aux = 0u;
-                if (cand_better(x, b)) { b = x; bt = tt; }
-            }
-            const Cand<float> w = wave_best(b);
-            if (w.id < 0) break;
-            if (bt >= 0 && b.id == w.id) cand_s[bt] = ninf;
-            if (lane == 0) { f_id[Kc] = w.id; f_s[Kc] = w.score; }
+        // ---- positives: the K best by (score desc, id desc) ----
+        // Radix select on the float bits (positive floats order like unsigned ints): four 8-bit
+        // histogram passes find the K-th largest score tau; everything above tau is taken, ties at
+        // tau are taken by descending id; the (at most K) winners are then ranked in LDS.  This
+        // replaces K dependent argmax rounds over global memory (150 us -> a few us per target).
+        int *hbin = F.hist;                           // 256 LDS bins
+        int npos = 0;
+        for (int tb = 0; tb < cn; tb += 64) {
+            const bool pos = (tb + lane < cn) && (cand_s[tb + lane] > 0.0f);
+            npos += __builtin_popcountll(__ballot(pos));
         }
+        uint32_t tau = 0u;        // scores strictly above tau are always selected
+        int need_tie = 0;         // how many candidates with score == tau are selected (highest ids)
+        if (npos > K) {
+            uint32_t prefix = 0u, mask = 0u;
+            int need = K;
+            for (int shift = 24; shift >= 0; shift -= 8) {
+                for (int bnk = lane; bnk < 256; bnk += 64) hbin[bnk] = 0;
+                for (int tt = lane; tt < cn; tt += 64) {
+                    const float v = cand_s[tt];
+                    if (v > 0.0f) {
+                        const uint32_t key = __float_as_uint(v);
+                        if ((key & mask) == prefix) atomicAdd(&hbin[(key >> shift) & 255u], 1);
+                    }
+                }
+                // lane l owns bins 4l..4l+3; walk from the top bin down until `need` is covered
+                const int c0 = hbin[4 * lane], c1 = hbin[4 * lane + 1], c2 = hbin[4 * lane + 2], c3 = hbin[4 * lane + 3];
+                const int tot = c0 + c1 + c2 + c3;
+                int above = 0, sel_lane = 0;
+                for (int l = 63; l >= 0; --l) {
+                    const int tl = readlane_i(tot, l);
+                    if (above + tl >= need) { sel_lane = l; break; }
+                    above += tl;
+                }
+                const int b3 = readlane_i(c3, sel_lane), b2 = readlane_i(c2, sel_lane), b1 = readlane_i(c1, sel_lane);
+                int bin = 4 * sel_lane + 3;
+                if (above + b3 < need) { above += b3; bin--; if (above + b2 < need) { above += b2; bin--; if (above + b1 < need) { above += b1; bin--; } } }
+                prefix |= static_cast<uint32_t>(bin) << shift;
+                mask |= 255u << shift;
+                need -= above;
+            }
+            tau = prefix;
+            need_tie = need;      // >= 1
+        }
+        // collect the winners (unsorted) into f_id / f_s
+        int n_sel = 0;
+        for (int tb = 0; tb < cn; tb += 64) {
+            const int tt = tb + lane;
+            float v = 0.0f;
+            int id = -1;
+            if (tt < cn) { v = cand_s[tt]; id = cand_i[tt]; }
+            const uint32_t key = __float_as_uint(v);
+            const bool take = (v > 0.0f) && (npos <= K || key > tau);
+            const unsigned long long m = __ballot(take);
+            if (m) {
+                if (take) { const int pos = n_sel + lane_prefix(m); f_id[pos] = id; f_s[pos] = v; }
+                n_sel += __builtin_popcountll(m);
+            }
+        }
+        if (npos > K) {
+            // ties at tau: highest ids first (exact score ties are rare with float ratings)
+            int last_id = 0x7fffffff;
+            for (int r = 0; r < need_tie; ++r) {
+                int best = -1;
+                for (int tt = lane; tt < cn; tt += 64) {
+                    const float v = cand_s[tt];
+                    if (__float_as_uint(v) == tau && v > 0.0f) { const int id = cand_i[tt]; if (id < last_id && id > best) best = id; }
+                }
+                best = wave_max(best);
+                last_id = best;
+                if (lane == 0) { f_id[n_sel] = best; f_s[n_sel] = __uint_as_float(tau); }
+                n_sel++;
+            }
+        }
+        // rank the winners: position = number of better entries (strict total order)
+        {
+            int *tmp_i = f_e;                                   // K ints of scratch
+            float *tmp_s = f_w;                                 // K floats of scratch (f_w is reset below)
+            for (int pb = 0; pb < n_sel; pb += 64) {
+                const int pp = pb + lane;
+                Cand<float> me; me.id = -1; me.score = ninf; me.aux = 0u;
+                if (pp < n_sel) { me.id = f_id[pp]; me.score = f_s[pp]; }
+                int rank = 0;
+                for (int q = 0; q < n_sel; ++q) {
+                    Cand<float> o; o.id = f_id[q]; o.score = f_s[q]; o.aux = 0u;
+                    rank += cand_better(o, me) ? 1 : 0;
+                }
+                if (pp < n_sel) { tmp_i[rank] = me.id; tmp_s[rank] = me.score; }
+            }
+            for (int pp = lane; pp < n_sel; pp += 64) { f_id[pp] = tmp_i[pp]; f_s[pp] = tmp_s[pp]; }
+        }
+        Kc = n_sel;
         // zero scores (untouched items, the target itself, exact-zero sums): higher id first
         for (int hi = I - 1; hi >= 0 && Kc < K; hi -= 64) {
             const int id = hi - lane;
@@ -678,7 +770,7 @@ extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
     if (allf) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true>), dim3(grid), dim3(64), 16, st, a);
     } else {
-        const size_t lds = static_cast<size_t>(K) * 7 * 4 + 16;
+        const size_t lds = feat_lds_bytes(K);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), lds, st, a);
     }
     return rtrec::launch_status();

@@ -276,9 +276,12 @@ class SlimEngine:
             be.column_sqnorms(I, X["cptr"], X["cval"], X["sqn"])
         n = len(targets)
         slots = int(n_slots or min(int(os.environ.get("RTREC_AMD_FIT_SLOTS", MAX_SLOTS)), max(1, n)))
-        # keep the per-slot scratch (R: U floats, s/touched/cand: I each) within ~24 GiB of the 288 GB
+        # Per-slot scratch is R (U floats) + s/touched/candidates (I each).  The X^T y step is a random
+        # read-modify-write over s, i.e. bound by cache lines moved, and measured faster with FEWER
+        # targets in flight once a slot is several MB (C4: 1024 slots 7.3 s, 5120 slots 9.2 s): keep
+        # the total near 16 GiB but never below 1024 slots.
         per_slot = 4 * (U + (5 if K <= 0 else 4) * I)
-        slots = max(1, min(slots, int((24 << 30) // max(per_slot, 1))))
+        slots = max(1, min(slots, max(1024, int((16 << 30) // max(per_slot, 1)))))
         ws_key = (U, I, slots, K if K > 0 else 0)
         if ws_key not in self._fit_ws:
             self._fit_ws.clear()
