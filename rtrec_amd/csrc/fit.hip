@@ -647,6 +647,316 @@ __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(Fit
     }
 }
 
+// =============================================================================================
+// Latency mode (K path): one multi-wave workgroup per target, used when a call fits few targets
+// (online partial_fit: a mini-batch touches ~1k items and the heaviest one is the critical path).
+//
+// The only sequential part of a coordinate update is folding the products R[r]*x[r] left to right.
+// Wave 0 (consumer) does nothing else: it pops 64-product chunks from an LDS ring in order and adds
+// them one by one.  The other waves (producers) run ahead: coalesced loads of the column, gather
+// of R, add-back, multiply, push to the ring (each keeps kProdDepth chunks in flight).  The
+// element-wise residual update, the R = y materialisation and the scratch reset are split over
+// all threads.  Results are bit-identical to the single-wave kernel.
+// =============================================================================================
+constexpr int kMwWaves = 8;
+constexpr int kMwThreads = kMwWaves * 64;
+constexpr int kProducers = kMwWaves - 1;
+constexpr int kProdDepth = 4;    // chunks a producer wave keeps in flight
+constexpr int kMwMaxTargets = 2048;  // calls with at most this many targets use the multi-wave kernel
+constexpr int kRing = 64;        // ring slots of 64 products (>= kProducers * kProdDepth, power of 2)
+
+struct MwLds {
+    float *ring;   // [kRing][64]
+    int *ready;    // [kRing]  tag = global chunk number + 1
+    int *done;     // [1]      chunks consumed so far
+    float *bc_f;   // [8]      broadcast floats
+    int *bc_i;     // [8]      broadcast ints
+};
+__host__ __device__ constexpr size_t mw_lds_bytes(int K) {
+    return ((feat_lds_bytes(K) + 15) / 16) * 16 + kRing * 64 * 4 + kRing * 4 + 16 + 32 + 32;
+}
+__device__ __forceinline__ MwLds carve_mw(unsigned char *smem, int K) {
+    MwLds M;
+    unsigned char *p = smem + ((feat_lds_bytes(K) + 15) / 16) * 16;
+    M.ring = reinterpret_cast<float *>(p);  p += kRing * 64 * 4;
+    M.ready = reinterpret_cast<int *>(p);   p += kRing * 4;
+    M.done = reinterpret_cast<int *>(p);    p += 16;
+    M.bc_f = reinterpret_cast<float *>(p);  p += 32;
+    M.bc_i = reinterpret_cast<int *>(p);
+    return M;
+}
+
+__device__ __forceinline__ int lds_load_acquire(int *p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(int *p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Ordered fold of one stream of 64-element chunks.
+//   MODE 0: sum over column entries [b, e) of (R[row] (+ x*w_old)) * x      (dot / XtA)
+//   MODE 1: sum over r in [b, e) of R[r]*R[r]                                (R . R)
+// Chunks are padded with +0.0 products, which never change the sum.  `seq` is the workgroup-wide
+// running chunk number (identical in every wave).  Returns the sum in wave 0, 0 elsewhere.
+template <int MODE>
+__device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, const MwLds &M,
+                         int b, int e, float w_old, int wave, int lane, int &seq) {
+    const int n_chunks = (e - b + 63) >> 6;
+    float tmp = 0.0f;
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int c = 0; c < n_chunks; ++c) {
+            const int G = seq + c, slot = G & (kRing - 1);
+            while (lds_load_acquire(&M.ready[slot]) != G + 1) __builtin_amdgcn_s_sleep(1);
+            const float4 *p4 = reinterpret_cast<const float4 *>(M.ring + slot * 64);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 v = p4[k];     // uniform address: LDS broadcast
+                tmp = __fadd_rn(tmp, v.x); tmp = __fadd_rn(tmp, v.y); tmp = __fadd_rn(tmp, v.z); tmp = __fadd_rn(tmp, v.w);
+            }
+            if (lane == 0) lds_store_release(M.done, G + 1);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    } else {
+        const bool add_back = (w_old != 0.0f);
+        for (int c0 = wave - 1; c0 < n_chunks; c0 += kProducers * kProdDepth) {
+            float prod[kProdDepth];
+            int rr[kProdDepth];
+            float xx[kProdDepth];
+#pragma unroll
+            for (int u = 0; u < kProdDepth; ++u) {       // all index / value loads first
+                const int c = c0 + kProducers * u;
+                const int o = b + c * 64 + lane;
+                rr[u] = -1; xx[u] = 0.0f;
+                if (c < n_chunks && o < e) {
+                    if (MODE == 0) { rr[u] = crow[o]; xx[u] = cval[o]; }
+                    else rr[u] = o;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kProdDepth; ++u) {       // then all gathers
+                float v = 0.0f;
+                if (rr[u] >= 0) v = R[rr[u]];
+                if (MODE == 0) {
+                    if (add_back) v = __fadd_rn(v, __fmul_rn(xx[u], w_old));
+                    prod[u] = (rr[u] >= 0) ? __fmul_rn(v, xx[u]) : 0.0f;
+                } else {
+                    prod[u] = __fmul_rn(v, v);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kProdDepth; ++u) {
+                const int c = c0 + kProducers * u;
+                if (c >= n_chunks) break;
+                const int G = seq + c, slot = G & (kRing - 1);
+                while (lds_load_acquire(M.done) <= G - kRing) __builtin_amdgcn_s_sleep(1);   // slot still in use
+                M.ring[slot * 64 + lane] = prod[u];
+                if (lane == 0) lds_store_release(&M.ready[slot], G + 1);
+            }
+        }
+    }
+    seq += n_chunks;
+    return tmp;
+}
+
+__device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *smem) {
+    const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
+    const int U = a.U, I = a.I;
+    const int j = a.targets[t];
+    float *R = a.R + static_cast<size_t>(slot) * U;
+    float *s = a.s + static_cast<size_t>(slot) * I;
+    int *touched = a.touched + static_cast<size_t>(slot) * I;
+    float *cand_s = a.cand_s + static_cast<size_t>(slot) * I;
+    int *cand_i = a.cand_i + static_cast<size_t>(slot) * I;
+    const int K = min(a.cfg.top_features, I);
+    const FeatLds F = carve_feat(smem, K);
+    const MwLds M = carve_mw(smem, K);
+    int *f_id = F.f_id, *f_b = F.f_b, *f_e = F.f_e, *f_ever = F.f_ever;
+    float *f_nrm = F.f_nrm, *f_w = F.f_w, *f_s = F.f_s;
+
+    const float alpha = a.cfg.l1_reg, beta = a.cfg.l2_reg;
+    const int positive = a.cfg.positive;
+    const int yb = a.cptr[j], ye = a.cptr[j + 1];
+    const int ny = ye - yb;
+
+    if (tid < kRing) M.ready[tid] = 0;
+    if (tid == 0) *M.done = 0;
+    int seq = 0;
+    if (wave == 0) {
+        const Prep P = prep_target<false>(a, j, K, s, touched, cand_s, cand_i, F);
+        if (lane == 0) { M.bc_f[0] = P.yy; M.bc_f[1] = P.tol_s; M.bc_i[0] = P.tc; M.bc_i[1] = P.Kc; }
+    }
+    __syncthreads();
+    const float yy = M.bc_f[0], tol_s = M.bc_f[1];
+    const int tc = M.bc_i[0], Kc = M.bc_i[1];
+    const int nf = Kc;
+
+    bool dirty = false;
+    float gap = __fadd_rn(a.cfg.tol, 1.0f);
+    uint32_t rng = a.cfg.seed;
+    const int max_iter = a.cfg.max_iter;
+    const bool skip_cd = (ny == 0) || (nf == 0);
+    int n_iter = skip_cd ? (max_iter > 0 ? max_iter - 1 : 0) : 0;
+    int upd = 0;   // parity of the broadcast slot
+
+    for (; !skip_cd && n_iter < max_iter; ++n_iter) {
+        float w_max = 0.0f, d_w_max = 0.0f;
+        for (int f = 0; f < nf; ++f) {
+            const int p = static_cast<int>(rand_int(static_cast<uint32_t>(nf), rng));
+            const float nrm = f_nrm[p];
+            if (nrm == 0.0f) continue;
+            const int b = f_b[p], e = f_e[p];
+            const float w_old = f_w[p];
+            float w_new;
+            if (!dirty) {
+                w_new = cd_update(f_s[p], alpha, beta, nrm, positive);     // identical in every wave
+            } else {
+                const float tmp = mw_fold<0>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq);
+                upd ^= 1;
+                if (tid == 0) M.bc_f[2 + upd] = cd_update(tmp, alpha, beta, nrm, positive);
+                __syncthreads();
+                w_new = M.bc_f[2 + upd];
+            }
+            const bool changed = __float_as_uint(w_new) != __float_as_uint(w_old);
+            const bool touch_r = (w_old != 0.0f || w_new != 0.0f);
+            if (!dirty && (changed || touch_r)) __syncthreads();   // every wave has read f_w[p] before it changes
+            if (changed && tid == 0) f_w[p] = w_new;
+            if (touch_r) {
+                if (!dirty) {   // materialise R = y
+                    for (int o = yb + tid; o < ye; o += kMwThreads) R[a.crow[o]] = a.cval[o];
+                    dirty = true;
+                    __syncthreads();
+                }
+                {   // element-wise, order free: 4 gathers in flight per thread
+                    int o = b + tid;
+                    for (; o + 3 * kMwThreads < e; o += 4 * kMwThreads) {
+                        int r[4];
+                        float x[4], v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { r[k] = a.crow[o + k * kMwThreads]; x[k] = a.cval[o + k * kMwThreads]; }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) v[k] = R[r[k]];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (w_old != 0.0f) v[k] = __fadd_rn(v[k], __fmul_rn(x[k], w_old));
+                            if (w_new != 0.0f) v[k] = __fsub_rn(v[k], __fmul_rn(x[k], w_new));
+                            R[r[k]] = v[k];
+                        }
+                    }
+                    for (; o < e; o += kMwThreads) {
+                        const int r = a.crow[o];
+                        const float x = a.cval[o];
+                        float v = R[r];
+                        if (w_old != 0.0f) v = __fadd_rn(v, __fmul_rn(x, w_old));
+                        if (w_new != 0.0f) v = __fsub_rn(v, __fmul_rn(x, w_new));
+                        R[r] = v;
+                    }
+                }
+                if (tid == 0) f_ever[p] = 1;
+            }
+            if (changed || touch_r) __syncthreads();
+            const float d = fabsf(__fsub_rn(w_new, w_old));
+            d_w_max = d > d_w_max ? d : d_w_max;
+            const float aw = fabsf(w_new);
+            w_max = aw > w_max ? aw : w_max;
+        }
+
+        if (w_max == 0.0f || __fdiv_rn(d_w_max, w_max) < a.cfg.tol || n_iter == max_iter - 1) {
+            float dn = 0.0f;
+            bool dn_init = false;
+            auto dn_take = [&](float xta) {
+                const float v = positive ? xta : fabsf(xta);
+                if (!dn_init) { dn = v; dn_init = true; } else if (v > dn) dn = v;
+            };
+            float R_norm2, Ry, w_norm2 = 0.0f, l1 = 0.0f;
+            if (!dirty) {
+                for (int p = 0; p < nf; ++p) dn_take(f_nrm[p] != 0.0f ? f_s[p] : 0.0f);
+                R_norm2 = yy; Ry = yy;
+            } else {
+                for (int p = 0; p < nf; ++p) {
+                    float xta = 0.0f;
+                    if (f_nrm[p] != 0.0f) {
+                        xta = mw_fold<0>(a.crow, a.cval, R, M, f_b[p], f_e[p], 0.0f, wave, lane, seq);
+                        xta = __fsub_rn(xta, __fmul_rn(beta, f_w[p]));
+                    }
+                    dn_take(xta);
+                }
+                R_norm2 = mw_fold<1>(a.crow, a.cval, R, M, 0, U, 0.0f, wave, lane, seq);
+                Ry = 0.0f;
+                if (wave == 0) {   // short folds stay on the consumer wave
+                    for (int o = yb; o < ye; o += 64) {
+                        const int n = min(64, ye - o);
+                        float prod = 0.0f;
+                        if (lane < n) prod = __fmul_rn(R[a.crow[o + lane]], a.cval[o + lane]);
+                        Ry = chain_add(Ry, prod, n);
+                    }
+                    for (int o = 0; o < nf; o += 64) {
+                        float wv = 0.0f;
+                        if (o + lane < nf) wv = f_w[o + lane];
+                        if (__ballot(wv != 0.0f)) {
+                            const int n = min(64, nf - o);
+                            w_norm2 = chain_add(w_norm2, __fmul_rn(wv, wv), n);
+                            l1 = chain_add(l1, fabsf(wv), n);
+                        }
+                    }
+                }
+            }
+            float cst;
+            if (dn > alpha) {
+                cst = __fdiv_rn(alpha, dn);
+                const float A_norm2 = __fmul_rn(R_norm2, __fmul_rn(cst, cst));
+                gap = static_cast<float>(0.5 * static_cast<double>(__fadd_rn(R_norm2, A_norm2)));
+            } else {
+                cst = 1.0f;
+                gap = R_norm2;
+            }
+            const float t12 = __fsub_rn(__fmul_rn(alpha, l1), __fmul_rn(cst, Ry));
+            const double t3 = 0.5 * static_cast<double>(beta) * static_cast<double>(__fadd_rn(1.0f, __fmul_rn(cst, cst))) *
+                              static_cast<double>(w_norm2);
+            gap = static_cast<float>(static_cast<double>(gap) + (static_cast<double>(t12) + t3));
+            bool stop = gap < tol_s;
+            if (dirty) {   // only wave 0 holds the folded sums: broadcast its decision
+                if (tid == 0) M.bc_i[2] = stop ? 1 : 0;
+                __syncthreads();
+                stop = M.bc_i[2] != 0;
+                __syncthreads();
+            }
+            if (stop) break;
+        }
+    }
+    const int n_iter_out = (n_iter < max_iter ? n_iter : max_iter - 1) + 1;
+
+    int *oi = a.out_items + static_cast<size_t>(t) * a.cap;
+    float *oc = a.out_coef + static_cast<size_t>(t) * a.cap;
+    for (int p = tid; p < Kc; p += kMwThreads) { oi[p] = f_id[p]; oc[p] = f_w[p]; }
+    if (tid == 0) { a.out_count[t] = Kc; a.out_niter[t] = n_iter_out; }
+
+    if (dirty) {
+        for (int o = yb + tid; o < ye; o += kMwThreads) R[a.crow[o]] = 0.0f;
+        for (int p = 0; p < Kc; ++p) {
+            if (f_ever[p] == 0) continue;
+            for (int o = f_b[p] + tid; o < f_e[p]; o += kMwThreads) R[a.crow[o]] = 0.0f;
+        }
+    }
+    for (int tt = tid; tt < tc; tt += kMwThreads) s[touched[tt]] = __uint_as_float(kUntouched);
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kMwThreads) void fit_columns_mw_kernel(FitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int slot = blockIdx.x;
+    const int K = min(a.cfg.top_features, a.I);
+    const MwLds M = carve_mw(smem, K);
+    for (;;) {
+        if (threadIdx.x == 0) M.bc_i[3] = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int t = M.bc_i[3];
+        __syncthreads();
+        if (t >= a.n_targets) return;
+        fit_one_mw(a, t, slot, smem);
+    }
+}
+
 __global__ __launch_bounds__(64) void column_sqnorms_kernel(int n_items, const int *cptr, const float *cval, float *sqn) {
     const int lane = lane_id();
     for (int c = blockIdx.x; c < n_items; c += gridDim.x) {
@@ -770,8 +1080,14 @@ extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
     if (allf) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true>), dim3(grid), dim3(64), 16, st, a);
     } else {
-        const size_t lds = feat_lds_bytes(K);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), lds, st, a);
+        // few targets (online partial_fit): the heaviest target is the critical path -> latency mode
+        const char *force = std::getenv("RTREC_AMD_FIT_MODE");            // "mw" / "sw": A/B switch
+        const bool latency_mode = force ? (force[0] == 'm') : (n_targets <= kMwMaxTargets);
+        if (latency_mode) {
+            hipLaunchKernelGGL(fit_columns_mw_kernel, dim3(grid), dim3(kMwThreads), mw_lds_bytes(K), st, a);
+        } else {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), feat_lds_bytes(K), st, a);
+        }
     }
     return rtrec::launch_status();
 }

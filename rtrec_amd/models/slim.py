@@ -74,10 +74,27 @@ class SLIM(BaseModel):
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
         if len(user_ids) == 0:
             return []
-        self._sync_interactions()
         dense_output = not self.item_ids.pass_through
-        ids, scores, counts = self.model._topk(None, candidate_item_ids, top_k, filter_interacted, dense_output,
-                                               row_ids=user_ids)
+        stamp = (self.interactions.version, self.interactions.max_timestamp)
+        n_users = self.interactions.shape[0]
+        if self._x_on_device == stamp or len(user_ids) * 16 >= n_users:
+            # bulk scoring: (re)upload all of X once and score it in place by row id
+            self._sync_interactions()
+            ids, scores, counts = self.model._topk(None, candidate_item_ids, top_k, filter_interacted, dense_output,
+                                                   row_ids=user_ids)
+        else:
+            # online serving after an update: ship only the requested users' rows (like the
+            # reference's to_csr(select_users=...), but without the empty rows)
+            uniq, inverse = np.unique(np.asarray(user_ids, dtype=np.int64), return_inverse=True)
+            rows, cols, data = self.interactions._triples(select_users=uniq)
+            indptr = np.zeros(len(uniq) + 1, dtype=np.int64)
+            indptr[1:] = np.bincount(np.searchsorted(uniq, rows), minlength=len(uniq))
+            np.cumsum(indptr, out=indptr)
+            from scipy.sparse import csr_matrix
+            Xb = csr_matrix((data.astype(np.float32), cols.astype(np.int32), indptr.astype(np.int32)),
+                            shape=(len(uniq), self.interactions.shape[1]))
+            ids, scores, counts = self.model._topk(Xb, candidate_item_ids, top_k, filter_interacted, dense_output)
+            ids, scores, counts = ids[inverse], scores[inverse], counts[inverse]
         return self.model._format(ids, scores, counts, ret_scores=False)
 
     def _similar_items(self, query_item_id: int, query_item_tags: Optional[List[str]] = None, top_k: int = 10

@@ -33,15 +33,27 @@ _DELTA_MERGE_MIN = 1 << 16
 
 class _Block:
     """Sorted (key, value, timestamp) columns."""
-    __slots__ = ("key", "val", "ts")
+    __slots__ = ("key", "val", "ts", "_perm", "_iptr")
 
     def __init__(self, key=None, val=None, ts=None):
         self.key = np.empty(0, np.int64) if key is None else key
         self.val = np.empty(0, np.float64) if val is None else val
         self.ts = np.empty(0, np.float64) if ts is None else ts
+        self._perm = None
+        self._iptr = None
 
     def __len__(self) -> int:
         return int(self.key.shape[0])
+
+    def item_index(self, n_items: int) -> Tuple[np.ndarray, np.ndarray]:
+        """(perm, iptr): positions of the entries in item-major order and the CSC-style pointer over
+        items.  Built lazily, valid until the block's key set changes."""
+        if self._iptr is None or self._iptr.shape[0] != n_items + 1:
+            items = self.key & _MASK
+            self._perm = np.argsort(items, kind="stable")        # users stay ascending inside an item
+            self._iptr = np.zeros(n_items + 1, dtype=np.int64)
+            np.cumsum(np.bincount(items, minlength=n_items), out=self._iptr[1:])
+        return self._perm, self._iptr
 
     def find(self, keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """(found mask, position) of each key."""
@@ -201,15 +213,19 @@ class UserItemInteractions:
         self.max_item_id = max(self.max_item_id, int(items.max()))
 
     # ------------------------------------------------------------------ queries
-    def _user_slice(self, blk: _Block, user_id: int) -> slice:
-        lo = np.searchsorted(blk.key, np.int64(user_id) << _SHIFT)
-        hi = np.searchsorted(blk.key, (np.int64(user_id) + 1) << _SHIFT)
-        return slice(int(lo), int(hi))
-
     def _user_entries(self, user_id: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        blk = self._compact()
-        s = self._user_slice(blk, user_id)
-        return blk.key[s] & _MASK, blk.val[s], blk.ts[s]
+        sb = self._select(self._base, np.array([user_id], np.int64), None)
+        sd = self._select(self._delta, np.array([user_id], np.int64), None)
+        if len(sd) == 0:
+            return self._base.key[sb] & _MASK, self._base.val[sb], self._base.ts[sb]
+        key = np.concatenate([self._delta.key[sd], self._base.key[sb]])
+        val = np.concatenate([self._delta.val[sd], self._base.val[sb]])
+        ts = np.concatenate([self._delta.ts[sd], self._base.ts[sb]])
+        order = np.argsort(key, kind="stable")
+        key, val, ts = key[order], val[order], ts[order]
+        keep = np.ones(len(key), bool)
+        keep[1:] = key[1:] != key[:-1]
+        return key[keep] & _MASK, val[keep], ts[keep]
 
     def has_interaction(self, user_id: int, item_id: int) -> bool:
         found, _, _ = self._lookup(self._keys(np.array([user_id]), np.array([item_id])))
@@ -269,27 +285,59 @@ class UserItemInteractions:
         return list(self.hot_items.get_freq_items(n, exclude_items=interacted))
 
     def get_users_by_items(self, item_ids: List[int]) -> List[int]:
-        blk = self._compact()
-        hit = np.isin(blk.key & _MASK, np.asarray(list(item_ids), dtype=np.int64))
-        return np.unique(blk.key[hit] >> _SHIFT).tolist()
+        rows, _, _ = self._triples(select_items=list(item_ids), weights=False)
+        return np.unique(rows).tolist()
 
     # ------------------------------------------------------------------ export
+    @staticmethod
+    def _ranges(lo: np.ndarray, hi: np.ndarray) -> np.ndarray:
+        """Concatenation of the index ranges [lo_k, hi_k)."""
+        cnt = hi - lo
+        total = int(cnt.sum())
+        if total == 0:
+            return np.empty(0, np.int64)
+        return np.repeat(lo - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(total)
+
+    def _select(self, blk: _Block, users: Optional[np.ndarray], items: Optional[np.ndarray]) -> np.ndarray:
+        """Positions of a block's entries restricted to the given users and/or items, without
+        scanning the block: user ranges come from the sorted keys, item ranges from the item index."""
+        if len(blk) == 0:
+            return np.empty(0, np.int64)
+        if users is not None:
+            sel = self._ranges(np.searchsorted(blk.key, users << _SHIFT), np.searchsorted(blk.key, (users + 1) << _SHIFT))
+            if items is not None:
+                sel = sel[np.isin(blk.key[sel] & _MASK, items)]
+            return sel
+        if items is not None:
+            if len(blk) < (1 << 15):
+                return np.flatnonzero(np.isin(blk.key & _MASK, items))
+            perm, iptr = blk.item_index(self.max_item_id + 1)
+            it = items[items <= self.max_item_id]
+            return np.sort(perm[self._ranges(iptr[it], iptr[it + 1])])
+        return np.arange(len(blk))
+
     def _triples(self, select_users: Optional[Sequence[int]] = None, select_items: Optional[Sequence[int]] = None,
                  weights: bool = True) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """(rows, cols, float64 decayed values) in key order (user-major, item ascending)."""
-        blk = self._compact()
-        key, val, ts = blk.key, blk.val, blk.ts
-        if select_users is not None:
-            su = np.unique(np.asarray(list(select_users), dtype=np.int64))
-            lo = np.searchsorted(key, su << _SHIFT)
-            hi = np.searchsorted(key, (su + 1) << _SHIFT)
-            cnt = hi - lo
-            total = int(cnt.sum())
-            sel = np.repeat(lo - np.concatenate(([0], np.cumsum(cnt)[:-1])), cnt) + np.arange(total)
-            key, val, ts = key[sel], val[sel], ts[sel]
-        if select_items is not None:
-            keep = np.isin(key & _MASK, np.asarray(list(select_items), dtype=np.int64))
-            key, val, ts = key[keep], val[keep], ts[keep]
+        """(rows, cols, float64 decayed values) in key order (user-major, item ascending).
+        Selections read only the selected rows / columns of the base and delta blocks, so a
+        mini-batch export costs O(selected entries), not O(all interactions)."""
+        users = None if select_users is None else np.unique(np.asarray(list(select_users), dtype=np.int64))
+        items = None if select_items is None else np.unique(np.asarray(list(select_items), dtype=np.int64))
+        if users is None and items is None:
+            blk = self._compact()
+            key, val, ts = blk.key, blk.val, blk.ts
+        else:
+            sb = self._select(self._base, users, items)
+            sd = self._select(self._delta, users, items)
+            key = np.concatenate([self._delta.key[sd], self._base.key[sb]])     # delta first: it wins
+            val = np.concatenate([self._delta.val[sd], self._base.val[sb]])
+            ts = np.concatenate([self._delta.ts[sd], self._base.ts[sb]])
+            if len(sd):
+                order = np.argsort(key, kind="stable")
+                key, val, ts = key[order], val[order], ts[order]
+                keep = np.ones(len(key), bool)
+                keep[1:] = key[1:] != key[:-1]
+                key, val, ts = key[keep], val[keep], ts[keep]
         data = self._decay_array(val, ts, self.max_timestamp) if weights else val
         return key >> _SHIFT, key & _MASK, data
 

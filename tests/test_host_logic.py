@@ -213,3 +213,33 @@ def test_shard_bounds_and_seed():
     assert [shard_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
     assert [shard_bounds(3, 8, r) for r in range(8)][:4] == [(0, 1), (1, 2), (2, 3), (3, 3)]
     assert sklearn_seed(43) == 494155588
+
+
+def test_store_selected_exports_use_indexes_and_match_full_export():
+    """Large store (item-index path), with a populated delta block on top of the base block."""
+    rng = np.random.default_rng(4)
+    n = 120_000
+    u, i = rng.integers(0, 3000, n), rng.integers(0, 900, n)
+    ts = 1.7e9 + np.sort(rng.random(n)) * 1e6
+    r = rng.integers(1, 6, n).astype(float)
+    s = UserItemInteractions(min_value=-5, max_value=50, decay_in_days=30)
+    s.add_interactions_batch(u[:100_000], i[:100_000], ts[:100_000], r[:100_000])
+    s._compact()
+    for a in range(100_000, n, 1000):          # mini-batches land in the delta block
+        s.add_interactions_batch(u[a:a + 1000], i[a:a + 1000], ts[a:a + 1000], r[a:a + 1000])
+    assert len(s._delta) > 0 and len(s._base) > (1 << 15)
+    sel_items = [5, 17, 123, 899, 400]
+    sel_users = [0, 7, 2999, 1500]
+    part_c = s.to_csc(sel_items)
+    part_r = s.to_csr(sel_users)
+    users_by = s.get_users_by_items(sel_items)
+    items_7 = s.get_user_items(7)
+    full_c, full_r = s.to_csc(), s.to_csr()          # compacts
+    mask_c = np.zeros(full_c.shape[1], bool); mask_c[sel_items] = True
+    exp_c = full_c.multiply(sp.csr_matrix(mask_c.astype(np.float32))).tocsc()
+    assert (part_c != exp_c).nnz == 0
+    mask_r = np.zeros(full_r.shape[0], bool); mask_r[sel_users] = True
+    exp_r = sp.diags(mask_r.astype(np.float32)).dot(full_r).tocsr()
+    assert (part_r != exp_r).nnz == 0
+    assert sorted(users_by) == sorted(np.unique(full_c[:, sel_items].tocoo().row).tolist())
+    assert sorted(items_7) == sorted(full_r[7].indices.tolist())
