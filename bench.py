@@ -199,6 +199,18 @@ def main() -> None:
             dist.destroy_process_group()
         return
 
+    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (FETCH_SIZE /
+    # WRITE_SIZE cannot be read from inside the process); the committed summary is attached when
+    # it belongs to this workload.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc_traffic.json")
+    if world == 1 and os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch_corrected"]
+            traffic_src = os.path.relpath(tpath, ROOT)
+        except Exception:
+            traffic = None
+
     line = {
         "metric": "users-scored/sec top-10 (SLIM recommend, int ids, filter_interacted) + fit interactions/sec in `fit`",
         "value": value, "unit": "users/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -213,7 +225,7 @@ def main() -> None:
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean())},
         "roofline": {"kernel": "score_sparse_kernel<float,false>", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
                      "kernel_ms_avg": kern_ms, "launches": int(n_launch.value)},
     }
 
