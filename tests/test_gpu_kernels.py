@@ -33,9 +33,12 @@ def bits(a):
     (3000, 800, 90000, 50, True, False),     # integer ratings: ties everywhere, same tie rule both sides
     (400, 30, 3000, 50, True, True),         # K > I
 ])
-@pytest.mark.parametrize("fit_mode", ["sw", "mw"])    # single-wave (throughput) and multi-wave (latency) kernels
+# single-wave (throughput) kernel, multi-wave (latency) kernel, and the latter with the column-walk X^T y forced
+@pytest.mark.parametrize("fit_mode", ["sw", "mw", "mw-colwalk"])
 def test_fit_columns_bit_exact(engine, oracle, U, I, draws, K, positive, float_ratings, fit_mode, monkeypatch):
-    monkeypatch.setenv("RTREC_AMD_FIT_MODE", fit_mode)
+    monkeypatch.setenv("RTREC_AMD_FIT_MODE", fit_mode[:2])
+    if fit_mode == "mw-colwalk":
+        monkeypatch.setenv("RTREC_AMD_COLWALK_MIN", "1")
     X = interaction_matrix(U, I, draws, seed=11, float_ratings=float_ratings)
     Xc = X.tocsc()
     Xc.sort_indices()
