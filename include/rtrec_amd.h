@@ -173,6 +173,17 @@ int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                           uint32_t *d_out_aux, int32_t *d_out_count,
                           void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* Score-vector export (replaces slim_elastic.py:566-626 predict / predict_selected / predict_all):
+ * d_out[r * out_stride + c] = sum_i X[row_r, i] * W[i, col_offset + c] for the n_cols columns of a
+ * PLAIN (not compacted, no dense blocks) tiled layout, accumulated in csr_matmat order;
+ * d_out is float32, or float64 when acc_f64 != 0. */
+int rtrec_slim_score_rows(int32_t n_rows, const int32_t *d_row_ids,
+                          const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
+                          int32_t n_items, int32_t n_cols, int32_t col_offset,
+                          int32_t tile_cols, int32_t n_tiles,
+                          const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
+                          int32_t acc_f64, void *d_out, int64_t out_stride, void *stream);
+
 /* Merge `n_lists` per-shard top-k lists per row (layout [n_lists][n_rows][top_k], as produced
  * by an all-gather of rtrec_slim_score_topk outputs) into one top-k per row, using the same
  * (score, aux, id) order.  d_in_scores64 may be NULL (then float32 scores are compared). */

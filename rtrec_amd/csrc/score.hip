@@ -510,6 +510,32 @@ __global__ __launch_bounds__(64) void score_tiles_dense_kernel(ScoreArgs a) {
     emit_result<ACC>(a, L, row, tile, n_out);
 }
 
+// ---- score-vector export (SLIMElastic.predict / predict_selected / predict_all) ----------------
+// Same accumulation as the DENSE mode, but the tile is written out instead of reduced:
+// out[row, t0 + c] for the columns of the plain layout.
+template <typename ACC>
+__global__ __launch_bounds__(64) void score_rows_kernel(ScoreArgs a, ACC *out, long long out_stride) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
+    const long long per_xcd = (total + 7) / 8;
+    const long long w = static_cast<long long>(blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+    if (blockIdx.x / 8 >= per_xcd || w >= total) return;
+    const int tile = static_cast<int>(w / a.n_rows);
+    const int row = static_cast<int>(w % a.n_rows);
+    const int lane = lane_id();
+    const int S = a.tile_cols;
+    const TileLds<ACC> L = carve_lds<ACC>(smem, S, false, false);
+    const int t0 = tile * S;
+    const int ncol = min(S, a.n_cols - t0);
+    const int xrow = a.row_ids ? a.row_ids[row] : row;
+    const int a0 = a.xb_ptr[xrow];
+    const int n_a = a.xb_ptr[xrow + 1] - a0;
+    for (int c = lane * 4; c < S; c += 256) { L.acc[c] = ACC(0); L.acc[c + 1] = ACC(0); L.acc[c + 2] = ACC(0); L.acc[c + 3] = ACC(0); }
+    accumulate_tile<ACC, false, false>(a, L, a0, n_a, tile);
+    ACC *o = out + static_cast<long long>(row) * out_stride + t0;
+    for (int c = lane; c < ncol; c += 64) o[c] = L.acc[c];
+}
+
 // ---- SPARSE mode: persistent waves, accumulators stay in LDS across jobs ----------------------
 // Between jobs every accumulator holds the "untouched" marker; a job only visits, selects from
 // and resets the columns it touched, so its cost follows the user's W rows, not the tile width.
@@ -921,6 +947,35 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     if (acc_f64)
         return score_impl<double>(a, top_k, 8, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st);
     return score_impl<float>(a, top_k, 4, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st);
+}
+
+extern "C" int rtrec_slim_score_rows(int32_t n_rows, const int32_t *d_row_ids,
+                                     const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
+                                     int32_t n_items, int32_t n_cols, int32_t col_offset,
+                                     int32_t tile_cols, int32_t n_tiles,
+                                     const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
+                                     int32_t acc_f64, void *d_out, int64_t out_stride, void *stream) {
+    if (n_rows < 0 || n_items <= 0 || n_cols <= 0 || out_stride < n_cols) return RTREC_ERR_INVALID_ARG;
+    if (n_rows == 0) return RTREC_OK;
+    if (!d_xb_ptr || !d_tile_ptr || !d_out) return RTREC_ERR_INVALID_ARG;
+    if (tile_cols < 256 || tile_cols > 16384 || (tile_cols % 256) != 0) return RTREC_ERR_UNSUPPORTED;
+    if (n_tiles != (n_cols + tile_cols - 1) / tile_cols) return RTREC_ERR_INVALID_ARG;
+    ScoreArgs a{};
+    a.n_rows = n_rows; a.row_ids = d_row_ids; a.xb_ptr = d_xb_ptr; a.xb_col = d_xb_col; a.xb_val = d_xb_val;
+    a.n_items = n_items; a.n_cols = n_cols; a.col_offset = col_offset;
+    a.tile_cols = tile_cols; a.n_tiles = n_tiles; a.tile_ptr = d_tile_ptr; a.w_col = d_w_col; a.w_val = d_w_val;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    const long long total = static_cast<long long>(n_rows) * n_tiles;
+    const unsigned grid = static_cast<unsigned>(((total + 7) / 8) * 8);
+    const size_t lds = score_lds_bytes(tile_cols, acc_f64 ? 8 : 4, false, false);
+    if (acc_f64)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_rows_kernel<double>), dim3(grid), dim3(64), lds, st, a,
+                           static_cast<double *>(d_out), static_cast<long long>(out_stride));
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_rows_kernel<float>), dim3(grid), dim3(64), lds, st, a,
+                           static_cast<float *>(d_out), static_cast<long long>(out_stride));
+    return rtrec::launch_status();
 }
 
 extern "C" int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t top_k,

@@ -185,6 +185,13 @@ class HipBackend:
             self.ptr(ids), self.ptr(sc), self.ptr(sc64), self.ptr(aux), self.ptr(cnt),
             self.ptr(ws), ws.numel(), self.stream()), "rtrec_slim_score_topk")
 
+    def score_rows(self, n_rows, row_ids, xb, n_items, col_lo, lay, acc_f64, out):
+        _native.check(self.lib.rtrec_slim_score_rows(
+            n_rows, self.ptr(row_ids), self.ptr(xb[0]), self.ptr(xb[1]), self.ptr(xb[2]),
+            n_items, lay["n_cols"], col_lo, lay["tile_cols"], lay["n_tiles"],
+            self.ptr(lay["tile_ptr"]), self.ptr(lay["w_col"]), self.ptr(lay["w_val"]),
+            int(acc_f64), self.ptr(out), int(out.stride(0)), self.stream()), "rtrec_slim_score_rows")
+
     def merge_topk(self, n_rows, n_lists, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt):
         _native.check(self.lib.rtrec_slim_merge_topk(n_rows, n_lists, top_k, self.ptr(g_ids), self.ptr(g_sc),
                                                      self.ptr(g_sc64), self.ptr(g_aux), self.ptr(g_cnt),
@@ -427,6 +434,34 @@ class SlimEngine:
               be.to_dev(np.asarray(Xb.data, dtype=np.float32)))
         ids, sc, cnt = self.score_topk_device(None, B, top_k, filter_interacted, mode, col_rank, xb=xb)
         return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+
+    # ------------------------------------------------------------------------------ score vectors
+    def predict_csr(self, Xb: sp.csr_matrix) -> np.ndarray:
+        """Dense score rows Xb . W (float32, or float64 for a float64 W) for a host CSR batch:
+        the SLIMElastic.predict* boundary.  [B, n_items]; with several ranks each computes its own
+        column block and the blocks are concatenated on the host."""
+        be, W = self.be, self._W
+        if not W:
+            raise RuntimeError("Model must be fitted before calling predict.")
+        torch = be.torch
+        B = Xb.shape[0]
+        if not Xb.has_sorted_indices:
+            Xb = Xb.sorted_indices()
+        xb = (be.to_dev(np.asarray(Xb.indptr, dtype=np.int32)), be.to_dev(np.asarray(Xb.indices, dtype=np.int32)),
+              be.to_dev(np.asarray(Xb.data, dtype=np.float32)))
+        lay = self._layout(compact=False)
+        dt = torch.float64 if W["acc_f64"] else torch.float32
+        n_local = W["col_hi"] - W["col_lo"]
+        out = be.zeros((B, max(n_local, 1)), dt)
+        if lay is not None and B > 0:
+            be.score_rows(B, None, xb, W["n_items"], W["col_lo"], lay, W["acc_f64"], out)
+        block = out.cpu().numpy()[:, :n_local]
+        if self.world_size == 1:
+            return block
+        import torch.distributed as dist
+        parts: List[Any] = [None] * self.world_size
+        dist.all_gather_object(parts, block, group=self.group)
+        return np.concatenate(parts, axis=1)
 
     # ------------------------------------------------------------------------------ similar
     def similar_items(self, queries: Sequence[int], top_k: int = 10) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

@@ -238,19 +238,34 @@ class SLIMElastic:
         if self.item_similarity is None:
             raise RuntimeError(f"Model must be fitted before calling {what}.")
 
+    def _predict_rows(self, Xb: sp.csr_matrix, dense_output: bool):
+        """Xb . W as the reference's safe_sparse_dot returns it: ndarray if dense_output, else a CSR
+        (canonical: sorted indices, exact zeros dropped -- scipy's unsorted product order is not kept)."""
+        self._sync_weights()
+        n_items = self._item_similarity.shape[1]
+        Xb = Xb.tocsr()
+        if Xb.shape[1] != n_items:
+            Xb = Xb.copy()
+            Xb.resize((Xb.shape[0], n_items))
+        S = self.engine.predict_csr(Xb)
+        return S if dense_output else sp.csr_matrix(S)
+
     def predict(self, user_id: int, interaction_matrix: sp.csr_matrix, dense_output: bool = True):
+        """Scores of one user for all items: shape (1, n_items) (slim_elastic.py:566-585)."""
         self._not_fitted("predict")
-        raise NotImplementedError("score-vector export (predict*) is not part of the GPU path yet; "
-                                  "use recommend()/recommend_batch()")
+        return self._predict_rows(interaction_matrix[user_id, :], dense_output)
 
     def predict_selected(self, user_id: int, item_ids: List[int], interaction_matrix: sp.csr_matrix,
                          dense_output: bool = True):
+        """Scores of one user for the given items: shape (1, len(item_ids)) (slim_elastic.py:587-608)."""
         self._not_fitted("predict_selected")
-        raise NotImplementedError("score-vector export (predict*) is not part of the GPU path yet")
+        S = self._predict_rows(interaction_matrix[user_id, :], True)[:, list(item_ids)]
+        return S if dense_output else sp.csr_matrix(S)
 
     def predict_all(self, interaction_matrix: sp.csr_matrix, dense_output: bool = True):
+        """Scores of every row of the matrix: shape (n_users, n_items) (slim_elastic.py:610-626)."""
         self._not_fitted("predict_all")
-        raise NotImplementedError("score-vector export (predict*) is not part of the GPU path yet")
+        return self._predict_rows(interaction_matrix, dense_output)
 
     # ---------------------------------------------------------------- item-to-item
     def similar_items(self, item_id: int, top_k: int = 10, ret_ndarrays: bool = False

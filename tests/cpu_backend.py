@@ -64,11 +64,7 @@ class OracleBackend:
         alpha = a + b
         return alpha, (a / alpha if alpha else 0.0)
 
-    def score_workspace_bytes(self, n_rows, n_tiles, top_k):
-        return 1
-
-    def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
-                   acc_f64, ids, sc, sc64, aux, cnt, ws):
+    def _shard_w(self, n_items, col_lo, lay):
         # rebuild this shard's W (n_items x n_items, only the shard's columns populated)
         S, T = lay["tile_cols"], lay["n_tiles"]
         tp = lay["tile_ptr"].numpy().reshape(T, n_items + 1)
@@ -92,6 +88,14 @@ class OracleBackend:
                 cols.append(lay["col_ids"].numpy()[loc] if lay["col_ids"] is not None else loc + col_lo)
                 vals.append(blk[nz])
         Wr = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n_items, n_items))
+        return Wr
+
+    def score_workspace_bytes(self, n_rows, n_tiles, top_k):
+        return 1
+
+    def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
+                   acc_f64, ids, sc, sc64, aux, cnt, ws):
+        Wr = self._shard_w(n_items, col_lo, lay)
         ptr, col, val = (t.numpy() for t in xb)
         Xall = sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, n_items))
         rsel = row_ids.numpy() if row_ids is not None else np.arange(n_rows)
@@ -101,6 +105,14 @@ class OracleBackend:
         aux.zero_()
         if sc64 is not None:
             sc64.copy_(torch.from_numpy(o_sc.astype(np.float64)))
+
+    def score_rows(self, n_rows, row_ids, xb, n_items, col_lo, lay, acc_f64, out):
+        Wr = self._shard_w(n_items, col_lo, lay)
+        ptr, col, val = (t.numpy() for t in xb)
+        Xall = sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, n_items))
+        dt = np.float64 if acc_f64 else np.float32
+        S = (Xall.astype(dt) @ Wr.astype(dt)).toarray()[:, col_lo:col_lo + lay["n_cols"]]
+        out[:, :lay["n_cols"]] = torch.from_numpy(np.ascontiguousarray(S))
 
     def merge_topk(self, n_rows, n_lists, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt):
         gi, gs, ga, gc = g_ids.numpy(), g_sc.numpy(), g_aux.numpy().view(np.uint32), g_cnt.numpy()

@@ -122,3 +122,22 @@ def test_slimelastic_matches_reference_models_and_scores():
         fin = int(np.sum(np.isfinite(g)))
         n = next((k for k in range(fin - 1) if g[k] == g[k + 1]), fin)
         assert ids[:n].tolist() == zs["similar_ids"][j, :n].tolist()
+
+
+def test_predict_score_vectors_on_gpu():
+    from rtrec_amd.models.internal.slim_elastic import SLIMElastic
+    z = np.load(os.path.join(G, "models.npz"))
+    zs = np.load(os.path.join(G, "scoring.npz"))
+    X2 = load_csc(z, "X2").tocsr()
+    m = SLIMElastic({"nn_feature_selection": 50})
+    m.item_similarity = load_csc(z, "W2_k50")
+    users, cands = zs["predict_users"].tolist(), zs["cands"].tolist()
+    for r, u in enumerate(users):
+        assert np.array_equal(bits(m.predict(u, X2).ravel()), bits(zs["predict_dense"][r]))
+        assert np.array_equal(bits(m.predict(u, X2, dense_output=False).toarray().ravel()), bits(zs["predict_sparse_as_dense"][r]))
+        assert np.array_equal(bits(m.predict_selected(u, cands, X2).ravel()), bits(zs["predict_selected"][r]))
+    assert np.array_equal(bits(m.predict_all(X2[:40])), bits(zs["predict_all_head"]))
+    m.item_similarity = sp.csc_matrix(m.item_similarity, dtype=np.float64)
+    for r, u in enumerate(users):
+        d64 = m.predict(u, X2)
+        assert d64.dtype == np.float64 and np.array_equal(d64.ravel(), zs["predict_dense_f64"][r])

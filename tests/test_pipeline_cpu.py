@@ -200,3 +200,25 @@ def test_two_rank_column_sharding_gloo():
     assert all(r[1] for r in res), "merged W differs from the single-process reference W"
     assert all(r[2] for r in res), "sharded top-k + merge differs from the reference top-k"
     assert res[0][3] + res[1][3] > 0
+
+
+def test_predict_score_vectors_match_reference():
+    z = np.load(os.path.join(G, "models.npz"))
+    zs = np.load(os.path.join(G, "scoring.npz"))
+    X2 = load_csc(z, "X2").tocsr()
+    m = SLIMElastic({"nn_feature_selection": 50}, engine=SlimEngine(backend=OracleBackend()))
+    with pytest.raises(RuntimeError, match="Model must be fitted before calling predict"):
+        m.predict(0, X2)
+    m.item_similarity = load_csc(z, "W2_k50")
+    users, cands = zs["predict_users"].tolist(), zs["cands"].tolist()
+    for r, u in enumerate(users):
+        d = m.predict(u, X2, dense_output=True)
+        assert d.shape == (1, 400) and d.dtype == np.float32
+        assert np.array_equal(bits(d.ravel()), bits(zs["predict_dense"][r]))
+        s_ = m.predict(u, X2, dense_output=False)
+        assert sp.issparse(s_) and np.array_equal(bits(s_.toarray().ravel()), bits(zs["predict_sparse_as_dense"][r]))
+        assert np.array_equal(bits(m.predict_selected(u, cands, X2).ravel()), bits(zs["predict_selected"][r]))
+    assert np.array_equal(bits(m.predict_all(X2[:40])), bits(zs["predict_all_head"]))
+    m.item_similarity = sp.csc_matrix(m.item_similarity, dtype=np.float64)
+    d64 = m.predict(users[1], X2)
+    assert d64.dtype == np.float64 and np.array_equal(d64.ravel(), zs["predict_dense_f64"][1])

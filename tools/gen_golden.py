@@ -180,6 +180,17 @@ def gen_scoring(X2, model):
         sim_s.append(b.astype(np.float64).tolist())
     out["similar_ids"] = pad_lists(sim_i, 6, -1)
     out["similar_scores"] = pad_lists(sim_s, 6, float("-inf"))
+    # score-vector export: predict / predict_selected / predict_all (slim_elastic.py:566-626)
+    pu = [0, 5, 333, 1199]
+    out["predict_users"] = np.array(pu)
+    out["predict_dense"] = np.stack([np.asarray(model.predict(u, Xr, dense_output=True)).ravel() for u in pu])
+    sp_rows = [model.predict(u, Xr, dense_output=False) for u in pu]
+    out["predict_sparse_as_dense"] = np.stack([np.asarray(m.toarray()).ravel() for m in sp_rows])
+    out["predict_selected"] = np.stack([np.asarray(model.predict_selected(u, cands, Xr)).ravel() for u in pu])
+    out["predict_all_head"] = np.asarray(model.predict_all(Xr[:40], dense_output=True))
+    model.item_similarity = W64
+    out["predict_dense_f64"] = np.stack([np.asarray(model.predict(u, Xr, dense_output=True)).ravel() for u in pu])
+    model.item_similarity = W32
     np.savez_compressed(os.path.join(OUT, "scoring.npz"), **out)
 
 
