@@ -250,7 +250,9 @@ class BaseModel(ABC):
 
     @classmethod
     def load(cls, f: FileLike) -> "BaseModel":
-        return cls._deserialize(pickle.loads(f.read()))
+        """Load a model saved by rtrec_amd OR by the reference (rtrec.models.SLIM.save)."""
+        from ..compat import loads as compat_loads
+        return cls._deserialize(compat_loads(f.read()))
 
     @classmethod
     def loads(cls, data: bytes) -> "BaseModel":

@@ -80,6 +80,17 @@ class SLIMElastic:
         state["_w_on_device"] = None
         return state
 
+    def __setstate__(self, state: Dict[str, Any]) -> None:
+        # the reference keeps `item_similarity` as a plain attribute (slim_elastic.py:193)
+        if "item_similarity" in state:
+            state = dict(state)
+            state["_item_similarity"] = state.pop("item_similarity")
+        self.__dict__.update(state)
+        self.__dict__.setdefault("_item_similarity", None)
+        self._engine = None
+        self._w_on_device = None
+        self.__dict__.setdefault("n_iter_", None)
+
     def _check_optim(self) -> None:
         if self.optim_name == "cd":
             return

@@ -24,6 +24,12 @@ class IndexedSet(Generic[T]):
         for item in iterable or ():
             self.add(item)
 
+    def __setstate__(self, state):
+        # reference layout: _key_to_index / _index_to_key (rtrec/utils/collections.py:11-12)
+        if "_key_to_index" in state:
+            state = {"_pos": state["_key_to_index"], "_keys": state["_index_to_key"]}
+        self.__dict__.update(state)
+
     def add(self, key: T) -> int:
         pos = self._pos.get(key)
         if pos is None:
@@ -102,6 +108,15 @@ class FeatureStore:
     def __init__(self) -> None:
         self._users = _Side()
         self._items = _Side()
+
+    def __setstate__(self, state):
+        # reference layout: user_features / item_features (IndexedSet) + *_feature_map dicts
+        if "user_features" in state:
+            self._users, self._items = _Side(), _Side()
+            self._users.vocab, self._users.by_entity = state["user_features"], state["user_feature_map"]
+            self._items.vocab, self._items.by_entity = state["item_features"], state["item_feature_map"]
+        else:
+            self.__dict__.update(state)
 
     @property
     def user_features(self) -> IndexedSet:

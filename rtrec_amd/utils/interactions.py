@@ -45,6 +45,14 @@ class _Block:
     def __len__(self) -> int:
         return int(self.key.shape[0])
 
+    def __getstate__(self):
+        return (self.key, self.val, self.ts)
+
+    def __setstate__(self, st):
+        self.key, self.val, self.ts = st
+        self._perm = None
+        self._iptr = None
+
     def item_index(self, n_items: int) -> Tuple[np.ndarray, np.ndarray]:
         """(perm, iptr): positions of the entries in item-major order and the CSC-style pointer over
         items.  Built lazily, valid until the block's key set changes."""
@@ -100,6 +108,25 @@ class UserItemInteractions:
         self._base = _Block()
         self._delta = _Block()
         self.version = 0   # bumped on every mutation; device mirrors key their caches on it
+
+    def __setstate__(self, state: Dict[str, Any]) -> None:
+        """Own pickles restore as they are; a REFERENCE pickle carries `interactions` as
+        {user: {item: (value, tstamp)}} (interactions.py:27) and is converted to sorted columns."""
+        nested = state.get("interactions") if isinstance(state.get("interactions"), dict) else None
+        if nested is None:
+            self.__dict__.update(state)
+            return
+        state = {k: v for k, v in state.items() if k != "interactions"}
+        self.__dict__.update(state)
+        users, items, vals, tss = [], [], [], []
+        for u, inner in nested.items():
+            for i, (v, t) in inner.items():
+                users.append(u); items.append(i); vals.append(v); tss.append(t)
+        key = self._keys(np.asarray(users, dtype=np.int64), np.asarray(items, dtype=np.int64))
+        order = np.argsort(key, kind="stable")
+        self._base = _Block(key[order], np.asarray(vals, dtype=np.float64)[order], np.asarray(tss, dtype=np.float64)[order])
+        self._delta = _Block()
+        self.version = 0
 
     # ------------------------------------------------------------------ decay
     def get_decay_rate(self) -> Optional[float]:

@@ -141,3 +141,14 @@ def test_predict_score_vectors_on_gpu():
     for r, u in enumerate(users):
         d64 = m.predict(u, X2)
         assert d64.dtype == np.float64 and np.array_equal(d64.ravel(), zs["predict_dense_f64"][r])
+
+
+def test_reference_written_model_file_serves_on_gpu():
+    from rtrec_amd import SLIM
+    exp = json.load(open(os.path.join(G, "ref_pickles.json")))
+    m = SLIM.loads(open(os.path.join(G, "ref_slim_int.pkl"), "rb").read())
+    assert m.recommend_batch(exp["int"]["users"], top_k=5) == exp["int"]["recs"]
+    assert m.similar_items(3, top_k=4) == exp["int"]["similar_3"]
+    s = SLIM.loads(open(os.path.join(G, "ref_slim_str.pkl"), "rb").read())
+    assert s.similar_items("item_1", top_k=5) == exp["str"]["similar_item_1"]
+    assert s.recommend("user_2", top_k=5) == exp["str"]["rec_user_2"]

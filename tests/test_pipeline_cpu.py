@@ -222,3 +222,28 @@ def test_predict_score_vectors_match_reference():
     m.item_similarity = sp.csc_matrix(m.item_similarity, dtype=np.float64)
     d64 = m.predict(users[1], X2)
     assert d64.dtype == np.float64 and np.array_equal(d64.ravel(), zs["predict_dense_f64"][1])
+
+
+def test_loads_model_files_written_by_the_reference():
+    """tests/golden/ref_slim_*.pkl were saved by rtrec.models.SLIM.save (tools/gen_golden.py);
+    rtrec is not importable here, the compat unpickler maps its classes."""
+    import sys
+    assert "rtrec" not in sys.modules
+    exp = json.load(open(os.path.join(G, "ref_pickles.json")))
+    m = SLIM.loads(open(os.path.join(G, "ref_slim_int.pkl"), "rb").read())
+    m.model._engine = SlimEngine(backend=OracleBackend())
+    assert type(m.interactions).__module__.startswith("rtrec_amd") and type(m.model).__module__.startswith("rtrec_amd")
+    assert np.array_equal(m.interactions.to_csr().toarray(), np.asarray(exp["int"]["csr"], dtype=np.float32))
+    assert m.interactions.get_hot_items(5, filter_interacted=False) == exp["int"]["hot"]
+    assert m.recommend_batch(exp["int"]["users"], top_k=5) == exp["int"]["recs"]
+    assert [list(x) for x in m.similar_items(3, top_k=4, ret_scores=False) and [[a] for a in m.similar_items(3, top_k=4)]] == [[a] for a in exp["int"]["similar_3"]]
+    # the loaded model keeps learning
+    m.fit([(0, 1, 1.8e9, 2.0), (1, 2, 1.8e9, 1.0)], progress_bar=False)
+    buf = io.BytesIO(); m.save(buf)
+    m2 = SLIM.loads(buf.getvalue())                    # and round-trips in rtrec_amd's own format
+    assert same_matrix(m2.model.item_similarity, m.model.item_similarity)
+    s = SLIM.loads(open(os.path.join(G, "ref_slim_str.pkl"), "rb").read())
+    s.model._engine = SlimEngine(backend=OracleBackend())
+    assert s.similar_items("item_1", top_k=5) == exp["str"]["similar_item_1"]
+    assert s.recommend("user_2", top_k=5) == exp["str"]["rec_user_2"]
+    assert s.feature_store.build_item_features_matrix(item_ids=[0]).nnz == exp["str"]["item_feature_nnz"]

@@ -259,6 +259,35 @@ def gen_api():
     json.dump(out, open(os.path.join(OUT, "api.json"), "w"), indent=1)
 
 
+# ------------------------------------------------------------------ N3: pickles written by the reference
+def gen_reference_pickles():
+    """Model files saved by the REFERENCE (data fixtures): rtrec_amd must load them and serve the
+    same recommendations."""
+    import io
+    z = np.load(os.path.join(OUT, "partial_fit.npz"))
+    a, b = z["A"]
+    batch = [(int(x), int(y), float(t), float(r)) for x, y, t, r in zip(z["u"][a:b], z["i"][a:b], z["ts"][a:b], z["v"][a:b])]
+    m = RefSLIM(min_value=0, max_value=15, nn_feature_selection=5, decay_in_days=None)
+    m.fit(batch, progress_bar=False)
+    buf = io.BytesIO(); m.save(buf)
+    open(os.path.join(OUT, "ref_slim_int.pkl"), "wb").write(buf.getvalue())
+    users = list(range(0, 150, 5)) + [100000]
+    exp = {"int": {"users": users, "recs": m.recommend_batch(users, top_k=5), "similar_3": m.similar_items(3, top_k=4),
+                   "csr": m.interactions.to_csr().toarray().tolist(), "hot": m.interactions.get_hot_items(5, filter_interacted=False)}}
+    s = RefSLIM()
+    t = T0
+    inter = [('user_1', 'item_1', t, 5.0), ('user_1', 'item_3', t, 4.0), ('user_1', 'item_4', t, 3.0),
+             ('user_2', 'item_1', t, 3.0), ('user_2', 'item_2', t, -2.0), ('user_2', 'item_4', t, 3.0),
+             ('user_3', 'item_1', t, 4.0), ('user_3', 'item_3', t, 2.0), ('user_3', 'item_4', t, 4.0)]
+    s.fit(inter, progress_bar=False)
+    s.register_item_feature('item_1', ['tagA', 'tagB'])
+    buf = io.BytesIO(); s.save(buf)
+    open(os.path.join(OUT, "ref_slim_str.pkl"), "wb").write(buf.getvalue())
+    exp["str"] = {"similar_item_1": s.similar_items('item_1', top_k=5), "rec_user_2": s.recommend('user_2', top_k=5),
+                  "item_feature_nnz": int(s.feature_store.build_item_features_matrix(item_ids=[0]).nnz)}
+    json.dump(exp, open(os.path.join(OUT, "ref_pickles.json"), "w"))
+
+
 if __name__ == "__main__":
     gen_rng()
     gen_cd_columns()
@@ -267,5 +296,6 @@ if __name__ == "__main__":
     gen_scoring(X2, model)
     gen_store()
     gen_api()
+    gen_reference_pickles()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
