@@ -45,6 +45,7 @@ struct FitArgs {
     const float *sqn;
     const int *col_order;   // optional: item ids by descending column length (column-walk balance)
     int colwalk_min_rows;   // latency mode: targets with at least this many users use the column walk
+    int screen_min;         // columns with at least this many entries are screened before an ordered fold
     const int *targets; int n_targets;
     rtrec_fit_cfg cfg;
     int *out_items; float *out_coef; int *out_count; int *out_niter; int cap;
@@ -55,6 +56,7 @@ struct FitArgs {
     int *cand_i;     // [slots][I]   K path: candidate ids;    ALL path: ever list
     float *w_all;    // [slots][I]   ALL path only
     int *queue;
+    long long *trace;   // optional [n_targets][4]: start, prep end, end (100 MHz ticks), folded entries
 };
 
 __device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, float nrm, int positive) {
@@ -162,6 +164,125 @@ __device__ void update_pass(const int *__restrict__ crow, const float *__restric
 // sum over [b, e) of x * R[r], left to right (XtA of _cd_fast.pyx:506-509).
 __device__ float xta_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, int b, int e) {
     return dot_pass(crow, cval, R, b, e, 0.0f);   // R[r]*x == x*R[r] (one rounding, commutative)
+}
+
+// ---------------------------------------------------------------------------------------------
+// Screening: an ORDER-FREE evaluation of the same products, with a rigorous bound on how far the
+// ordered (left-to-right) float32 sum can be from it.
+//
+// A coordinate whose coefficient is 0 stays 0 whenever tmp <= alpha (|tmp| <= alpha without
+// `positive`), and then nothing else about tmp matters: no residual update, d_w = 0.  Likewise
+// the duality gap only needs max_p XtA[p].  So the 64-step dependent fold -- the whole cost of
+// this kernel -- is only required for coordinates that are non-zero, close to the threshold, or
+// candidates for that maximum; every other column gets one parallel pass (64 lanes, 8 gathers in
+// flight, three VALU ops per 64 entries instead of 128).
+//
+// Bound: both evaluations add the SAME n rounded products p_i.  For any summation order
+// |computed - exact| <= gamma_k * S with S = sum |p_i|, gamma_k = k u / (1 - k u), u = 2^-24
+// and k the longest chain of additions (n-1 for the ordered sum, at most n/64 + 16 for per-thread
+// partial sums + shuffle tree + the 8 wave partials of the multi-wave kernel); float addition is
+// exact when the result is subnormal, so there is no underflow term.  With n <= 2^20
+// (k u <= 1/16, so gamma_k <= 1.0667 k u) and S <= asum / (1 - gamma_par) <= 1.002 asum:
+//   |ordered - parallel| <= 1.0667 * 1.002 * (n - 1 + n/64 + 16) u asum <= (1.0856 n + 17) u asum
+//                        <  1.125 (n + 24) u asum =: err.
+// The result of a screened decision is therefore bit-identical to the reference's.
+// ---------------------------------------------------------------------------------------------
+constexpr int kScreenMaxLen = 1 << 20;
+constexpr int kScreenMinDefault = 192;
+
+struct Screen { double lo, hi; };   // the ordered sum lies in [lo, hi]
+
+__device__ __forceinline__ Screen screen_interval(float psum, float pasum, int n) {
+    const double err = 1.125 * static_cast<double>(n + 24) * 0x1p-24 * static_cast<double>(pasum);
+    Screen r;
+    r.lo = static_cast<double>(psum) - err;
+    r.hi = static_cast<double>(psum) + err;
+    return r;
+}
+
+// sum and sum of |.| of R[r]*x[r] over [b, e), any order (one wave).
+__device__ void screen_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
+                            int b, int e, float &psum, float &pasum) {
+    const int lane = lane_id();
+    float s0 = 0.0f, a0 = 0.0f;
+    int o = b;
+    for (; o + 512 <= e; o += 512) {
+        int r[8];
+        float x[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { r[u] = crow[o + u * 64 + lane]; x[u] = cval[o + u * 64 + lane]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = R[r[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float p = __fmul_rn(v[u], x[u]);
+            s0 = __fadd_rn(s0, p);
+            a0 = __fadd_rn(a0, fabsf(p));
+        }
+    }
+    for (; o < e; o += 256) {
+        int r[4];
+        float x[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int oo = o + u * 64 + lane;
+            r[u] = -1; x[u] = 0.0f;
+            if (oo < e) { r[u] = crow[oo]; x[u] = cval[oo]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (r[u] >= 0) ? R[r[u]] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float p = __fmul_rn(v[u], x[u]);
+            s0 = __fadd_rn(s0, p);
+            a0 = __fadd_rn(a0, fabsf(p));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s0 = __fadd_rn(s0, shfl_xor_t(s0, m));
+        a0 = __fadd_rn(a0, shfl_xor_t(a0, m));
+    }
+    psum = s0; pasum = a0;
+}
+
+// Decision for a coordinate whose coefficient is (+-)0: true -> it provably stays zero, w_new set.
+__device__ __forceinline__ bool screen_stays_zero(const Screen &S, float alpha, int positive, float &w_new) {
+    const double a = static_cast<double>(alpha);
+    if (positive) {
+        if (S.hi <= a) { w_new = 0.0f; return true; }      // tmp < 0 -> 0; 0 <= tmp <= alpha -> +0
+        return false;
+    }
+    if (S.hi <= a && S.lo >= -a) {                           // |tmp| <= alpha: zero, signed like tmp
+        if (S.lo >= 0.0) { w_new = 0.0f; return true; }      // tmp >= 0 -> +0 (sign(0) = 0 -> +0 as well)
+        if (S.hi < 0.0) { w_new = -0.0f; return true; }      // tmp < 0 -> -1 * 0 / d = -0
+    }
+    return false;
+}
+
+__device__ __forceinline__ float float_next_down(float f) {   // largest float < f (f finite)
+    const uint32_t b = __float_as_uint(f);
+    if ((b << 1) == 0u) return __uint_as_float(0x80000001u);
+    return __uint_as_float((b >> 31) ? b + 1u : b - 1u);
+}
+__device__ __forceinline__ float float_next_up(float f) {     // smallest float > f (f finite)
+    const uint32_t b = __float_as_uint(f);
+    if ((b << 1) == 0u) return __uint_as_float(0x00000001u);
+    return __uint_as_float((b >> 31) ? b - 1u : b + 1u);
+}
+
+// Interval of fl(xta - beta_w) (or of its absolute value without `positive`) for xta in S, rounded
+// outward to float; fl(. - c) and fabs-after-it are monotone, so the ordered value lies inside.
+__device__ __forceinline__ void screen_xta_interval(const Screen &S, float bw, int positive, float &lo, float &hi) {
+    float lf = static_cast<float>(S.lo);
+    if (static_cast<double>(lf) > S.lo) lf = float_next_down(lf);
+    float hf = static_cast<float>(S.hi);
+    if (static_cast<double>(hf) < S.hi) hf = float_next_up(hf);
+    const float vl = __fsub_rn(lf, bw), vh = __fsub_rn(hf, bw);
+    if (positive) { lo = vl; hi = vh; return; }
+    const float al = fabsf(vl), ah = fabsf(vh);
+    hi = al > ah ? al : ah;
+    lo = (vl > 0.0f) ? vl : (vh < 0.0f ? -vh : 0.0f);
 }
 
 // LDS arrays describing the selected features of the current target (K path).
@@ -434,7 +555,10 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
     const int yb = a.cptr[j], ye = a.cptr[j + 1];
     const int ny = ye - yb;
 
+    const long long tr0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
+    long long tr_folded = 0;
     const Prep P = prep_target<ALLF>(a, j, K, s, touched, cand_s, cand_i, F);
+    const long long tr1 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
     const float yy = P.yy, tol_s = P.tol_s;
     const int tc = P.tc, Kc = P.Kc;
     const int nf = ALLF ? I : Kc;
@@ -472,10 +596,18 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                 b = f_b[p]; e = f_e[p];
                 w_old = f_w[p];
             }
-            float tmp;
+            float tmp = 0.0f, w_new = 0.0f;
+            bool screened = false;
             if (!dirty) tmp = ALLF ? s_value(p) : f_s[p];
-            else tmp = dot_pass(a.crow, a.cval, R, b, e, w_old);
-            const float w_new = cd_update(tmp, alpha, beta, nrm, positive);
+            else {
+                if (w_old == 0.0f && e - b >= a.screen_min && e - b <= kScreenMaxLen) {
+                    float ps, pa;
+                    screen_pass(a.crow, a.cval, R, b, e, ps, pa);
+                    screened = screen_stays_zero(screen_interval(ps, pa, e - b), alpha, positive, w_new);
+                }
+                if (!screened) { tmp = dot_pass(a.crow, a.cval, R, b, e, w_old); tr_folded += e - b; }
+            }
+            if (!screened) w_new = cd_update(tmp, alpha, beta, nrm, positive);
             if (w_old != 0.0f || w_new != 0.0f) {
                 if (!dirty) {   // materialise R = y
                     for (int o = yb + lane; o < ye; o += 64) R[a.crow[o]] = a.cval[o];
@@ -527,17 +659,41 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                         dn_take(xta);
                     }
                 }
+            } else if (!dirty) {
+                for (int p = 0; p < nf; ++p) dn_take(f_nrm[p] != 0.0f ? f_s[p] : 0.0f);
             } else {
+                // Only max_p XtA[p] is needed: screen every column, then fold in order only the
+                // columns whose interval reaches the best lower bound (the maximum is among them).
+                float *x_lo = cand_s, *x_hi = reinterpret_cast<float *>(cand_i);   // free after step 2
+                float best_lo = -__builtin_huge_valf();
                 for (int p = 0; p < nf; ++p) {
-                    float xta = 0.0f;
+                    float lo = 0.0f, hi = 0.0f;
                     if (f_nrm[p] != 0.0f) {
-                        if (!dirty) xta = f_s[p];
-                        else {
-                            xta = xta_pass(a.crow, a.cval, R, f_b[p], f_e[p]);
-                            xta = __fsub_rn(xta, __fmul_rn(beta, f_w[p]));
+                        const int b = f_b[p], e = f_e[p];
+                        const float bw = __fmul_rn(beta, f_w[p]);
+                        if (e - b >= a.screen_min && e - b <= kScreenMaxLen) {
+                            float ps, pa;
+                            screen_pass(a.crow, a.cval, R, b, e, ps, pa);
+                            screen_xta_interval(screen_interval(ps, pa, e - b), bw, positive, lo, hi);
+                        } else {
+                            const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, b, e), bw);
+                            tr_folded += e - b;
+                            lo = hi = positive ? xta : fabsf(xta);
                         }
                     }
-                    dn_take(xta);
+                    if (lane == 0) { x_lo[p] = lo; x_hi[p] = hi; }
+                    best_lo = lo > best_lo ? lo : best_lo;
+                }
+                for (int p = 0; p < nf; ++p) {
+                    const float lo = x_lo[p], hi = x_hi[p];
+                    if (!(hi >= best_lo)) continue;
+                    float v = lo;
+                    if (lo != hi) {
+                        const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, f_b[p], f_e[p]), __fmul_rn(beta, f_w[p]));
+                        tr_folded += f_e[p] - f_b[p];
+                        v = positive ? xta : fabsf(xta);
+                    }
+                    dn_take(v);
                 }
             }
             // R.R, R.y, w.w, |w|_1 in ascending index order (canonical order)
@@ -634,6 +790,10 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
         for (int k = lane; k < n_ever; k += 64) { const int p = ever_list[k]; w_all[p] = 0.0f; ever_flag[p] = 0; }
     }
     for (int tt = lane; tt < tc; tt += 64) s[touched[tt]] = __uint_as_float(kUntouched);
+    if (a.trace && lane == 0) {
+        long long *tr = a.trace + static_cast<size_t>(t) * 4;
+        tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
+    }
 }
 
 template <bool ALLF>
@@ -674,9 +834,10 @@ struct MwLds {
     int *done;     // [1]      chunks consumed so far
     float *bc_f;   // [8]      broadcast floats
     int *bc_i;     // [8]      broadcast ints
+    float *red;    // [2 * kMwWaves] per-wave partial sums of a screening pass
 };
 __host__ __device__ constexpr size_t mw_lds_bytes(int K) {
-    return ((feat_lds_bytes(K) + 15) / 16) * 16 + kRing * 64 * 4 + kRing * 4 + 16 + 32 + 32;
+    return ((feat_lds_bytes(K) + 15) / 16) * 16 + kRing * 64 * 4 + kRing * 4 + 16 + 32 + 32 + 2 * kMwWaves * 4;
 }
 __device__ __forceinline__ MwLds carve_mw(unsigned char *smem, int K) {
     MwLds M;
@@ -685,7 +846,8 @@ __device__ __forceinline__ MwLds carve_mw(unsigned char *smem, int K) {
     M.ready = reinterpret_cast<int *>(p);   p += kRing * 4;
     M.done = reinterpret_cast<int *>(p);    p += 16;
     M.bc_f = reinterpret_cast<float *>(p);  p += 32;
-    M.bc_i = reinterpret_cast<int *>(p);
+    M.bc_i = reinterpret_cast<int *>(p);    p += 32;
+    M.red = reinterpret_cast<float *>(p);
     return M;
 }
 
@@ -760,6 +922,43 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
     }
     seq += n_chunks;
     return tmp;
+}
+
+// Screening pass (see screen_pass) by all threads of the workgroup; every thread returns the
+// same interval.  Contains two barriers.
+__device__ Screen mw_screen(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
+                            const MwLds &M, int b, int e, int tid) {
+    float s0 = 0.0f, a0 = 0.0f;
+    for (int o = b + tid; o < e; o += 4 * kMwThreads) {
+        int r[4];
+        float x[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int oo = o + u * kMwThreads;
+            r[u] = -1; x[u] = 0.0f;
+            if (oo < e) { r[u] = crow[oo]; x[u] = cval[oo]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (r[u] >= 0) ? R[r[u]] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float p = __fmul_rn(v[u], x[u]);
+            s0 = __fadd_rn(s0, p);
+            a0 = __fadd_rn(a0, fabsf(p));
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        s0 = __fadd_rn(s0, shfl_xor_t(s0, m));
+        a0 = __fadd_rn(a0, shfl_xor_t(a0, m));
+    }
+    if ((tid & 63) == 0) { M.red[2 * (tid >> 6)] = s0; M.red[2 * (tid >> 6) + 1] = a0; }
+    __syncthreads();
+    float ps = 0.0f, pa = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kMwWaves; ++w) { ps = __fadd_rn(ps, M.red[2 * w]); pa = __fadd_rn(pa, M.red[2 * w + 1]); }
+    __syncthreads();
+    return screen_interval(ps, pa, e - b);
 }
 
 // X^T y by COLUMN walk, all waves of the workgroup (latency mode, popular targets).
@@ -837,6 +1036,8 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     const int yb = a.cptr[j], ye = a.cptr[j + 1];
     const int ny = ye - yb;
 
+    const long long tr0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
+    long long tr_folded = 0;
     if (tid < kRing) M.ready[tid] = 0;
     if (tid == 0) *M.done = 0;
     int seq = 0;
@@ -849,6 +1050,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
         if (lane == 0) { M.bc_f[0] = P.yy; M.bc_f[1] = P.tol_s; M.bc_i[0] = P.tc; M.bc_i[1] = P.Kc; }
     }
     __syncthreads();
+    const long long tr1 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
     const float yy = M.bc_f[0], tol_s = M.bc_f[1];
     const int tc = M.bc_i[0], Kc = M.bc_i[1];
     const int nf = Kc;
@@ -870,15 +1072,21 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
             if (nrm == 0.0f) continue;
             const int b = f_b[p], e = f_e[p];
             const float w_old = f_w[p];
-            float w_new;
+            float w_new = 0.0f;
             if (!dirty) {
                 w_new = cd_update(f_s[p], alpha, beta, nrm, positive);     // identical in every wave
             } else {
-                const float tmp = mw_fold<0>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq);
-                upd ^= 1;
-                if (tid == 0) M.bc_f[2 + upd] = cd_update(tmp, alpha, beta, nrm, positive);
-                __syncthreads();
-                w_new = M.bc_f[2 + upd];
+                bool screened = false;
+                if (w_old == 0.0f && e - b >= a.screen_min && e - b <= kScreenMaxLen)
+                    screened = screen_stays_zero(mw_screen(a.crow, a.cval, R, M, b, e, tid), alpha, positive, w_new);
+                if (!screened) {
+                    const float tmp = mw_fold<0>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq);
+                    tr_folded += e - b;
+                    upd ^= 1;
+                    if (tid == 0) M.bc_f[2 + upd] = cd_update(tmp, alpha, beta, nrm, positive);
+                    __syncthreads();
+                    w_new = M.bc_f[2 + upd];
+                }
             }
             const bool changed = __float_as_uint(w_new) != __float_as_uint(w_old);
             const bool touch_r = (w_old != 0.0f || w_new != 0.0f);
@@ -936,13 +1144,35 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                 for (int p = 0; p < nf; ++p) dn_take(f_nrm[p] != 0.0f ? f_s[p] : 0.0f);
                 R_norm2 = yy; Ry = yy;
             } else {
+                // screen every column, fold in order only the candidates for the maximum (see fit_one)
+                float *x_lo = cand_s, *x_hi = reinterpret_cast<float *>(cand_i);
+                float best_lo = -__builtin_huge_valf();
                 for (int p = 0; p < nf; ++p) {
-                    float xta = 0.0f;
+                    float lo = 0.0f, hi = 0.0f;
                     if (f_nrm[p] != 0.0f) {
-                        xta = mw_fold<0>(a.crow, a.cval, R, M, f_b[p], f_e[p], 0.0f, wave, lane, seq);
-                        xta = __fsub_rn(xta, __fmul_rn(beta, f_w[p]));
+                        const int b = f_b[p], e = f_e[p];
+                        const float bw = __fmul_rn(beta, f_w[p]);
+                        if (e - b >= a.screen_min && e - b <= kScreenMaxLen) {
+                            screen_xta_interval(mw_screen(a.crow, a.cval, R, M, b, e, tid), bw, positive, lo, hi);
+                        } else {
+                            lo = -__builtin_huge_valf(); hi = __builtin_huge_valf();   // short column: always folded
+                        }
                     }
-                    dn_take(xta);
+                    if (tid == 0) { x_lo[p] = lo; x_hi[p] = hi; }
+                    best_lo = lo > best_lo ? lo : best_lo;
+                }
+                __syncthreads();
+                for (int p = 0; p < nf; ++p) {
+                    const float lo = x_lo[p], hi = x_hi[p];
+                    if (!(hi >= best_lo)) continue;
+                    float v = lo;
+                    if (lo != hi) {
+                        const float xta = __fsub_rn(mw_fold<0>(a.crow, a.cval, R, M, f_b[p], f_e[p], 0.0f, wave, lane, seq),
+                                                    __fmul_rn(beta, f_w[p]));
+                        tr_folded += f_e[p] - f_b[p];
+                        v = positive ? xta : fabsf(xta);
+                    }
+                    dn_take(v);
                 }
                 R_norm2 = mw_fold<1>(a.crow, a.cval, R, M, 0, U, 0.0f, wave, lane, seq);
                 Ry = 0.0f;
@@ -1003,6 +1233,10 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     }
     for (int tt = tid; tt < tc; tt += kMwThreads) s[touched[tt]] = __uint_as_float(kUntouched);
     __syncthreads();
+    if (a.trace && tid == 0) {
+        long long *tr = a.trace + static_cast<size_t>(t) * 4;
+        tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
+    }
 }
 
 __global__ __launch_bounds__(kMwThreads) void fit_columns_mw_kernel(FitArgs a) {
@@ -1099,16 +1333,16 @@ extern "C" int rtrec_slim_fit_workspace_init(void *d_workspace, size_t workspace
     return rtrec::launch_status();
 }
 
-extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
-                                      const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
-                                      const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
-                                      const float *d_sqnorm,
-                                      const int32_t *d_targets, int32_t n_targets,
-                                      const rtrec_fit_cfg *cfg,
-                                      int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
-                                      int32_t *d_out_n_iter, int32_t cap,
-                                      void *d_workspace, size_t workspace_bytes, int32_t n_slots,
-                                      int32_t *d_queue, void *stream) {
+static int fit_columns_impl(int32_t n_users, int32_t n_items,
+                            const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                            const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
+                            const float *d_sqnorm,
+                            const int32_t *d_targets, int32_t n_targets,
+                            const rtrec_fit_cfg *cfg,
+                            int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
+                            int32_t *d_out_n_iter, int32_t cap,
+                            void *d_workspace, size_t workspace_bytes, int32_t n_slots,
+                            int32_t *d_queue, void *stream, int64_t *d_trace) {
     if (n_users <= 0 || n_items <= 0 || n_targets < 0 || !cfg || n_slots <= 0) return RTREC_ERR_INVALID_ARG;
     if (n_targets == 0) return RTREC_OK;
     if (!d_csc_ptr || !d_csr_ptr || !d_sqnorm || !d_targets || !d_out_items || !d_out_coef || !d_out_count ||
@@ -1137,7 +1371,9 @@ extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
     a.cand_i = reinterpret_cast<int *>(ws + L.cand_i);
     a.w_all = allf ? reinterpret_cast<float *>(ws + L.w_all) : nullptr;
     a.queue = d_queue;
+    a.trace = reinterpret_cast<long long *>(d_trace);
     { const char *cw = std::getenv("RTREC_AMD_COLWALK_MIN"); a.colwalk_min_rows = cw ? std::atoi(cw) : kColWalkMinRows; }
+    { const char *sm = std::getenv("RTREC_AMD_SCREEN_MIN"); a.screen_min = sm ? std::atoi(sm) : kScreenMinDefault; }
     (void)hipGetLastError();
     if (hipMemsetAsync(d_queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const int grid = n_slots < n_targets ? n_slots : n_targets;
@@ -1154,4 +1390,34 @@ extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
         }
     }
     return rtrec::launch_status();
+}
+
+extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
+                                      const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                                      const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
+                                      const float *d_sqnorm,
+                                      const int32_t *d_targets, int32_t n_targets,
+                                      const rtrec_fit_cfg *cfg,
+                                      int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
+                                      int32_t *d_out_n_iter, int32_t cap,
+                                      void *d_workspace, size_t workspace_bytes, int32_t n_slots,
+                                      int32_t *d_queue, void *stream) {
+    return fit_columns_impl(n_users, n_items, d_csc_ptr, d_csc_row, d_csc_val, d_csr_ptr, d_csr_col, d_csr_val, d_sqnorm,
+                            d_targets, n_targets, cfg, d_out_items, d_out_coef, d_out_count, d_out_n_iter, cap,
+                            d_workspace, workspace_bytes, n_slots, d_queue, stream, nullptr);
+}
+
+extern "C" int rtrec_slim_fit_columns_traced(int32_t n_users, int32_t n_items,
+                                             const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                                             const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
+                                             const float *d_sqnorm,
+                                             const int32_t *d_targets, int32_t n_targets,
+                                             const rtrec_fit_cfg *cfg,
+                                             int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
+                                             int32_t *d_out_n_iter, int32_t cap,
+                                             void *d_workspace, size_t workspace_bytes, int32_t n_slots,
+                                             int32_t *d_queue, void *stream, int64_t *d_trace) {
+    return fit_columns_impl(n_users, n_items, d_csc_ptr, d_csc_row, d_csc_val, d_csr_ptr, d_csr_col, d_csr_val, d_sqnorm,
+                            d_targets, n_targets, cfg, d_out_items, d_out_coef, d_out_count, d_out_n_iter, cap,
+                            d_workspace, workspace_bytes, n_slots, d_queue, stream, d_trace);
 }

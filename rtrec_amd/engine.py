@@ -27,6 +27,11 @@ from . import _native
 DEFAULT_TILE_COLS = 8192
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
 MAX_SLOTS = 5120   # 5 single-wave workgroups per SIMD (fit kernel: <= 96 VGPRs)
+FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
+FIT_MW_MAX_TARGETS = 2048   # kMwMaxTargets of csrc/fit.hip: calls up to this size run the multi-wave kernel
+FIT_HEAVY_TARGETS = 256     # head of a bulk call sent to the multi-wave kernel (one workgroup per CU)
+FIT_HEAVY_SLOTS = 256
+FIT_HEAVY_MIN_ROWS = 2048   # ... as long as the target has at least this many users
 
 
 def sklearn_seed(random_state: Optional[int]) -> int:
@@ -162,13 +167,13 @@ class HipBackend:
         return ws, self.zeros((1,), self.torch.int32)
 
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
-                    ws, queue, slots):
-        _native.check(self.lib.rtrec_slim_fit_columns(
+                    ws, queue, slots, trace=None):
+        _native.check(self.lib.rtrec_slim_fit_columns_traced(
             n_users, n_items, self.ptr(X["cptr"]), self.ptr(X["crow"]), self.ptr(X["cval"]),
             self.ptr(X["rptr"]), self.ptr(X["rcol"]), self.ptr(X["rval"]), self.ptr(X["sqn"]),
             self.ptr(targets), int(targets.shape[0]), C.byref(cfg), self.ptr(out_items), self.ptr(out_coef),
             self.ptr(out_count), self.ptr(out_niter), cap, self.ptr(ws), ws.numel(), slots, self.ptr(queue),
-            self.stream()), "rtrec_slim_fit_columns")
+            self.stream(), self.ptr(trace)), "rtrec_slim_fit_columns")
 
     def score_workspace_bytes(self, n_rows, n_tiles, top_k):
         return int(self.lib.rtrec_slim_score_workspace_bytes(n_rows, n_tiles, top_k))
@@ -256,7 +261,8 @@ class SlimEngine:
 
     def fit_columns(self, targets: Sequence[int], alpha: float = 0.1, l1_ratio: float = 0.1,
                     positive: bool = True, max_iter: int = 100, tol: float = 1e-4, random_state: Optional[int] = 43,
-                    nn_feature_selection: Optional[int] = None, n_slots: Optional[int] = None
+                    nn_feature_selection: Optional[int] = None, n_slots: Optional[int] = None,
+                    trace: bool = False
                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
         """Fit the given target columns on this GPU.
 
@@ -288,12 +294,29 @@ class SlimEngine:
         # targets in flight once a slot is several MB (C4: 1024 slots 7.3 s, 5120 slots 9.2 s): keep
         # the total near 16 GiB but never below 1024 slots.
         per_slot = 4 * (U + (5 if K <= 0 else 4) * I)
-        slots = max(1, min(slots, max(1024, int((16 << 30) // max(per_slot, 1)))))
-        ws_key = (U, I, slots, K if K > 0 else 0)
-        if ws_key not in self._fit_ws:
-            self._fit_ws.clear()
-            self._fit_ws[ws_key] = be.fit_workspace(U, I, slots, K)
-        ws, queue = self._fit_ws[ws_key]
+        scratch_gib = float(os.environ.get("RTREC_AMD_FIT_SCRATCH_GIB", FIT_SCRATCH_GIB))
+        slots = max(1, min(slots, max(1024, int(scratch_gib * (1 << 30)) // max(per_slot, 1))))
+
+        # Bulk calls end on their heaviest targets: a popular item's X^T y is a walk over tens of
+        # thousands of user rows and one wave does it strictly row after row.  The head of the
+        # (length-sorted) list therefore goes to the multi-wave latency kernel on a side stream while
+        # the single-wave throughput kernel works through the rest; the C-ABI picks the kernel by
+        # call size (<= FIT_MW_MAX_TARGETS targets -> multi-wave), so this is two plain calls.
+        n_heavy = 0
+        if K > 0 and n > FIT_MW_MAX_TARGETS:
+            want = int(os.environ.get("RTREC_AMD_FIT_HEAVY", FIT_HEAVY_TARGETS))
+            nnz_sorted = X["col_nnz"][targets]
+            n_heavy = int(min(want, n - FIT_MW_MAX_TARGETS - 1, np.searchsorted(-nnz_sorted, -FIT_HEAVY_MIN_ROWS,
+                                                                                 side="right")))
+            n_heavy = max(n_heavy, 0)
+
+        def workspace(n_slots_: int):
+            key = (U, I, n_slots_, K if K > 0 else 0)
+            if key not in self._fit_ws:
+                if len(self._fit_ws) >= 2:
+                    self._fit_ws.clear()
+                self._fit_ws[key] = be.fit_workspace(U, I, n_slots_, K)
+            return self._fit_ws[key]
 
         # chunk so that the output block stays below ~1 GiB (matters for K=None, cap = I)
         chunk = max(1, min(n, int((1 << 30) // max(cap * 8, 1)))) if n else 1
@@ -301,20 +324,42 @@ class SlimEngine:
         coef_out = np.empty((n, cap), dtype=np.float32)
         count_out = np.empty((n,), dtype=np.int32)
         niter_out = np.empty((n,), dtype=np.int32)
-        for s in range(0, n, chunk):
-            tg = targets[s:s + chunk]
+        trace_out = np.zeros((n, 4), dtype=np.int64) if trace else None
+
+        def launch(lo_: int, hi_: int, n_slots_: int):
+            tg = targets[lo_:hi_]
             m = len(tg)
-            d_t = be.to_dev(tg.astype(np.int32))
-            d_items = be.empty((m, cap), torch.int32)
-            d_coef = be.empty((m, cap), torch.float32)
-            d_count = be.empty((m,), torch.int32)
-            d_niter = be.empty((m,), torch.int32)
-            be.fit_columns(U, I, X, d_t, cfg, d_items, d_coef, d_count, d_niter, cap, ws, queue, slots)
-            items_out[s:s + m] = d_items.cpu().numpy()
-            coef_out[s:s + m] = d_coef.cpu().numpy()
-            count_out[s:s + m] = d_count.cpu().numpy()
-            niter_out[s:s + m] = d_niter.cpu().numpy()
-        self.last_fit_stats = {"n_targets": n, "slots": slots, "cap": cap}
+            ws, queue = workspace(n_slots_)
+            d = dict(lo=lo_, hi=hi_, t=be.to_dev(tg.astype(np.int32)), items=be.empty((m, cap), torch.int32),
+                     coef=be.empty((m, cap), torch.float32), count=be.empty((m,), torch.int32),
+                     niter=be.empty((m,), torch.int32), trace=be.zeros((m, 4), torch.int64) if trace else None,
+                     ws=(ws, queue))   # keeps the scratch alive while the kernel runs
+            be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
+                           n_slots_, d["trace"])
+            return d
+
+        def collect(d):
+            lo_, hi_ = d["lo"], d["hi"]
+            items_out[lo_:hi_] = d["items"].cpu().numpy()
+            coef_out[lo_:hi_] = d["coef"].cpu().numpy()
+            count_out[lo_:hi_] = d["count"].cpu().numpy()
+            niter_out[lo_:hi_] = d["niter"].cpu().numpy()
+            if trace:
+                trace_out[lo_:hi_] = d["trace"].cpu().numpy()
+
+        heavy = None
+        if n_heavy > 0:
+            main = torch.cuda.current_stream(be.device)
+            side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(be.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                heavy = launch(0, n_heavy, min(n_heavy, FIT_HEAVY_SLOTS))
+        for s in range(n_heavy, n, chunk):
+            collect(launch(s, min(n, s + chunk), min(slots, max(1, min(n, s + chunk) - s))))
+        if heavy is not None:
+            torch.cuda.current_stream(be.device).wait_stream(side)
+            collect(heavy)
+        self.last_fit_stats = {"n_targets": n, "slots": slots, "cap": cap, "trace": trace_out, "n_heavy": n_heavy}
         return targets, items_out, coef_out, count_out, niter_out
 
     # ------------------------------------------------------------------------------ W

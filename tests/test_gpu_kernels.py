@@ -35,8 +35,14 @@ def bits(a):
 ])
 # single-wave (throughput) kernel, multi-wave (latency) kernel, and the latter with the column-walk X^T y forced
 @pytest.mark.parametrize("fit_mode", ["sw", "mw", "mw-colwalk"])
-def test_fit_columns_bit_exact(engine, oracle, U, I, draws, K, positive, float_ratings, fit_mode, monkeypatch):
+# screening (order-free pass + error bound before an ordered fold) from its default length, and forced on
+# every column so that these small matrices exercise it
+@pytest.mark.parametrize("screen_min", [None, "1"])
+def test_fit_columns_bit_exact(engine, oracle, U, I, draws, K, positive, float_ratings, fit_mode, screen_min,
+                               monkeypatch):
     monkeypatch.setenv("RTREC_AMD_FIT_MODE", fit_mode[:2])
+    if screen_min is not None:
+        monkeypatch.setenv("RTREC_AMD_SCREEN_MIN", screen_min)
     if fit_mode == "mw-colwalk":
         monkeypatch.setenv("RTREC_AMD_COLWALK_MIN", "1")
     X = interaction_matrix(U, I, draws, seed=11, float_ratings=float_ratings)
