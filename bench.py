@@ -108,6 +108,18 @@ def main() -> None:
     torch.cuda.synchronize()
     fit_local = time.time() - t0
     rows, cols, vals = coefficients_to_updates(tg, items, coef, count)
+    # algorithmic bytes of this rank's fit (every datum once per target column):
+    # y (8 nnz_j) + the co-occurring user rows that form X^T y (8 |I_u| per u in U_j) + the K selected
+    # feature columns (8 nnz(c)) + the written coefficients (8 |S_j|)
+    col_nnz_all = np.diff(Xc.indptr).astype(np.float64)
+    row_nnz_all = np.diff(X.indptr).astype(np.float64)
+    owned = np.zeros(I, dtype=bool)
+    owned[lo:hi] = True
+    # sum over owned targets j of sum_{u in U_j} |I_u|  ==  sum over interactions (u, j owned) of |I_u|
+    cooc = float(np.repeat(row_nnz_all, np.diff(X.indptr))[owned[X.indices]].sum())
+    sel_mask = np.arange(items.shape[1])[None, :] < count[:, None]
+    feat = float(col_nnz_all[items[sel_mask]].sum())
+    fit_algo_bytes = 8.0 * float(col_nnz_all[lo:hi].sum()) + 8.0 * cooc + 8.0 * feat + 8.0 * float(count.sum())
     if world > 1:
         parts = [None] * world
         dist.all_gather_object(parts, (rows, cols, vals))
@@ -131,24 +143,10 @@ def main() -> None:
     xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
 
     def step():
-        d_rank = None
-        ids, sc, sc64, aux, cnt = eng._local_topk(d_rows, U, xb, top_k, True, _native.TOPK_SPARSE, d_rank)
-        if world == 1:
-            return ids, sc, cnt
-        G = world
-        outs = []
-        for t_ in (ids, sc, aux, cnt):
-            o = eng.be.empty((G * t_.shape[0],) + tuple(t_.shape[1:]), t_.dtype)
-            dist.all_gather_into_tensor(o, t_.contiguous())
-            outs.append(o)
-        o_ids = eng.be.empty((U, top_k), torch.int32)
-        o_sc = eng.be.empty((U, top_k), torch.float32)
-        o_cnt = eng.be.empty((U,), torch.int32)
-        be = eng.be
-        _native.check(be.lib.rtrec_slim_merge_topk(U, G, top_k, be.ptr(outs[0]), be.ptr(outs[1]), None,
-                                                   be.ptr(outs[2]), be.ptr(outs[3]), be.ptr(o_ids), be.ptr(o_sc),
-                                                   be.ptr(o_cnt), be.stream()), "merge")
-        return o_ids, o_sc, o_cnt
+        # world == 1: one fused launch.  world > 1: the engine's sharded path -- local top-k per
+        # column shard in row chunks, one packed RCCL all-gather per chunk overlapped with the next
+        # chunk's kernel, strided merge (SlimEngine.score_topk_device).
+        return eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
 
     for _ in range(args.warmup):
         out = step()
@@ -194,6 +192,9 @@ def main() -> None:
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
     lay = eng._layout(True) or {"tile_cols": None, "n_tiles": 0, "n_cols": 0}
+    import zlib
+    # same value for every --gpus N: the sharded path returns the unsharded answer
+    topk_crc = zlib.crc32(out[0].cpu().numpy().tobytes()) if rank == 0 else 0
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -220,9 +221,17 @@ def main() -> None:
                    "nn_feature_selection": K, "top_k": top_k, "tile_cols": lay["tile_cols"], "n_tiles": lay["n_tiles"],
                    "active_columns": lay["n_cols"],
                    "parallelism": f"item-column shard x{world}" if world > 1 else "single GPU"},
-        "pcie_inclusive_users_per_sec": pcie_users_per_s,
+        "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
-                "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean())},
+                "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()),
+                "roofline": {"kernel": "fit_columns_kernel<false> (+ fit_columns_mw_kernel for the heaviest targets)",
+                             "bound": "hbm", "achieved": fit_algo_bytes / fit_local / 1e9, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": fit_algo_bytes / fit_local / 1e9 / HBM_PEAK_GBS,
+                             "algorithmic_bytes": fit_algo_bytes, "seconds": fit_local,
+                             "note": "rank 0's columns; the coordinate-descent sweeps re-read the K feature columns "
+                                     "and the residual (not counted): measured fabric traffic is ~10 TB on c3 "
+                                     "(profiles/r01_c3_fit_pmc.json), i.e. the kernel is bound by random 64-B sector "
+                                     "traffic at ~3 TB/s, not by its compulsory bytes"}},
         "roofline": {"kernel": "score_sparse_kernel<float,false>", "bound": "hbm", "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,

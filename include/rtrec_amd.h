@@ -208,6 +208,21 @@ int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t top_k,
                           int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
                           void *stream);
 
+/* The same merge over lists that live inside a larger buffer -- e.g. one all-gathered block of
+ * packed per-user records [n_lists][n_rows][scores | ids | aux | count].  Strides are in ELEMENTS of
+ * the respective array: entry r of list l for row u is at  l * list_stride + u * row_stride + r
+ * (ids, float32 scores and aux share list_stride/row_stride; the float64 scores and the counts
+ * have their own). */
+int rtrec_slim_merge_topk_strided(int32_t n_rows, int32_t n_lists, int32_t top_k,
+                                  const int32_t *d_in_ids, const float *d_in_scores,
+                                  const double *d_in_scores64, const uint32_t *d_in_aux,
+                                  const int32_t *d_in_count,
+                                  int64_t list_stride, int64_t row_stride,
+                                  int64_t score64_list_stride, int64_t score64_row_stride,
+                                  int64_t count_list_stride, int64_t count_row_stride,
+                                  int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
+                                  void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * SIMILAR ITEMS  (replaces slim_elastic.py:820-857)
  * W in CSC (d_wc_ptr[I+1], d_wc_row, d_wc_val).  For each query item: stored entries of its

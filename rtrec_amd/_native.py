@@ -22,7 +22,7 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
 EXPORTS = [
     "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_amd_score_timer", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
     "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_traced", "rtrec_slim_score_workspace_bytes",
-    "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_similar_topk",
+    "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
 ]
 
 
@@ -83,6 +83,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_score_rows.argtypes = [i32] + [vp] * 4 + [i32] * 5 + [vp] * 3 + [i32, vp, C.c_int64, vp]
     L.rtrec_slim_merge_topk.restype = C.c_int
     L.rtrec_slim_merge_topk.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.rtrec_slim_merge_topk_strided.restype = C.c_int
+    L.rtrec_slim_merge_topk_strided.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp] + [C.c_int64] * 6 + [vp, vp, vp, vp]
     L.rtrec_slim_similar_topk.restype = C.c_int
     L.rtrec_slim_similar_topk.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp, vp, vp]
     _lib = L

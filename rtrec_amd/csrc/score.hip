@@ -605,8 +605,9 @@ struct MergeArgs {
     int n_lists;      // lists per row
     int kk;           // entries per list
     int top_k;
-    long long list_stride;  // element stride between consecutive lists of one row
-    long long row_stride;   // element stride between rows
+    long long list_stride;  // element stride between consecutive lists of one row (ids, aux)
+    long long row_stride;   // element stride between rows (ids, aux)
+    long long s_list_stride, s_row_stride;   // the same for the score array (in ACC elements)
     long long cnt_list_stride, cnt_row_stride;
     const void *in_score;   // ACC
     const int *in_id;
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs m) {
             const int c = m.in_cnt[l * m.cnt_list_stride + row * m.cnt_row_stride];
             if (r < c) {
                 const long long off = l * m.list_stride + row * m.row_stride + r;
-                mine[j].score = sc[off];
+                mine[j].score = sc[l * m.s_list_stride + row * m.s_row_stride + r];
                 mine[j].id = m.in_id[off];
                 mine[j].aux = m.in_aux ? m.in_aux[off] : 0u;
             }
@@ -851,6 +852,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     MergeArgs m{};
     m.n_rows = a.n_rows; m.n_lists = a.n_tiles; m.kk = a.kk; m.top_k = top_k;
     m.list_stride = a.kk; m.row_stride = static_cast<long long>(a.n_tiles) * a.kk;
+    m.s_list_stride = m.list_stride; m.s_row_stride = m.row_stride;
     m.cnt_list_stride = 1; m.cnt_row_stride = a.n_tiles;
     m.in_score = a.cand_score; m.in_id = a.cand_id; m.in_aux = a.cand_aux; m.in_cnt = a.cand_cnt;
     m.out_id = d_out_ids; m.out_score = d_out_scores; m.out_score64 = d_out_scores64; m.out_aux = d_out_aux;
@@ -877,6 +879,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
             MergeArgs mf = m;
             mf.kk = top_k;
             mf.list_stride = top_k; mf.row_stride = static_cast<long long>(a.n_tiles) * top_k;
+            mf.s_list_stride = mf.list_stride; mf.s_row_stride = mf.row_stride;
             mf.detect_ties = 0;
             mf.row_list = flag_list; mf.row_list_len = flag_len;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, mf);
@@ -978,19 +981,23 @@ extern "C" int rtrec_slim_score_rows(int32_t n_rows, const int32_t *d_row_ids,
     return rtrec::launch_status();
 }
 
-extern "C" int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t top_k,
-                                     const int32_t *d_in_ids, const float *d_in_scores, const double *d_in_scores64,
-                                     const uint32_t *d_in_aux, const int32_t *d_in_count,
-                                     int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
-                                     void *stream) {
+extern "C" int rtrec_slim_merge_topk_strided(int32_t n_rows, int32_t n_lists, int32_t top_k,
+                                             const int32_t *d_in_ids, const float *d_in_scores,
+                                             const double *d_in_scores64, const uint32_t *d_in_aux,
+                                             const int32_t *d_in_count,
+                                             int64_t list_stride, int64_t row_stride,
+                                             int64_t score64_list_stride, int64_t score64_row_stride,
+                                             int64_t count_list_stride, int64_t count_row_stride,
+                                             int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
+                                             void *stream) {
     if (n_rows < 0 || n_lists <= 0 || top_k <= 0) return RTREC_ERR_INVALID_ARG;
     if (n_rows == 0) return RTREC_OK;
     if (!d_in_ids || !d_in_scores || !d_in_count || !d_out_ids || !d_out_scores || !d_out_count) return RTREC_ERR_INVALID_ARG;
     if (static_cast<long long>(n_lists) * top_k > 1024) return RTREC_ERR_UNSUPPORTED;
     MergeArgs m{};
     m.n_rows = n_rows; m.n_lists = n_lists; m.kk = top_k; m.top_k = top_k;
-    m.list_stride = static_cast<long long>(n_rows) * top_k; m.row_stride = top_k;
-    m.cnt_list_stride = n_rows; m.cnt_row_stride = 1;
+    m.list_stride = list_stride; m.row_stride = row_stride;
+    m.cnt_list_stride = count_list_stride; m.cnt_row_stride = count_row_stride;
     m.in_id = d_in_ids; m.in_aux = d_in_aux; m.in_cnt = d_in_count;
     m.out_id = d_out_ids; m.out_score = d_out_scores; m.out_score64 = nullptr; m.out_aux = nullptr; m.out_cnt = d_out_count;
     m.detect_ties = 0; m.flag_list = nullptr; m.flag_len = nullptr; m.row_list = nullptr; m.row_list_len = nullptr;
@@ -998,12 +1005,25 @@ extern "C" int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t to
     (void)hipGetLastError();
     if (d_in_scores64) {
         m.in_score = d_in_scores64;
+        m.s_list_stride = score64_list_stride; m.s_row_stride = score64_row_stride;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<double>), dim3(n_rows), dim3(64), 0, st, m);
     } else {
         m.in_score = d_in_scores;
+        m.s_list_stride = list_stride; m.s_row_stride = row_stride;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<float>), dim3(n_rows), dim3(64), 0, st, m);
     }
     return rtrec::launch_status();
+}
+
+extern "C" int rtrec_slim_merge_topk(int32_t n_rows, int32_t n_lists, int32_t top_k,
+                                     const int32_t *d_in_ids, const float *d_in_scores, const double *d_in_scores64,
+                                     const uint32_t *d_in_aux, const int32_t *d_in_count,
+                                     int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
+                                     void *stream) {
+    const int64_t ls = static_cast<int64_t>(n_rows) * top_k;
+    return rtrec_slim_merge_topk_strided(n_rows, n_lists, top_k, d_in_ids, d_in_scores, d_in_scores64, d_in_aux,
+                                         d_in_count, ls, top_k, ls, top_k, n_rows, 1,
+                                         d_out_ids, d_out_scores, d_out_count, stream);
 }
 
 extern "C" int rtrec_slim_similar_topk(int32_t n_queries, const int32_t *d_queries,

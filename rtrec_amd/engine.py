@@ -27,6 +27,8 @@ from . import _native
 DEFAULT_TILE_COLS = 8192
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
 MAX_SLOTS = 5120   # 5 single-wave workgroups per SIMD (fit kernel: <= 96 VGPRs)
+GATHER_CHUNK_ROWS = 32768   # rows per all-gather chunk of a sharded scoring call
+MAX_GATHER_CHUNKS = 8
 FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
 FIT_MW_MAX_TARGETS = 2048   # kMwMaxTargets of csrc/fit.hip: calls up to this size run the multi-wave kernel
 FIT_HEAVY_TARGETS = 256     # head of a bulk call sent to the multi-wave kernel (one workgroup per CU)
@@ -198,10 +200,16 @@ class HipBackend:
             int(acc_f64), self.ptr(out), int(out.stride(0)), self.stream()), "rtrec_slim_score_rows")
 
     def merge_topk(self, n_rows, n_lists, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt):
-        _native.check(self.lib.rtrec_slim_merge_topk(n_rows, n_lists, top_k, self.ptr(g_ids), self.ptr(g_sc),
-                                                     self.ptr(g_sc64), self.ptr(g_aux), self.ptr(g_cnt),
-                                                     self.ptr(o_ids), self.ptr(o_sc), self.ptr(o_cnt),
-                                                     self.stream()), "rtrec_slim_merge_topk")
+        """g_* are [n_lists, n_rows, top_k] tensors (g_cnt [n_lists, n_rows]); they may be strided views
+        into one packed all-gather buffer as long as the last dimension is contiguous."""
+        assert g_ids.stride(2) == 1 and g_sc.stride(2) == 1 and g_aux.stride(2) == 1
+        assert g_ids.stride() == g_sc.stride() == g_aux.stride()
+        s64 = g_sc64.stride() if g_sc64 is not None else (0, 0, 1)
+        assert s64[2] == 1
+        _native.check(self.lib.rtrec_slim_merge_topk_strided(
+            n_rows, n_lists, top_k, self.ptr(g_ids), self.ptr(g_sc), self.ptr(g_sc64), self.ptr(g_aux), self.ptr(g_cnt),
+            g_ids.stride(0), g_ids.stride(1), s64[0], s64[1], g_cnt.stride(0), g_cnt.stride(1),
+            self.ptr(o_ids), self.ptr(o_sc), self.ptr(o_cnt), self.stream()), "rtrec_slim_merge_topk_strided")
 
     def similar_topk(self, queries, W, top_k, ids, sc, cnt):
         _native.check(self.lib.rtrec_slim_similar_topk(int(queries.shape[0]), self.ptr(queries), self.ptr(W["cptr"]),
@@ -224,6 +232,7 @@ class SlimEngine:
         self._W: Dict[str, Any] = {}
         self._fit_ws: Dict[Tuple[int, int, int, int], Any] = {}
         self._score_ws = None
+        self.gather_chunk_rows = GATHER_CHUNK_ROWS
         self.last_fit_stats: Dict[str, Any] = {}
 
     # ------------------------------------------------------------------------------ X
@@ -426,34 +435,70 @@ class SlimEngine:
         return ids, sc, sc64, aux, cnt
 
     def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
-                          mode: int, col_rank: Optional[np.ndarray] = None, xb=None):
+                          mode: int, col_rank: Optional[np.ndarray] = None, xb=None, d_rows=None):
         """Device tensors (ids, scores, counts) of the GLOBAL top-k for the given rows of X
-        (or of the CSR batch `xb` = (ptr, col, val) device tensors)."""
+        (or of the CSR batch `xb` = (ptr, col, val) device tensors).  `d_rows` may pass the row ids
+        as a device tensor that is already resident (bench.py reuses it across steps).
+
+        Multi-GPU: every rank scores the rows against its own column shard; the per-shard lists are
+        packed into ONE int32 record per user -- [scores | ids | first-touch aux | count] (float64
+        scores in front when W is float64) -- so a step needs a single all-gather, and the rows are
+        processed in chunks whose all-gathers (RCCL, asynchronous on its own stream) overlap the
+        scoring kernel of the next chunk; merge_topk_kernel then reads the gathered block in place
+        through strides."""
         be = self.be
         if not self._W:
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
         if xb is None:
             xb = (self._X["rptr"], self._X["rcol"], self._X["rval"])
-        d_rows = be.to_dev(np.asarray(row_ids, dtype=np.int32)) if row_ids is not None else None
+        if d_rows is None and row_ids is not None:
+            d_rows = be.to_dev(np.asarray(row_ids, dtype=np.int32))
         d_rank = be.to_dev(np.asarray(col_rank, dtype=np.int32)) if col_rank is not None else None
-        ids, sc, sc64, aux, cnt = self._local_topk(d_rows, n_rows, xb, top_k, filter_interacted, mode, d_rank)
         if self.world_size == 1:
+            ids, sc, sc64, aux, cnt = self._local_topk(d_rows, n_rows, xb, top_k, filter_interacted, mode, d_rank)
             return ids, sc, cnt
         import torch.distributed as dist
         torch = be.torch
-        G = self.world_size
-
-        def gather(t):   # one fused all-gather per array: [G * n_rows, ...] viewed as [G, n_rows, ...]
-            out = be.empty((G * t.shape[0],) + tuple(t.shape[1:]), t.dtype)
-            dist.all_gather_into_tensor(out, t.contiguous(), group=self.group)
-            return out.view((G,) + tuple(t.shape))
-        g_ids, g_sc, g_aux, g_cnt = gather(ids), gather(sc), gather(aux), gather(cnt)
-        g_sc64 = gather(sc64) if sc64 is not None else None
-        o_ids = be.empty((n_rows, top_k), torch.int32)
-        o_sc = be.empty((n_rows, top_k), torch.float32)
+        G, k = self.world_size, top_k
+        f64 = bool(self._W["acc_f64"])
+        if d_rows is None:
+            d_rows = torch.arange(n_rows, dtype=torch.int32, device=xb[0].device)
+        per = max(1, int(self.gather_chunk_rows))
+        n_chunks = max(1, min(MAX_GATHER_CHUNKS, -(-n_rows // per)))
+        per = -(-n_rows // n_chunks)
+        # record layout (int32 words): [2k float64 scores]? | k scores | k ids | k aux | count | pad to even
+        o_sc = 2 * k if f64 else 0
+        width = o_sc + 3 * k + 1
+        width += width & 1
+        o_ids = be.empty((n_rows, k), torch.int32)
+        o_scs = be.empty((n_rows, k), torch.float32)
         o_cnt = be.empty((n_rows,), torch.int32)
-        be.merge_topk(n_rows, G, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt)
-        return o_ids, o_sc, o_cnt
+        pending = []
+        for c in range(n_chunks):
+            a, b = c * per, min(n_rows, (c + 1) * per)
+            m = b - a
+            if m <= 0:
+                break
+            ids, sc, sc64, aux, cnt = self._local_topk(d_rows[a:b], m, xb, k, filter_interacted, mode, d_rank)
+            parts = ([sc64.view(torch.int32)] if f64 else []) + [sc.view(torch.int32), ids, aux.view(torch.int32),
+                                                                 cnt.view(m, 1)]
+            if (o_sc + 3 * k + 1) & 1:
+                parts.append(torch.zeros((m, 1), dtype=torch.int32, device=ids.device))
+            packed = torch.cat(parts, dim=1)
+            g = be.empty((G * m, width), torch.int32)
+            work = dist.all_gather_into_tensor(g, packed, group=self.group, async_op=True)
+            pending.append((a, b, g, packed, work))
+        for a, b, g, packed, work in pending:
+            work.wait()
+            m = b - a
+            g3 = g.view(G, m, width)
+            g_sc = g3[:, :, o_sc:o_sc + k].view(torch.float32)
+            g_ids = g3[:, :, o_sc + k:o_sc + 2 * k]
+            g_aux = g3[:, :, o_sc + 2 * k:o_sc + 3 * k]
+            g_cnt = g3[:, :, o_sc + 3 * k]
+            g_sc64 = g.view(torch.float64).view(G, m, width // 2)[:, :, :k] if f64 else None
+            be.merge_topk(m, G, k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids[a:b], o_scs[a:b], o_cnt[a:b])
+        return o_ids, o_scs, o_cnt
 
     def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
                        mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None

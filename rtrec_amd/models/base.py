@@ -85,6 +85,29 @@ class BaseModel(ABC):
                 continue
         return np.asarray(u_out, dtype=np.int64), np.asarray(i_out, dtype=np.int64)
 
+    def add_interactions_columns(self, users: np.ndarray, items: np.ndarray, tstamps: np.ndarray, ratings: np.ndarray,
+                                 update_interaction: bool = False, record_interactions: bool = False) -> None:
+        """Columnar add_interactions: the same state change as add_interactions(zip(users, items,
+        tstamps, ratings)) without materialising a Python tuple per interaction.  Integer id columns
+        pass through in one vectorised call; anything else (string ids, negative ids, mixed kinds)
+        goes through the tuple path and its per-interaction warn-and-skip handling."""
+        users, items = np.asarray(users), np.asarray(items)
+        fast = (users.dtype.kind in "iu" and items.dtype.kind in "iu" and len(users) > 0
+                and not self.user_ids.force_identify and not self.item_ids.force_identify
+                and self.user_ids.pass_through is not False and self.item_ids.pass_through is not False
+                and int(users.min()) >= 0 and int(items.min()) >= 0)
+        if not fast:
+            self.add_interactions(list(zip(users.tolist(), items.tolist(), np.asarray(tstamps).tolist(),
+                                           np.asarray(ratings).tolist())),
+                                  update_interaction=update_interaction, record_interactions=record_interactions)
+            return
+        uid = self.user_ids.identify_many(users)
+        iid = self.item_ids.identify_many(items)
+        self.interactions.add_interactions_batch(uid, iid, np.asarray(tstamps, dtype=np.float64),
+                                                 np.asarray(ratings, dtype=np.float64), upsert=update_interaction)
+        if record_interactions:
+            self._record_batch(uid, iid)
+
     @staticmethod
     def _batch_is_homogeneous(objs: Tuple[Any, ...], ident: Identifier) -> bool:
         """True when identify() cannot raise for any element of the batch."""

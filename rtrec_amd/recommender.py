@@ -18,6 +18,7 @@ from .models.base import BaseModel
 from .utils.metrics import compute_scores
 
 _COLUMNS = ["user", "item", "tstamp", "rating"]
+_COLUMNAR_CHUNK = 1 << 18
 
 
 class Recommender:
@@ -46,6 +47,17 @@ class Recommender:
         frame = train_data[_COLUMNS]
         if not assume_sorted:
             frame = frame.sort_values("tstamp", ascending=True)
+        columnar = getattr(self.model, "add_interactions_columns", None)
+        if columnar is not None and all(frame[c].dtype.kind in "iuf" for c in _COLUMNS):
+            # numeric frame: hand the columns over as arrays.  The store applies a chunk with the same
+            # sequential semantics as one add_interaction per row, so mini-batch boundaries (batch_size)
+            # do not change the result; only the per-row Python objects of the reference loop go away.
+            u, i, t, r = (frame[c].to_numpy() for c in _COLUMNS)
+            for s in range(0, len(frame), _COLUMNAR_CHUNK):
+                e = s + _COLUMNAR_CHUNK
+                columnar(u[s:e], i[s:e], t[s:e], r[s:e], update_interaction=update_interaction,
+                         record_interactions=record)
+            return
         for batch in Recommender.generate_batches(frame, batch_size, as_generator=self.use_generator):
             self.model.add_interactions(batch, update_interaction=update_interaction, record_interactions=record)
 

@@ -235,7 +235,7 @@ class UserItemInteractions:
         self.all_item_ids.update(np.unique(items).tolist())
         pos = dl > 0
         if pos.any():
-            self.hot_items.add_many(items[pos].tolist())
+            self.hot_items.add_many(items[pos])
         self.max_user_id = max(self.max_user_id, int(users.max()))
         self.max_item_id = max(self.max_item_id, int(items.max()))
 

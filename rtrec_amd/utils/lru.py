@@ -11,6 +11,8 @@ from collections import OrderedDict
 from collections.abc import MutableSet
 from typing import Any, Iterable, Iterator, List, Optional
 
+import numpy as np
+
 
 class LRUFreqSet(MutableSet):
     def __init__(self, capacity: int):
@@ -29,6 +31,10 @@ class LRUFreqSet(MutableSet):
 
     def add_many(self, values: Iterable[Any]) -> None:
         """Same end state as calling add() for each value in order."""
+        if isinstance(values, np.ndarray) and values.dtype.kind in "iu" and values.ndim == 1 and len(values) > 64:
+            if self._add_many_ints(values):
+                return
+            values = values.tolist()
         values = list(values)
         fresh = {v for v in values if v not in self.data}
         if len(self.data) + len(fresh) > self.capacity:
@@ -47,6 +53,25 @@ class LRUFreqSet(MutableSet):
                 last_order.append(v)
         for v in reversed(last_order):
             self.data[v] = self.data.pop(v, 0) + hits[v]
+
+    def _add_many_ints(self, values: "np.ndarray") -> bool:
+        """Vectorised add_many for an integer array: hit counts and the order of LAST occurrence come
+        from numpy, the dict is touched once per distinct key.  Returns False (nothing done) when
+        the batch would overflow the capacity -- evictions depend on the exact interleaving."""
+        n = len(values)
+        uniq, rev_first, counts = np.unique(values[::-1], return_index=True, return_counts=True)
+        keys = uniq.tolist()
+        data = self.data
+        fresh = sum(1 for k in keys if k not in data)
+        if len(data) + fresh > self.capacity:
+            return False
+        last_pos = n - 1 - rev_first
+        order = np.argsort(last_pos, kind="stable")
+        cnt = counts.tolist()
+        for j in order.tolist():
+            k = keys[j]
+            data[k] = data.pop(k, 0) + cnt[j]
+        return True
 
     def discard(self, value: Any) -> None:
         if value not in self.data:

@@ -243,3 +243,51 @@ def test_store_selected_exports_use_indexes_and_match_full_export():
     assert (part_r != exp_r).nnz == 0
     assert sorted(users_by) == sorted(np.unique(full_c[:, sel_items].tocoo().row).tolist())
     assert sorted(items_7) == sorted(full_r[7].indices.tolist())
+
+
+def test_lru_vectorised_add_many_equals_sequential_adds():
+    """LRUFreqSet.add_many on an integer array (numpy counts + last-occurrence order) must leave
+    exactly the state that one add() per value leaves, including when the capacity overflows."""
+    rng = np.random.default_rng(3)
+    for cap, n_keys in ((1000, 300), (200, 300), (64, 5000)):
+        a, b = LRUFreqSet(cap), LRUFreqSet(cap)
+        for _ in range(6):
+            vals = rng.integers(0, n_keys, size=int(rng.integers(65, 900)))
+            a.add_many(vals)
+            for v in vals.tolist():
+                b.add(v)
+            assert list(a.data.items()) == list(b.data.items())
+
+
+def test_columnar_ingest_equals_tuple_ingest():
+    """Recommender's numeric-DataFrame fast path (columns handed over as arrays in big chunks) must
+    leave the model in the state the reference's 1000-tuple mini-batch loop leaves it in."""
+    import pandas as pd
+    from rtrec_amd.models.slim import SLIM
+    from rtrec_amd.recommender import Recommender
+    rng = np.random.default_rng(11)
+    n = 5000
+    df = pd.DataFrame({"user": rng.integers(0, 300, n), "item": rng.integers(0, 120, n),
+                       "tstamp": 1.7e9 + np.sort(rng.random(n) * 5e6), "rating": rng.integers(-2, 6, n).astype(float)})
+    for kw in ({}, {"decay_in_days": 30}):
+        fast = Recommender(SLIM(min_value=-3, max_value=12, **kw))
+        fast._ingest_frame(df, 1000, False, True, True)
+        slow = Recommender(SLIM(min_value=-3, max_value=12, **kw))
+        for batch in Recommender.generate_batches(df[["user", "item", "tstamp", "rating"]], 1000):
+            slow.model.add_interactions(batch, update_interaction=False, record_interactions=True)
+        A, B = fast.model.interactions, slow.model.interactions
+        assert A.shape == B.shape and A.max_timestamp == B.max_timestamp
+        Xa, Xb = A.to_csr(), B.to_csr()
+        assert np.array_equal(Xa.indptr, Xb.indptr) and np.array_equal(Xa.indices, Xb.indices)
+        assert np.array_equal(Xa.data, Xb.data)
+        assert list(A.hot_items.data.items()) == list(B.hot_items.data.items())
+        assert fast.model.recorded_item_ids == slow.model.recorded_item_ids
+        assert fast.model.item_ids.pass_through is True and fast.model.user_ids.pass_through is True
+    # string ids and negative ids take the tuple path (same warn-and-skip semantics)
+    m = SLIM()
+    m.add_interactions_columns(np.array(["a", "b"], dtype=object), np.array(["x", "y"], dtype=object),
+                               np.array([1.0, 2.0]), np.array([1.0, 1.0]))
+    assert m.item_ids.pass_through is False and m.interactions.nnz == 2
+    m2 = SLIM()
+    m2.add_interactions_columns(np.array([1, -1]), np.array([2, 3]), np.array([1.0, 2.0]), np.array([1.0, 1.0]))
+    assert m2.interactions.nnz >= 1

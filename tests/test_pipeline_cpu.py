@@ -172,6 +172,7 @@ def _worker(rank, world, port, q):
         z = np.load(os.path.join(G, "models.npz"))
         X = load_csc(z, "X2")
         eng = SlimEngine(backend=OracleBackend(), rank=rank, world_size=world)
+        eng.gather_chunk_rows = 7          # several chunks -> several asynchronous all-gathers in flight
         m = SLIMElastic({"nn_feature_selection": 50}, engine=eng)
         m.partial_fit_items(X.copy(), list(range(400)))            # each rank fits its own column shard
         ok_w = same_matrix(m.item_similarity, load_csc(z, "W2_k50"))

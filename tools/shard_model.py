@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Single-GPU model of the column-sharded scoring pass (what each rank of an N-GPU job runs).
+
+For N in --worlds: build rank r's shard of W (r = 0..N-1) on cuda:0, time its local
+score_topk launch over ALL users, and report max-over-ranks (the compute part of one bench step
+at N GPUs; the RCCL all-gather of [B, k] ids/scores/aux/counts and the merge kernel come on top:
+their byte counts are printed).  W comes from a real fit of the workload.
+
+    python tools/shard_model.py --workload c3 --worlds 1,2,4,8
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main() -> None:
+    from bench import WORKLOADS
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--worlds", default="1,2,4,8")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--top-k", type=int, default=10)
+    args = ap.parse_args()
+    import torch
+    from rtrec_amd import _native
+    from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients
+    from rtrec_amd.synth import interaction_matrix
+
+    wl = WORKLOADS[args.workload]
+    U, I, K = wl["U"], wl["I"], wl["K"]
+    X = interaction_matrix(U, I, wl["draws"], seed=20251003, float_ratings=True)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(Xc, X)
+    t0 = time.time()
+    tg, items, coef, count, n_iter = eng.fit_columns(np.arange(I), nn_feature_selection=K)
+    torch.cuda.synchronize()
+    fit_s = time.time() - t0
+    W = merge_coefficients(None, I, *coefficients_to_updates(tg, items, coef, count))
+    print(json.dumps({"workload": args.workload, "fit_s": fit_s, "W_nnz": int(W.nnz)}), flush=True)
+    d_rows = eng.be.to_dev(np.arange(U, dtype=np.int32))
+    xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
+    k = args.top_k
+    base = None
+    for N in [int(x) for x in args.worlds.split(",")]:
+        per_rank = []
+        for r in range(N):
+            e = SlimEngine(device="cuda:0", rank=r, world_size=N)
+            e._X = eng._X
+            e.n_users, e.n_items = U, I
+            e.set_weights(W)
+            e._local_topk(d_rows, U, xb, k, True, _native.TOPK_SPARSE, None)     # builds the layout, warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                e._local_topk(d_rows, U, xb, k, True, _native.TOPK_SPARSE, None)
+            torch.cuda.synchronize()
+            per_rank.append((time.perf_counter() - t0) / args.steps * 1e3)
+            lay = e._layout(True)
+        worst = max(per_rank)
+        base = base or worst
+        gather_bytes = N * U * (k * 12 + 4)      # ids + scores + aux per entry, count per row, from every rank
+        print(json.dumps({"world": N, "local_ms_max": worst, "local_ms_min": min(per_rank),
+                          "speedup_vs_1": base / worst, "allgather_bytes_per_rank_out": gather_bytes,
+                          "users_per_s_compute_only": U / (worst * 1e-3)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
