@@ -36,7 +36,8 @@ class NativeLibraryError(RuntimeError):
 
 
 def lib_path() -> str:
-    return _build.LIB_PATH
+    # RTREC_AMD_LIB: load another build of the same ABI (A/B timing of kernel variants, tools/ab_build.sh)
+    return os.environ.get("RTREC_AMD_LIB") or _build.LIB_PATH
 
 
 def load() -> C.CDLL:

@@ -66,16 +66,24 @@ struct ScoreArgs {
     int ablate;           // diagnostics: bit0 skip accumulate, bit1 skip select, bit2 skip reset, bit3 skip filter
 };
 
-constexpr int kListCap = 512;    // threshold-candidate list (uint16 columns)
-constexpr int kTouchCap = 1536;  // touched-column list of the sparse kernel (uint16 columns)
+#ifndef SCORE_LIST_CAP
+#define SCORE_LIST_CAP 256
+#endif
+#ifndef SCORE_TOUCH_CAP
+#define SCORE_TOUCH_CAP 1024
+#endif
+constexpr int kListCap = SCORE_LIST_CAP;    // threshold-candidate list (uint16 columns)
+constexpr int kTouchCap = SCORE_TOUCH_CAP;  // touched-column list of the sparse kernel (uint16 columns)
 constexpr int kResCap = 64;      // top_k + 1 <= 64
 constexpr int kQueueChunk = 8;   // jobs claimed per work-queue atomic
 constexpr int kRowGroup = 8;     // W rows whose first loads are issued together
 constexpr int kStreamDepth = 8;  // 64-entry chunks of a long W row requested per round trip
+constexpr int kDenseUnroll = 4;  // 256-column steps of a dense W block per pipeline stage
+typedef float vf4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr size_t score_lds_bytes(int tile_cols, int acc_bytes, bool ft, bool touched) {
     return static_cast<size_t>(tile_cols) * (acc_bytes + (ft ? 4 : 0)) + (touched ? kTouchCap * 2 : 0) + kListCap * 2 +
-           kResCap * (8 + 4 + 4);
+           kResCap * (8 + 4 + 4) + 16;
 }
 
 template <typename ACC>
@@ -117,6 +125,7 @@ struct TileLds {
     uint32_t *ft;
     uint16_t *tlist;
     uint16_t *clist;
+    int *ccnt;       // length of clist while it is being filled
     ACC *res_s;
     int *res_i;
     uint32_t *res_a;
@@ -132,7 +141,8 @@ __device__ __forceinline__ TileLds<ACC> carve_lds(unsigned char *smem, int S, bo
     L.res_i = reinterpret_cast<int *>(p);          p += kResCap * 4;
     L.res_a = reinterpret_cast<uint32_t *>(p);     p += kResCap * 4;
     L.tlist = reinterpret_cast<uint16_t *>(p);     if (touched) p += kTouchCap * 2;
-    L.clist = reinterpret_cast<uint16_t *>(p);
+    L.clist = reinterpret_cast<uint16_t *>(p);     p += kListCap * 2;
+    L.ccnt = reinterpret_cast<int *>(p);
     return L;
 }
 
@@ -177,11 +187,11 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
 
     // pass 1: per-lane best key, then tau = kk-th largest lane best (lower bound of the answer)
     ACC best = ninf;
-    if (IDX::kAll) {   // whole tile: 4 columns per lane and step (columns >= n_idx hold invalid keys)
+    if (IDX::kAll) {   // whole tile: 4 columns per lane and step
         for (int c = lane * 4; c < n_idx; c += 256) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const ACC k = sel_key(acc[c + j], zero_valid);
+                const ACC k = (c + j < n_idx) ? sel_key(acc[c + j], zero_valid) : ninf;
                 best = k > best ? k : best;
             }
         }
@@ -204,23 +214,31 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
         const unsigned long long at = __ballot(rank == a.kk - 1);
         if (at) tau = readlane_t(best, __builtin_ctzll(at));
     }
-    // pass 2: collect the columns with key >= tau
+    // pass 2: collect the columns with key >= tau (about kk of them): one wave-wide test per
+    // 256-column step, the per-column ballots only where something was found
     int cnt = 0;
     if (IDX::kAll) {
         for (int c0 = lane * 4; c0 < n_idx + 256; c0 += 256) {   // uniform trip count
             if (c0 - lane * 4 >= n_idx) break;
+            bool hit[4];
+            bool any = false;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + j;
-                bool hit = false;
+                hit[j] = false;
                 if (c < n_idx) {
                     const ACC k = sel_key(acc[c], zero_valid);
-                    hit = (k != ninf) && (k >= tau);
+                    hit[j] = (k != ninf) && (k >= tau);
                 }
-                const unsigned long long m = __ballot(hit);
+                any = any || hit[j];
+            }
+            if (!__ballot(any)) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned long long m = __ballot(hit[j]);
                 if (m) {
                     const int pos = cnt + lane_prefix(m);
-                    if (hit && pos < kListCap) L.clist[pos] = static_cast<uint16_t>(c);
+                    if (hit[j] && pos < kListCap) L.clist[pos] = static_cast<uint16_t>(c0 + j);
                     cnt += __builtin_popcountll(m);
                 }
             }
@@ -393,6 +411,38 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                     // never changes a sum, so the zero padding is inert.
                     const float *dv = a.dense_val + static_cast<size_t>(dd[j]) * a.tile_cols;
                     const ACC xj = xx[j];
+                    if (!FT && sizeof(ACC) == 4) {
+                        // float tile: whole-vector arithmetic (v_pk_mul_f32 / v_pk_add_f32 on the
+                        // registers the 128-bit loads filled, no repacking moves) and a two-stage
+                        // pipeline -- the W block of steps s+4..s+7 is in flight while steps s..s+3
+                        // are read from LDS, updated (one rounded product, one rounded add per
+                        // column, as in the scalar form) and written back.
+                        const vf4 *dv4 = reinterpret_cast<const vf4 *>(dv) + lane;
+                        vf4 *acc4 = reinterpret_cast<vf4 *>(acc) + lane;
+                        const int steps = a.tile_cols >> 8;          // tile_cols is a multiple of 256
+                        const float xs = static_cast<float>(xj);
+                        int sidx = 0;
+                        if (steps >= kDenseUnroll) {
+                            vf4 wn[kDenseUnroll];
+#pragma unroll
+                            for (int u = 0; u < kDenseUnroll; ++u) wn[u] = dv4[64 * u];
+                            for (; sidx + kDenseUnroll <= steps; sidx += kDenseUnroll) {
+                                vf4 w[kDenseUnroll], o[kDenseUnroll];
+#pragma unroll
+                                for (int u = 0; u < kDenseUnroll; ++u) w[u] = wn[u];
+                                if (sidx + 2 * kDenseUnroll <= steps) {
+#pragma unroll
+                                    for (int u = 0; u < kDenseUnroll; ++u) wn[u] = dv4[64 * (sidx + kDenseUnroll + u)];
+                                }
+#pragma unroll
+                                for (int u = 0; u < kDenseUnroll; ++u) o[u] = acc4[64 * (sidx + u)];
+#pragma unroll
+                                for (int u = 0; u < kDenseUnroll; ++u) acc4[64 * (sidx + u)] = o[u] + w[u] * xs;
+                            }
+                        }
+                        for (; sidx < steps; ++sidx) acc4[64 * sidx] = acc4[64 * sidx] + dv4[64 * sidx] * xs;
+                        continue;
+                    }
                     for (int c = lane * 4; c < a.tile_cols; c += 256) {
                         const float4 w4 = *reinterpret_cast<const float4 *>(dv + c);
                         ACC o0 = acc[c], o1 = acc[c + 1], o2 = acc[c + 2], o3 = acc[c + 3];

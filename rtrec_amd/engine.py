@@ -24,7 +24,7 @@ import scipy.sparse as sp
 
 from . import _native
 
-DEFAULT_TILE_COLS = 8192
+DEFAULT_TILE_COLS = 4096   # 16 KB of float accumulators: 8 persistent waves per CU (2 per SIMD) hide each other's latency
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
 MAX_SLOTS = 5120   # 5 single-wave workgroups per SIMD (fit kernel: <= 96 VGPRs)
 GATHER_CHUNK_ROWS = 32768   # rows per all-gather chunk of a sharded scoring call

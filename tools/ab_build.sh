@@ -1,0 +1,8 @@
+#!/bin/bash
+# Build the current csrc/ into rtrec_amd/lib/ab_<name>.so (select it with RTREC_AMD_LIB=<path>).
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p rtrec_amd/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $AB_FLAGS \
+  -o rtrec_amd/lib/ab_$1.so rtrec_amd/csrc/score.hip rtrec_amd/csrc/fit.hip
+echo rtrec_amd/lib/ab_$1.so
