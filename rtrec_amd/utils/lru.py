@@ -31,10 +31,10 @@ class LRUFreqSet(MutableSet):
 
     def add_many(self, values: Iterable[Any]) -> None:
         """Same end state as calling add() for each value in order."""
-        if isinstance(values, np.ndarray) and values.dtype.kind in "iu" and values.ndim == 1 and len(values) > 64:
-            if self._add_many_ints(values):
+        if isinstance(values, np.ndarray):
+            if values.dtype.kind in "iu" and values.ndim == 1 and len(values) > 64 and self._add_many_ints(values):
                 return
-            values = values.tolist()
+            values = values.tolist()       # python scalars: the keys are handed back to callers
         values = list(values)
         fresh = {v for v in values if v not in self.data}
         if len(self.data) + len(fresh) > self.capacity:

@@ -152,3 +152,17 @@ def test_reference_written_model_file_serves_on_gpu():
     s = SLIM.loads(open(os.path.join(G, "ref_slim_str.pkl"), "rb").read())
     assert s.similar_items("item_1", top_k=5) == exp["str"]["similar_item_1"]
     assert s.recommend("user_2", top_k=5) == exp["str"]["rec_user_2"]
+
+
+@pytest.mark.parametrize("session", ["str", "int"])
+def test_serving_shell_on_the_gpu_replays_the_reference_transcript(session):
+    """The HTTP shell with its default model (GPU engine) against the transcript of the reference's
+    FastAPI app (tests/golden/serving.json)."""
+    from fastapi.testclient import TestClient
+    from rtrec_amd.serving.app import create_app
+    steps = json.load(open(os.path.join(G, "serving.json")))[session]
+    client = TestClient(create_app())
+    for st in steps:
+        r = client.get(st["path"]) if st["method"] == "GET" else client.post(st["path"], json=st["json"], headers=st["headers"])
+        assert r.status_code == st["status"], st
+        assert r.json() == st["response"], st

@@ -248,3 +248,25 @@ def test_loads_model_files_written_by_the_reference():
     assert s.similar_items("item_1", top_k=5) == exp["str"]["similar_item_1"]
     assert s.recommend("user_2", top_k=5) == exp["str"]["rec_user_2"]
     assert s.feature_store.build_item_features_matrix(item_ids=[0]).nnz == exp["str"]["item_feature_nnz"]
+
+
+@pytest.mark.parametrize("session", ["str", "int"])
+def test_serving_shell_replays_the_reference_transcript(session):
+    """tests/golden/serving.json is the request/response transcript of the reference's FastAPI app
+    (rtrec/serving/app.py) for a fixed request sequence; rtrec_amd.serving.app must answer alike."""
+    from fastapi.testclient import TestClient
+    from rtrec_amd.serving.app import create_app
+    steps = json.load(open(os.path.join(G, "serving.json")))[session]
+    client = TestClient(create_app(lambda: cpu_slim(min_value=-5, max_value=10, decay_in_days=365)))
+    for st in steps:
+        r = client.get(st["path"]) if st["method"] == "GET" else client.post(st["path"], json=st["json"], headers=st["headers"])
+        assert r.status_code == st["status"], st
+        assert r.json() == st["response"], st
+    # the batched route (an addition) answers like one /recommend per KNOWN user (for an unknown user
+    # the reference's single-user cold path returns internal ids, base.py:162-167, its batch path raw ids)
+    users = [s["json"]["user"] for s in steps if s["path"] == "/recommend" and s["status"] == 200][-4:-1]
+    r = client.post("/recommend_batch", json={"users": users, "top_k": 3, "filter_interacted": False},
+                    headers={"X-Token": "fake_secret_token"})
+    assert r.status_code == 200
+    assert r.json()["recommendations"] == [s["response"]["recommendations"] for s in steps
+                                           if s["path"] == "/recommend" and s["status"] == 200][-4:-1]

@@ -288,6 +288,46 @@ def gen_reference_pickles():
     json.dump(exp, open(os.path.join(OUT, "ref_pickles.json"), "w"))
 
 
+# ------------------------------------------------------------------ N2: the HTTP shell
+def gen_serving():
+    """Request/response transcript of the REFERENCE FastAPI app (rtrec/serving/app.py) for a fixed
+    request sequence; tests replay it against rtrec_amd.serving.app."""
+    from fastapi.testclient import TestClient
+    from rtrec.serving.app import create_app
+    tok = {"X-Token": "fake_secret_token"}
+    str_inter = [{"user": "user1", "item": "item1", "timestamp": 1672531200.0, "rating": 5.0},
+                 {"user": "user1", "item": "item2", "timestamp": 1672617600.0, "rating": 3.0},
+                 {"user": "user2", "item": "item1", "timestamp": 1672704000.0, "rating": 4.0},
+                 {"user": "user2", "item": "item3", "timestamp": 1672704000.0, "rating": 4.0},
+                 {"user": "user2", "item": "item4", "timestamp": 1672704000.0, "rating": 3.0},
+                 {"user": "user3", "item": "item2", "timestamp": 1672790400.0, "rating": 2.0},
+                 {"user": "user3", "item": "item4", "timestamp": 1672790400.0, "rating": 5.0}]
+    int_inter = [{"user": 1, "item": 1, "timestamp": 1672531200.0, "rating": 5.0},
+                 {"user": 1, "item": 2, "timestamp": 1672617600.0, "rating": 3.0},
+                 {"user": 2, "item": 1, "timestamp": 1672704000.0, "rating": 4.0},
+                 {"user": 2, "item": 3, "timestamp": 1672704000.0, "rating": 4.0},
+                 {"user": 2, "item": 4, "timestamp": 1672704000.0, "rating": 3.0},
+                 {"user": 3, "item": 2, "timestamp": 1672790400.0, "rating": 2.0},
+                 {"user": 3, "item": 4, "timestamp": 1672790400.0, "rating": 5.0}]
+    sessions = {}
+    for name, inter, users in (("str", str_inter, ["user1", "user2", "user3", "nobody"]), ("int", int_inter, [1, 2, 3, 99])):
+        c = TestClient(create_app())
+        steps = [("GET", "/", None, {}), ("POST", "/fit", inter[:5], {"X-Token": "wrong"}), ("POST", "/fit", inter[:5], tok)]
+        for u in users:
+            steps.append(("POST", "/recommend", {"user": u, "top_k": 5, "filter_interacted": True}, tok))
+        steps.append(("POST", "/fit", inter[5:], tok))
+        for u in users:
+            steps.append(("POST", "/recommend", {"user": u, "top_k": 3, "filter_interacted": False}, tok))
+        steps.append(("POST", "/recommend", {"user": users[0]}, {"X-Token": "wrong"}))
+        out = []
+        for method, path, payload, headers in steps:
+            r = c.get(path) if method == "GET" else c.post(path, json=payload, headers=headers)
+            out.append({"method": method, "path": path, "json": payload, "headers": headers, "status": r.status_code,
+                        "response": r.json()})
+        sessions[name] = out
+    json.dump(sessions, open(os.path.join(OUT, "serving.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     gen_rng()
     gen_cd_columns()
@@ -297,5 +337,6 @@ if __name__ == "__main__":
     gen_store()
     gen_api()
     gen_reference_pickles()
+    gen_serving()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
