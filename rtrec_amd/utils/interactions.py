@@ -166,11 +166,14 @@ class UserItemInteractions:
             ts[fd] = self._delta.ts[pd_[fd]]
         return fb | fd, val, ts
 
-    def _write(self, keys: np.ndarray, val: np.ndarray, ts: np.ndarray) -> None:
+    def _write(self, keys: np.ndarray, val: np.ndarray, ts: np.ndarray, presorted: bool = False) -> None:
         """Store unique keys (any order) into the delta block; merge down when it has grown."""
-        order = np.argsort(keys, kind="stable")
-        self._delta = _merge_blocks(self._delta, _Block(keys[order], val[order].astype(np.float64),
-                                                        ts[order].astype(np.float64)))
+        if presorted:
+            blk = _Block(keys, val.astype(np.float64), ts.astype(np.float64))
+        else:
+            order = np.argsort(keys, kind="stable")
+            blk = _Block(keys[order], val[order].astype(np.float64), ts[order].astype(np.float64))
+        self._delta = _merge_blocks(self._delta, blk)
         if len(self._delta) >= max(_DELTA_MERGE_MIN, len(self._base) // 8):
             self._compact()
         self.version += 1
@@ -215,7 +218,7 @@ class UserItemInteractions:
         first = np.ones(n, bool)
         first[1:] = sk[1:] != sk[:-1]
         if first.all():
-            rounds = [np.arange(n)]
+            rounds = [order]          # distinct pairs: one round, visited in key order (already sorted for the store)
         else:   # occurrence rank of every interaction within its (user, item) group
             start = np.flatnonzero(first)
             grp = np.cumsum(first) - 1
@@ -229,7 +232,7 @@ class UserItemInteractions:
                 found, old, old_ts = self._lookup(k)
                 cur = np.where(found & (old != 0.0), self._decay_array(old, old_ts, seen[idx]), 0.0)
                 new = np.clip(cur + dl[idx], self.min_value, self.max_value)
-            self._write(k, new, ts[idx])
+            self._write(k, new, ts[idx], presorted=True)     # every round is a subsequence of the key-sorted order
 
         self.max_timestamp = float(seen[-1])
         self.all_item_ids.update(np.unique(items).tolist())
@@ -390,7 +393,9 @@ class UserItemInteractions:
         """U x I CSC; with select_items only those columns are populated (interactions.py:291-303)."""
         rows, cols, data = self._triples(select_items=select_items)
         n_u, n_i = self.shape
-        order = np.argsort(cols, kind="stable")     # rows stay ascending inside each column
+        # rows stay ascending inside each column; 16-bit keys take numpy's radix sort (several times
+        # faster than the merge sort used for wider integers)
+        order = np.argsort(cols.astype(np.uint16) if n_i <= 65536 else cols, kind="stable")
         indptr = np.zeros(n_i + 1, dtype=np.int64)
         indptr[1:] = np.bincount(cols, minlength=n_i)
         np.cumsum(indptr, out=indptr)
