@@ -158,11 +158,15 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
     const ACC ninf = NegInf<ACC>::value();
     const ACC *acc = L.acc;
 
+    // Candidates carry the LAYOUT column t0 + c instead of the item id: col_ids is ascending, so both
+    // order alike and the (global-memory) translation is done once for the <= kk winners in
+    // emit_result instead of sitting on the critical path of every comparison.
     auto make_cand = [&](int c) {
         Cand<ACC> x;
         x.score = acc[c];
-        x.id = global_col(a, t0 + c);
-        x.aux = FT ? L.ft[c] : (a.mode == RTREC_TOPK_CANDIDATES ? static_cast<uint32_t>(a.col_rank[x.id]) : 0u);
+        x.id = t0 + c;
+        x.aux = FT ? L.ft[c]
+                   : (a.mode == RTREC_TOPK_CANDIDATES ? static_cast<uint32_t>(a.col_rank[global_col(a, t0 + c)]) : 0u);
         return x;
     };
     auto rank_and_store = [&](bool have, const Cand<ACC> &mine, int n_lanes) {
@@ -317,7 +321,7 @@ __device__ __forceinline__ void emit_result(const ScoreArgs &a, const TileLds<AC
             const long long o = static_cast<long long>(row) * a.top_k + lane;
             const bool ok = lane < n_fin;
             const ACC sc = ok ? L.res_s[lane] : NegInf<ACC>::value();
-            a.out_id[o] = ok ? L.res_i[lane] : -1;
+            a.out_id[o] = ok ? global_col(a, L.res_i[lane]) : -1;
             a.out_score[o] = static_cast<float>(sc);
             if (a.out_score64) a.out_score64[o] = static_cast<double>(sc);
             if (a.out_aux) a.out_aux[o] = ok ? L.res_a[lane] : 0u;
@@ -333,7 +337,7 @@ __device__ __forceinline__ void emit_result(const ScoreArgs &a, const TileLds<AC
         const size_t base = (static_cast<size_t>(row) * a.n_tiles + tile) * a.kk;
         if (lane < n_out) {
             reinterpret_cast<ACC *>(a.cand_score)[base + lane] = L.res_s[lane];
-            a.cand_id[base + lane] = L.res_i[lane];
+            a.cand_id[base + lane] = global_col(a, L.res_i[lane]);
             a.cand_aux[base + lane] = L.res_a[lane];
         }
         if (lane == 0) a.cand_cnt[static_cast<size_t>(row) * a.n_tiles + tile] = n_out;
@@ -347,8 +351,14 @@ __device__ __forceinline__ void emit_result(const ScoreArgs &a, const TileLds<AC
 // per CU on gfx950, a read+write pair ~14: tools/microbench/lds_atomic_rate.hip.)
 // TOUCH: the value read back tells whether this is the first contribution to the column; such
 // columns are appended to tlist.  FT: the first-touch position of the column is recorded.
-template <typename ACC, bool FT, bool TOUCH>
-__device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds<ACC> &L, int a0, int n_a, int tile) {
+// PREFILTER (sparse kernel, filter_interacted): the user's own items are taken out of the race while
+// their row headers are loaded -- the accumulator of an interacted column is set to -inf (an
+// absorbing value: -inf + p = -inf) and the column joins the touched list so that it is reset with
+// the rest.  This replaces a separate pass (two dependent global loads per job) after the
+// accumulation; scores of the other columns are untouched.
+template <typename ACC, bool FT, bool TOUCH, bool PREFILTER = false>
+__device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds<ACC> &L, int a0, int n_a, int tile,
+                                               int t0 = 0, int ncol = 0) {
     const int lane = lane_id();
     ACC *acc = L.acc;
     const int *tp = a.tile_ptr + static_cast<size_t>(tile) * (a.n_items + 1);
@@ -370,6 +380,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
         const int p = base + lane;
         float x = 0.0f;
         int s = 0, e = 0, d = -1;
+        int lc = -1;
         if (p < n_a) {
             const int item = a.xb_col[a0 + p];
             x = a.xb_val[a0 + p];
@@ -378,6 +389,17 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                 e = tp[item + 1];
                 if (a.dense_idx) d = a.dense_idx[static_cast<size_t>(tile) * a.n_items + item];
             }
+            if (PREFILTER && a.filter)
+                lc = (a.col_map ? (item < a.n_items ? a.col_map[item] : -1) : item - a.col_offset) - t0;
+        }
+        if (PREFILTER && a.filter) {
+            const bool mine = lc >= 0 && lc < ncol;        // the items of one row are distinct: no two lanes collide
+            bool first = false;
+            if (mine) {
+                first = is_untouched(acc[lc]);
+                acc[lc] = NegInf<ACC>::value();
+            }
+            push(first, lc);
         }
         unsigned long long live = __ballot(e > s || d >= 0);
         if (TOUCH && track && __ballot(e - s >= kTouchCap / 4 || d >= 0)) { track = false; tcnt = kTouchCap + 1; }
@@ -620,16 +642,9 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
         const int a0 = a.xb_ptr[xrow];
         const int n_a = a.xb_ptr[xrow + 1] - a0;
 
-        const int tcnt = (a.ablate & 1) ? 0 : accumulate_tile<ACC, FT, true>(a, L, a0, n_a, tile);
+        // interacted items leave the race inside accumulate_tile (PREFILTER)
+        const int tcnt = (a.ablate & 1) ? 0 : accumulate_tile<ACC, FT, true, true>(a, L, a0, n_a, tile, t0, ncol);
         const bool overflow = tcnt > kTouchCap;
-
-        if (a.filter && tcnt > 0 && !(a.ablate & 8)) {   // interacted items that received a score leave the race
-            for (int p = lane; p < n_a; p += 64) {
-                const int item = a.xb_col[a0 + p];
-                const int lc = (a.col_map ? (item < a.n_items ? a.col_map[item] : -1) : item - a.col_offset) - t0;
-                if (lc >= 0 && lc < ncol && !is_untouched(L.acc[lc])) L.acc[lc] = ninf;
-            }
-        }
         int n_out = 0;
         if (tcnt > 0 && !(a.ablate & 2)) {
             if (!overflow) n_out = select_topk<ACC, FT>(a, L, IdxList{L.tlist}, tcnt, t0, /*zero_valid=*/false);
