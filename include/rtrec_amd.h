@@ -139,6 +139,10 @@ int rtrec_slim_fit_columns_traced(int32_t n_users, int32_t n_items,
  * a block of tile_cols floats in d_dense_val (zero where W[i, c] is not stored) and the CSR range
  * of that (tile, row) is then empty; pass both NULL when no segment is dense.  Adding x * 0 never
  * changes an accumulator, so results are identical; dense blocks are updated 4 columns per lane.
+ * Optionally the per-item lookups are given once more as ONE record table, d_row_hdr[(t * n_items + i) * 4
+ * + 0..3] = { d_tile_ptr[t][i], d_tile_ptr[t][i + 1], dense block or -1, tile-local layout column of
+ * item i if it lies in tile t else -1 } (16-byte aligned): scoring a user row then costs one memory
+ * sector per item instead of three.  NULL = use the separate tables.
  * ------------------------------------------------------------------------------------- */
 
 typedef enum {
@@ -182,6 +186,7 @@ int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                           int32_t tile_cols, int32_t n_tiles,
                           const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
                           const int32_t *d_dense_idx, const float *d_dense_val,
+                          const int32_t *d_row_hdr,
                           const int32_t *d_col_rank,
                           int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
                           int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,

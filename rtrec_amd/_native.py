@@ -78,7 +78,7 @@ def load() -> C.CDLL:
     L.rtrec_slim_score_workspace_bytes.restype = u64
     L.rtrec_slim_score_workspace_bytes.argtypes = [i32, i32, i32]
     L.rtrec_slim_score_topk.restype = C.c_int
-    L.rtrec_slim_score_topk.argtypes = ([i32] + [vp] * 4 + [i32] * 3 + [vp] * 2 + [i32] * 2 + [vp] * 6
+    L.rtrec_slim_score_topk.argtypes = ([i32] + [vp] * 4 + [i32] * 3 + [vp] * 2 + [i32] * 2 + [vp] * 7
                                         + [i32] * 4 + [vp] * 5 + [vp, u64, vp])
     L.rtrec_slim_score_rows.restype = C.c_int
     L.rtrec_slim_score_rows.argtypes = [i32] + [vp] * 4 + [i32] * 5 + [vp] * 3 + [i32, vp, C.c_int64, vp]

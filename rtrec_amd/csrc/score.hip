@@ -39,6 +39,7 @@ struct ScoreArgs {
     const float *w_val;
     const int *dense_idx;  // optional: [n_tiles * n_items] dense block of (tile, row) or -1
     const float *dense_val; // optional: [n_dense * tile_cols]
+    const int4 *row_hdr;    // optional: [n_tiles * n_items] {ptr begin, ptr end, dense block, tile-local column of the item}
     const int *col_rank;
     int kk;               // entries kept per (row, tile): top_k, or top_k + 1 when ties are detected
     int top_k;
@@ -384,13 +385,23 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
         if (p < n_a) {
             const int item = a.xb_col[a0 + p];
             x = a.xb_val[a0 + p];
-            if (item < a.n_items) {   // items newer than W have no row yet
-                s = tp[item];
-                e = tp[item + 1];
-                if (a.dense_idx) d = a.dense_idx[static_cast<size_t>(tile) * a.n_items + item];
+            if (a.row_hdr) {
+                // one 16-byte record per (tile, item) instead of three gathers from three tables:
+                // a user row costs one memory sector per item
+                if (item < a.n_items) {
+                    const int4 h = a.row_hdr[static_cast<size_t>(tile) * a.n_items + item];
+                    s = h.x; e = h.y; d = h.z;
+                    if (PREFILTER && a.filter) lc = h.w;
+                }
+            } else {
+                if (item < a.n_items) {   // items newer than W have no row yet
+                    s = tp[item];
+                    e = tp[item + 1];
+                    if (a.dense_idx) d = a.dense_idx[static_cast<size_t>(tile) * a.n_items + item];
+                }
+                if (PREFILTER && a.filter)
+                    lc = (a.col_map ? (item < a.n_items ? a.col_map[item] : -1) : item - a.col_offset) - t0;
             }
-            if (PREFILTER && a.filter)
-                lc = (a.col_map ? (item < a.n_items ? a.col_map[item] : -1) : item - a.col_offset) - t0;
         }
         if (PREFILTER && a.filter) {
             const bool mine = lc >= 0 && lc < ncol;        // the items of one row are distinct: no two lanes collide
@@ -980,12 +991,14 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                                      int32_t tile_cols, int32_t n_tiles,
                                      const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
                                      const int32_t *d_dense_idx, const float *d_dense_val,
+                                     const int32_t *d_row_hdr,
                                      const int32_t *d_col_rank,
                                      int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
                                      int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,
                                      uint32_t *d_out_aux, int32_t *d_out_count,
                                      void *d_workspace, size_t workspace_bytes, void *stream) {
     if (n_rows < 0 || n_items <= 0 || n_cols <= 0 || top_k <= 0) return RTREC_ERR_INVALID_ARG;
+    if (d_row_hdr && (reinterpret_cast<uintptr_t>(d_row_hdr) & 15u)) return RTREC_ERR_INVALID_ARG;
     if (n_rows == 0) return RTREC_OK;
     if (!d_xb_ptr || !d_tile_ptr || !d_out_ids || !d_out_scores || !d_out_count || !d_workspace) return RTREC_ERR_INVALID_ARG;
     if (mode < 0 || mode > 2) return RTREC_ERR_INVALID_ARG;
@@ -1008,6 +1021,7 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     a.tile_cols = tile_cols; a.n_tiles = n_tiles;
     a.tile_ptr = d_tile_ptr; a.w_col = d_w_col; a.w_val = d_w_val; a.col_rank = d_col_rank;
     a.dense_idx = d_dense_idx; a.dense_val = d_dense_val;
+    a.row_hdr = reinterpret_cast<const int4 *>(d_row_hdr);
     a.filter = filter_interacted; a.mode = mode;
     { const char *ab = std::getenv("RTREC_AMD_ABLATE"); a.ablate = ab ? std::atoi(ab) : 0; }
     hipStream_t st = static_cast<hipStream_t>(stream);

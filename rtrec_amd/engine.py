@@ -121,6 +121,23 @@ def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int
                   col_ids, col_map, dense_idx, dense_val)
 
 
+def row_header_table(T: TiledW) -> np.ndarray:
+    """[n_tiles, n_items, 4] int32 records {ptr begin, ptr end, dense block or -1, tile-local layout column
+    of the item or -1}: everything the kernel looks up per (tile, user item), in one 16-byte gather."""
+    n_items, S = T.n_items, T.tile_cols
+    tp = T.tile_ptr.reshape(T.n_tiles, n_items + 1)
+    hdr = np.empty((T.n_tiles, n_items, 4), dtype=np.int32)
+    hdr[:, :, 0] = tp[:, :-1]
+    hdr[:, :, 1] = tp[:, 1:]
+    hdr[:, :, 2] = T.dense_idx.reshape(T.n_tiles, n_items) if T.dense_idx is not None else -1
+    loc = T.col_map.astype(np.int64) if T.col_map is not None else np.arange(n_items, dtype=np.int64) - T.col_lo
+    loc = np.where((loc >= 0) & (loc < T.n_cols), loc, -1)
+    for t in range(T.n_tiles):
+        l = loc - t * S
+        hdr[t, :, 3] = np.where((loc >= 0) & (l >= 0) & (l < S), l, -1)
+    return hdr
+
+
 class HipBackend:
     """Thin marshalling layer over librtrec_amd.so; all arrays are torch CUDA tensors."""
 
@@ -187,7 +204,8 @@ class HipBackend:
             n_items, lay["n_cols"], col_lo, self.ptr(lay["col_ids"]), self.ptr(lay["col_map"]),
             lay["tile_cols"], lay["n_tiles"],
             self.ptr(lay["tile_ptr"]), self.ptr(lay["w_col"]), self.ptr(lay["w_val"]),
-            self.ptr(lay.get("dense_idx")), self.ptr(lay.get("dense_val")), self.ptr(col_rank),
+            self.ptr(lay.get("dense_idx")), self.ptr(lay.get("dense_val")), self.ptr(None if os.environ.get("RTREC_AMD_NO_ROWHDR") else lay.get("row_hdr")),
+            self.ptr(col_rank),
             top_k, int(bool(filter_interacted)), int(mode), int(acc_f64),
             self.ptr(ids), self.ptr(sc), self.ptr(sc64), self.ptr(aux), self.ptr(cnt),
             self.ptr(ws), ws.numel(), self.stream()), "rtrec_slim_score_topk")
@@ -407,7 +425,8 @@ class SlimEngine:
                                tile_ptr=be.to_dev(T.tile_ptr), w_col=be.to_dev(T.w_col.view(np.int16)),
                                w_val=be.to_dev(T.w_val),
                                col_ids=be.to_dev(T.col_ids) if T.col_ids is not None else None,
-                               col_map=be.to_dev(T.col_map) if T.col_map is not None else None)
+                               col_map=be.to_dev(T.col_map) if T.col_map is not None else None,
+                               row_hdr=be.to_dev(row_header_table(T)))
             W["layouts"][compact] = lay
         return W["layouts"][compact]
 
