@@ -92,6 +92,19 @@ def _merge_blocks(old: _Block, new: _Block) -> _Block:
     return _Block(np.insert(old.key, ins, nk), np.insert(old.val, ins, nv), np.insert(old.ts, ins, nt))
 
 
+def _stable_order(users: np.ndarray, items: np.ndarray, keys: np.ndarray) -> np.ndarray:
+    """argsort(keys, kind="stable").  When (user, item, arrival index) fit one int64 the composite is
+    VALUE-sorted instead (numpy's vectorised quicksort; the arrival index in the low bits both makes the
+    keys distinct -- so an unstable sort yields the stable order -- and is the permutation)."""
+    n = keys.shape[0]
+    ib, xb = int(items.max()).bit_length(), max(1, (n - 1).bit_length())
+    if n >= (1 << 12) and int(users.max()).bit_length() + ib + xb <= 63:
+        comp = (users << (ib + xb)) | (items << xb) | np.arange(n, dtype=np.int64)
+        comp.sort()
+        return comp & ((1 << xb) - 1)
+    return np.argsort(keys, kind="stable")
+
+
 class UserItemInteractions:
     def __init__(self, min_value: int = -5, max_value: int = 10, decay_in_days: Optional[int] = None,
                  **kwargs: Any) -> None:
@@ -213,7 +226,7 @@ class UserItemInteractions:
         seen = np.maximum.accumulate(np.concatenate(([self.max_timestamp], ts + 1.0)))[1:]
         keys = self._keys(users, items)
 
-        order = np.argsort(keys, kind="stable")
+        order = _stable_order(users, items, keys)
         sk = keys[order]
         first = np.ones(n, bool)
         first[1:] = sk[1:] != sk[:-1]
@@ -395,7 +408,16 @@ class UserItemInteractions:
         n_u, n_i = self.shape
         # rows stay ascending inside each column; 16-bit keys take numpy's radix sort (several times
         # faster than the merge sort used for wider integers)
-        order = np.argsort(cols.astype(np.uint16) if n_i <= 65536 else cols, kind="stable")
+        n_e = cols.shape[0]
+        xb = max(1, (n_e - 1).bit_length())
+        if n_i <= 65536:
+            order = np.argsort(cols.astype(np.uint16), kind="stable")
+        elif n_e >= (1 << 12) and int(n_i).bit_length() + xb <= 63:     # value sort of (item, position)
+            comp = (cols.astype(np.int64) << xb) | np.arange(n_e, dtype=np.int64)
+            comp.sort()
+            order = comp & ((1 << xb) - 1)
+        else:
+            order = np.argsort(cols, kind="stable")
         indptr = np.zeros(n_i + 1, dtype=np.int64)
         indptr[1:] = np.bincount(cols, minlength=n_i)
         np.cumsum(indptr, out=indptr)

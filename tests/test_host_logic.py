@@ -291,3 +291,19 @@ def test_columnar_ingest_equals_tuple_ingest():
     m2 = SLIM()
     m2.add_interactions_columns(np.array([1, -1]), np.array([2, 3]), np.array([1.0, 2.0]), np.array([1.0, 1.0]))
     assert m2.interactions.nnz >= 1
+
+
+def test_csc_export_of_a_wide_catalogue_matches_scipy():
+    """> 65536 items: the CSC export orders entries by a value sort of (item, position) composites."""
+    rng = np.random.default_rng(2)
+    n = 20000
+    u, i = rng.integers(0, 500, n), rng.integers(0, 100_000, n)
+    st = UserItemInteractions(min_value=-5, max_value=10)
+    st.add_interactions_batch(u, i, 1.7e9 + np.arange(n, dtype=float), rng.integers(1, 6, n).astype(float))
+    C, R = st.to_csc(), st.to_csr()
+    ref = R.tocsc()
+    ref.sort_indices()
+    assert C.has_sorted_indices and np.array_equal(C.indptr, ref.indptr) and np.array_equal(C.indices, ref.indices)
+    assert np.array_equal(C.data, ref.data)
+    part = st.to_csc(select_items=[int(x) for x in np.unique(i)[:50]])
+    assert part.nnz == int(np.isin(R.tocoo().col, np.unique(i)[:50]).sum())
