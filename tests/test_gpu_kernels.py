@@ -192,3 +192,45 @@ def test_merge_topk_equals_unsharded(oracle):
     assert np.array_equal(o_ids.cpu().numpy(), ids)
     assert np.array_equal(bits(o_sc.cpu().numpy()), bits(sc))
     assert np.array_equal(o_cnt.cpu().numpy(), cnt)
+
+
+@pytest.mark.parametrize("tile_cols", [1024, 4096])
+@pytest.mark.parametrize("top_k", [1, 10, 50])
+def test_score_wide_catalogue_heavy_users(oracle, tile_cols, top_k):
+    """Users that touch more columns than the touched list holds (> 1024 per tile: the full-tile scan /
+    reset path), several tiles, dense W row blocks next to sparse ones, k from 1 to 50."""
+    rng = np.random.default_rng(4)
+    I, U = 5000, 260
+    # W: 40 "popular" rows that reach most columns (dense blocks), the rest sparse
+    rows, cols, vals = [], [], []
+    for i in rng.choice(I, 40, replace=False):
+        c = rng.choice(I, 3500, replace=False)
+        rows.append(np.full(len(c), i)); cols.append(c); vals.append(rng.random(len(c)).astype(np.float32) + 0.01)
+    r2 = rng.integers(0, I, 30000); c2 = rng.integers(0, I, 30000)
+    rows.append(r2); cols.append(c2); vals.append(rng.random(30000).astype(np.float32) + 0.01)
+    W = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(I, I), dtype=np.float32)
+    W.sum_duplicates(); W.sort_indices()
+    # users: light (5 items), medium (80), heavy (900 items incl. the popular rows)
+    n_items = np.concatenate([np.full(100, 5), np.full(100, 80), np.full(60, 900)])
+    ur = np.repeat(np.arange(U), n_items)
+    uc = np.concatenate([rng.choice(I, n, replace=False) for n in n_items])
+    X = sp.csr_matrix(((rng.integers(1, 6, len(ur)) * np.exp(-rng.random(len(ur)))).astype(np.float32), (ur, uc)),
+                      shape=(U, I), dtype=np.float32)
+    X.sort_indices()
+    Wr = W.tocsr()
+    for world, rank in ((1, 0), (3, 1)):
+        eng = SlimEngine(device="cuda:0", tile_cols=tile_cols, rank=rank, world_size=world)
+        eng.set_interactions(None, X, need_csc=False)
+        eng.set_weights(W)
+        for filt in (True, False):
+            d_rows = eng.be.to_dev(np.arange(U, dtype=np.int32))
+            xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
+            ids, sc, sc64, aux, cnt = eng._local_topk(d_rows, U, xb, top_k, filt, _native.TOPK_SPARSE, None)
+            lo, hi = eng._W["col_lo"], eng._W["col_hi"]
+            Wshard = sp.csr_matrix(Wr.shape, dtype=np.float32).tolil()
+            Wshard = sp.hstack([sp.csr_matrix((I, lo), dtype=np.float32), Wr[:, lo:hi],
+                                sp.csr_matrix((I, I - hi), dtype=np.float32)]).tocsr()
+            o_ids, o_sc, o_cnt = oracle.recommend_batch(X, Wshard, top_k=top_k, filter_interacted=filt)
+            assert np.array_equal(cnt.cpu().numpy(), o_cnt)
+            assert np.array_equal(ids.cpu().numpy(), o_ids)
+            assert np.array_equal(bits(sc.cpu().numpy()), bits(o_sc))
