@@ -103,20 +103,34 @@ int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
                            void *d_workspace, size_t workspace_bytes, int32_t n_slots,
                            int32_t *d_queue, void *stream);
 
-/* Same call with a per-target trace for profiling (tools/fit_trace.py): d_trace[t*4 + 0..3] =
- * start, end of the X^T y / feature-selection step, end of the target (ticks of the 100 MHz
- * constant clock) and the number of column entries folded by the coordinate descent.
- * d_trace == NULL behaves exactly like rtrec_slim_fit_columns. */
-int rtrec_slim_fit_columns_traced(int32_t n_users, int32_t n_items,
-                                  const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
-                                  const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
-                                  const float *d_sqnorm,
-                                  const int32_t *d_targets, int32_t n_targets,
-                                  const rtrec_fit_cfg *cfg,
-                                  int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
-                                  int32_t *d_out_n_iter, int32_t cap,
-                                  void *d_workspace, size_t workspace_bytes, int32_t n_slots,
-                                  int32_t *d_queue, void *stream, int64_t *d_trace);
+/* Optional inputs / outputs of a fit call. */
+typedef struct {
+    /* per-target trace for profiling (tools/fit_trace.py), or NULL: d_trace[t*4 + 0..3] = start, end of
+     * the X^T y / feature-selection step, end of the target (ticks of the 100 MHz constant clock) and
+     * the number of column entries folded in order by the coordinate descent */
+    int64_t       *d_trace;
+    /* Gram matrix of the gram_n most popular items, or NULL: d_gram[a * gram_n + b] = X[:, item_a] .
+     * X[:, item_b] in float64 with relative error <= gram_rel_err (< 1e-6), d_gram_index[i] = row of item
+     * i or -1.  ONLY for a non-negative X: the kernel then tracks X_p . R of zero coordinates through
+     * the coordinate updates (D_p -= dw G_pq, with rigorous rounding bounds) and skips their passes
+     * over memory while the interval decides; results are unchanged (csrc/fit.hip, "Gram tracking"). */
+    const double  *d_gram;
+    const int32_t *d_gram_index;
+    int32_t        gram_n;
+    double         gram_rel_err;
+} rtrec_fit_opts;
+
+/* rtrec_slim_fit_columns with options; opts == NULL behaves exactly like rtrec_slim_fit_columns. */
+int rtrec_slim_fit_columns_opt(int32_t n_users, int32_t n_items,
+                               const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                               const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
+                               const float *d_sqnorm,
+                               const int32_t *d_targets, int32_t n_targets,
+                               const rtrec_fit_cfg *cfg,
+                               int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
+                               int32_t *d_out_n_iter, int32_t cap,
+                               void *d_workspace, size_t workspace_bytes, int32_t n_slots,
+                               int32_t *d_queue, void *stream, const rtrec_fit_opts *opts);
 
 /* ---------------------------------------------------------------------------------------
  * SCORE + TOP-K  (replaces slim_elastic.py:566-626 predict*, :628-741 recommend /

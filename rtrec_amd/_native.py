@@ -21,7 +21,7 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
 
 EXPORTS = [
     "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_amd_score_timer", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
-    "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_traced", "rtrec_slim_score_workspace_bytes",
+    "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
 ]
 
@@ -29,6 +29,11 @@ EXPORTS = [
 class FitCfg(C.Structure):
     _fields_ = [("l1_reg", C.c_float), ("l2_reg", C.c_float), ("tol", C.c_float), ("max_iter", C.c_int32),
                 ("seed", C.c_uint32), ("positive", C.c_int32), ("top_features", C.c_int32)]
+
+
+class FitOpts(C.Structure):
+    _fields_ = [("d_trace", C.c_void_p), ("d_gram", C.c_void_p), ("d_gram_index", C.c_void_p),
+                ("gram_n", C.c_int32), ("gram_rel_err", C.c_double)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -73,8 +78,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_fit_columns.restype = C.c_int
     L.rtrec_slim_fit_columns.argtypes = [i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, C.POINTER(FitCfg),
                                          vp, vp, vp, vp, i32, vp, u64, i32, vp, vp]
-    L.rtrec_slim_fit_columns_traced.restype = C.c_int
-    L.rtrec_slim_fit_columns_traced.argtypes = L.rtrec_slim_fit_columns.argtypes + [vp]
+    L.rtrec_slim_fit_columns_opt.restype = C.c_int
+    L.rtrec_slim_fit_columns_opt.argtypes = L.rtrec_slim_fit_columns.argtypes + [C.POINTER(FitOpts)]
     L.rtrec_slim_score_workspace_bytes.restype = u64
     L.rtrec_slim_score_workspace_bytes.argtypes = [i32, i32, i32]
     L.rtrec_slim_score_topk.restype = C.c_int

@@ -57,6 +57,10 @@ struct FitArgs {
     float *w_all;    // [slots][I]   ALL path only
     int *queue;
     long long *trace;   // optional [n_targets][4]: start, prep end, end (100 MHz ticks), folded entries
+    const double *gram;       // optional [gram_n][gram_n]: X_p . X_q of the gram_n tracked (popular) items
+    const int *gram_index;    // optional [I]: item -> row of `gram`, or -1
+    int gram_n;
+    double gram_rel_err;      // |gram - exact| <= gram_rel_err * exact
 };
 
 __device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, float nrm, int positive) {
@@ -284,6 +288,36 @@ __device__ __forceinline__ void screen_xta_interval(const Screen &S, float bw, i
     hi = al > ah ? al : ah;
     lo = (vl > 0.0f) ? vl : (vh < 0.0f ? -vh : 0.0f);
 }
+
+// ---------------------------------------------------------------------------------------------
+// Gram tracking (non-negative X, K <= 64): screening WITHOUT touching memory.
+//
+// For a feature p let D_p = sum_r x_pr R[r] in exact arithmetic over the current float residual.
+// A coordinate update of feature q changes R[r] <- fl(fl(R[r] + fl(x_qr w_old)) - fl(x_qr w_new)) =
+// R[r] - dw x_qr + eps_r with |eps_r| <= 3.05 u (|R[r]| + x_qr (|w_old| + |w_new|)), hence
+//     D_p <- D_p - dw G_pq + sum_r x_pr eps_r,      G_pq = X_p . X_q .
+// G is shared by all targets: the host computes it once per fit for the most popular items (the
+// features of nearly every target) with a float64 GEMM of the densified columns (products of
+// floats are exact in double, so |G^ - G| <= gram_rel_err G with gram_rel_err ~ n 2^-53).
+// Lane p keeps  c_p ~ D_p,  r_p >= |c_p - D_p|  and  a_p >= sum_r x_pr (|y_r| + sum_q |w_q| x_qr),
+// which bounds A_p = sum_r x_pr |R[r]| up to the rounding already counted in r_p:
+//   start (R == y):  c = s_p (the float X^T y entry: the ordered sum of m = |U_p ^ U_j| rounded
+//                    products), r = 1.2 (m+1) u s_p, a = s_p (1 + 1.1 (m+1) u);
+//   update of q:     c -= dw G^;  a += (|w_new| - |w_old|) G^ (1 +- gram_rel_err);
+//                    r += |dw| G^ gram_rel_err' + 3.05 u (a + r + (|w_old| + |w_new|) G^) + double rounding.
+// The ordered float32 sum tmp_p of the n_p rounded products then satisfies
+//   |tmp_p - c_p| <= r_p + 1.07 (n_p + 1) u (a_p + r_p)
+// (u A for rounding the products, gamma_{n-1} (1+u) A for the ordered additions), which feeds the
+// same decisions as a screening pass; whenever it does not decide, the screening pass and then the
+// ordered fold follow, so the result is bit-identical to the reference's.  An update of a feature
+// that is not in G ends the tracking for the target.
+// ---------------------------------------------------------------------------------------------
+constexpr double kU = 0x1p-24;
+
+struct GramLane {   // per-lane state, lane p = feature p
+    double c, r, a;
+    int g;          // row of the Gram matrix, -1: not tracked
+};
 
 // LDS arrays describing the selected features of the current target (K path).
 struct FeatLds {
@@ -563,6 +597,47 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
     const int tc = P.tc, Kc = P.Kc;
     const int nf = ALLF ? I : Kc;
 
+    // Gram tracking state (see above); starts with the pristine residual R == y
+    bool gram_on = !ALLF && a.gram != nullptr && Kc <= 64;
+    GramLane GL; GL.c = 0.0; GL.r = 0.0; GL.a = 0.0; GL.g = -1;
+    if (gram_on && lane < Kc && f_nrm[lane] != 0.0f) {
+        GL.g = a.gram_index[f_id[lane]];
+        if (GL.g >= 0) {
+            const double fs = static_cast<double>(f_s[lane]);
+            const double m1 = static_cast<double>(min(f_e[lane] - f_b[lane], ny) + 1);
+            GL.c = fs;
+            GL.r = 1.2 * m1 * kU * fs;
+            GL.a = fs * (1.0 + 1.1 * m1 * kU);
+            if (!(fs >= 0.0) || m1 * kU > 0x1p-4) GL.g = -1;
+        }
+    }
+    auto gram_interval = [&](int p, int n, Screen &S) -> bool {   // uniform p; true if feature p is tracked
+        if (!gram_on) return false;
+        if (readlane_i(GL.g, p) < 0) return false;
+        const double c = readlane_d(GL.c, p), r = readlane_d(GL.r, p), aa = readlane_d(GL.a, p);
+        const double band = r + 1.07 * static_cast<double>(n + 1) * kU * (aa + r);
+        S.lo = c - band; S.hi = c + band;
+        return n <= kScreenMaxLen;
+    };
+    auto gram_update = [&](int q, float w_old, float w_new) {     // after the residual update of feature q
+        if (!gram_on) return;
+        const int gq = readlane_i(GL.g, q);
+        if (gq < 0) { gram_on = false; return; }                  // G has no row for q: tracking ends
+        if (GL.g >= 0) {
+            const double g = a.gram[static_cast<size_t>(gq) * a.gram_n + GL.g];
+            const double d = a.gram_rel_err;
+            const double awo = fabs(static_cast<double>(w_old)), awn = fabs(static_cast<double>(w_new));
+            const double dw = static_cast<double>(w_new) - static_cast<double>(w_old);
+            const double da = (awn - awo) * g * (awn > awo ? 1.0 + d : 1.0 - d);
+            const double a_new = GL.a + da + 1e-15 * (GL.a + fabs(da));
+            const double abar = (a_new > GL.a ? a_new : GL.a) + GL.r;
+            GL.r += fabs(dw) * g * d * (1.0 + d) + 3.05 * kU * (abar + (awo + awn) * g * (1.0 + d)) +
+                    4e-16 * (fabs(GL.c) + fabs(dw * g));
+            GL.c -= dw * g;
+            GL.a = a_new;
+        }
+    };
+
     // ---- 3. coordinate descent (_cd_fast.pyx:428-548) ----
     bool dirty = false;            // false while every w is still 0, i.e. R == y
     int n_ever = 0;                // ALL path: features whose w was ever non-zero
@@ -600,10 +675,14 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
             bool screened = false;
             if (!dirty) tmp = ALLF ? s_value(p) : f_s[p];
             else {
-                if (w_old == 0.0f && e - b >= a.screen_min && e - b <= kScreenMaxLen) {
-                    float ps, pa;
-                    screen_pass(a.crow, a.cval, R, b, e, ps, pa);
-                    screened = screen_stays_zero(screen_interval(ps, pa, e - b), alpha, positive, w_new);
+                if (w_old == 0.0f) {
+                    Screen S;
+                    if (!ALLF && gram_interval(p, e - b, S)) screened = screen_stays_zero(S, alpha, positive, w_new);
+                    if (!screened && e - b >= a.screen_min && e - b <= kScreenMaxLen) {
+                        float ps, pa;
+                        screen_pass(a.crow, a.cval, R, b, e, ps, pa);
+                        screened = screen_stays_zero(screen_interval(ps, pa, e - b), alpha, positive, w_new);
+                    }
                 }
                 if (!screened) { tmp = dot_pass(a.crow, a.cval, R, b, e, w_old); tr_folded += e - b; }
             }
@@ -614,6 +693,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                     dirty = true;
                 }
                 update_pass(a.crow, a.cval, R, b, e, w_old, w_new);
+                if (!ALLF) gram_update(p, w_old, w_new);
                 if (ALLF) {
                     if (ever_flag[p] == 0) { if (lane == 0) { ever_flag[p] = 1; ever_list[n_ever] = p; } n_ever++; }
                     if (lane == 0) w_all[p] = w_new;
@@ -671,7 +751,10 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                     if (f_nrm[p] != 0.0f) {
                         const int b = f_b[p], e = f_e[p];
                         const float bw = __fmul_rn(beta, f_w[p]);
-                        if (e - b >= a.screen_min && e - b <= kScreenMaxLen) {
+                        Screen S;
+                        if (gram_interval(p, e - b, S)) {
+                            screen_xta_interval(S, bw, positive, lo, hi);
+                        } else if (e - b >= a.screen_min && e - b <= kScreenMaxLen) {
                             float ps, pa;
                             screen_pass(a.crow, a.cval, R, b, e, ps, pa);
                             screen_xta_interval(screen_interval(ps, pa, e - b), bw, positive, lo, hi);
@@ -1342,7 +1425,7 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
                             int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
                             int32_t *d_out_n_iter, int32_t cap,
                             void *d_workspace, size_t workspace_bytes, int32_t n_slots,
-                            int32_t *d_queue, void *stream, int64_t *d_trace) {
+                            int32_t *d_queue, void *stream, const rtrec_fit_opts *opts) {
     if (n_users <= 0 || n_items <= 0 || n_targets < 0 || !cfg || n_slots <= 0) return RTREC_ERR_INVALID_ARG;
     if (n_targets == 0) return RTREC_OK;
     if (!d_csc_ptr || !d_csr_ptr || !d_sqnorm || !d_targets || !d_out_items || !d_out_coef || !d_out_count ||
@@ -1371,7 +1454,13 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
     a.cand_i = reinterpret_cast<int *>(ws + L.cand_i);
     a.w_all = allf ? reinterpret_cast<float *>(ws + L.w_all) : nullptr;
     a.queue = d_queue;
-    a.trace = reinterpret_cast<long long *>(d_trace);
+    if (opts) {
+        a.trace = reinterpret_cast<long long *>(opts->d_trace);
+        if (opts->d_gram && opts->d_gram_index && opts->gram_n > 0 && opts->gram_rel_err >= 0.0 && opts->gram_rel_err < 1e-6) {
+            a.gram = opts->d_gram; a.gram_index = opts->d_gram_index; a.gram_n = opts->gram_n;
+            a.gram_rel_err = opts->gram_rel_err;
+        }
+    }
     { const char *cw = std::getenv("RTREC_AMD_COLWALK_MIN"); a.colwalk_min_rows = cw ? std::atoi(cw) : kColWalkMinRows; }
     { const char *sm = std::getenv("RTREC_AMD_SCREEN_MIN"); a.screen_min = sm ? std::atoi(sm) : kScreenMinDefault; }
     (void)hipGetLastError();
@@ -1407,17 +1496,17 @@ extern "C" int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
                             d_workspace, workspace_bytes, n_slots, d_queue, stream, nullptr);
 }
 
-extern "C" int rtrec_slim_fit_columns_traced(int32_t n_users, int32_t n_items,
-                                             const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
-                                             const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
-                                             const float *d_sqnorm,
-                                             const int32_t *d_targets, int32_t n_targets,
-                                             const rtrec_fit_cfg *cfg,
-                                             int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
-                                             int32_t *d_out_n_iter, int32_t cap,
-                                             void *d_workspace, size_t workspace_bytes, int32_t n_slots,
-                                             int32_t *d_queue, void *stream, int64_t *d_trace) {
+extern "C" int rtrec_slim_fit_columns_opt(int32_t n_users, int32_t n_items,
+                                          const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                                          const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
+                                          const float *d_sqnorm,
+                                          const int32_t *d_targets, int32_t n_targets,
+                                          const rtrec_fit_cfg *cfg,
+                                          int32_t *d_out_items, float *d_out_coef, int32_t *d_out_count,
+                                          int32_t *d_out_n_iter, int32_t cap,
+                                          void *d_workspace, size_t workspace_bytes, int32_t n_slots,
+                                          int32_t *d_queue, void *stream, const rtrec_fit_opts *opts) {
     return fit_columns_impl(n_users, n_items, d_csc_ptr, d_csc_row, d_csc_val, d_csr_ptr, d_csr_col, d_csr_val, d_sqnorm,
                             d_targets, n_targets, cfg, d_out_items, d_out_coef, d_out_count, d_out_n_iter, cap,
-                            d_workspace, workspace_bytes, n_slots, d_queue, stream, d_trace);
+                            d_workspace, workspace_bytes, n_slots, d_queue, stream, opts);
 }

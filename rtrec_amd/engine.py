@@ -26,9 +26,10 @@ from . import _native
 
 DEFAULT_TILE_COLS = 4096   # 16 KB of float accumulators: 8 persistent waves per CU (2 per SIMD) hide each other's latency
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
-MAX_SLOTS = 5120   # 5 single-wave workgroups per SIMD (fit kernel: <= 96 VGPRs)
+MAX_SLOTS = 4096   # 4 single-wave workgroups per SIMD; with Gram tracking the sweet spot moved down from 5120 (C3: 2.16 s vs 2.3 s)
 GATHER_CHUNK_ROWS = 32768   # rows per all-gather chunk of a sharded scoring call
 MAX_GATHER_CHUNKS = 8
+GRAM_ITEMS = 512            # most popular items whose pairwise dot products the fit kernel may look up
 FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
 FIT_MW_MAX_TARGETS = 2048   # kMwMaxTargets of csrc/fit.hip: calls up to this size run the multi-wave kernel
 FIT_HEAVY_TARGETS = 256     # head of a bulk call sent to the multi-wave kernel (one workgroup per CU)
@@ -149,6 +150,10 @@ class HipBackend:
         self.torch = torch
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.lib = _native.load()
+        # rocBLAS loads its kernels on the first GEMM of a process (~0.1 s): do that here, next to
+        # the HIP context creation, not inside the first fit (gram_matrix uses one float64 GEMM)
+        w = torch.ones((8, 8), dtype=torch.float64, device=self.device)
+        (w @ w).sum().item()
 
     # -- helpers -------------------------------------------------------------------------
     def to_dev(self, a: np.ndarray):
@@ -185,14 +190,43 @@ class HipBackend:
                       "rtrec_slim_fit_workspace_init")
         return ws, self.zeros((1,), self.torch.int32)
 
+    supports_gram = True
+
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
-                    ws, queue, slots, trace=None):
-        _native.check(self.lib.rtrec_slim_fit_columns_traced(
+                    ws, queue, slots, trace=None, gram=None):
+        opts = _native.FitOpts(self.ptr(trace), None, None, 0, 0.0)
+        if gram is not None:
+            opts.d_gram, opts.d_gram_index = self.ptr(gram["G"]), self.ptr(gram["index"])
+            opts.gram_n, opts.gram_rel_err = int(gram["n"]), float(gram["rel_err"])
+        _native.check(self.lib.rtrec_slim_fit_columns_opt(
             n_users, n_items, self.ptr(X["cptr"]), self.ptr(X["crow"]), self.ptr(X["cval"]),
             self.ptr(X["rptr"]), self.ptr(X["rcol"]), self.ptr(X["rval"]), self.ptr(X["sqn"]),
             self.ptr(targets), int(targets.shape[0]), C.byref(cfg), self.ptr(out_items), self.ptr(out_coef),
             self.ptr(out_count), self.ptr(out_niter), cap, self.ptr(ws), ws.numel(), slots, self.ptr(queue),
-            self.stream(), self.ptr(trace)), "rtrec_slim_fit_columns")
+            self.stream(), C.byref(opts)), "rtrec_slim_fit_columns_opt")
+
+    def gram_matrix(self, X, n_users, n_items, n_top):
+        """Gram matrix X_P^T X_P of the n_top most popular items in float64, for the fit kernel's Gram
+        tracking: the P columns are densified on the device and multiplied by one library GEMM
+        (products of float32 values are exact in float64; the sums carry ~n 2^-53 relative error)."""
+        torch = self.torch
+        col_nnz = X["col_nnz"]
+        pop = np.argsort(-col_nnz, kind="stable")[:n_top]
+        pop = pop[col_nnz[pop] > 0]
+        P = int(len(pop))
+        if P == 0:
+            return None
+        gidx = np.full(n_items, -1, dtype=np.int32)
+        gidx[pop] = np.arange(P, dtype=np.int32)
+        d_gidx = self.to_dev(gidx)
+        counts = torch.diff(X["cptr"]).long()
+        col_of = torch.repeat_interleave(torch.arange(n_items, device=self.device), counts)
+        pid = d_gidx[col_of].long()
+        keep = pid >= 0
+        XP = torch.zeros((n_users, P), dtype=torch.float64, device=self.device)
+        XP[X["crow"][keep].long(), pid[keep]] = X["cval"][keep].double()
+        G = (XP.T @ XP).contiguous()
+        return {"G": G, "index": d_gidx, "n": P, "rel_err": max(1e-9, 64.0 * n_users * 2.0 ** -53)}
 
     def score_workspace_bytes(self, n_rows, n_tiles, top_k):
         return int(self.lib.rtrec_slim_score_workspace_bytes(n_rows, n_tiles, top_k))
@@ -278,6 +312,7 @@ class SlimEngine:
             X["crow"] = be.to_dev(np.asarray(X_csc.indices, dtype=np.int32))
             X["cval"] = be.to_dev(np.asarray(X_csc.data, dtype=np.float32))
             X["col_nnz"] = np.diff(np.asarray(X_csc.indptr, dtype=np.int64))
+            X["nonneg"] = bool(X_csc.nnz == 0 or float(X_csc.data.min()) >= 0.0)
         self._X = X
 
     # ------------------------------------------------------------------------------ fit
@@ -337,6 +372,17 @@ class SlimEngine:
                                                                                  side="right")))
             n_heavy = max(n_heavy, 0)
 
+        # Gram tracking (csrc/fit.hip): bulk calls on a non-negative X get the Gram matrix of the most
+        # popular items, which lets the kernel decide most zero coordinates without a pass over memory.
+        gram = None
+        mode = os.environ.get("RTREC_AMD_GRAM", "auto")
+        if (K > 0 and min(K, I) <= 64 and X.get("nonneg") and getattr(be, "supports_gram", False) and mode != "0"
+                and (n > FIT_MW_MAX_TARGETS or mode == "force")):
+            n_top = min(I, int(os.environ.get("RTREC_AMD_GRAM_ITEMS", GRAM_ITEMS)))
+            if X.get("gram_n") != n_top:
+                X["gram"], X["gram_n"] = be.gram_matrix(X, U, I, n_top), n_top
+            gram = X["gram"]
+
         def workspace(n_slots_: int):
             key = (U, I, n_slots_, K if K > 0 else 0)
             if key not in self._fit_ws:
@@ -362,7 +408,7 @@ class SlimEngine:
                      niter=be.empty((m,), torch.int32), trace=be.zeros((m, 4), torch.int64) if trace else None,
                      ws=(ws, queue))   # keeps the scratch alive while the kernel runs
             be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
-                           n_slots_, d["trace"])
+                           n_slots_, d["trace"], gram)
             return d
 
         def collect(d):

@@ -38,7 +38,7 @@ class OracleBackend:
         return torch.zeros(1, dtype=torch.uint8), torch.zeros(1, dtype=torch.int32)
 
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
-                    ws, queue, slots, trace=None):
+                    ws, queue, slots, trace=None, gram=None):
         Xc = sp.csc_matrix((X["cval"].numpy(), X["crow"].numpy(), X["cptr"].numpy()), shape=(n_users, n_items))
         tg = targets.numpy()
         L = so.lib()

@@ -234,3 +234,36 @@ def test_score_wide_catalogue_heavy_users(oracle, tile_cols, top_k):
             assert np.array_equal(cnt.cpu().numpy(), o_cnt)
             assert np.array_equal(ids.cpu().numpy(), o_ids)
             assert np.array_equal(bits(sc.cpu().numpy()), bits(o_sc))
+
+
+@pytest.mark.parametrize("U,I,draws,K,positive,float_ratings", [
+    (600, 200, 12000, 8, True, True),
+    (600, 200, 12000, 8, False, True),
+    (3000, 800, 90000, 50, True, True),
+    (3000, 800, 90000, 50, True, False),
+    (5000, 300, 400000, 50, True, True),      # dense catalogue: every coordinate of the popular targets is non-zero
+])
+@pytest.mark.parametrize("gram_items", ["512", "64"])        # 64: most features are NOT in the Gram matrix
+@pytest.mark.parametrize("screen_min", [None, "1000000000"])  # the latter: Gram tracking is the only screen
+def test_fit_gram_tracking_bit_exact(engine, oracle, U, I, draws, K, positive, float_ratings, gram_items, screen_min,
+                                     monkeypatch):
+    """Gram tracking (zero coordinates decided from D_p -= dw G_pq with rounding bounds instead of a pass
+    over memory) must leave coefficients and sweep counts bit-identical to the oracle."""
+    monkeypatch.setenv("RTREC_AMD_FIT_MODE", "sw")
+    monkeypatch.setenv("RTREC_AMD_GRAM", "force")
+    monkeypatch.setenv("RTREC_AMD_GRAM_ITEMS", gram_items)
+    if screen_min is not None:
+        monkeypatch.setenv("RTREC_AMD_SCREEN_MIN", screen_min)
+    X = interaction_matrix(U, I, draws, seed=23, float_ratings=float_ratings)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    tg, items, coef, count, n_iter = engine.fit_columns(np.arange(I), positive=positive, nn_feature_selection=K)
+    assert engine._X.get("gram") is not None
+    ptr, idx, val, nit = oracle.fit_columns(Xc, tg, positive=positive, nn_feature_selection=K)
+    assert np.array_equal(n_iter, nit), f"n_iter differs on {np.flatnonzero(n_iter != nit)[:10]}"
+    for t in range(len(tg)):
+        c = count[t]
+        o = np.argsort(items[t, :c], kind="stable")
+        assert np.array_equal(items[t, :c][o], idx[ptr[t]:ptr[t + 1]]), f"feature set differs for column {tg[t]}"
+        assert np.array_equal(bits(coef[t, :c][o]), bits(val[ptr[t]:ptr[t + 1]])), f"coefficient bits differ for column {tg[t]}"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-target timeline of the fit kernel (rtrec_slim_fit_columns_traced).
+"""Per-target timeline of the fit kernel (rtrec_slim_fit_columns_opt).
 
 Runs the bulk fit of a bench workload on cuda:0 with the device-side trace enabled and prints
 where the time goes: X^T y / feature selection vs coordinate descent, the longest targets
