@@ -73,12 +73,35 @@ __device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, f
     return static_cast<float>(sgn * (num > 0.0 ? num : 0.0) / static_cast<double>(den));
 }
 
+// Ordered fold of 64 products (one per lane) through LDS: one ds_write_b32, then 16 uniform-address
+// ds_read_b128 (LDS broadcast) feeding the 64 dependent v_add_f32 -- ~1.3 instructions per entry where
+// v_readlane + v_add needs 2.  `buf` is a wave-private slice of 64 floats; the LDS operations of one
+// wave execute in program order, so no barrier is involved.  Lanes beyond the data hold +0.0, which
+// never changes the running sum (it starts at +0 and a float sum cannot become -0 again).
+constexpr int kFoldBufBytes = 4 * 64 * 4;   // four slices: the four chunks of one dot_pass batch
+__device__ __forceinline__ float fold64_lds(float acc, const float *buf, int n4 = 16) {
+    const float4 *b4 = reinterpret_cast<const float4 *>(buf);
+    if (n4 >= 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 v = b4[k];
+            acc = __fadd_rn(acc, v.x); acc = __fadd_rn(acc, v.y); acc = __fadd_rn(acc, v.z); acc = __fadd_rn(acc, v.w);
+        }
+        return acc;
+    }
+    for (int k = 0; k < n4; ++k) {
+        const float4 v = b4[k];
+        acc = __fadd_rn(acc, v.x); acc = __fadd_rn(acc, v.y); acc = __fadd_rn(acc, v.z); acc = __fadd_rn(acc, v.w);
+    }
+    return acc;
+}
+
 // tmp = sum over column entries [b, e) of (R[r] (+ x*w_old)) * x, strictly left to right.
 // Software-pipelined over batches of 4 x 64 entries: while batch k is folded (256 dependent adds),
 // the R gathers of batch k+1 and the index/value loads of batch k+2 are already in flight, so the
 // wave is bound by the fold itself instead of by two dependent memory round trips per batch.
 __device__ float dot_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
-                          int b, int e, float w_old) {
+                          int b, int e, float w_old, float *fold_buf) {
     const int lane = lane_id();
     const bool add_back = (w_old != 0.0f);
     float tmp = 0.0f;
@@ -113,8 +136,10 @@ __device__ float dot_pass(const int *__restrict__ crow, const float *__restrict_
             for (int u = 0; u < 4; ++u) {
                 float v = va[u];
                 if (add_back) v = __fadd_rn(v, __fmul_rn(xa[u], w_old));
-                tmp = chain_add_full(tmp, __fmul_rn(v, xa[u]));
+                fold_buf[u * 64 + lane] = __fmul_rn(v, xa[u]);
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tmp = fold64_lds(tmp, fold_buf + u * 64);
 #pragma unroll
             for (int u = 0; u < 4; ++u) { va[u] = vn[u]; xa[u] = xb[u]; rb[u] = rc[u]; xb[u] = xc[u]; }
             o += 256;
@@ -130,7 +155,8 @@ __device__ float dot_pass(const int *__restrict__ crow, const float *__restrict_
             if (add_back) v = __fadd_rn(v, __fmul_rn(x, w_old));
             prod = __fmul_rn(v, x);
         }
-        tmp = chain_add(tmp, prod, n);
+        fold_buf[lane] = prod;                       // lanes >= n hold +0.0
+        tmp = fold64_lds(tmp, fold_buf, (n + 3) >> 2);
     }
     return tmp;
 }
@@ -166,8 +192,9 @@ __device__ void update_pass(const int *__restrict__ crow, const float *__restric
 }
 
 // sum over [b, e) of x * R[r], left to right (XtA of _cd_fast.pyx:506-509).
-__device__ float xta_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, int b, int e) {
-    return dot_pass(crow, cval, R, b, e, 0.0f);   // R[r]*x == x*R[r] (one rounding, commutative)
+__device__ float xta_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, int b, int e,
+                          float *fold_buf) {
+    return dot_pass(crow, cval, R, b, e, 0.0f, fold_buf);   // R[r]*x == x*R[r] (one rounding, commutative)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -580,7 +607,8 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
     int *ever_list = cand_i;                            // ALL path
 
     const int K = ALLF ? 0 : min(a.cfg.top_features, I);
-    const FeatLds F = carve_feat(smem, K);
+    float *fold_buf = reinterpret_cast<float *>(smem);           // kFoldBufBytes, then the feature arrays
+    const FeatLds F = carve_feat(smem + kFoldBufBytes, K);
     int *f_id = F.f_id, *f_b = F.f_b, *f_e = F.f_e, *f_ever = F.f_ever;
     float *f_nrm = F.f_nrm, *f_w = F.f_w, *f_s = F.f_s;
 
@@ -684,7 +712,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                         screened = screen_stays_zero(screen_interval(ps, pa, e - b), alpha, positive, w_new);
                     }
                 }
-                if (!screened) { tmp = dot_pass(a.crow, a.cval, R, b, e, w_old); tr_folded += e - b; }
+                if (!screened) { tmp = dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf); tr_folded += e - b; }
             }
             if (!screened) w_new = cd_update(tmp, alpha, beta, nrm, positive);
             if (w_old != 0.0f || w_new != 0.0f) {
@@ -733,7 +761,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                         float xta = 0.0f;
                         const int b = a.cptr[p], e = a.cptr[p + 1];
                         if (p != j && b != e) {
-                            xta = xta_pass(a.crow, a.cval, R, b, e);
+                            xta = xta_pass(a.crow, a.cval, R, b, e, fold_buf);
                             xta = __fsub_rn(xta, __fmul_rn(beta, w_all[p]));
                         }
                         dn_take(xta);
@@ -759,7 +787,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                             screen_pass(a.crow, a.cval, R, b, e, ps, pa);
                             screen_xta_interval(screen_interval(ps, pa, e - b), bw, positive, lo, hi);
                         } else {
-                            const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, b, e), bw);
+                            const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, b, e, fold_buf), bw);
                             tr_folded += e - b;
                             lo = hi = positive ? xta : fabsf(xta);
                         }
@@ -772,7 +800,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                     if (!(hi >= best_lo)) continue;
                     float v = lo;
                     if (lo != hi) {
-                        const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, f_b[p], f_e[p]), __fmul_rn(beta, f_w[p]));
+                        const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, f_b[p], f_e[p], fold_buf), __fmul_rn(beta, f_w[p]));
                         tr_folded += f_e[p] - f_b[p];
                         v = positive ? xta : fabsf(xta);
                     }
@@ -1467,7 +1495,7 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
     if (hipMemsetAsync(d_queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const int grid = n_slots < n_targets ? n_slots : n_targets;
     if (allf) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true>), dim3(grid), dim3(64), 16, st, a);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true>), dim3(grid), dim3(64), kFoldBufBytes + 16, st, a);
     } else {
         // few targets (online partial_fit): the heaviest target is the critical path -> latency mode
         const char *force = std::getenv("RTREC_AMD_FIT_MODE");            // "mw" / "sw": A/B switch
@@ -1475,7 +1503,7 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
         if (latency_mode) {
             hipLaunchKernelGGL(fit_columns_mw_kernel, dim3(grid), dim3(kMwThreads), mw_lds_bytes(K), st, a);
         } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), feat_lds_bytes(K), st, a);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), kFoldBufBytes + feat_lds_bytes(K), st, a);
         }
     }
     return rtrec::launch_status();
