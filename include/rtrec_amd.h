@@ -103,6 +103,17 @@ int rtrec_slim_fit_columns(int32_t n_users, int32_t n_items,
                            void *d_workspace, size_t workspace_bytes, int32_t n_slots,
                            int32_t *d_queue, void *stream);
 
+/* Gram matrix of `n_top` item columns for rtrec_fit_opts.d_gram: d_gram[a * P64 + b] = X[:, top[a]] .
+ * X[:, top[b]] accumulated in float64 (exact products, relative error of the sums <= ~n_users 2^-53),
+ * P64 = n_top rounded up to a multiple of 64 = the row stride to pass as rtrec_fit_opts.gram_n; rows /
+ * columns beyond n_top are zero.  d_gram holds P64 * P64 doubles; the workspace (a dense float32 copy of
+ * the columns) is rtrec_slim_gram_workspace_bytes(n_users, n_top). */
+size_t rtrec_slim_gram_workspace_bytes(int32_t n_users, int32_t n_top);
+int rtrec_slim_gram_matrix(int32_t n_users, int32_t n_items,
+                           const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                           const int32_t *d_top_items, int32_t n_top,
+                           void *d_workspace, size_t workspace_bytes, double *d_gram, void *stream);
+
 /* Optional inputs / outputs of a fit call. */
 typedef struct {
     /* per-target trace for profiling (tools/fit_trace.py), or NULL: d_trace[t*4 + 0..3] = start, end of

@@ -21,7 +21,7 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
 
 EXPORTS = [
     "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_amd_score_timer", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
-    "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_score_workspace_bytes",
+    "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_gram_workspace_bytes", "rtrec_slim_gram_matrix", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
 ]
 
@@ -80,6 +80,10 @@ def load() -> C.CDLL:
                                          vp, vp, vp, vp, i32, vp, u64, i32, vp, vp]
     L.rtrec_slim_fit_columns_opt.restype = C.c_int
     L.rtrec_slim_fit_columns_opt.argtypes = L.rtrec_slim_fit_columns.argtypes + [C.POINTER(FitOpts)]
+    L.rtrec_slim_gram_workspace_bytes.restype = u64
+    L.rtrec_slim_gram_workspace_bytes.argtypes = [i32, i32]
+    L.rtrec_slim_gram_matrix.restype = C.c_int
+    L.rtrec_slim_gram_matrix.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, u64, vp, vp]
     L.rtrec_slim_score_workspace_bytes.restype = u64
     L.rtrec_slim_score_workspace_bytes.argtypes = [i32, i32, i32]
     L.rtrec_slim_score_topk.restype = C.c_int

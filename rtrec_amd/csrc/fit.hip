@@ -1380,6 +1380,82 @@ __global__ __launch_bounds__(64) void column_sqnorms_kernel(int n_items, const i
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Gram matrix of the most popular items (input of the Gram tracking above): G = X_P^T X_P in float64.
+// The P columns are first densified into XP[U][P64] (float32, zero where absent), then each workgroup
+// accumulates one 64 x 64 tile of G over a chunk of rows -- 32-row slabs staged through LDS, 4 x 4
+// double accumulators per thread (products of float32 values are exact in float64) -- and adds it to
+// G with float64 atomics; only tiles on or above the diagonal are computed, the mirror image is
+// written with them.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGramTile = 64;
+constexpr int kGramSlab = 32;
+constexpr int kGramChunkRows = 4096;
+
+__global__ __launch_bounds__(64) void gram_densify_kernel(int n_top, int p64, const int *top_items, const int *cptr,
+                                                          const int *crow, const float *cval, float *xp) {
+    const int lane = lane_id();
+    for (int p = blockIdx.x; p < n_top; p += gridDim.x) {
+        const int c = top_items[p];
+        for (int o = cptr[c] + lane; o < cptr[c + 1]; o += 64) xp[static_cast<size_t>(crow[o]) * p64 + p] = cval[o];
+    }
+}
+
+__global__ __launch_bounds__(256) void gram_tile_kernel(int n_users, int p64, const float *__restrict__ xp, double *G) {
+    __shared__ __attribute__((aligned(16))) float As[kGramSlab][kGramTile];
+    __shared__ __attribute__((aligned(16))) float Bs[kGramSlab][kGramTile];
+    // blockIdx.x enumerates tile pairs (ti <= tj)
+    const int T = p64 / kGramTile;
+    int ti = 0, rem = static_cast<int>(blockIdx.x);
+    while (rem >= T - ti) { rem -= T - ti; ++ti; }
+    const int tj = ti + rem;
+    const int tid = static_cast<int>(threadIdx.x), ty = tid >> 4, tx = tid & 15;
+    const int r0 = static_cast<int>(blockIdx.y) * kGramChunkRows;
+    const int r1 = min(n_users, r0 + kGramChunkRows);
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = 0.0;
+    for (int rb = r0; rb < r1; rb += kGramSlab) {
+        // 32 x 64 floats per slab = 2048: 8 per thread, coalesced 256-byte rows
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int e = tid + q * 256, rr = e >> 6, cc = e & 63;
+            const int row = rb + rr;
+            float va = 0.0f, vb = 0.0f;
+            if (row < r1) {
+                va = xp[static_cast<size_t>(row) * p64 + ti * kGramTile + cc];
+                vb = xp[static_cast<size_t>(row) * p64 + tj * kGramTile + cc];
+            }
+            As[rr][cc] = va; Bs[rr][cc] = vb;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int rr = 0; rr < kGramSlab; ++rr) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(&As[rr][ty * 4]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&Bs[rr][tx * 4]);
+            const double av[4] = {a4.x, a4.y, a4.z, a4.w};
+            const double bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i][k] += av[i] * bv[k];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (acc[i][k] == 0.0) continue;
+            const int gi = ti * kGramTile + ty * 4 + i, gj = tj * kGramTile + tx * 4 + k;
+            atomicAdd(&G[static_cast<size_t>(gi) * p64 + gj], acc[i][k]);
+            if (ti != tj) atomicAdd(&G[static_cast<size_t>(gj) * p64 + gi], acc[i][k]);
+        }
+}
+
 __global__ void fill_u32_kernel(uint32_t *p, size_t n, uint32_t v) {
     for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < n;
          i += static_cast<size_t>(gridDim.x) * blockDim.x)
@@ -1422,6 +1498,35 @@ extern "C" int rtrec_slim_column_sqnorms(int32_t n_items, const int32_t *d_csc_p
     const int grid = n_items < 8192 ? n_items : 8192;
     hipLaunchKernelGGL(column_sqnorms_kernel, dim3(grid), dim3(64), 0, static_cast<hipStream_t>(stream),
                        n_items, d_csc_ptr, d_csc_val, d_sqnorm);
+    return rtrec::launch_status();
+}
+
+extern "C" size_t rtrec_slim_gram_workspace_bytes(int32_t n_users, int32_t n_top) {
+    if (n_users <= 0 || n_top <= 0) return 0;
+    const size_t p64 = (static_cast<size_t>(n_top) + 63) / 64 * 64;
+    return static_cast<size_t>(n_users) * p64 * sizeof(float);
+}
+
+extern "C" int rtrec_slim_gram_matrix(int32_t n_users, int32_t n_items,
+                                      const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
+                                      const int32_t *d_top_items, int32_t n_top,
+                                      void *d_workspace, size_t workspace_bytes, double *d_gram, void *stream) {
+    if (n_users <= 0 || n_items <= 0 || n_top <= 0 || n_top > 4096) return RTREC_ERR_INVALID_ARG;
+    if (!d_csc_ptr || !d_csc_row || !d_csc_val || !d_top_items || !d_workspace || !d_gram) return RTREC_ERR_INVALID_ARG;
+    const int p64 = (n_top + 63) / 64 * 64;
+    const size_t need = static_cast<size_t>(n_users) * p64 * sizeof(float);
+    if (workspace_bytes < need) return RTREC_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    (void)hipGetLastError();
+    if (hipMemsetAsync(d_workspace, 0, need, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    if (hipMemsetAsync(d_gram, 0, static_cast<size_t>(p64) * p64 * sizeof(double), st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    float *xp = static_cast<float *>(d_workspace);
+    hipLaunchKernelGGL(gram_densify_kernel, dim3(n_top < 4096 ? n_top : 4096), dim3(64), 0, st, n_top, p64, d_top_items,
+                       d_csc_ptr, d_csc_row, d_csc_val, xp);
+    const int T = p64 / kGramTile;
+    const unsigned chunks = static_cast<unsigned>((n_users + kGramChunkRows - 1) / kGramChunkRows);
+    hipLaunchKernelGGL(gram_tile_kernel, dim3(static_cast<unsigned>(T * (T + 1) / 2), chunks), dim3(256), 0, st, n_users, p64,
+                       xp, d_gram);
     return rtrec::launch_status();
 }
 

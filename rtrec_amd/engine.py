@@ -150,10 +150,6 @@ class HipBackend:
         self.torch = torch
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.lib = _native.load()
-        # rocBLAS loads its kernels on the first GEMM of a process (~0.1 s): do that here, next to
-        # the HIP context creation, not inside the first fit (gram_matrix uses one float64 GEMM)
-        w = torch.ones((8, 8), dtype=torch.float64, device=self.device)
-        (w @ w).sum().item()
 
     # -- helpers -------------------------------------------------------------------------
     def to_dev(self, a: np.ndarray):
@@ -206,9 +202,8 @@ class HipBackend:
             self.stream(), C.byref(opts)), "rtrec_slim_fit_columns_opt")
 
     def gram_matrix(self, X, n_users, n_items, n_top):
-        """Gram matrix X_P^T X_P of the n_top most popular items in float64, for the fit kernel's Gram
-        tracking: the P columns are densified on the device and multiplied by one library GEMM
-        (products of float32 values are exact in float64; the sums carry ~n 2^-53 relative error)."""
+        """Gram matrix X_P^T X_P of the n_top most popular items in float64 for the fit kernel's Gram
+        tracking (rtrec_slim_gram_matrix: densify + tiled float64 accumulation on the device)."""
         torch = self.torch
         col_nnz = X["col_nnz"]
         pop = np.argsort(-col_nnz, kind="stable")[:n_top]
@@ -216,17 +211,17 @@ class HipBackend:
         P = int(len(pop))
         if P == 0:
             return None
+        p64 = -(-P // 64) * 64
         gidx = np.full(n_items, -1, dtype=np.int32)
         gidx[pop] = np.arange(P, dtype=np.int32)
-        d_gidx = self.to_dev(gidx)
-        counts = torch.diff(X["cptr"]).long()
-        col_of = torch.repeat_interleave(torch.arange(n_items, device=self.device), counts)
-        pid = d_gidx[col_of].long()
-        keep = pid >= 0
-        XP = torch.zeros((n_users, P), dtype=torch.float64, device=self.device)
-        XP[X["crow"][keep].long(), pid[keep]] = X["cval"][keep].double()
-        G = (XP.T @ XP).contiguous()
-        return {"G": G, "index": d_gidx, "n": P, "rel_err": max(1e-9, 64.0 * n_users * 2.0 ** -53)}
+        d_gidx, d_top = self.to_dev(gidx), self.to_dev(pop.astype(np.int32))
+        nbytes = int(self.lib.rtrec_slim_gram_workspace_bytes(n_users, P))
+        ws = self.empty((nbytes,), torch.uint8)
+        G = self.empty((p64, p64), torch.float64)
+        _native.check(self.lib.rtrec_slim_gram_matrix(n_users, n_items, self.ptr(X["cptr"]), self.ptr(X["crow"]),
+                                                      self.ptr(X["cval"]), self.ptr(d_top), P, self.ptr(ws), nbytes,
+                                                      self.ptr(G), self.stream()), "rtrec_slim_gram_matrix")
+        return {"G": G, "index": d_gidx, "n": p64, "rel_err": max(1e-9, 64.0 * n_users * 2.0 ** -53), "items": pop}
 
     def score_workspace_bytes(self, n_rows, n_tiles, top_k):
         return int(self.lib.rtrec_slim_score_workspace_bytes(n_rows, n_tiles, top_k))

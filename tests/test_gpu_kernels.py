@@ -267,3 +267,22 @@ def test_fit_gram_tracking_bit_exact(engine, oracle, U, I, draws, K, positive, f
         o = np.argsort(items[t, :c], kind="stable")
         assert np.array_equal(items[t, :c][o], idx[ptr[t]:ptr[t + 1]]), f"feature set differs for column {tg[t]}"
         assert np.array_equal(bits(coef[t, :c][o]), bits(val[ptr[t]:ptr[t + 1]])), f"coefficient bits differ for column {tg[t]}"
+
+
+def test_gram_matrix_kernel(engine):
+    """rtrec_slim_gram_matrix vs numpy float64 (exact products, ~1e-16 relative sums)."""
+    X = interaction_matrix(9000, 700, 300000, seed=31)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    for n_top in (700, 100, 64):
+        g = engine.be.gram_matrix(engine._X, 9000, 700, n_top)
+        P, p64 = len(g["items"]), g["n"]
+        assert p64 % 64 == 0 and p64 >= P
+        G = g["G"].cpu().numpy()
+        XP = Xc[:, g["items"]].toarray().astype(np.float64)
+        ref = XP.T @ XP
+        assert np.allclose(G[:P, :P], ref, rtol=1e-12, atol=0)
+        assert not G[P:, :].any() and not G[:, P:].any()
+        idx = g["index"].cpu().numpy()
+        assert np.array_equal(np.flatnonzero(idx >= 0), np.sort(g["items"])) and np.array_equal(idx[g["items"]], np.arange(P))
