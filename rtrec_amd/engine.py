@@ -150,6 +150,12 @@ class HipBackend:
         self.torch = torch
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.lib = _native.load()
+        from . import ops as _ops  # noqa: F401  (registers torch.ops.rtrec_amd.*)
+        self.ops = torch.ops.rtrec_amd
+        # one-time costs of a process (custom-op dispatcher set-up, loading the gfx950 code objects)
+        # belong here, next to the HIP context creation, not inside the first fit or recommend call
+        w = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.ops.column_sqnorms(torch.tensor([0, 1], dtype=torch.int32, device=self.device), w, torch.empty_like(w))
 
     # -- helpers -------------------------------------------------------------------------
     def to_dev(self, a: np.ndarray):
@@ -172,34 +178,28 @@ class HipBackend:
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
 
-    # -- the C-ABI, one method per entry point (tests substitute a CPU stand-in with the same
-    #    methods to exercise the multi-process orchestration without a GPU) -------------------
+    # -- one method per entry point, each a call of the matching torch.ops.rtrec_amd custom op
+    #    (rtrec_amd/ops.py -> C-ABI); tests substitute a CPU stand-in with the same methods to
+    #    exercise the multi-process orchestration without a GPU ---------------------------------
     def column_sqnorms(self, n_items, cptr, cval, out):
-        _native.check(self.lib.rtrec_slim_column_sqnorms(n_items, self.ptr(cptr), self.ptr(cval), self.ptr(out),
-                                                         self.stream()), "rtrec_slim_column_sqnorms")
+        self.ops.column_sqnorms(cptr, cval, out)
 
     def fit_workspace(self, n_users, n_items, slots, top_features):
         nbytes = int(self.lib.rtrec_slim_fit_workspace_bytes(n_users, n_items, slots, top_features))
         ws = self.empty((nbytes,), self.torch.uint8)
-        _native.check(self.lib.rtrec_slim_fit_workspace_init(self.ptr(ws), nbytes, n_users, n_items, slots,
-                                                             top_features, self.stream()),
-                      "rtrec_slim_fit_workspace_init")
+        self.ops.fit_workspace_init(ws, n_users, n_items, slots, top_features)
         return ws, self.zeros((1,), self.torch.int32)
 
     supports_gram = True
 
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
                     ws, queue, slots, trace=None, gram=None):
-        opts = _native.FitOpts(self.ptr(trace), None, None, 0, 0.0)
-        if gram is not None:
-            opts.d_gram, opts.d_gram_index = self.ptr(gram["G"]), self.ptr(gram["index"])
-            opts.gram_n, opts.gram_rel_err = int(gram["n"]), float(gram["rel_err"])
-        _native.check(self.lib.rtrec_slim_fit_columns_opt(
-            n_users, n_items, self.ptr(X["cptr"]), self.ptr(X["crow"]), self.ptr(X["cval"]),
-            self.ptr(X["rptr"]), self.ptr(X["rcol"]), self.ptr(X["rval"]), self.ptr(X["sqn"]),
-            self.ptr(targets), int(targets.shape[0]), C.byref(cfg), self.ptr(out_items), self.ptr(out_coef),
-            self.ptr(out_count), self.ptr(out_niter), cap, self.ptr(ws), ws.numel(), slots, self.ptr(queue),
-            self.stream(), C.byref(opts)), "rtrec_slim_fit_columns_opt")
+        g = gram or {}
+        self.ops.fit_columns(X["cptr"], X["crow"], X["cval"], X["rptr"], X["rcol"], X["rval"], X["sqn"], targets,
+                             n_users, n_items, float(cfg.l1_reg), float(cfg.l2_reg), float(cfg.tol), int(cfg.max_iter),
+                             int(cfg.seed), bool(cfg.positive), int(cfg.top_features),
+                             out_items, out_coef, out_count, out_niter, cap, ws, slots, queue, trace,
+                             g.get("G"), g.get("index"), int(g.get("n", 0)), float(g.get("rel_err", 0.0)))
 
     def gram_matrix(self, X, n_users, n_items, n_top):
         """Gram matrix X_P^T X_P of the n_top most popular items in float64 for the fit kernel's Gram
@@ -218,9 +218,7 @@ class HipBackend:
         nbytes = int(self.lib.rtrec_slim_gram_workspace_bytes(n_users, P))
         ws = self.empty((nbytes,), torch.uint8)
         G = self.empty((p64, p64), torch.float64)
-        _native.check(self.lib.rtrec_slim_gram_matrix(n_users, n_items, self.ptr(X["cptr"]), self.ptr(X["crow"]),
-                                                      self.ptr(X["cval"]), self.ptr(d_top), P, self.ptr(ws), nbytes,
-                                                      self.ptr(G), self.stream()), "rtrec_slim_gram_matrix")
+        self.ops.gram_matrix(X["cptr"], X["crow"], X["cval"], d_top, ws, G, n_users, n_items)
         return {"G": G, "index": d_gidx, "n": p64, "rel_err": max(1e-9, 64.0 * n_users * 2.0 ** -53), "items": pop}
 
     def score_workspace_bytes(self, n_rows, n_tiles, top_k):
@@ -228,41 +226,24 @@ class HipBackend:
 
     def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
                    acc_f64, ids, sc, sc64, aux, cnt, ws):
-        _native.check(self.lib.rtrec_slim_score_topk(
-            n_rows, self.ptr(row_ids), self.ptr(xb[0]), self.ptr(xb[1]), self.ptr(xb[2]),
-            n_items, lay["n_cols"], col_lo, self.ptr(lay["col_ids"]), self.ptr(lay["col_map"]),
-            lay["tile_cols"], lay["n_tiles"],
-            self.ptr(lay["tile_ptr"]), self.ptr(lay["w_col"]), self.ptr(lay["w_val"]),
-            self.ptr(lay.get("dense_idx")), self.ptr(lay.get("dense_val")), self.ptr(None if os.environ.get("RTREC_AMD_NO_ROWHDR") else lay.get("row_hdr")),
-            self.ptr(col_rank),
-            top_k, int(bool(filter_interacted)), int(mode), int(acc_f64),
-            self.ptr(ids), self.ptr(sc), self.ptr(sc64), self.ptr(aux), self.ptr(cnt),
-            self.ptr(ws), ws.numel(), self.stream()), "rtrec_slim_score_topk")
+        row_hdr = None if os.environ.get("RTREC_AMD_NO_ROWHDR") else lay.get("row_hdr")
+        self.ops.score_topk(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo,
+                            lay["col_ids"], lay["col_map"], lay["tile_cols"], lay["n_tiles"],
+                            lay["tile_ptr"], lay["w_col"], lay["w_val"], lay.get("dense_idx"), lay.get("dense_val"),
+                            row_hdr, col_rank, top_k, bool(filter_interacted), int(mode), bool(acc_f64),
+                            ids, sc, sc64, aux, cnt, ws)
 
     def score_rows(self, n_rows, row_ids, xb, n_items, col_lo, lay, acc_f64, out):
-        _native.check(self.lib.rtrec_slim_score_rows(
-            n_rows, self.ptr(row_ids), self.ptr(xb[0]), self.ptr(xb[1]), self.ptr(xb[2]),
-            n_items, lay["n_cols"], col_lo, lay["tile_cols"], lay["n_tiles"],
-            self.ptr(lay["tile_ptr"]), self.ptr(lay["w_col"]), self.ptr(lay["w_val"]),
-            int(acc_f64), self.ptr(out), int(out.stride(0)), self.stream()), "rtrec_slim_score_rows")
+        self.ops.score_rows(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo, lay["tile_cols"],
+                            lay["n_tiles"], lay["tile_ptr"], lay["w_col"], lay["w_val"], bool(acc_f64), out)
 
     def merge_topk(self, n_rows, n_lists, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt):
         """g_* are [n_lists, n_rows, top_k] tensors (g_cnt [n_lists, n_rows]); they may be strided views
         into one packed all-gather buffer as long as the last dimension is contiguous."""
-        assert g_ids.stride(2) == 1 and g_sc.stride(2) == 1 and g_aux.stride(2) == 1
-        assert g_ids.stride() == g_sc.stride() == g_aux.stride()
-        s64 = g_sc64.stride() if g_sc64 is not None else (0, 0, 1)
-        assert s64[2] == 1
-        _native.check(self.lib.rtrec_slim_merge_topk_strided(
-            n_rows, n_lists, top_k, self.ptr(g_ids), self.ptr(g_sc), self.ptr(g_sc64), self.ptr(g_aux), self.ptr(g_cnt),
-            g_ids.stride(0), g_ids.stride(1), s64[0], s64[1], g_cnt.stride(0), g_cnt.stride(1),
-            self.ptr(o_ids), self.ptr(o_sc), self.ptr(o_cnt), self.stream()), "rtrec_slim_merge_topk_strided")
+        self.ops.merge_topk(g_ids, g_sc, g_sc64, g_aux, g_cnt, top_k, o_ids, o_sc, o_cnt)
 
     def similar_topk(self, queries, W, top_k, ids, sc, cnt):
-        _native.check(self.lib.rtrec_slim_similar_topk(int(queries.shape[0]), self.ptr(queries), self.ptr(W["cptr"]),
-                                                       self.ptr(W["crow"]), self.ptr(W["cval"]), top_k,
-                                                       self.ptr(ids), self.ptr(sc), self.ptr(cnt), self.stream()),
-                      "rtrec_slim_similar_topk")
+        self.ops.similar_topk(queries, W["cptr"], W["crow"], W["cval"], top_k, ids, sc, cnt)
 
 
 class SlimEngine:

@@ -286,3 +286,40 @@ def test_gram_matrix_kernel(engine):
         assert not G[P:, :].any() and not G[:, P:].any()
         idx = g["index"].cpu().numpy()
         assert np.array_equal(np.flatnonzero(idx >= 0), np.sort(g["items"])) and np.array_equal(idx[g["items"]], np.arange(P))
+
+
+def test_torch_custom_ops_direct_use(oracle):
+    """torch.ops.rtrec_amd.* (rtrec_amd/ops.py) called directly by a holder of device tensors:
+    schema / mutation annotations (opcheck) and results."""
+    import torch
+    from rtrec_amd import ops  # noqa: F401
+    X = interaction_matrix(300, 90, 4000, seed=8)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    dev = torch.device("cuda:0")
+    cptr = torch.from_numpy(Xc.indptr.astype(np.int32)).to(dev)
+    cval = torch.from_numpy(Xc.data.astype(np.float32)).to(dev)
+    out = torch.empty(90, dtype=torch.float32, device=dev)
+    torch.ops.rtrec_amd.column_sqnorms(cptr, cval, out)
+    ref = np.zeros(90, np.float32)
+    for c in range(90):
+        acc = np.float32(0)
+        for v in Xc.data[Xc.indptr[c]:Xc.indptr[c + 1]]:
+            acc = np.float32(acc + np.float32(v * v))
+        ref[c] = acc
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+    torch.library.opcheck(torch.ops.rtrec_amd.column_sqnorms.default, (cptr, cval, out), test_utils=("test_schema",))
+    # similar_topk on a small W
+    W, _ = oracle_w(oracle, Xc, np.arange(90), nn_feature_selection=10)
+    wp = torch.from_numpy(W.indptr.astype(np.int32)).to(dev)
+    wr = torch.from_numpy(W.indices.astype(np.int32)).to(dev)
+    wv = torch.from_numpy(W.data.astype(np.float32)).to(dev)
+    q = torch.arange(90, dtype=torch.int32, device=dev)
+    ids = torch.empty((90, 5), dtype=torch.int32, device=dev)
+    sc = torch.empty((90, 5), dtype=torch.float32, device=dev)
+    cnt = torch.empty(90, dtype=torch.int32, device=dev)
+    torch.ops.rtrec_amd.similar_topk(q, wp, wr, wv, 5, ids, sc, cnt)
+    for j in range(90):
+        oi, ov = oracle.similar_items(W, j, top_k=5)
+        n = int(cnt[j])
+        assert n == len(oi) and np.array_equal(ids[j, :n].cpu().numpy(), oi)
