@@ -60,3 +60,21 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_torch_custom_ops_are_registered_with_mutation_annotations():
+    """rtrec_amd/ops.py: one PyTorch custom op per C-ABI entry point; outputs and scratch are declared
+    as mutated, so the ops are safe under torch's functionalization / compile stack."""
+    import torch
+    from rtrec_amd import ops
+    for name in ops.OPS:
+        schema = str(getattr(torch.ops.rtrec_amd, name).default._schema)
+        assert schema.startswith(f"rtrec_amd::{name}(") and schema.endswith("-> ()")
+        assert "!" in schema, f"{name} declares no mutated argument"
+    s = str(torch.ops.rtrec_amd.score_topk.default._schema)
+    for out in ("ids", "scores", "aux", "count", "ws"):
+        assert f"!) {out}" in s or f"!)? {out}" in s
+    # on a CPU tensor the CUDA-only op is refused instead of silently computing somewhere else
+    if not torch.cuda.is_available():
+        with pytest.raises((NotImplementedError, RuntimeError)):
+            torch.ops.rtrec_amd.column_sqnorms(torch.tensor([0, 1], dtype=torch.int32), torch.ones(1), torch.empty(1))
