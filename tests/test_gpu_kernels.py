@@ -323,3 +323,31 @@ def test_torch_custom_ops_direct_use(oracle):
         oi, ov = oracle.similar_items(W, j, top_k=5)
         n = int(cnt[j])
         assert n == len(oi) and np.array_equal(ids[j, :n].cpu().numpy(), oi)
+
+
+@pytest.mark.parametrize("fit_mode", ["sw", "mw"])
+@pytest.mark.parametrize("positive", [True, False])
+@pytest.mark.parametrize("K", [12, None])
+def test_fit_with_negative_ratings_bit_exact(engine, oracle, fit_mode, positive, K, monkeypatch):
+    """The reference's default store clips to [-5, 10]: X may hold negative values (dislikes).  Gram
+    tracking must switch itself off, screening bounds use |products|, signs of zeros follow sklearn."""
+    monkeypatch.setenv("RTREC_AMD_FIT_MODE", fit_mode)
+    monkeypatch.setenv("RTREC_AMD_SCREEN_MIN", "1")
+    monkeypatch.setenv("RTREC_AMD_GRAM", "force")
+    X = interaction_matrix(1500, 300, 40000, seed=77)
+    rng = np.random.default_rng(5)
+    X.data = (X.data * np.where(rng.random(X.nnz) < 0.25, -1.0, 1.0)).astype(np.float32)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    assert engine._X["nonneg"] is False
+    tg, items, coef, count, n_iter = engine.fit_columns(np.arange(300), positive=positive, nn_feature_selection=K)
+    assert engine._X.get("gram") is None
+    ptr, idx, val, nit = oracle.fit_columns(Xc, tg, positive=positive, nn_feature_selection=K)
+    assert np.array_equal(n_iter, nit)
+    assert np.array_equal(count, np.diff(ptr))
+    for t in range(len(tg)):
+        c = count[t]
+        o = np.argsort(items[t, :c], kind="stable")
+        assert np.array_equal(items[t, :c][o], idx[ptr[t]:ptr[t + 1]])
+        assert np.array_equal(bits(coef[t, :c][o]), bits(val[ptr[t]:ptr[t + 1]]))
