@@ -1,15 +1,15 @@
 """HTTP shell around the GPU SLIM model: the drop-in for rtrec.serving.app
 (/root/reference/rtrec/serving/app.py:35-93).
 
-Same routes, request/response models, X-Token check and status codes: GET / (liveness),
+Same routes, request/response payloads, X-Token check and status codes: GET / (liveness),
 POST /fit (a list of interactions -> SLIM.fit, i.e. ingest + refit of the touched item columns on
-the GPU), POST /recommend (one user's top-k).  Two differences, both forced by the device:
-  * one lock serialises model calls -- the engine owns one HIP stream and is not re-entrant
-    (SURVEY.md section 8b "Threading"; the reference calls its model with no lock, app.py:57-91);
-  * the handlers are plain `def`, so FastAPI runs them in its worker pool and a long /fit does
-    not stall the event loop (the reference's `async def` handlers block it).
-POST /recommend_batch is an addition for callers that can batch (one kernel launch per request
-instead of one per user); it returns {"users": [...], "recommendations": [[...], ...]}.
+the GPU), POST /recommend (one user's top-k).  Differences, all forced by the device:
+  * `ModelGate` serialises every model call with one lock -- the engine owns one HIP stream and is
+    not re-entrant (SURVEY.md section 8b "Threading"; the reference calls its model unlocked);
+  * handlers are plain functions, so FastAPI runs them in its worker pool and a long /fit does
+    not stall the event loop;
+  * POST /recommend_batch is an addition for callers that can batch (one kernel launch per request
+    instead of one per user): {"users": [...]} -> {"users": [...], "recommendations": [[...], ...]}.
 """
 from __future__ import annotations
 
@@ -18,12 +18,12 @@ import os
 import threading
 from typing import Any, Callable, List, Optional
 
-from fastapi import FastAPI, Header, HTTPException
+from fastapi import APIRouter, FastAPI, Header, HTTPException
 from fastapi.middleware.cors import CORSMiddleware
 from pydantic import BaseModel
 
-DEFAULT_SECRET_TOKEN = "fake_secret_token"
-SECRET_TOKEN = os.getenv("X_TOKEN", DEFAULT_SECRET_TOKEN)
+SECRET_TOKEN = os.getenv("X_TOKEN", "fake_secret_token")
+log = logging.getLogger("rtrec_amd.serving")
 
 
 class Interaction(BaseModel):
@@ -33,10 +33,17 @@ class Interaction(BaseModel):
     rating: float
 
 
-class RecommendationRequest(BaseModel):
-    user: Any
+class _TopKOptions(BaseModel):
     top_k: int = 10
     filter_interacted: bool = True
+
+
+class RecommendationRequest(_TopKOptions):
+    user: Any
+
+
+class BatchRecommendationRequest(_TopKOptions):
+    users: List[Any]
 
 
 class RecommendationResponse(BaseModel):
@@ -44,75 +51,76 @@ class RecommendationResponse(BaseModel):
     recommendations: List[Any]
 
 
-class BatchRecommendationRequest(BaseModel):
-    users: List[Any]
-    top_k: int = 10
-    filter_interacted: bool = True
-
-
 class BatchRecommendationResponse(BaseModel):
     users: List[Any]
     recommendations: List[List[Any]]
 
 
+class ModelGate:
+    """The model plus the lock that serialises GPU work; failures become the reference's 500s."""
+
+    def __init__(self, model: Any):
+        self.model = model
+        self._lock = threading.Lock()
+
+    def call(self, what: str, fn: Callable[[Any], Any]) -> Any:
+        try:
+            with self._lock:
+                return fn(self.model)
+        except Exception as exc:  # same catch-all as the reference handlers
+            log.error("%s failed: %s", what, exc)
+            raise HTTPException(status_code=500, detail=f"{what} failed")
+
+
+def _authorise(x_token: str) -> None:
+    if x_token != SECRET_TOKEN:
+        raise HTTPException(status_code=400, detail="Invalid X-Token header")
+
+
+def build_router(gate: ModelGate) -> APIRouter:
+    api = APIRouter()
+
+    @api.get("/")
+    def alive():
+        return {"message": "Recommender System API is running"}
+
+    @api.post("/fit")
+    def fit(interactions: List[Interaction], x_token: str = Header()):
+        _authorise(x_token)
+        batch = [(row.user, row.item, row.timestamp, row.rating) for row in interactions]
+        gate.call("Training", lambda m: m.fit(batch, progress_bar=False))
+        return {"message": "Training successful"}
+
+    @api.post("/recommend", response_model=RecommendationResponse)
+    def recommend(request: RecommendationRequest, x_token: str = Header()):
+        _authorise(x_token)
+        items = gate.call("Recommendation", lambda m: m.recommend(
+            user=request.user, top_k=request.top_k, filter_interacted=request.filter_interacted))
+        return RecommendationResponse(user=request.user, recommendations=items)
+
+    @api.post("/recommend_batch", response_model=BatchRecommendationResponse)
+    def recommend_batch(request: BatchRecommendationRequest, x_token: str = Header()):
+        _authorise(x_token)
+        lists = gate.call("Recommendation", lambda m: m.recommend_batch(
+            request.users, top_k=request.top_k, filter_interacted=request.filter_interacted))
+        return BatchRecommendationResponse(users=request.users, recommendations=lists)
+
+    return api
+
+
 def create_app(model_factory: Optional[Callable[[], Any]] = None) -> FastAPI:
-    """App factory.  `model_factory` builds the model (default: the reference's
-    SLIM(min_value=-5, max_value=10, decay_in_days=365), app.py:49); tests pass a factory whose
+    """App factory.  `model_factory` builds the model; the default is the reference's
+    SLIM(min_value=-5, max_value=10, decay_in_days=365) (app.py:49).  Tests pass a factory whose
     engine runs on the CPU oracle backend."""
+    if model_factory is None:
+        from ..models.slim import SLIM
+
+        def model_factory():
+            return SLIM(min_value=-5, max_value=10, decay_in_days=365)
     app = FastAPI()
     app.add_middleware(CORSMiddleware, allow_origins=["*"], allow_credentials=True, allow_methods=["*"],
                        allow_headers=["*"])
-    if model_factory is None:
-        from ..models.slim import SLIM
-        recommender = SLIM(min_value=-5, max_value=10, decay_in_days=365)
-    else:
-        recommender = model_factory()
-    lock = threading.Lock()
-
-    def check(x_token: str) -> None:
-        if x_token != SECRET_TOKEN:
-            raise HTTPException(status_code=400, detail="Invalid X-Token header")
-
-    @app.get("/")
-    def read_root():
-        return {"message": "Recommender System API is running"}
-
-    @app.post("/fit")
-    def fit(interactions: List[Interaction], x_token: str = Header()):
-        check(x_token)
-        try:
-            rows = [(i.user, i.item, i.timestamp, i.rating) for i in interactions]
-            with lock:
-                recommender.fit(rows, progress_bar=False)
-            return {"message": "Training successful"}
-        except Exception as e:
-            logging.error(f"Training failed: {e}")
-            raise HTTPException(status_code=500, detail="Training failed")
-
-    @app.post("/recommend", response_model=RecommendationResponse)
-    def recommend(request: RecommendationRequest, x_token: str = Header()):
-        check(x_token)
-        try:
-            with lock:
-                recs = recommender.recommend(user=request.user, top_k=request.top_k,
-                                             filter_interacted=request.filter_interacted)
-            return {"user": request.user, "recommendations": recs}
-        except Exception as e:
-            logging.error(f"Recommendation failed: {e}")
-            raise HTTPException(status_code=500, detail="Recommendation failed")
-
-    @app.post("/recommend_batch", response_model=BatchRecommendationResponse)
-    def recommend_batch(request: BatchRecommendationRequest, x_token: str = Header()):
-        check(x_token)
-        try:
-            with lock:
-                recs = recommender.recommend_batch(request.users, top_k=request.top_k,
-                                                   filter_interacted=request.filter_interacted)
-            return {"users": request.users, "recommendations": recs}
-        except Exception as e:
-            logging.error(f"Recommendation failed: {e}")
-            raise HTTPException(status_code=500, detail="Recommendation failed")
-
+    app.include_router(build_router(ModelGate(model_factory())))
     return app
 
 
