@@ -87,8 +87,10 @@ int rtrec_slim_fit_workspace_init(void *d_workspace, size_t workspace_bytes,
  *       selected feature (descending X^T y, ties -> higher id), d_out_coef the matching
  *       coefficient -- i.e. model.sparse_coef_ INCLUDING explicit zeros (slim_elastic.py:153);
  *       d_out_count[t] = min(top_features, I).
- *   top_features <= 0: cap >= I.  Non-zero coefficients only, ascending item id
- *       (sparse.csr_matrix(coef_), _coordinate_descent.py:1133-1136); d_out_count[t] = nnz.
+ *   top_features <= 0: any cap >= 1.  Non-zero coefficients only, ascending item id
+ *       (sparse.csr_matrix(coef_), _coordinate_descent.py:1133-1136); d_out_count[t] = nnz.  When nnz
+ *       exceeds cap only the first cap entries are stored: refit that target with cap >= nnz
+ *       (cap = I can never overflow).
  *   d_out_n_iter[t] = sklearn's n_iter_.
  * d_queue: one int32 work-queue counter, must be zero on entry (the call resets it to zero
  * on the stream before launching). */

@@ -46,6 +46,7 @@ struct FitArgs {
     const int *col_order;   // optional: item ids by descending column length (column-walk balance)
     int colwalk_min_rows;   // latency mode: targets with at least this many users use the column walk
     int screen_min;         // columns with at least this many entries are screened before an ordered fold
+    int lane_max;           // every-item path: columns up to this length are folded one per lane
     const int *targets; int n_targets;
     rtrec_fit_cfg cfg;
     int *out_items; float *out_coef; int *out_count; int *out_niter; int cap;
@@ -55,6 +56,7 @@ struct FitArgs {
     float *cand_s;   // [slots][I]   K path: candidate scores; ALL path: ever_flag (as int)
     int *cand_i;     // [slots][I]   K path: candidate ids;    ALL path: ever list
     float *w_all;    // [slots][I]   ALL path only
+    int *long_list;  // [slots][I]   ALL path only: columns longer than lane_max, per duality-gap evaluation
     int *queue;
     long long *trace;   // optional [n_targets][4]: start, prep end, end (100 MHz ticks), folded entries
     const double *gram;       // optional [gram_n][gram_n]: X_p . X_q of the gram_n tracked (popular) items
@@ -907,6 +909,329 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
     }
 }
 
+
+// =============================================================================================
+// Every-item-is-a-feature path (nn_feature_selection = None, the reference's default): I draws per
+// sweep, nearly all of them over SHORT columns whose coefficient is and stays zero.
+//
+// The draws of a sweep are taken 64 at a time: the xorshift sequence is advanced 64 steps, the
+// per-draw metadata (norm, column range, current coefficient) arrives in one round trip, and every
+// lane folds ITS OWN column strictly in order -- a lane-private sequential accumulation is exactly
+// the reference's operation order, so for columns of up to kLaneMax entries the batch yields 64 exact
+// dot products at once instead of one.  The draws are then committed in order: zero-stays-zero draws
+// are no-ops; the first draw that changes the residual is applied (wave-wide update pass), after
+// which the lane-private dots of the LATER draws are recomputed, because they saw the old residual.
+// Columns longer than kLaneMax keep the wave-wide screening pass + ordered fold.
+// The duality gap's max_p XtA[p] is computed the same way: exact per lane for short columns,
+// screened (and folded only if they can be the maximum) for long ones.
+// =============================================================================================
+constexpr int kLaneMaxDefault = 256;   // FitArgs::lane_max
+
+__device__ __forceinline__ float lane_dot(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
+                                          int b, int e, float w_old) {
+    // 8 entries per step, software-pipelined: while the residual gathers of group g are in flight the
+    // (independent) index / value loads of group g+1 are issued, so a step costs one memory round trip
+    const bool add_back = (w_old != 0.0f);
+    float tmp = 0.0f;
+    int o = b;
+    if (o + 8 <= e) {
+        int r[8];
+        float x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { r[u] = crow[o + u]; x[u] = cval[o + u]; }
+        for (;;) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = R[r[u]];
+            const int on = o + 8;
+            const bool more = on + 8 <= e;
+            int rn[8];
+            float xn[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { rn[u] = 0; xn[u] = 0.0f; }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { rn[u] = crow[on + u]; xn[u] = cval[on + u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float vv = v[u];
+                if (add_back) vv = __fadd_rn(vv, __fmul_rn(x[u], w_old));
+                tmp = __fadd_rn(tmp, __fmul_rn(vv, x[u]));
+            }
+            o = on;
+            if (!more) break;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { r[u] = rn[u]; x[u] = xn[u]; }
+        }
+    }
+    for (; o < e; ++o) {
+        const float x = cval[o];
+        float vv = R[crow[o]];
+        if (add_back) vv = __fadd_rn(vv, __fmul_rn(x, w_old));
+        tmp = __fadd_rn(tmp, __fmul_rn(vv, x));
+    }
+    return tmp;
+}
+
+__device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *smem) {
+    const int lane = lane_id();
+    const int U = a.U, I = a.I;
+    const int j = a.targets[t];
+    float *R = a.R + static_cast<size_t>(slot) * U;
+    float *s = a.s + static_cast<size_t>(slot) * I;
+    int *touched = a.touched + static_cast<size_t>(slot) * I;
+    float *cand_s = a.cand_s + static_cast<size_t>(slot) * I;
+    int *cand_i = a.cand_i + static_cast<size_t>(slot) * I;
+    float *w_all = a.w_all + static_cast<size_t>(slot) * I;
+    int *ever_flag = reinterpret_cast<int *>(cand_s);
+    int *ever_list = cand_i;
+    float *fold_buf = reinterpret_cast<float *>(smem);
+    const FeatLds F = carve_feat(smem + kFoldBufBytes, 0);
+    int *oi = a.out_items + static_cast<size_t>(t) * a.cap;
+    float *oc = a.out_coef + static_cast<size_t>(t) * a.cap;
+    int *long_list = a.long_list + static_cast<size_t>(slot) * I;
+
+    const float alpha = a.cfg.l1_reg, beta = a.cfg.l2_reg;
+    const int positive = a.cfg.positive;
+    const int yb = a.cptr[j], ye = a.cptr[j + 1];
+    const int ny = ye - yb;
+
+    const long long tr0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
+    long long tr_folded = 0;
+    const Prep P = prep_target<true>(a, j, 0, s, touched, cand_s, cand_i, F);
+    const long long tr1 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
+    const float yy = P.yy, tol_s = P.tol_s;
+    const int tc = P.tc;
+    const int nf = I;
+
+    bool dirty = false;
+    int n_ever = 0;
+    float gap = __fadd_rn(a.cfg.tol, 1.0f);
+    uint32_t rng = a.cfg.seed;
+    const int max_iter = a.cfg.max_iter;
+    const bool skip_cd = (ny == 0) || (nf == 0);
+    int n_iter = skip_cd ? (max_iter > 0 ? max_iter - 1 : 0) : 0;
+    const float ninf = -__builtin_huge_valf();
+
+    auto s_value = [&](int p) -> float {
+        const float v = s[p];
+        return (__float_as_uint(v) == kUntouched) ? 0.0f : v;
+    };
+    // wave-wide exact / screened evaluation of one long column (uniform arguments)
+    auto long_tmp = [&](int p, int b, int e, float w_old, bool &screened, float &w_new) -> float {
+        screened = false;
+        if (!dirty) return s_value(p);
+        if (w_old == 0.0f && e - b >= a.screen_min && e - b <= kScreenMaxLen) {
+            float ps, pa;
+            screen_pass(a.crow, a.cval, R, b, e, ps, pa);
+            screened = screen_stays_zero(screen_interval(ps, pa, e - b), alpha, positive, w_new);
+            if (screened) return 0.0f;
+        }
+        tr_folded += e - b;
+        return dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf);
+    };
+
+    for (; !skip_cd && n_iter < max_iter; ++n_iter) {
+        float w_max = 0.0f, d_w_max = 0.0f;
+        for (int f0 = 0; f0 < nf; f0 += 64) {
+            const int nb = min(64, nf - f0);
+            int p_l = 0;
+            for (int k = 0; k < nb; ++k) {
+                const int p = static_cast<int>(rand_int(static_cast<uint32_t>(nf), rng));
+                if (lane == k) p_l = p;
+            }
+            float nrm_l = 0.0f, wold_l = 0.0f, tmp_l = 0.0f;
+            int b_l = 0, e_l = 0;
+            if (lane < nb) {
+                nrm_l = (p_l == j) ? 0.0f : a.sqn[p_l];
+                b_l = a.cptr[p_l]; e_l = a.cptr[p_l + 1];
+                wold_l = w_all[p_l];
+            }
+            const bool cand_l = lane < nb && nrm_l != 0.0f;
+            const bool short_l = cand_l && (e_l - b_l) <= a.lane_max;
+            auto lane_dots = [&](int from) {
+                if (short_l && lane >= from)
+                    tmp_l = dirty ? lane_dot(a.crow, a.cval, R, b_l, e_l, wold_l) : s_value(p_l);
+            };
+            lane_dots(0);
+            int k = 0;
+            while (k < nb) {
+                float wnew_l = 0.0f;
+                if (short_l) wnew_l = cd_update(tmp_l, alpha, beta, nrm_l, positive);
+                const bool need_l = cand_l && lane >= k && (!short_l || wold_l != 0.0f || wnew_l != 0.0f);
+                const unsigned long long m = __ballot(need_l);
+                if (!m) break;
+                const int q = __builtin_ctzll(m);
+                const int p = readlane_i(p_l, q);
+                const float nrm = readlane_f(nrm_l, q);
+                const int b = readlane_i(b_l, q), e = readlane_i(e_l, q);
+                const float w_old = readlane_f(wold_l, q);
+                float w_new = 0.0f;
+                if (e - b <= a.lane_max) {
+                    w_new = readlane_f(wnew_l, q);
+                } else {
+                    bool screened = false;
+                    const float tmp = long_tmp(p, b, e, w_old, screened, w_new);
+                    if (!screened) w_new = cd_update(tmp, alpha, beta, nrm, positive);
+                }
+                if (w_old != 0.0f || w_new != 0.0f) {
+                    if (!dirty) {   // materialise R = y
+                        for (int o = yb + lane; o < ye; o += 64) R[a.crow[o]] = a.cval[o];
+                        dirty = true;
+                    }
+                    update_pass(a.crow, a.cval, R, b, e, w_old, w_new);
+                    if (ever_flag[p] == 0) { if (lane == 0) { ever_flag[p] = 1; ever_list[n_ever] = p; } n_ever++; }
+                    if (lane == 0) w_all[p] = w_new;
+                    // later draws of the batch: the same coordinate sees the new coefficient, and every
+                    // lane-private dot is stale because the residual changed
+                    if (lane > q && lane < nb && p_l == p) wold_l = w_new;
+                    lane_dots(q + 1);
+                }
+                const float d = fabsf(__fsub_rn(w_new, w_old));
+                d_w_max = d > d_w_max ? d : d_w_max;
+                const float aw = fabsf(w_new);
+                w_max = aw > w_max ? aw : w_max;
+                k = q + 1;
+            }
+        }
+
+        if (w_max == 0.0f || __fdiv_rn(d_w_max, w_max) < a.cfg.tol || n_iter == max_iter - 1) {
+            float dn = 0.0f;       // the target itself contributes XtA = 0, so the maximum is >= 0
+            float R_norm2, Ry, w_norm2 = 0.0f, l1 = 0.0f;
+            if (!dirty) {
+                // XtA[p] = s[p] for every feature (0 for untouched ones and the target)
+                for (int tb = 0; tb < tc; tb += 64) {
+                    float v = 0.0f;
+                    if (tb + lane < tc) { v = s[touched[tb + lane]]; v = positive ? v : fabsf(v); }
+                    const float mx = wave_max(v);
+                    dn = mx > dn ? mx : dn;
+                }
+                R_norm2 = yy; Ry = yy;
+            } else {
+                // short columns: exact per lane; long columns: listed, screened, folded if they can win
+                float lmax = 0.0f;
+                int n_long = 0;
+                for (int p0 = 0; p0 < I; p0 += 64) {
+                    const int p = p0 + lane;
+                    int b = 0, e = 0;
+                    if (p < I && p != j) { b = a.cptr[p]; e = a.cptr[p + 1]; }
+                    const bool is_long = (e - b) > a.lane_max;
+                    if (e > b && !is_long) {
+                        const float xta = __fsub_rn(lane_dot(a.crow, a.cval, R, b, e, 0.0f), __fmul_rn(beta, w_all[p]));
+                        const float v = positive ? xta : fabsf(xta);
+                        lmax = v > lmax ? v : lmax;
+                    }
+                    const unsigned long long m = __ballot(is_long);
+                    if (m) {
+                        if (is_long) long_list[n_long + lane_prefix(m)] = p;
+                        n_long += __builtin_popcountll(m);
+                    }
+                }
+                dn = wave_max(lmax);
+                float best_lo = dn;
+                for (int pass = 0; pass < 2; ++pass) {
+                    for (int q = 0; q < n_long; ++q) {
+                        const int p = long_list[q];
+                        const int b = a.cptr[p], e = a.cptr[p + 1];
+                        const float bw = __fmul_rn(beta, w_all[p]);
+                        float lo = ninf, hi = __builtin_huge_valf();
+                        if (e - b >= a.screen_min && e - b <= kScreenMaxLen) {
+                            float ps, pa;
+                            screen_pass(a.crow, a.cval, R, b, e, ps, pa);
+                            screen_xta_interval(screen_interval(ps, pa, e - b), bw, positive, lo, hi);
+                        }
+                        if (pass == 0) { best_lo = lo > best_lo ? lo : best_lo; continue; }
+                        if (!(hi >= best_lo)) continue;
+                        float v = lo;
+                        if (lo != hi) {
+                            const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, b, e, fold_buf), bw);
+                            tr_folded += e - b;
+                            v = positive ? xta : fabsf(xta);
+                        }
+                        dn = v > dn ? v : dn;
+                    }
+                }
+                R_norm2 = 0.0f;
+                for (int o = 0; o < U; o += 64) {
+                    float prod = 0.0f;
+                    if (o + lane < U) { const float v = R[o + lane]; prod = __fmul_rn(v, v); }
+                    if (__ballot(prod != 0.0f)) R_norm2 = chain_add(R_norm2, prod, min(64, U - o));
+                }
+                Ry = 0.0f;
+                for (int o = yb; o < ye; o += 64) {
+                    const int n = min(64, ye - o);
+                    float prod = 0.0f;
+                    if (lane < n) prod = __fmul_rn(R[a.crow[o + lane]], a.cval[o + lane]);
+                    Ry = chain_add(Ry, prod, n);
+                }
+                for (int o = 0; o < nf; o += 64) {
+                    float wv = 0.0f;
+                    if (o + lane < nf) wv = w_all[o + lane];
+                    if (__ballot(wv != 0.0f)) {
+                        const int n = min(64, nf - o);
+                        w_norm2 = chain_add(w_norm2, __fmul_rn(wv, wv), n);
+                        l1 = chain_add(l1, fabsf(wv), n);
+                    }
+                }
+            }
+            float cst;
+            if (dn > alpha) {
+                cst = __fdiv_rn(alpha, dn);
+                const float A_norm2 = __fmul_rn(R_norm2, __fmul_rn(cst, cst));
+                gap = static_cast<float>(0.5 * static_cast<double>(__fadd_rn(R_norm2, A_norm2)));
+            } else {
+                cst = 1.0f;
+                gap = R_norm2;
+            }
+            const float t12 = __fsub_rn(__fmul_rn(alpha, l1), __fmul_rn(cst, Ry));
+            const double t3 = 0.5 * static_cast<double>(beta) * static_cast<double>(__fadd_rn(1.0f, __fmul_rn(cst, cst))) *
+                              static_cast<double>(w_norm2);
+            gap = static_cast<float>(static_cast<double>(gap) + (static_cast<double>(t12) + t3));
+            if (gap < tol_s) break;
+        }
+    }
+    const int n_iter_out = (n_iter < max_iter ? n_iter : max_iter - 1) + 1;
+
+    // ---- outputs: non-zero coefficients ascending by id; n_ever is small, so rank the ever-list.
+    //      Only the first `cap` are stored; out_count reports all of them (the caller refits a
+    //      target whose count exceeds its cap with a larger one) ----
+    for (int k = lane; k < n_ever; k += 64) {
+        const int p = ever_list[k];
+        const float wv = w_all[p];
+        if (wv != 0.0f) {
+            int rank = 0;
+            for (int q = 0; q < n_ever; ++q) {
+                const int pq = ever_list[q];
+                if (pq < p && w_all[pq] != 0.0f) rank++;
+            }
+            if (rank < a.cap) { oi[rank] = p; oc[rank] = wv; }
+        }
+    }
+    int cnt = 0;
+    for (int k = 0; k < n_ever; k += 64) {
+        bool nz = false;
+        if (k + lane < n_ever) nz = (w_all[ever_list[k + lane]] != 0.0f);
+        cnt += __builtin_popcountll(__ballot(nz));
+    }
+    if (lane == 0) { a.out_count[t] = cnt; a.out_niter[t] = n_iter_out; }
+
+    // ---- restore the scratch invariants ----
+    if (dirty) {
+        for (int o = yb + lane; o < ye; o += 64) R[a.crow[o]] = 0.0f;
+        for (int k = 0; k < n_ever; ++k) {
+            const int p = ever_list[k];
+            for (int o = a.cptr[p] + lane; o < a.cptr[p + 1]; o += 64) R[a.crow[o]] = 0.0f;
+        }
+    }
+    for (int k = lane; k < n_ever; k += 64) { const int p = ever_list[k]; w_all[p] = 0.0f; ever_flag[p] = 0; }
+    for (int tt = lane; tt < tc; tt += 64) s[touched[tt]] = __uint_as_float(kUntouched);
+    if (a.trace && lane == 0) {
+        long long *tr = a.trace + static_cast<size_t>(t) * 4;
+        tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
+    }
+}
+
 template <bool ALLF>
 __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(FitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -916,7 +1241,8 @@ __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(Fit
         if (lane_id() == 0) t = atomicAdd(a.queue, 1);
         t = readfirst_i(t);
         if (t >= a.n_targets) return;
-        fit_one<ALLF>(a, t, slot, smem);
+        if (ALLF) fit_one_allf(a, t, slot, smem);
+        else fit_one<false>(a, t, slot, smem);
     }
 }
 
@@ -1468,7 +1794,7 @@ using namespace rtrec;
 
 namespace {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-struct FitWs { size_t R, s, touched, cand_s, cand_i, w_all, total; };
+struct FitWs { size_t R, s, touched, cand_s, cand_i, w_all, long_list, total; };
 FitWs fit_ws_layout(int U, int I, int slots, int top_features) {
     FitWs w;
     size_t o = 0;
@@ -1479,6 +1805,7 @@ FitWs fit_ws_layout(int U, int I, int slots, int top_features) {
     w.cand_s = o;  o = align_up(o + sl * I * 4, 256);
     w.cand_i = o;  o = align_up(o + sl * I * 4, 256);
     w.w_all = o;   if (top_features <= 0) o = align_up(o + sl * I * 4, 256);
+    w.long_list = o; if (top_features <= 0) o = align_up(o + sl * I * 4, 256);
     w.total = o;
     return w;
 }
@@ -1566,7 +1893,7 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
         return RTREC_ERR_INVALID_ARG;
     const bool allf = cfg->top_features <= 0;
     const int K = allf ? n_items : (cfg->top_features < n_items ? cfg->top_features : n_items);
-    if (cap < K) return RTREC_ERR_INVALID_ARG;
+    if (cap < (allf ? 1 : K)) return RTREC_ERR_INVALID_ARG;
     if (!allf && K > 4096) return RTREC_ERR_UNSUPPORTED;   // 7 LDS arrays of K entries per wave
     if (cfg->max_iter <= 0) return RTREC_ERR_INVALID_ARG;
     const FitWs L = fit_ws_layout(n_users, n_items, n_slots, cfg->top_features);
@@ -1586,6 +1913,7 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
     a.cand_s = reinterpret_cast<float *>(ws + L.cand_s);
     a.cand_i = reinterpret_cast<int *>(ws + L.cand_i);
     a.w_all = allf ? reinterpret_cast<float *>(ws + L.w_all) : nullptr;
+    a.long_list = allf ? reinterpret_cast<int *>(ws + L.long_list) : nullptr;
     a.queue = d_queue;
     if (opts) {
         a.trace = reinterpret_cast<long long *>(opts->d_trace);
@@ -1596,6 +1924,7 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
     }
     { const char *cw = std::getenv("RTREC_AMD_COLWALK_MIN"); a.colwalk_min_rows = cw ? std::atoi(cw) : kColWalkMinRows; }
     { const char *sm = std::getenv("RTREC_AMD_SCREEN_MIN"); a.screen_min = sm ? std::atoi(sm) : kScreenMinDefault; }
+    { const char *lm = std::getenv("RTREC_AMD_LANE_MAX"); a.lane_max = lm ? std::atoi(lm) : kLaneMaxDefault; }
     (void)hipGetLastError();
     if (hipMemsetAsync(d_queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const int grid = n_slots < n_targets ? n_slots : n_targets;

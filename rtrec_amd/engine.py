@@ -29,6 +29,7 @@ DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dens
 MAX_SLOTS = 4096   # 4 single-wave workgroups per SIMD; with Gram tracking the sweet spot moved down from 5120 (C3: 2.16 s vs 2.3 s)
 GATHER_CHUNK_ROWS = 32768   # rows per all-gather chunk of a sharded scoring call
 MAX_GATHER_CHUNKS = 8
+ALLF_OUTPUT_CAP = 2048      # coefficients per target the K=None output block holds before a refit with cap = I
 GRAM_ITEMS = 512            # most popular items whose pairwise dot products the fit kernel may look up
 FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
 FIT_MW_MAX_TARGETS = 2048   # kMwMaxTargets of csrc/fit.hip: calls up to this size run the multi-wave kernel
@@ -318,7 +319,9 @@ class SlimEngine:
         K = int(nn_feature_selection) if nn_feature_selection is not None else 0
         if nn_feature_selection is not None and K <= 0:
             raise AssertionError(f"n_neighbors must be a positive integer: {K}")
-        cap = min(K, I) if K > 0 else I
+        # K = None: a column's solution is sparse, so the output block is sized for ALLF_OUTPUT_CAP
+        # coefficients per target and the rare target that has more is refitted with room for all I
+        cap = min(K, I) if K > 0 else min(I, int(os.environ.get("RTREC_AMD_ALLF_CAP", ALLF_OUTPUT_CAP)))
         cfg = _native.FitCfg(np.float32(alpha * l1_ratio * U), np.float32(alpha * (1.0 - l1_ratio) * U),
                              np.float32(tol), int(max_iter), sklearn_seed(random_state), int(bool(positive)), K)
         torch = be.torch
@@ -408,8 +411,33 @@ class SlimEngine:
         if heavy is not None:
             torch.cuda.current_stream(be.device).wait_stream(side)
             collect(heavy)
+        if K <= 0 and cap < I:
+            over = np.flatnonzero(count_out > cap)
+            if over.size:      # refit these with room for every item, then widen the block
+                full = self._fit_overflow(targets[over], cfg, U, I, slots)
+                wide = int(max(int(full[2].max()), cap))
+                items_w = np.zeros((n, wide), dtype=np.int32); items_w[:, :cap] = items_out
+                coef_w = np.zeros((n, wide), dtype=np.float32); coef_w[:, :cap] = coef_out
+                items_w[over] = full[0][:, :wide]; coef_w[over] = full[1][:, :wide]
+                niter_out[over] = full[3]
+                items_out, coef_out = items_w, coef_w
         self.last_fit_stats = {"n_targets": n, "slots": slots, "cap": cap, "trace": trace_out, "n_heavy": n_heavy}
         return targets, items_out, coef_out, count_out, niter_out
+
+    def _fit_overflow(self, targets: np.ndarray, cfg, U: int, I: int, slots: int):
+        """K = None targets whose solution did not fit the output block: fit them again with cap = I."""
+        be, X, torch = self.be, self._X, self.be.torch
+        m = len(targets)
+        n_slots = max(1, min(slots, m))
+        key = (U, I, n_slots, 0)
+        if key not in self._fit_ws:
+            self._fit_ws[key] = be.fit_workspace(U, I, n_slots, 0)
+        ws, queue = self._fit_ws[key]
+        d_t = be.to_dev(targets.astype(np.int32))
+        items, coef = be.empty((m, I), torch.int32), be.empty((m, I), torch.float32)
+        count, niter = be.empty((m,), torch.int32), be.empty((m,), torch.int32)
+        be.fit_columns(U, I, X, d_t, cfg, items, coef, count, niter, I, ws, queue, n_slots, None, None)
+        return items.cpu().numpy(), coef.cpu().numpy(), count.cpu().numpy(), niter.cpu().numpy()
 
     # ------------------------------------------------------------------------------ W
     def set_weights(self, W_csc: sp.csc_matrix, acc_f64: bool = False) -> None:

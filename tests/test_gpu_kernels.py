@@ -351,3 +351,45 @@ def test_fit_with_negative_ratings_bit_exact(engine, oracle, fit_mode, positive,
         o = np.argsort(items[t, :c], kind="stable")
         assert np.array_equal(items[t, :c][o], idx[ptr[t]:ptr[t + 1]])
         assert np.array_equal(bits(coef[t, :c][o]), bits(val[ptr[t]:ptr[t + 1]]))
+
+
+@pytest.mark.parametrize("lane_max", [None, "16", "0"])      # 16 / 0: most / all columns take the wave-wide path
+@pytest.mark.parametrize("screen_min", [None, "1"])
+@pytest.mark.parametrize("positive,float_ratings", [(True, True), (False, True), (True, False)])
+def test_fit_every_item_path_bit_exact(engine, oracle, lane_max, screen_min, positive, float_ratings, monkeypatch):
+    """nn_feature_selection=None (the reference's default): draws are taken 64 at a time and every lane
+    folds its own column in order; committing them one by one must equal the sequential loop."""
+    if lane_max is not None:
+        monkeypatch.setenv("RTREC_AMD_LANE_MAX", lane_max)
+    if screen_min is not None:
+        monkeypatch.setenv("RTREC_AMD_SCREEN_MIN", screen_min)
+    X = interaction_matrix(2500, 260, 70000, seed=41, float_ratings=float_ratings)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    tg, items, coef, count, n_iter = engine.fit_columns(np.arange(260), positive=positive, nn_feature_selection=None)
+    ptr, idx, val, nit = oracle.fit_columns(Xc, tg, positive=positive, nn_feature_selection=None)
+    assert np.array_equal(n_iter, nit), f"n_iter differs on {np.flatnonzero(n_iter != nit)[:10]}"
+    assert np.array_equal(count, np.diff(ptr))
+    for t in range(len(tg)):
+        c = count[t]
+        assert np.array_equal(items[t, :c], idx[ptr[t]:ptr[t + 1]]), f"support differs for column {tg[t]}"
+        assert np.array_equal(bits(coef[t, :c]), bits(val[ptr[t]:ptr[t + 1]])), f"coefficient bits differ for column {tg[t]}"
+
+
+def test_fit_every_item_output_overflow_is_refitted(engine, oracle, monkeypatch):
+    """K=None output blocks hold ALLF_OUTPUT_CAP coefficients per target; a target with more is refitted
+    with room for all items, so the result does not depend on the cap."""
+    monkeypatch.setenv("RTREC_AMD_ALLF_CAP", "3")
+    X = interaction_matrix(2500, 260, 70000, seed=41)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    tg, items, coef, count, n_iter = engine.fit_columns(np.arange(260), nn_feature_selection=None)
+    ptr, idx, val, nit = oracle.fit_columns(Xc, tg, nn_feature_selection=None)
+    assert count.max() > 3, "the scenario must overflow the 3-entry cap"
+    assert np.array_equal(n_iter, nit) and np.array_equal(count, np.diff(ptr))
+    for t in range(len(tg)):
+        c = count[t]
+        assert np.array_equal(items[t, :c], idx[ptr[t]:ptr[t + 1]])
+        assert np.array_equal(bits(coef[t, :c]), bits(val[ptr[t]:ptr[t + 1]]))

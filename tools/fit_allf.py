@@ -36,6 +36,12 @@ def main():
                       "sum_target_s": float(((tr[:, 2] - tr[:, 0]) * 1e-8).sum()),
                       "max_target_s": float(((tr[:, 2] - tr[:, 0]) * 1e-8).max()),
                       "prep_share": float(((tr[:, 1] - tr[:, 0]).sum()) / max((tr[:, 2] - tr[:, 0]).sum(), 1))}))
+    dur = (tr[:, 2] - tr[:, 0]) * 1e-8
+    col_nnz = np.diff(Xc.indptr)[tg]
+    for i in np.argsort(-dur)[:6]:
+        print(json.dumps({"item": int(tg[i]), "nnz": int(col_nnz[i]), "dur_s": float(dur[i]), "prep_s": float((tr[i, 1] - tr[i, 0]) * 1e-8),
+                          "sweeps": int(n_iter[i]), "nonzero": int(count[i]), "folded": float(tr[i, 3]),
+                          "start_s": float((tr[i, 0] - tr[:, 0].min()) * 1e-8)}))
 
 
 if __name__ == "__main__":
