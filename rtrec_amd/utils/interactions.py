@@ -88,8 +88,10 @@ def _merge_blocks(old: _Block, new: _Block) -> _Block:
         nk, nv, nt = new.key[rest], new.val[rest], new.ts[rest]
     else:
         nk, nv, nt = new.key, new.val, new.ts
-    ins = np.searchsorted(old.key, nk)
-    return _Block(np.insert(old.key, ins, nk), np.insert(old.val, ins, nv), np.insert(old.ts, ins, nt))
+    # two sorted runs: numpy's stable sort (timsort) merges them in one linear pass
+    key = np.concatenate([old.key, nk])
+    order = np.argsort(key, kind="stable")
+    return _Block(key[order], np.concatenate([old.val, nv])[order], np.concatenate([old.ts, nt])[order])
 
 
 def _stable_order(users: np.ndarray, items: np.ndarray, keys: np.ndarray) -> np.ndarray:
@@ -182,7 +184,7 @@ class UserItemInteractions:
     def _write(self, keys: np.ndarray, val: np.ndarray, ts: np.ndarray, presorted: bool = False) -> None:
         """Store unique keys (any order) into the delta block; merge down when it has grown."""
         if presorted:
-            blk = _Block(keys, val.astype(np.float64), ts.astype(np.float64))
+            blk = _Block(keys, np.asarray(val, dtype=np.float64), np.asarray(ts, dtype=np.float64))
         else:
             order = np.argsort(keys, kind="stable")
             blk = _Block(keys[order], val[order].astype(np.float64), ts[order].astype(np.float64))
@@ -248,7 +250,11 @@ class UserItemInteractions:
             self._write(k, new, ts[idx], presorted=True)     # every round is a subsequence of the key-sorted order
 
         self.max_timestamp = float(seen[-1])
-        self.all_item_ids.update(np.unique(items).tolist())
+        i_hi = int(items.max())
+        if i_hi <= max(4 * n, 1 << 22):
+            self.all_item_ids.update(np.flatnonzero(np.bincount(items, minlength=i_hi + 1)).tolist())
+        else:
+            self.all_item_ids.update(np.unique(items).tolist())
         pos = dl > 0
         if pos.any():
             self.hot_items.add_many(items[pos])

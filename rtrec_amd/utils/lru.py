@@ -56,16 +56,26 @@ class LRUFreqSet(MutableSet):
 
     def _add_many_ints(self, values: "np.ndarray") -> bool:
         """Vectorised add_many for an integer array: hit counts and the order of LAST occurrence come
-        from numpy, the dict is touched once per distinct key.  Returns False (nothing done) when
-        the batch would overflow the capacity -- evictions depend on the exact interleaving."""
+        from numpy (bincount + a scatter of positions: with repeated indices the last write wins), the
+        dict is touched once per distinct key.  Returns False (nothing done) when the batch would
+        overflow the capacity -- evictions depend on the exact interleaving."""
         n = len(values)
-        uniq, rev_first, counts = np.unique(values[::-1], return_index=True, return_counts=True)
+        lo, hi = int(values.min()), int(values.max())
+        if lo < 0 or hi - lo > max(4 * n, 1 << 22):       # sparse id range: sort-based grouping instead
+            uniq, rev_first, counts = np.unique(values[::-1], return_index=True, return_counts=True)
+            last_pos = n - 1 - rev_first
+        else:
+            shifted = values - lo
+            counts_all = np.bincount(shifted, minlength=hi - lo + 1)
+            last_all = np.zeros(hi - lo + 1, dtype=np.int64)
+            last_all[shifted] = np.arange(n, dtype=np.int64)
+            present = np.flatnonzero(counts_all)
+            uniq, counts, last_pos = present + lo, counts_all[present], last_all[present]
         keys = uniq.tolist()
         data = self.data
         fresh = sum(1 for k in keys if k not in data)
         if len(data) + fresh > self.capacity:
             return False
-        last_pos = n - 1 - rev_first
         order = np.argsort(last_pos, kind="stable")
         cnt = counts.tolist()
         for j in order.tolist():
