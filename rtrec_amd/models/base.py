@@ -202,6 +202,8 @@ class BaseModel(ABC):
         candidate_item_ids = self._candidate_ids(candidate_items)
 
         def to_items(rows: List[List[int]]) -> List[List[Any]]:
+            if self.item_ids.pass_through:          # integer ids are their own internal ids
+                return rows
             return [[self.item_ids.get(i) for i in row] for row in rows]
 
         if not cold_ids:

@@ -235,14 +235,10 @@ class SLIMElastic:
 
     @staticmethod
     def _format(ids: ndarray, scores: ndarray, counts: ndarray, ret_scores: bool):
-        out: List[Any] = []
-        for r in range(ids.shape[0]):
-            c = int(counts[r])
-            if ret_scores:
-                out.append((ids[r, :c].tolist(), scores[r, :c].copy()))
-            else:
-                out.append(ids[r, :c].tolist())
-        return out
+        rows, cnt = ids.tolist(), counts.tolist()          # one conversion for the whole batch
+        if not ret_scores:
+            return [row[:c] for row, c in zip(rows, cnt)]
+        return [(row[:c], scores[r, :c].copy()) for r, (row, c) in enumerate(zip(rows, cnt))]
 
     # ---------------------------------------------------------------- predict (dense / sparse score rows)
     def _not_fitted(self, what: str) -> None:
