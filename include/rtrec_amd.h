@@ -205,7 +205,9 @@ size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t
  * DENSE mode and by higher candidate rank in CANDIDATES mode (numpy's unstable argsort leaves
  * those two unspecified -- DESIGN.md D1).
  * acc_f64 != 0 accumulates in float64 (W built by the serial SLIMElastic.fit is a float64
- * matrix, slim_elastic.py:252). */
+ * matrix, slim_elastic.py:252).
+ * Limits: top_k <= 1023 and n_tiles * (top_k + 1) <= 1024 (RTREC_ERR_UNSUPPORTED otherwise); up to
+ * top_k = 63 the selection is a two-pass threshold filter, beyond that one scan per result. */
 int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                           const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
                           int32_t n_items, int32_t n_cols, int32_t col_offset,

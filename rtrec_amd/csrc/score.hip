@@ -75,16 +75,18 @@ struct ScoreArgs {
 #endif
 constexpr int kListCap = SCORE_LIST_CAP;    // threshold-candidate list (uint16 columns)
 constexpr int kTouchCap = SCORE_TOUCH_CAP;  // touched-column list of the sparse kernel (uint16 columns)
-constexpr int kResCap = 64;      // top_k + 1 <= 64
+constexpr int kResCap = 64;      // result slots for top_k + 1 <= 64; larger k: res_cap() slots
+constexpr int kMaxTopK = 1023;
 constexpr int kQueueChunk = 8;   // jobs claimed per work-queue atomic
 constexpr int kRowGroup = 8;     // W rows whose first loads are issued together
 constexpr int kStreamDepth = 8;  // 64-entry chunks of a long W row requested per round trip
 constexpr int kDenseUnroll = 4;  // 256-column steps of a dense W block per pipeline stage
 typedef float vf4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ constexpr size_t score_lds_bytes(int tile_cols, int acc_bytes, bool ft, bool touched) {
+__host__ __device__ constexpr int res_cap(int kk) { return kk <= kResCap ? kResCap : (kk + 63) / 64 * 64; }
+__host__ __device__ constexpr size_t score_lds_bytes(int tile_cols, int acc_bytes, bool ft, bool touched, int kk = kResCap) {
     return static_cast<size_t>(tile_cols) * (acc_bytes + (ft ? 4 : 0)) + (touched ? kTouchCap * 2 : 0) + kListCap * 2 +
-           kResCap * (8 + 4 + 4) + 16;
+           res_cap(kk) * (8 + 4 + 4) + 16;
 }
 
 template <typename ACC>
@@ -133,14 +135,15 @@ struct TileLds {
 };
 
 template <typename ACC>
-__device__ __forceinline__ TileLds<ACC> carve_lds(unsigned char *smem, int S, bool ft, bool touched) {
+__device__ __forceinline__ TileLds<ACC> carve_lds(unsigned char *smem, int S, bool ft, bool touched, int kk) {
     TileLds<ACC> L;
+    const int rc = res_cap(kk);
     unsigned char *p = smem;
-    L.res_s = reinterpret_cast<ACC *>(p);          p += kResCap * 8;
+    L.res_s = reinterpret_cast<ACC *>(p);          p += rc * 8;
     L.acc = reinterpret_cast<ACC *>(p);            p += static_cast<size_t>(S) * sizeof(ACC);
     L.ft = reinterpret_cast<uint32_t *>(p);        if (ft) p += static_cast<size_t>(S) * 4;
-    L.res_i = reinterpret_cast<int *>(p);          p += kResCap * 4;
-    L.res_a = reinterpret_cast<uint32_t *>(p);     p += kResCap * 4;
+    L.res_i = reinterpret_cast<int *>(p);          p += rc * 4;
+    L.res_a = reinterpret_cast<uint32_t *>(p);     p += rc * 4;
     L.tlist = reinterpret_cast<uint16_t *>(p);     if (touched) p += kTouchCap * 2;
     L.clist = reinterpret_cast<uint16_t *>(p);     p += kListCap * 2;
     L.ccnt = reinterpret_cast<int *>(p);
@@ -188,6 +191,29 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
             if (sel_key(acc[c], zero_valid) != ninf) { mine = make_cand(c); have = true; }
         }
         return rank_and_store(have, mine, n_idx);
+    }
+
+    if (a.kk > 64) {
+        // more results than lanes: the lane-best threshold below cannot bound the answer.  Successive
+        // scans, each bounded above by the previously emitted candidate (rare: top_k >= 64 requests)
+        Cand<ACC> last; last.id = -1; last.score = ninf; last.aux = 0u;
+        int n_big = 0;
+        for (int r = 0; r < a.kk; ++r) {
+            Cand<ACC> b; b.id = -1; b.score = ninf; b.aux = 0u;
+            for (int t = lane; t < n_idx; t += 64) {
+                const int c = idx(t);
+                if (sel_key(acc[c], zero_valid) == ninf) continue;
+                const Cand<ACC> x = make_cand(c);
+                if (last.id >= 0 && !cand_better(last, x)) continue;
+                if (cand_better(x, b)) b = x;
+            }
+            const Cand<ACC> w = wave_best(b);
+            if (w.id < 0) break;
+            last = w;
+            if (lane == 0) { L.res_s[r] = w.score; L.res_i[r] = w.id; L.res_a[r] = w.aux; }
+            n_big = r + 1;
+        }
+        return n_big;
     }
 
     // pass 1: per-lane best key, then tau = kk-th largest lane best (lower bound of the answer)
@@ -318,17 +344,19 @@ __device__ __forceinline__ void emit_result(const ScoreArgs &a, const TileLds<AC
     const int lane = lane_id();
     if (a.direct) {
         const int n_fin = min(n_out, a.top_k);
-        if (lane < a.top_k) {
-            const long long o = static_cast<long long>(row) * a.top_k + lane;
-            const bool ok = lane < n_fin;
-            const ACC sc = ok ? L.res_s[lane] : NegInf<ACC>::value();
-            a.out_id[o] = ok ? global_col(a, L.res_i[lane]) : -1;
+        for (int l = lane; l < a.top_k; l += 64) {
+            const long long o = static_cast<long long>(row) * a.top_k + l;
+            const bool ok = l < n_fin;
+            const ACC sc = ok ? L.res_s[l] : NegInf<ACC>::value();
+            a.out_id[o] = ok ? global_col(a, L.res_i[l]) : -1;
             a.out_score[o] = static_cast<float>(sc);
             if (a.out_score64) a.out_score64[o] = static_cast<double>(sc);
-            if (a.out_aux) a.out_aux[o] = ok ? L.res_a[lane] : 0u;
+            if (a.out_aux) a.out_aux[o] = ok ? L.res_a[l] : 0u;
         }
         bool tie = false;
-        if (a.detect_ties && lane + 1 < n_out) tie = (L.res_s[lane] == L.res_s[lane + 1]);
+        if (a.detect_ties) {
+            for (int l = lane; l + 1 < n_out; l += 64) tie = tie || (L.res_s[l] == L.res_s[l + 1]);
+        }
         const unsigned long long any_tie = __ballot(tie);
         if (lane == 0) {
             a.out_cnt[row] = n_fin;
@@ -336,10 +364,10 @@ __device__ __forceinline__ void emit_result(const ScoreArgs &a, const TileLds<AC
         }
     } else {
         const size_t base = (static_cast<size_t>(row) * a.n_tiles + tile) * a.kk;
-        if (lane < n_out) {
-            reinterpret_cast<ACC *>(a.cand_score)[base + lane] = L.res_s[lane];
-            a.cand_id[base + lane] = global_col(a, L.res_i[lane]);
-            a.cand_aux[base + lane] = L.res_a[lane];
+        for (int l = lane; l < n_out; l += 64) {
+            reinterpret_cast<ACC *>(a.cand_score)[base + l] = L.res_s[l];
+            a.cand_id[base + l] = global_col(a, L.res_i[l]);
+            a.cand_aux[base + l] = L.res_a[l];
         }
         if (lane == 0) a.cand_cnt[static_cast<size_t>(row) * a.n_tiles + tile] = n_out;
     }
@@ -568,7 +596,7 @@ __global__ __launch_bounds__(64) void score_tiles_dense_kernel(ScoreArgs a) {
 
     const int lane = lane_id();
     const int S = a.tile_cols;
-    const TileLds<ACC> L = carve_lds<ACC>(smem, S, false, false);
+    const TileLds<ACC> L = carve_lds<ACC>(smem, S, false, false, a.kk);
     const ACC ninf = NegInf<ACC>::value();
     const int t0 = tile * S;
     const int ncol = min(S, a.n_cols - t0);
@@ -607,7 +635,7 @@ __global__ __launch_bounds__(64) void score_rows_kernel(ScoreArgs a, ACC *out, l
     const int row = static_cast<int>(w % a.n_rows);
     const int lane = lane_id();
     const int S = a.tile_cols;
-    const TileLds<ACC> L = carve_lds<ACC>(smem, S, false, false);
+    const TileLds<ACC> L = carve_lds<ACC>(smem, S, false, false, a.kk);
     const int t0 = tile * S;
     const int ncol = min(S, a.n_cols - t0);
     const int xrow = a.row_ids ? a.row_ids[row] : row;
@@ -627,7 +655,7 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
     const int S = a.tile_cols;
-    const TileLds<ACC> L = carve_lds<ACC>(smem, S, FT, true);
+    const TileLds<ACC> L = carve_lds<ACC>(smem, S, FT, true, a.kk);
     const ACC ninf = NegInf<ACC>::value();
     const ACC unt = untouched_value(ACC(0));
     for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
@@ -913,11 +941,11 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     debug_stage(st, "score: begin");
     if (tm.enabled) { timer_collect(tm); (void)hipEventRecord(tm.start, st); }
     if (sparse) {
-        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true);
+        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true, a.kk);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, false>), dim3(persistent_grid(lds, total)), dim3(64),
                            lds, st, a);
     } else {
-        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, false);
+        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, false, a.kk);
         const long long per_xcd = (total + 7) / 8;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_tiles_dense_kernel<ACC>), dim3(static_cast<unsigned>(per_xcd * 8)),
                            dim3(64), lds, st, a);
@@ -947,7 +975,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.kk = top_k;
         f.detect_ties = 0;
         f.queue = queue + 1;
-        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, true, true);
+        const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, true, true, f.kk);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, true>), dim3(persistent_grid(lds, total)), dim3(64),
                            lds, st, f);
         debug_stage(st, "score_sparse_kernel (exact ties)");
@@ -1009,8 +1037,8 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     if (n_tiles != (n_cols + tile_cols - 1) / tile_cols) return RTREC_ERR_INVALID_ARG;
     const int acc_bytes = acc_f64 ? 8 : 4;
     // the exact-tie instantiation keeps an accumulator AND a first-touch word per column in LDS
-    if (score_lds_bytes(tile_cols, acc_bytes, true, true) > 160u * 1024u) return RTREC_ERR_UNSUPPORTED;
-    if (top_k + 1 > kResCap || static_cast<long long>(n_tiles) * (top_k + 1) > 1024) return RTREC_ERR_UNSUPPORTED;
+    if (top_k > kMaxTopK || static_cast<long long>(n_tiles) * (top_k + 1) > 1024) return RTREC_ERR_UNSUPPORTED;
+    if (score_lds_bytes(tile_cols, acc_bytes, true, true, top_k + 1) > 160u * 1024u) return RTREC_ERR_UNSUPPORTED;
     if (static_cast<long long>(n_rows) * n_tiles >= (1ll << 31)) return RTREC_ERR_UNSUPPORTED;
     const ScoreWs L = score_ws_layout(n_rows, n_tiles, top_k);
     if (workspace_bytes < L.total) return RTREC_ERR_WORKSPACE;

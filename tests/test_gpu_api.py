@@ -166,3 +166,22 @@ def test_serving_shell_on_the_gpu_replays_the_reference_transcript(session):
         r = client.get(st["path"]) if st["method"] == "GET" else client.post(st["path"], json=st["json"], headers=st["headers"])
         assert r.status_code == st["status"], st
         assert r.json() == st["response"], st
+
+
+def test_large_top_k_through_the_api():
+    """top_k beyond one wave's lanes (the reference accepts any k): ids and order vs the oracle."""
+    from oracle import slim_oracle as so
+    from rtrec_amd import SLIM
+    from rtrec_amd.synth import interaction_matrix
+    X = interaction_matrix(400, 900, 30000, seed=12)
+    coo = X.tocoo()
+    m = SLIM(min_value=0, max_value=15, nn_feature_selection=40)
+    m.fit(list(zip(coo.row.tolist(), coo.col.tolist(), (1.7e9 + np.arange(coo.nnz)).tolist(), coo.data.astype(float).tolist())),
+          progress_bar=False)
+    users = list(range(0, 400, 7))
+    W = m.model.item_similarity.tocsr()
+    Xs = m.interactions.to_csr()
+    for k in (100, 300):
+        got = m.recommend_batch(users, top_k=k)
+        o_ids, _, o_cnt = so.recommend_batch(Xs[users], W, top_k=k, filter_interacted=True)
+        assert got == [o_ids[r, :o_cnt[r]].tolist() for r in range(len(users))]

@@ -195,7 +195,7 @@ def test_merge_topk_equals_unsharded(oracle):
 
 
 @pytest.mark.parametrize("tile_cols", [1024, 4096])
-@pytest.mark.parametrize("top_k", [1, 10, 50])
+@pytest.mark.parametrize("top_k", [1, 10, 50, 64, 200])    # > 63: the successive-scan selection
 def test_score_wide_catalogue_heavy_users(oracle, tile_cols, top_k):
     """Users that touch more columns than the touched list holds (> 1024 per tile: the full-tile scan /
     reset path), several tiles, dense W row blocks next to sparse ones, k from 1 to 50."""
