@@ -456,15 +456,25 @@ class SlimEngine:
         W["cval"] = be.to_dev(np.asarray(W_csc.data, dtype=np.float32))
         self._W = W
 
-    def _layout(self, compact: bool) -> Optional[Dict[str, Any]]:
+    def _layout(self, compact: bool, top_k: int = 10) -> Optional[Dict[str, Any]]:
+        """Tiled layout of this rank's shard.  The tile width is self.tile_cols unless the merge of the
+        per-tile lists (n_tiles * (top_k + 1) <= 1024 candidates per user) needs wider tiles; it is
+        capped by what the exact-tie pass fits in LDS (accumulator + first-touch word per column)."""
         W, be = self._W, self.be
-        if compact not in W["layouts"]:
+        acc = 8 if W["acc_f64"] else 4
+        max_tile = 256
+        while max_tile * 2 * (acc + 4) + 4096 + 16 * (top_k + 64) <= 160 * 1024 and max_tile < 32768:
+            max_tile *= 2
+        tile = min(self.tile_cols, max_tile)
+        width = W["col_hi"] - W["col_lo"]
+        if compact and "n_active" in W:
+            width = W["n_active"]
+        while tile < max_tile and -(-max(width, 1) // tile) * (top_k + 1) > 1024:
+            tile *= 2
+        key = (compact, tile)
+        if key not in W["layouts"]:
             lay = None
             if W["col_hi"] > W["col_lo"]:
-                # the exact-tie pass keeps an accumulator AND a first-touch word per column in LDS
-                tile = self.tile_cols
-                while tile > 256 and tile * ((8 if W["acc_f64"] else 4) + 4) + 8192 > 160 * 1024:
-                    tile //= 2
                 T = build_tiled_w(W["host"], W["col_lo"], W["col_hi"], tile, compact=compact,
                                   dense_fill=DENSE_ROW_FILL if compact else None)
                 if T.n_cols > 0:
@@ -477,8 +487,10 @@ class SlimEngine:
                                col_ids=be.to_dev(T.col_ids) if T.col_ids is not None else None,
                                col_map=be.to_dev(T.col_map) if T.col_map is not None else None,
                                row_hdr=be.to_dev(row_header_table(T)))
-            W["layouts"][compact] = lay
-        return W["layouts"][compact]
+                    if compact:
+                        W["n_active"] = T.n_cols
+            W["layouts"][key] = lay
+        return W["layouts"][key]
 
     # ------------------------------------------------------------------------------ score
     def _local_topk(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
@@ -490,7 +502,7 @@ class SlimEngine:
         aux = be.empty((n_rows, top_k), torch.int32)
         cnt = be.empty((n_rows,), torch.int32)
         sc64 = be.empty((n_rows, top_k), torch.float64) if W["acc_f64"] else None
-        lay = self._layout(compact=(mode == _native.TOPK_SPARSE))
+        lay = self._layout(compact=(mode == _native.TOPK_SPARSE), top_k=top_k)
         if lay is None:
             ids.fill_(-1); sc.fill_(float("-inf")); aux.zero_(); cnt.zero_()
             if sc64 is not None:

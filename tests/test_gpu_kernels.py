@@ -194,7 +194,7 @@ def test_merge_topk_equals_unsharded(oracle):
     assert np.array_equal(o_cnt.cpu().numpy(), cnt)
 
 
-@pytest.mark.parametrize("tile_cols", [1024, 4096])
+@pytest.mark.parametrize("tile_cols", [256, 1024, 4096])     # 256: the engine widens the tiles for large k
 @pytest.mark.parametrize("top_k", [1, 10, 50, 64, 200])    # > 63: the successive-scan selection
 def test_score_wide_catalogue_heavy_users(oracle, tile_cols, top_k):
     """Users that touch more columns than the touched list holds (> 1024 per tile: the full-tile scan /
