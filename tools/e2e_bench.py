@@ -2,7 +2,7 @@
 """End-to-end drop-in timing through the DataFrame API (the reference's own definition of
 "samples/sec": len(train) / (ingest + fit wall time), recommender.py:81,126).
 
-Same calls and the same ML-1M-shaped synthetic DataFrame as tools/time_reference.py runs against
+Same calls and the same ML-1M-shaped synthetic DataFrame as tests/calibration/time_reference.py runs against
 the real rtrec + scikit-learn (59,623 interactions/s bulk_fit, 520 users/s
 recommend_batch in the build container), here through rtrec_amd on the GPU:
     Recommender(SLIM(min_value=0, max_value=15, nn_feature_selection=50)).bulk_fit(df)
