@@ -362,13 +362,25 @@ class SlimEngine:
                 X["gram"], X["gram_n"] = be.gram_matrix(X, U, I, n_top), n_top
             gram = X["gram"]
 
-        def workspace(n_slots_: int):
-            key = (U, I, n_slots_, K if K > 0 else 0)
-            if key not in self._fit_ws:
-                if len(self._fit_ws) >= 2:
+        def workspace(n_slots_: int, role: str = "main"):
+            """(scratch, queue, slots of the scratch layout); `role` keeps the side-stream launch of the
+            heavy targets on a scratch of its own (the two kernels run concurrently).  A cached scratch of the same problem shape
+            with at least n_slots_ slots is reused as it is -- the kernel launches min(slots, targets)
+            workgroups, so extra slots are simply idle -- which keeps mini-batches of varying size
+            (online partial_fit) from re-allocating and re-initialising it every call."""
+            kk = K if K > 0 else 0
+            fits = [k for k in self._fit_ws
+                    if k[0] == U and k[1] == I and k[3] == kk and k[2] >= n_slots_ and k[4] == role]
+            if fits:
+                key = min(fits, key=lambda k: k[2])
+            else:
+                want = 1 << max(0, int(n_slots_ - 1).bit_length())          # next power of two
+                key = (U, I, int(min(max(want, n_slots_), max(slots, n_slots_))), kk, role)
+                if len(self._fit_ws) >= 4:
                     self._fit_ws.clear()
-                self._fit_ws[key] = be.fit_workspace(U, I, n_slots_, K)
-            return self._fit_ws[key]
+                self._fit_ws[key] = be.fit_workspace(U, I, key[2], K)
+            ws_, queue_ = self._fit_ws[key]
+            return ws_, queue_, key[2]
 
         # chunk so that the output block stays below ~1 GiB (matters for K=None, cap = I)
         chunk = max(1, min(n, int((1 << 30) // max(cap * 8, 1)))) if n else 1
@@ -378,16 +390,16 @@ class SlimEngine:
         niter_out = np.empty((n,), dtype=np.int32)
         trace_out = np.zeros((n, 4), dtype=np.int64) if trace else None
 
-        def launch(lo_: int, hi_: int, n_slots_: int):
+        def launch(lo_: int, hi_: int, n_slots_: int, role: str = "main"):
             tg = targets[lo_:hi_]
             m = len(tg)
-            ws, queue = workspace(n_slots_)
+            ws, queue, ws_slots = workspace(n_slots_, role)
             d = dict(lo=lo_, hi=hi_, t=be.to_dev(tg.astype(np.int32)), items=be.empty((m, cap), torch.int32),
                      coef=be.empty((m, cap), torch.float32), count=be.empty((m,), torch.int32),
                      niter=be.empty((m,), torch.int32), trace=be.zeros((m, 4), torch.int64) if trace else None,
                      ws=(ws, queue))   # keeps the scratch alive while the kernel runs
             be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
-                           n_slots_, d["trace"], gram)
+                           ws_slots, d["trace"], gram)
             return d
 
         def collect(d):
@@ -405,7 +417,7 @@ class SlimEngine:
             side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(be.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                heavy = launch(0, n_heavy, min(n_heavy, FIT_HEAVY_SLOTS))
+                heavy = launch(0, n_heavy, min(n_heavy, FIT_HEAVY_SLOTS), role="heavy")
         for s in range(n_heavy, n, chunk):
             collect(launch(s, min(n, s + chunk), min(slots, max(1, min(n, s + chunk) - s))))
         if heavy is not None:
@@ -429,7 +441,7 @@ class SlimEngine:
         be, X, torch = self.be, self._X, self.be.torch
         m = len(targets)
         n_slots = max(1, min(slots, m))
-        key = (U, I, n_slots, 0)
+        key = (U, I, n_slots, 0, "overflow")
         if key not in self._fit_ws:
             self._fit_ws[key] = be.fit_workspace(U, I, n_slots, 0)
         ws, queue = self._fit_ws[key]
