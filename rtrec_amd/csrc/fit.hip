@@ -58,7 +58,7 @@ struct FitArgs {
     float *w_all;    // [slots][I]   ALL path only
     int *long_list;  // [slots][I]   ALL path only: columns longer than lane_max, per duality-gap evaluation
     int *queue;
-    long long *trace;   // optional [n_targets][4]: start, prep end, end (100 MHz ticks), folded entries
+    long long *trace;   // optional [n_targets][8]: start, prep end, end (100 MHz ticks), folded entries, 4 kernel-specific phase counters
     const double *gram;       // optional [gram_n][gram_n]: X_p . X_q of the gram_n tracked (popular) items
     const int *gram_index;    // optional [I]: item -> row of `gram`, or -1
     int gram_n;
@@ -904,7 +904,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
     }
     for (int tt = lane; tt < tc; tt += 64) s[touched[tt]] = __uint_as_float(kUntouched);
     if (a.trace && lane == 0) {
-        long long *tr = a.trace + static_cast<size_t>(t) * 4;
+        long long *tr = a.trace + static_cast<size_t>(t) * 8;
         tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
     }
 }
@@ -1032,11 +1032,14 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
         return dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf);
     };
 
+    long long ph_rng = 0, ph_dots = 0, ph_loop = 0, ph_gap = 0;      // phase clocks (trace only)
+    const bool prof = a.trace != nullptr;
     for (; !skip_cd && n_iter < max_iter; ++n_iter) {
         float w_max = 0.0f, d_w_max = 0.0f;
         for (int f0 = 0; f0 < nf; f0 += 64) {
             const int nb = min(64, nf - f0);
             int p_l = 0;
+            const long long c0 = prof ? static_cast<long long>(wall_clock64()) : 0;
             for (int k = 0; k < nb; ++k) {
                 const int p = static_cast<int>(rand_int(static_cast<uint32_t>(nf), rng));
                 if (lane == k) p_l = p;
@@ -1054,7 +1057,10 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
                 if (short_l && lane >= from)
                     tmp_l = dirty ? lane_dot(a.crow, a.cval, R, b_l, e_l, wold_l) : s_value(p_l);
             };
+            const long long c1 = prof ? static_cast<long long>(wall_clock64()) : 0;
             lane_dots(0);
+            const long long c2 = prof ? static_cast<long long>(wall_clock64()) : 0;
+            ph_rng += c1 - c0; ph_dots += c2 - c1;
             int k = 0;
             while (k < nb) {
                 float wnew_l = 0.0f;
@@ -1094,8 +1100,10 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
                 w_max = aw > w_max ? aw : w_max;
                 k = q + 1;
             }
+            if (prof) ph_loop += static_cast<long long>(wall_clock64()) - c2;
         }
 
+        const long long g0 = prof ? static_cast<long long>(wall_clock64()) : 0;
         if (w_max == 0.0f || __fdiv_rn(d_w_max, w_max) < a.cfg.tol || n_iter == max_iter - 1) {
             float dn = 0.0f;       // the target itself contributes XtA = 0, so the maximum is >= 0
             float R_norm2, Ry, w_norm2 = 0.0f, l1 = 0.0f;
@@ -1188,6 +1196,7 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
             const double t3 = 0.5 * static_cast<double>(beta) * static_cast<double>(__fadd_rn(1.0f, __fmul_rn(cst, cst))) *
                               static_cast<double>(w_norm2);
             gap = static_cast<float>(static_cast<double>(gap) + (static_cast<double>(t12) + t3));
+            if (prof) ph_gap += static_cast<long long>(wall_clock64()) - g0;
             if (gap < tol_s) break;
         }
     }
@@ -1227,8 +1236,9 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
     for (int k = lane; k < n_ever; k += 64) { const int p = ever_list[k]; w_all[p] = 0.0f; ever_flag[p] = 0; }
     for (int tt = lane; tt < tc; tt += 64) s[touched[tt]] = __uint_as_float(kUntouched);
     if (a.trace && lane == 0) {
-        long long *tr = a.trace + static_cast<size_t>(t) * 4;
+        long long *tr = a.trace + static_cast<size_t>(t) * 8;
         tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
+        tr[4] = ph_rng; tr[5] = ph_dots; tr[6] = ph_loop; tr[7] = ph_gap;
     }
 }
 
@@ -1671,7 +1681,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     for (int tt = tid; tt < tc; tt += kMwThreads) s[touched[tt]] = __uint_as_float(kUntouched);
     __syncthreads();
     if (a.trace && tid == 0) {
-        long long *tr = a.trace + static_cast<size_t>(t) * 4;
+        long long *tr = a.trace + static_cast<size_t>(t) * 8;
         tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
     }
 }

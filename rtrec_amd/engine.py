@@ -388,7 +388,7 @@ class SlimEngine:
         coef_out = np.empty((n, cap), dtype=np.float32)
         count_out = np.empty((n,), dtype=np.int32)
         niter_out = np.empty((n,), dtype=np.int32)
-        trace_out = np.zeros((n, 4), dtype=np.int64) if trace else None
+        trace_out = np.zeros((n, 8), dtype=np.int64) if trace else None
 
         def launch(lo_: int, hi_: int, n_slots_: int, role: str = "main"):
             tg = targets[lo_:hi_]
@@ -396,7 +396,7 @@ class SlimEngine:
             ws, queue, ws_slots = workspace(n_slots_, role)
             d = dict(lo=lo_, hi=hi_, t=be.to_dev(tg.astype(np.int32)), items=be.empty((m, cap), torch.int32),
                      coef=be.empty((m, cap), torch.float32), count=be.empty((m,), torch.int32),
-                     niter=be.empty((m,), torch.int32), trace=be.zeros((m, 4), torch.int64) if trace else None,
+                     niter=be.empty((m,), torch.int32), trace=be.zeros((m, 8), torch.int64) if trace else None,
                      ws=(ws, queue))   # keeps the scratch alive while the kernel runs
             be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
                            ws_slots, d["trace"], gram)

@@ -41,7 +41,9 @@ def main():
     for i in np.argsort(-dur)[:6]:
         print(json.dumps({"item": int(tg[i]), "nnz": int(col_nnz[i]), "dur_s": float(dur[i]), "prep_s": float((tr[i, 1] - tr[i, 0]) * 1e-8),
                           "sweeps": int(n_iter[i]), "nonzero": int(count[i]), "folded": float(tr[i, 3]),
-                          "start_s": float((tr[i, 0] - tr[:, 0].min()) * 1e-8)}))
+                          "start_s": float((tr[i, 0] - tr[:, 0].min()) * 1e-8),
+                          "rng_s": float(tr[i, 4] * 1e-8), "dots_s": float(tr[i, 5] * 1e-8), "loop_s": float(tr[i, 6] * 1e-8),
+                          "gap_s": float(tr[i, 7] * 1e-8)}))
 
 
 if __name__ == "__main__":
