@@ -5,12 +5,13 @@
 // two top-k helpers (_sparse_topk_indicies :782-818, _dense_topk_indicies :744-779).
 //
 // Layout: W is cut into column tiles of `tile_cols` columns; each tile is a CSR over all item
-// rows with tile-local uint16 column ids (6 bytes per stored weight).  One wavefront owns one
-// (user row, tile) job: it streams the W rows of the user's items IN ASCENDING ITEM ORDER and
-// adds x_ui * W[i, c] into an LDS accumulator with ds_add_f32 / ds_add_f64.  LDS operations of
-// one wave execute in program order and a W row never repeats a column, so every accumulator
-// receives its addends in exactly scipy's csr_matmat order -> bit-identical scores.  The tile is
-// then reduced to its top-(k+1) in registers/LDS and a second kernel merges the tiles of a row.
+// rows with tile-local uint16 column ids (6 bytes per stored weight; well-filled row segments are
+// zero-padded dense blocks).  One wavefront owns one (user row, tile) job: it streams the W rows of
+// the user's items IN ASCENDING ITEM ORDER and adds x_ui * W[i, c] into an LDS accumulator with a
+// plain read-modify-write (no atomics: one wave owns the tile).  LDS operations of one wave execute
+// in program order and a W row never repeats a column, so every accumulator receives its addends
+// in exactly scipy's csr_matmat order -> bit-identical scores.  The tile is then reduced to its
+// top-(k+1) in registers/LDS and a second kernel merges the tiles of a row.
 //
 // Tie order of the SPARSE mode (Python's stable sorted() over scipy's reverse-first-touch
 // product order) needs the first-touch rank of a column, which costs a second LDS array.  The
