@@ -104,7 +104,8 @@ def main() -> None:
     if world > 1:
         dist.barrier()
     t0 = time.time()
-    tg, items, coef, count, n_iter = eng.fit_columns(np.arange(lo, hi), nn_feature_selection=K)
+    mine = eng.owned_columns(np.arange(I))       # this rank's fit targets, balanced by column length
+    tg, items, coef, count, n_iter = eng.fit_columns(mine, nn_feature_selection=K)
     torch.cuda.synchronize()
     fit_local = time.time() - t0
     rows, cols, vals = coefficients_to_updates(tg, items, coef, count)
@@ -114,12 +115,12 @@ def main() -> None:
     col_nnz_all = np.diff(Xc.indptr).astype(np.float64)
     row_nnz_all = np.diff(X.indptr).astype(np.float64)
     owned = np.zeros(I, dtype=bool)
-    owned[lo:hi] = True
+    owned[mine] = True
     # sum over owned targets j of sum_{u in U_j} |I_u|  ==  sum over interactions (u, j owned) of |I_u|
     cooc = float(np.repeat(row_nnz_all, np.diff(X.indptr))[owned[X.indices]].sum())
     sel_mask = np.arange(items.shape[1])[None, :] < count[:, None]
     feat = float(col_nnz_all[items[sel_mask]].sum())
-    fit_algo_bytes = 8.0 * float(col_nnz_all[lo:hi].sum()) + 8.0 * cooc + 8.0 * feat + 8.0 * float(count.sum())
+    fit_algo_bytes = 8.0 * float(col_nnz_all[mine].sum()) + 8.0 * cooc + 8.0 * feat + 8.0 * float(count.sum())
     if world > 1:
         parts = [None] * world
         dist.all_gather_object(parts, (rows, cols, vals))

@@ -294,9 +294,21 @@ class SlimEngine:
 
     # ------------------------------------------------------------------------------ fit
     def owned_columns(self, columns: np.ndarray) -> np.ndarray:
-        lo, hi = shard_bounds(self.n_items, self.world_size, self.rank)
+        """The part of `columns` (the same list on every rank) THIS rank fits.  Fitting has no
+        collective and a popular item costs far more than a rare one, so the targets are dealt out
+        by column length: sorted by nnz(X[:, j]) descending and dealt in snake order (ranks 0..G-1,
+        then G-1..0, ...) -- every rank gets the same mix of heavy and light targets.  Which
+        rank fitted a column is independent of which rank scores it: W is assembled on every rank
+        after the fit and re-sharded by contiguous column block for scoring (shard_bounds)."""
         columns = np.asarray(columns, dtype=np.int64)
-        return columns[(columns >= lo) & (columns < hi)]
+        if self.world_size == 1:
+            return columns
+        nnz = self._X["col_nnz"][columns] if "col_nnz" in self._X else np.zeros(len(columns), dtype=np.int64)
+        order = np.lexsort((columns, -nnz))            # nnz descending, ties by id: identical on all ranks
+        pos = np.arange(len(columns))
+        blk, off = pos // self.world_size, pos % self.world_size
+        owner = np.where(blk % 2 == 0, off, self.world_size - 1 - off)
+        return np.sort(columns[order[owner == self.rank]])
 
     def fit_columns(self, targets: Sequence[int], alpha: float = 0.1, l1_ratio: float = 0.1,
                     positive: bool = True, max_iter: int = 100, tol: float = 1e-4, random_state: Optional[int] = 43,

@@ -307,3 +307,27 @@ def test_csc_export_of_a_wide_catalogue_matches_scipy():
     assert np.array_equal(C.data, ref.data)
     part = st.to_csc(select_items=[int(x) for x in np.unique(i)[:50]])
     assert part.nnz == int(np.isin(R.tocoo().col, np.unique(i)[:50]).sum())
+
+
+def test_fit_targets_are_dealt_out_by_column_length():
+    """owned_columns: disjoint, complete, identical on every rank, and balanced in work (nnz)."""
+    from tests.cpu_backend import OracleBackend
+    from rtrec_amd.engine import SlimEngine
+    from rtrec_amd.synth import interaction_matrix
+    X = interaction_matrix(3000, 500, 60000, seed=2)
+    Xc = X.tocsc()
+    cols = np.arange(500)
+    parts, loads = [], []
+    for r in range(4):
+        eng = SlimEngine(backend=OracleBackend(), rank=r, world_size=4)
+        eng.set_interactions(Xc, X)
+        mine = eng.owned_columns(cols)
+        parts.append(mine)
+        loads.append(int(np.diff(Xc.indptr)[mine].sum()))
+    assert np.array_equal(np.sort(np.concatenate(parts)), cols)
+    assert max(loads) <= 1.1 * min(loads), loads
+    sub = np.array([7, 3, 400, 12, 250])
+    got = [SlimEngine(backend=OracleBackend(), rank=r, world_size=2) for r in range(2)]
+    for g in got:
+        g.set_interactions(Xc, X)
+    assert np.array_equal(np.sort(np.concatenate([g.owned_columns(sub) for g in got])), np.sort(sub))
