@@ -121,7 +121,8 @@ typedef struct {
     /* per-target trace for profiling (tools/fit_trace.py), or NULL: d_trace[t*8 + 0..3] = start, end of
      * the X^T y / feature-selection step, end of the target (ticks of the 100 MHz constant clock) and
      * the number of column entries folded in order by the coordinate descent; [4..7] are kernel-
-     * specific phase clocks (every-item path: draw generation, lane-private dots, commit loop, gap) */
+     * specific phase clocks (every-item path: draw generation, lane-private dots, commit loop, gap;
+     * latency-mode kernel: ordered folds, residual updates, duality gaps, s_memtime cycles in the folds) */
     int64_t       *d_trace;
     /* Gram matrix of the gram_n most popular items, or NULL: d_gram[a * gram_n + b] = X[:, item_a] .
      * X[:, item_b] in float64 with relative error <= gram_rel_err (< 1e-6), d_gram_index[i] = row of item

@@ -1270,10 +1270,10 @@ __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(Fit
 constexpr int kMwWaves = 8;
 constexpr int kMwThreads = kMwWaves * 64;
 constexpr int kProducers = kMwWaves - 1;
-constexpr int kProdDepth = 4;    // chunks a producer wave keeps in flight
+constexpr int kProdDepth = 8;    // chunks a producer wave keeps in flight
 constexpr int kMwMaxTargets = 2048;  // calls with at most this many targets use the multi-wave kernel
 constexpr int kColWalkMinRows = 1024;  // targets with at least this many users take the column-walk X^T y
-constexpr int kRing = 64;        // ring slots of 64 products (>= kProducers * kProdDepth, power of 2)
+constexpr int kRing = 128;       // ring slots of 64 products (>= kProducers * kProdDepth, power of 2)
 
 struct MwLds {
     float *ring;   // [kRing][64]
@@ -1305,6 +1305,84 @@ __device__ __forceinline__ void lds_store_release(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Ordered fold of one 64-product chunk held as one float4 per lane in lanes 0..15 (product i = component
+// i%4 of lane i/4): lane 0 adds them left to right, fetching lane n's components with the DPP modifier
+// row_shl:n on the product operand.  That operand is written by an LDS read, not by a VALU instruction, so
+// no DPP wait states apply; the accumulator is the plain second source.  64 instructions per 64 products
+// and nothing else on the chain: no broadcast reads, no v_readlane, no SGPR traffic.  Lanes 0..15 must be
+// enabled in EXEC (DPP does not read disabled lanes); only lane 0's result is meaningful.
+__device__ __forceinline__ float chain64_dpp(float acc, const float4 &p) {
+    asm volatile(
+        "v_add_f32 %0, %1, %0\n\t"
+        "v_add_f32 %0, %2, %0\n\t"
+        "v_add_f32 %0, %3, %0\n\t"
+        "v_add_f32 %0, %4, %0\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %0 row_shl:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %0 row_shl:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %3, %0 row_shl:15 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %4, %0 row_shl:15 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(p.x), "v"(p.y), "v"(p.z), "v"(p.w)
+        : "memory");
+    return acc;
+}
+
 // Ordered fold of one stream of 64-element chunks.
 //   MODE 0: sum over column entries [b, e) of (R[row] (+ x*w_old)) * x      (dot / XtA)
 //   MODE 1: sum over r in [b, e) of R[r]*R[r]                                (R . R)
@@ -1313,47 +1391,92 @@ __device__ __forceinline__ void lds_store_release(int *p, int v) {
 template <int MODE>
 __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, const MwLds &M,
                          int b, int e, float w_old, int wave, int lane, int &seq) {
-    const int n_chunks = (e - b + 63) >> 6;
+    // padded to whole groups of four chunks: the extra products are +0.0 and never change the sum
+    const int n_chunks = (((e - b + 63) >> 6) + 3) & ~3;
     float tmp = 0.0f;
     if (wave == 0) {
+        // The chain of dependent v_add_f32 is the critical path of a popular target (~1e8 entries), so
+        // nothing else may sit on it: the ring is read half a chunk (8 x ds_read_b128, uniform address =
+        // LDS broadcast) AHEAD of the adds, the ready flag of the next chunk is requested before the
+        // adds of this one and tested after them, and `done` is published every fourth chunk.
+        // Consumer: lanes 0..15 hold a chunk (one ds_read_b128 each = ONE LDS instruction per chunk), lane 0
+        // folds it with 64 DPP adds (chain64_dpp).  A wave issues in order, so every other instruction
+        // sits on the chain: the loop therefore works in groups of four chunks (n_chunks is padded to a
+        // multiple of four with +0.0 products) -- the ring reads of group g+1 and the ready flags of group
+        // g+2 are requested before the 256 adds of group g, and `done` is published once per group.
         __builtin_amdgcn_s_setprio(3);
-        for (int c = 0; c < n_chunks; ++c) {
-            const int G = seq + c, slot = G & (kRing - 1);
-            while (lds_load_acquire(&M.ready[slot]) != G + 1) __builtin_amdgcn_s_sleep(1);
-            const float4 *p4 = reinterpret_cast<const float4 *>(M.ring + slot * 64);
+        if (n_chunks > 0 && lane < 16) {
+            const float4 *ring4 = reinterpret_cast<const float4 *>(M.ring);
+            auto slot_of = [&](int c) { return (seq + c) & (kRing - 1); };
+            float4 A[4], B[4];
+            int f[4];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float4 v = p4[k];     // uniform address: LDS broadcast
-                tmp = __fadd_rn(tmp, v.x); tmp = __fadd_rn(tmp, v.y); tmp = __fadd_rn(tmp, v.z); tmp = __fadd_rn(tmp, v.w);
+            for (int k = 0; k < 4; ++k) {
+                while (lds_load_acquire(&M.ready[slot_of(k)]) != seq + k + 1) __builtin_amdgcn_s_sleep(1);
+                A[k] = ring4[slot_of(k) * 16 + lane];
             }
-            if (lane == 0) lds_store_release(M.done, G + 1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(4 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int c = 0; c < n_chunks; c += 4) {
+                if (c + 4 < n_chunks) {
+                    while ((f[0] != seq + c + 5) | (f[1] != seq + c + 6) | (f[2] != seq + c + 7) | (f[3] != seq + c + 8)) {
+                        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            f[k] = __hip_atomic_load(&M.ready[slot_of(c + 4 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+                for (int k = 0; k < 4; ++k) B[k] = ring4[slot_of(c + 4 + k) * 16 + lane];     // past the end: stale, unused
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(c + 8 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                tmp = chain64_dpp(tmp, A[0]);
+                tmp = chain64_dpp(tmp, A[1]);
+                tmp = chain64_dpp(tmp, A[2]);
+                tmp = chain64_dpp(tmp, A[3]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) A[k] = B[k];
+                if (lane == 0) lds_store_release(M.done, seq + c + 4);
+            }
         }
+        tmp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tmp)));
         __builtin_amdgcn_s_setprio(0);
     } else {
+        // Producers are latency machines: a round is one index load and one dependent gather, so the
+        // indices of round k+1 are requested before the gathers of round k are consumed (one memory
+        // round trip per round instead of two) and a round carries kProdDepth chunks per wave.
         const bool add_back = (w_old != 0.0f);
-        for (int c0 = wave - 1; c0 < n_chunks; c0 += kProducers * kProdDepth) {
-            float prod[kProdDepth];
-            int rr[kProdDepth];
-            float xx[kProdDepth];
+        constexpr int kStride = kProducers * kProdDepth;
+        int rr[kProdDepth], rn[kProdDepth];
+        float xx[kProdDepth], xn[kProdDepth];
+        auto load_idx = [&](int c0, int (&r)[kProdDepth], float (&x)[kProdDepth]) {
 #pragma unroll
-            for (int u = 0; u < kProdDepth; ++u) {       // all index / value loads first
+            for (int u = 0; u < kProdDepth; ++u) {
                 const int c = c0 + kProducers * u;
                 const int o = b + c * 64 + lane;
-                rr[u] = -1; xx[u] = 0.0f;
+                r[u] = -1; x[u] = 0.0f;
                 if (c < n_chunks && o < e) {
-                    if (MODE == 0) { rr[u] = crow[o]; xx[u] = cval[o]; }
-                    else rr[u] = o;
+                    if (MODE == 0) { r[u] = crow[o]; x[u] = cval[o]; }
+                    else r[u] = o;
                 }
             }
+        };
+        int c0 = wave - 1;
+        if (c0 < n_chunks) load_idx(c0, rr, xx);
+        for (; c0 < n_chunks; c0 += kStride) {
+            float prod[kProdDepth];
 #pragma unroll
-            for (int u = 0; u < kProdDepth; ++u) {       // then all gathers
-                float v = 0.0f;
-                if (rr[u] >= 0) v = R[rr[u]];
+            for (int u = 0; u < kProdDepth; ++u) prod[u] = (rr[u] >= 0) ? R[rr[u]] : 0.0f;     // gathers
+            if (c0 + kStride < n_chunks) load_idx(c0 + kStride, rn, xn);
+#pragma unroll
+            for (int u = 0; u < kProdDepth; ++u) {
                 if (MODE == 0) {
+                    float v = prod[u];
                     if (add_back) v = __fadd_rn(v, __fmul_rn(xx[u], w_old));
                     prod[u] = (rr[u] >= 0) ? __fmul_rn(v, xx[u]) : 0.0f;
                 } else {
-                    prod[u] = __fmul_rn(v, v);
+                    prod[u] = __fmul_rn(prod[u], prod[u]);
                 }
             }
 #pragma unroll
@@ -1365,10 +1488,48 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
                 M.ring[slot * 64 + lane] = prod[u];
                 if (lane == 0) lds_store_release(&M.ready[slot], G + 1);
             }
+#pragma unroll
+            for (int u = 0; u < kProdDepth; ++u) { rr[u] = rn[u]; xx[u] = xn[u]; }
         }
     }
     seq += n_chunks;
     return tmp;
+}
+
+// R[r] <- (R[r] + x*w_old) - x*w_new over the column by all threads of the workgroup (element-wise,
+// order free).  Latency-bound like the producers: kUpdDepth entries per thread and round, and the
+// indices of the next round are requested before the gathers of this one are consumed.
+constexpr int kUpdDepth = 8;
+__device__ void mw_update(const int *__restrict__ crow, const float *__restrict__ cval, float *R, int b, int e,
+                          float w_old, float w_new, int tid) {
+    int r[kUpdDepth], rn[kUpdDepth];
+    float x[kUpdDepth], xn[kUpdDepth];
+    auto load_idx = [&](int o0, int (&rr)[kUpdDepth], float (&xx)[kUpdDepth]) {
+#pragma unroll
+        for (int k = 0; k < kUpdDepth; ++k) {
+            const int o = o0 + k * kMwThreads;
+            rr[k] = -1; xx[k] = 0.0f;
+            if (o < e) { rr[k] = crow[o]; xx[k] = cval[o]; }
+        }
+    };
+    int o = b + tid;
+    if (o < e) load_idx(o, r, x);
+    for (; o < e; o += kUpdDepth * kMwThreads) {
+        float v[kUpdDepth];
+#pragma unroll
+        for (int k = 0; k < kUpdDepth; ++k) v[k] = (r[k] >= 0) ? R[r[k]] : 0.0f;
+        if (o + kUpdDepth * kMwThreads < e) load_idx(o + kUpdDepth * kMwThreads, rn, xn);
+#pragma unroll
+        for (int k = 0; k < kUpdDepth; ++k) {
+            if (r[k] < 0) continue;
+            float t = v[k];
+            if (w_old != 0.0f) t = __fadd_rn(t, __fmul_rn(x[k], w_old));
+            if (w_new != 0.0f) t = __fsub_rn(t, __fmul_rn(x[k], w_new));
+            R[r[k]] = t;
+        }
+#pragma unroll
+        for (int k = 0; k < kUpdDepth; ++k) { r[k] = rn[k]; x[k] = xn[k]; }
+    }
 }
 
 // Screening pass (see screen_pass) by all threads of the workgroup; every thread returns the
@@ -1484,7 +1645,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     const int ny = ye - yb;
 
     const long long tr0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
-    long long tr_folded = 0;
+    long long tr_folded = 0, ph_fold = 0, ph_upd = 0, ph_gap = 0, ph_cyc = 0;
     if (tid < kRing) M.ready[tid] = 0;
     if (tid == 0) *M.done = 0;
     int seq = 0;
@@ -1527,7 +1688,10 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                 if (w_old == 0.0f && e - b >= a.screen_min && e - b <= kScreenMaxLen)
                     screened = screen_stays_zero(mw_screen(a.crow, a.cval, R, M, b, e, tid), alpha, positive, w_new);
                 if (!screened) {
+                    const long long c0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
+                    const long long k0 = a.trace ? static_cast<long long>(__builtin_amdgcn_s_memtime()) : 0;
                     const float tmp = mw_fold<0>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq);
+                    if (a.trace) { ph_fold += static_cast<long long>(wall_clock64()) - c0; ph_cyc += static_cast<long long>(__builtin_amdgcn_s_memtime()) - k0; }
                     tr_folded += e - b;
                     upd ^= 1;
                     if (tid == 0) M.bc_f[2 + upd] = cd_update(tmp, alpha, beta, nrm, positive);
@@ -1545,31 +1709,9 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                     dirty = true;
                     __syncthreads();
                 }
-                {   // element-wise, order free: 4 gathers in flight per thread
-                    int o = b + tid;
-                    for (; o + 3 * kMwThreads < e; o += 4 * kMwThreads) {
-                        int r[4];
-                        float x[4], v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) { r[k] = a.crow[o + k * kMwThreads]; x[k] = a.cval[o + k * kMwThreads]; }
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) v[k] = R[r[k]];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            if (w_old != 0.0f) v[k] = __fadd_rn(v[k], __fmul_rn(x[k], w_old));
-                            if (w_new != 0.0f) v[k] = __fsub_rn(v[k], __fmul_rn(x[k], w_new));
-                            R[r[k]] = v[k];
-                        }
-                    }
-                    for (; o < e; o += kMwThreads) {
-                        const int r = a.crow[o];
-                        const float x = a.cval[o];
-                        float v = R[r];
-                        if (w_old != 0.0f) v = __fadd_rn(v, __fmul_rn(x, w_old));
-                        if (w_new != 0.0f) v = __fsub_rn(v, __fmul_rn(x, w_new));
-                        R[r] = v;
-                    }
-                }
+                const long long c0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
+                mw_update(a.crow, a.cval, R, b, e, w_old, w_new, tid);
+                if (a.trace) { __syncthreads(); ph_upd += static_cast<long long>(wall_clock64()) - c0; }
                 if (tid == 0) f_ever[p] = 1;
             }
             if (changed || touch_r) __syncthreads();
@@ -1579,6 +1721,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
             w_max = aw > w_max ? aw : w_max;
         }
 
+        const long long g0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
         if (w_max == 0.0f || __fdiv_rn(d_w_max, w_max) < a.cfg.tol || n_iter == max_iter - 1) {
             float dn = 0.0f;
             bool dn_init = false;
@@ -1661,6 +1804,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                 stop = M.bc_i[2] != 0;
                 __syncthreads();
             }
+            if (a.trace) ph_gap += static_cast<long long>(wall_clock64()) - g0;
             if (stop) break;
         }
     }
@@ -1683,10 +1827,11 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     if (a.trace && tid == 0) {
         long long *tr = a.trace + static_cast<size_t>(t) * 8;
         tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
+        tr[4] = ph_fold; tr[5] = ph_upd; tr[6] = ph_gap; tr[7] = ph_cyc;
     }
 }
 
-__global__ __launch_bounds__(kMwThreads) void fit_columns_mw_kernel(FitArgs a) {
+__global__ __launch_bounds__(kMwThreads, 4) void fit_columns_mw_kernel(FitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int slot = blockIdx.x;
     const int K = min(a.cfg.top_features, a.I);
