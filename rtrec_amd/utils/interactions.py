@@ -33,14 +33,25 @@ _DELTA_MERGE_MIN = 1 << 16
 
 class _Block:
     """Sorted (key, value, timestamp) columns."""
-    __slots__ = ("key", "val", "ts", "_perm", "_iptr")
+    __slots__ = ("key", "val", "ts", "_perm", "_iptr", "_rows_im", "_val_im", "_ts_im", "_d32_im")
 
     def __init__(self, key=None, val=None, ts=None):
         self.key = np.empty(0, np.int64) if key is None else key
         self.val = np.empty(0, np.float64) if val is None else val
         self.ts = np.empty(0, np.float64) if ts is None else ts
+        self._reset_index()
+
+    def _reset_index(self) -> None:
         self._perm = None
         self._iptr = None
+        self._rows_im = None
+        self.values_changed()
+
+    def values_changed(self) -> None:
+        """val / ts were overwritten in place (same keys): the item-major value mirrors are stale."""
+        self._val_im = None
+        self._ts_im = None
+        self._d32_im = None
 
     def __len__(self) -> int:
         return int(self.key.shape[0])
@@ -50,18 +61,36 @@ class _Block:
 
     def __setstate__(self, st):
         self.key, self.val, self.ts = st
-        self._perm = None
-        self._iptr = None
+        self._reset_index()
 
     def item_index(self, n_items: int) -> Tuple[np.ndarray, np.ndarray]:
         """(perm, iptr): positions of the entries in item-major order and the CSC-style pointer over
-        items.  Built lazily, valid until the block's key set changes."""
-        if self._iptr is None or self._iptr.shape[0] != n_items + 1:
+        items.  Built lazily, valid until the block's key set changes; a catalogue that has grown since
+        (items this block has never seen) only pads the pointer."""
+        if self._iptr is None:
             items = self.key & _MASK
+            own = int(items.max()) + 1 if len(self) else 0
             self._perm = np.argsort(items, kind="stable")        # users stay ascending inside an item
-            self._iptr = np.zeros(n_items + 1, dtype=np.int64)
-            np.cumsum(np.bincount(items, minlength=n_items), out=self._iptr[1:])
+            self._iptr = np.zeros(own + 1, dtype=np.int64)
+            np.cumsum(np.bincount(items, minlength=own), out=self._iptr[1:])
+        if self._iptr.shape[0] < n_items + 1:
+            self._iptr = np.concatenate([self._iptr, np.full(n_items + 1 - self._iptr.shape[0], self._iptr[-1])])
         return self._perm, self._iptr
+
+    def item_major(self, n_items: int, static_values: bool):
+        """(iptr, rows, val, ts, data32): the block's columns mirrored in item-major (CSC) order, so the
+        export of selected item columns is a copy of contiguous slices instead of three random gathers
+        and two sorts.  `data32` (float32 values) is kept only when values do not decay with time."""
+        perm, iptr = self.item_index(n_items)
+        if self._rows_im is None:
+            self._rows_im = (self.key[perm] >> _SHIFT).astype(np.int32)
+        if self._val_im is None:
+            self._val_im = self.val[perm]
+            self._ts_im = self.ts[perm]
+            self._d32_im = None
+        if static_values and self._d32_im is None:
+            self._d32_im = self._val_im.astype(np.float32)
+        return iptr, self._rows_im, self._val_im, self._ts_im, self._d32_im
 
     def find(self, keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
         """(found mask, position) of each key."""
@@ -82,6 +111,7 @@ def _merge_blocks(old: _Block, new: _Block) -> _Block:
     if found.any():   # overwrite in place, append the rest
         old.val[pos[found]] = new.val[found]
         old.ts[pos[found]] = new.ts[found]
+        old.values_changed()
         rest = ~found
         if not rest.any():
             return old
@@ -408,8 +438,62 @@ class UserItemInteractions:
         m.has_sorted_indices = True
         return m
 
+    _ITEM_MAJOR_MIN = 1 << 15      # smaller base blocks are exported through the generic path
+
+    def _csc_selected(self, items: np.ndarray) -> csc_matrix:
+        """CSC with only the columns `items` (sorted, unique) populated -- the matrix a mini-batch refit
+        works on (slim.py:33-36).  The base block's item-major mirror yields the selected columns as
+        contiguous slices; the (small) delta block's entries for those items then overwrite their base
+        entry or are inserted at their row position.  Same result as the generic path, ~6x less work."""
+        n_u, n_i = self.shape
+        static = self.decay_rate is None
+        iptr, rows_im, val_im, ts_im, d32_im = self._base.item_major(n_i, static)
+        it = items[items < n_i]
+        lo, hi = iptr[it], iptr[it + 1]
+        cnt = hi - lo
+        sel = self._ranges(lo, hi)                       # contiguous runs: a streaming copy
+        rows = rows_im[sel]
+        if static:
+            data = d32_im[sel]
+        else:
+            data = self._decay_array(val_im[sel], ts_im[sel], self.max_timestamp).astype(np.float32)
+        counts = np.zeros(n_i, dtype=np.int64)
+        counts[it] = cnt
+        sd = self._select(self._delta, None, it)
+        if len(sd):
+            kd = self._delta.key[sd]
+            it_d, us_d = kd & _MASK, kd >> _SHIFT
+            od = np.argsort((it_d << _SHIFT) | us_d, kind="stable")      # item-major, users ascending
+            it_d, us_d = it_d[od], us_d[od]
+            dat_d = self._decay_array(self._delta.val[sd][od], self._delta.ts[sd][od], self.max_timestamp).astype(np.float32)
+            start = np.concatenate(([0], np.cumsum(cnt)))               # slice of each selected item in `rows`
+            slot = np.searchsorted(it, it_d)                             # which selected item each delta entry belongs to
+            grp = np.flatnonzero(np.concatenate(([True], it_d[1:] != it_d[:-1], [True])))
+            pos = np.empty(len(it_d), dtype=np.int64)
+            us32 = us_d.astype(np.int32)
+            for g in range(len(grp) - 1):                                # one search per item that has delta entries
+                a, b = grp[g], grp[g + 1]
+                s0, s1 = start[slot[a]], start[slot[a] + 1]
+                pos[a:b] = s0 + np.searchsorted(rows[s0:s1], us32[a:b])
+            end = start[slot + 1]
+            found = pos < end
+            found[found] = rows[pos[found]] == us32[found]
+            data[pos[found]] = dat_d[found]                              # the delta entry shadows the base entry
+            new = ~found
+            if new.any():
+                rows = np.insert(rows, pos[new], us32[new])
+                data = np.insert(data, pos[new], dat_d[new])
+                counts += np.bincount(it_d[new], minlength=n_i)
+        indptr = np.zeros(n_i + 1, dtype=np.int64)
+        np.cumsum(counts, out=indptr[1:])
+        m = csc_matrix((data, rows, indptr.astype(np.int32)), shape=(n_u, n_i), dtype=np.float32)
+        m.has_sorted_indices = True
+        return m
+
     def to_csc(self, select_items: Optional[List[int]] = None) -> csc_matrix:
         """U x I CSC; with select_items only those columns are populated (interactions.py:291-303)."""
+        if select_items is not None and len(self._base) >= self._ITEM_MAJOR_MIN:
+            return self._csc_selected(np.unique(np.asarray(list(select_items), dtype=np.int64)))
         rows, cols, data = self._triples(select_items=select_items)
         n_u, n_i = self.shape
         # rows stay ascending inside each column; 16-bit keys take numpy's radix sort (several times

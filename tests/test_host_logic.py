@@ -331,3 +331,39 @@ def test_fit_targets_are_dealt_out_by_column_length():
     for g in got:
         g.set_interactions(Xc, X)
     assert np.array_equal(np.sort(np.concatenate([g.owned_columns(sub) for g in got])), np.sort(sub))
+
+
+@pytest.mark.parametrize("decay", [None, 30])
+def test_selected_column_export_through_the_item_major_mirror(decay, monkeypatch):
+    """to_csc(select_items) on a large store takes the base block's item-major mirror plus a merge of
+    the delta block; it must equal the generic export bit for bit -- through overwritten pairs, new
+    pairs, new users and new items, with and without time decay."""
+    rng = np.random.default_rng(0)
+    st = UserItemInteractions(min_value=0, max_value=15, decay_in_days=decay)
+    U, I, n = 3000, 700, 120_000
+    u, i = rng.integers(0, U, n), rng.zipf(1.3, n) % I
+    ts = 1.7e9 + np.arange(n) * 50.0
+    st.add_interactions_batch(u, i, ts, rng.integers(1, 6, n).astype(float))
+    st._compact()
+    assert len(st._base) >= st._ITEM_MAJOR_MIN
+    for step in range(5):
+        m = 400 * (step + 1)
+        u2, i2 = rng.integers(0, U + 50 * step, m), rng.integers(0, I + 20 * step, m)
+        st.add_interactions_batch(u2, i2, ts[-1] + 1000.0 * (step + 1) + np.arange(m), rng.integers(1, 6, m).astype(float))
+        items = np.unique(i2).tolist() + [10 ** 6]          # an id the store has never seen is ignored
+        fast = st.to_csc(items)
+        with monkeypatch.context() as mp:
+            mp.setattr(UserItemInteractions, "_ITEM_MAJOR_MIN", 1 << 62)
+            generic = st.to_csc(items)
+        assert fast.shape == generic.shape and fast.data.dtype == np.float32 and fast.indices.dtype == np.int32
+        assert np.array_equal(fast.indptr, generic.indptr)
+        assert np.array_equal(fast.indices, generic.indices)
+        assert np.array_equal(fast.data, generic.data)
+    st._compact()                                            # in-place overwrites invalidate the value mirror
+    items = list(range(0, 300, 7))
+    fast = st.to_csc(items)
+    with monkeypatch.context() as mp:
+        mp.setattr(UserItemInteractions, "_ITEM_MAJOR_MIN", 1 << 62)
+        generic = st.to_csc(items)
+    assert np.array_equal(fast.indptr, generic.indptr) and np.array_equal(fast.indices, generic.indices)
+    assert np.array_equal(fast.data, generic.data)
