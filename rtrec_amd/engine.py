@@ -192,6 +192,7 @@ class HipBackend:
         return ws, self.zeros((1,), self.torch.int32)
 
     supports_gram = True
+    supports_device_store = True     # X can stay resident as sorted COO (utils/device_store.py)
 
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
                     ws, queue, slots, trace=None, gram=None):
@@ -291,6 +292,14 @@ class SlimEngine:
             X["col_nnz"] = np.diff(np.asarray(X_csc.indptr, dtype=np.int64))
             X["nonneg"] = bool(X_csc.nnz == 0 or float(X_csc.data.min()) >= 0.0)
         self._X = X
+
+    def set_interactions_device(self, X: Dict[str, Any], n_users: int, n_items: int) -> None:
+        """Use an X whose arrays are already resident on this device (utils/device_store.py): the same
+        keys as set_interactions builds (rptr/rcol/rval, cptr/crow/cval, col_nnz, nonneg)."""
+        if int(X["rcol"].shape[0]) >= 2 ** 31:
+            raise ValueError("more than 2**31 interactions per GPU are not supported")
+        self.n_users, self.n_items = int(n_users), int(n_items)
+        self._X = dict(X)          # per-matrix caches (column norms, Gram matrix) attach to this copy
 
     # ------------------------------------------------------------------------------ fit
     def owned_columns(self, columns: np.ndarray) -> np.ndarray:

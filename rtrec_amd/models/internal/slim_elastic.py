@@ -105,8 +105,12 @@ class SLIMElastic:
         """Fit `targets` on the GPU(s) and write the coefficients back like the reference's LIL loop."""
         self._check_optim()
         eng = self.engine
-        n_items = X_csc.shape[1]
-        eng.set_interactions(X_csc)
+        if isinstance(X_csc, dict):       # already resident on the device (utils/device_store.py)
+            n_items = int(X_csc["n_items"])
+            eng.set_interactions_device(X_csc, X_csc["n_users"], n_items)
+        else:
+            n_items = X_csc.shape[1]
+            eng.set_interactions(X_csc)
         mine = eng.owned_columns(targets)
         tg, items, coef, count, n_iter = eng.fit_columns(
             mine, alpha=self.alpha, l1_ratio=self.l1_ratio, positive=self.positive_only, max_iter=self.max_iter,
@@ -175,6 +179,14 @@ class SLIMElastic:
             return self.fit_in_parallel(interaction_matrix, item_ids=np.array(updated_items), progress_bar=progress_bar)
         X = self._as_csc(interaction_matrix,
                          "Interaction matrix must be a scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
+        W_old = self.item_similarity
+        dtype = np.float32 if W_old is None else W_old.dtype
+        self.item_similarity = self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), W_old, dtype)
+        return self
+
+    def partial_fit_items_device(self, X: Dict[str, Any], updated_items: List[int]) -> "SLIMElastic":
+        """partial_fit_items for a matrix that is already resident on the device: `X` is the array set of
+        DeviceInteractions.partial() plus n_users / n_items."""
         W_old = self.item_similarity
         dtype = np.float32 if W_old is None else W_old.dtype
         self.item_similarity = self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), W_old, dtype)

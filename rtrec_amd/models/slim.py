@@ -7,10 +7,12 @@ calls and scored in place by row id instead of being rebuilt and sliced per requ
 """
 from __future__ import annotations
 
-from typing import Any, Iterable, List, Optional, Tuple
+import os
+from typing import Any, Dict, Iterable, List, Optional, Tuple
 
 import numpy as np
 
+from ..utils.device_store import DeviceInteractions
 from .base import BaseModel
 from .internal.slim_elastic import SLIMElastic
 
@@ -21,6 +23,52 @@ class SLIM(BaseModel):
         self.model = SLIMElastic(kwargs)
         self.recorded_item_ids: set = set()
         self._x_on_device: Optional[Tuple[int, float]] = None   # (store version, max_timestamp) of the GPU copy
+        self._dev_x: Optional[DeviceInteractions] = None        # X resident in HBM (utils/device_store.py)
+
+    # ------------------------------------------------------------ device-resident X
+    def _mirror(self) -> Optional[DeviceInteractions]:
+        """The device-resident copy of X, or None where it does not apply: a store with time decay
+        (every value is then a float64 `pow` of max_timestamp, which the host evaluates) or a backend
+        without device arrays.  RTREC_AMD_DEVICE_STORE=0 forces the host-export path."""
+        if self.interactions.decay_rate is not None or os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0":
+            return None
+        be = self.model.engine.be
+        if not getattr(be, "supports_device_store", False):
+            return None
+        if self._dev_x is None:
+            self._dev_x = DeviceInteractions(be.torch, be.device)
+        return self._dev_x
+
+    def _mirror_synced(self) -> Optional[DeviceInteractions]:
+        """The mirror, brought up to the host store's state (one full export if it has fallen behind)."""
+        mir = self._mirror()
+        if mir is not None and mir.version != self.interactions.version:
+            csr = self.interactions.to_csr()
+            mir.load_csr(csr.indptr, csr.indices, csr.data, csr.shape[0], csr.shape[1], self.interactions.version)
+        return mir
+
+    def _ingest(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool
+                ) -> Tuple[np.ndarray, np.ndarray]:
+        """Store a batch; a mirror that was in step with the store is advanced by the batch's distinct
+        (user, item) pairs -- their new values come from the host store, which owns the semantics."""
+        st = self.interactions
+        v0 = st.version
+        uid, iid = super()._ingest(interactions, update_interaction)
+        mir = self._dev_x
+        if mir is not None and mir.version == v0 and st.decay_rate is None and st.version != v0:
+            keys = np.unique(st._keys(uid, iid))
+            _, val, _ = st._lookup(keys)
+            mir.apply(keys >> 32, keys & 0xFFFFFFFF, val.astype(np.float32), st.shape[0], st.shape[1], st.version)
+        return uid, iid
+
+    def _device_matrix(self, item_ids: Optional[List[int]]) -> Optional[Dict[str, Any]]:
+        """X (or X with only `item_ids`' columns populated) as device arrays, or None -> host export."""
+        mir = self._mirror_synced()
+        if mir is None:
+            return None
+        X = dict(mir.full() if item_ids is None else mir.partial(np.asarray(item_ids, dtype=np.int64)))
+        X["n_users"], X["n_items"] = mir.n_users, mir.n_items
+        return X
 
     # ------------------------------------------------------------ fit
     def fit(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool = False,
@@ -29,10 +77,17 @@ class SLIM(BaseModel):
         handed to the solver has ONLY those items' columns populated."""
         _, iid = self._ingest(interactions, update_interaction)
         item_ids = np.unique(iid).tolist()
-        interaction_matrix = self.interactions.to_csc(item_ids)
-        self.model.partial_fit_items(interaction_matrix, item_ids, progress_bar=progress_bar)
-        self._x_on_device = None
+        self._fit_items(item_ids, False, progress_bar)
         return self
+
+    def _fit_items(self, item_ids: List[int], parallel: bool, progress_bar: bool) -> None:
+        X = self._device_matrix(item_ids) if item_ids else None
+        if X is not None:
+            self.model.partial_fit_items_device(X, item_ids)
+        else:
+            interaction_matrix = self.interactions.to_csc(item_ids)
+            self.model.partial_fit_items(interaction_matrix, item_ids, parallel=parallel, progress_bar=progress_bar)
+        self._x_on_device = None
 
     def _record_interactions(self, user_id: int, item_id: int, tstamp: float, rating: float) -> None:
         self.recorded_item_ids.add(item_id)
@@ -42,16 +97,18 @@ class SLIM(BaseModel):
 
     def _fit_recorded(self, parallel: bool = False, progress_bar: bool = True) -> "SLIM":
         item_ids = sorted(self.recorded_item_ids)
-        interaction_matrix = self.interactions.to_csc(item_ids)
-        self.model.partial_fit_items(interaction_matrix, item_ids, parallel=parallel, progress_bar=progress_bar)
+        self._fit_items(item_ids, parallel, progress_bar)
         self.recorded_item_ids.clear()
-        self._x_on_device = None
         return self
 
     def bulk_fit(self, parallel: bool = False, progress_bar: bool = True) -> "SLIM":
         interaction_matrix = self.interactions.to_csc()
         self.model.fit(interaction_matrix, parallel=parallel, progress_bar=progress_bar)
         self._x_on_device = None
+        mir = self._mirror()
+        if mir is not None:      # the full X the fit has just uploaded becomes the resident copy
+            eng = self.model.engine
+            mir.adopt(eng._X, eng.n_users, eng.n_items, self.interactions.version)
         return self
 
     # ------------------------------------------------------------ recommend
@@ -59,7 +116,11 @@ class SLIM(BaseModel):
         """Make the GPU copy of X (CSR, decayed to the current max_timestamp) current."""
         stamp = (self.interactions.version, self.interactions.max_timestamp)
         if self._x_on_device != stamp:
-            self.model.engine.set_interactions(None, self.interactions.to_csr(), need_csc=False)
+            mir = self._mirror()
+            if mir is not None and mir.version == self.interactions.version:
+                self.model.engine.set_interactions_device(mir.full(), mir.n_users, mir.n_items)
+            else:
+                self.model.engine.set_interactions(None, self.interactions.to_csr(), need_csc=False)
             self._x_on_device = stamp
 
     def _recommend(self, user_id: int, candidate_item_ids: Optional[List[int]] = None,
@@ -77,7 +138,8 @@ class SLIM(BaseModel):
         dense_output = not self.item_ids.pass_through
         stamp = (self.interactions.version, self.interactions.max_timestamp)
         n_users = self.interactions.shape[0]
-        if self._x_on_device == stamp or len(user_ids) * 16 >= n_users:
+        resident = self._dev_x is not None and self._dev_x.version == self.interactions.version
+        if self._x_on_device == stamp or resident or len(user_ids) * 16 >= n_users:
             # bulk scoring: (re)upload all of X once and score it in place by row id
             self._sync_interactions()
             ids, scores, counts = self.model._topk(None, candidate_item_ids, top_k, filter_interacted, dense_output,

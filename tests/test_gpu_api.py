@@ -185,3 +185,38 @@ def test_large_top_k_through_the_api():
         got = m.recommend_batch(users, top_k=k)
         o_ids, _, o_cnt = so.recommend_batch(Xs[users], W, top_k=k, filter_interacted=True)
         assert got == [o_ids[r, :o_cnt[r]].tolist() for r in range(len(users))]
+
+
+def test_streaming_through_the_device_resident_store_equals_host_exports(monkeypatch):
+    """SLIM.fit mini-batches served from the device-resident X (utils/device_store.py: bulk_fit's upload
+    adopted, every batch merged on the GPU, touched-columns matrix gathered there) give the same W,
+    bit for bit, and the same recommendations as the host-export path (RTREC_AMD_DEVICE_STORE=0),
+    including new users / items and re-rated pairs."""
+    from rtrec_amd import SLIM
+    rng = np.random.default_rng(11)
+    U, I, n = 1500, 300, 40_000
+    u, i = rng.integers(0, U, n), rng.zipf(1.3, n) % I
+    r = (rng.integers(1, 6, n) * np.exp(-rng.random(n))).astype(float)
+    ts = 1.7e9 + np.arange(n, dtype=float)
+    n_bulk = n - 6 * 400
+
+    def run(device_store):
+        monkeypatch.setenv("RTREC_AMD_DEVICE_STORE", "1" if device_store else "0")
+        m = SLIM(min_value=0, max_value=15, nn_feature_selection=8)
+        m.add_interactions(list(zip(u[:n_bulk].tolist(), i[:n_bulk].tolist(), ts[:n_bulk].tolist(), r[:n_bulk].tolist())))
+        m.bulk_fit(parallel=True, progress_bar=False)
+        assert (m._dev_x is not None and m._dev_x.version == m.interactions.version) == device_store
+        out = []
+        for k in range(6):
+            a = n_bulk + 400 * k
+            uu, ii = u[a:a + 400] + (30 * k if k % 2 else 0), i[a:a + 400] + (7 * k if k % 3 == 0 else 0)   # some new ids
+            m.fit(list(zip(uu.tolist(), ii.tolist(), ts[a:a + 400].tolist(), r[a:a + 400].tolist())), progress_bar=False)
+            if device_store:
+                assert m._dev_x.version == m.interactions.version and m._dev_x.nnz == m.interactions.nnz
+            out.append((m.model.item_similarity.copy(), m.recommend_batch(list(range(0, 200, 3)), top_k=7)))
+        return out
+
+    dev, host = run(True), run(False)
+    for (Wd, rd), (Wh, rh) in zip(dev, host):
+        assert same_matrix(Wd, Wh)
+        assert rd == rh

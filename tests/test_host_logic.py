@@ -367,3 +367,62 @@ def test_selected_column_export_through_the_item_major_mirror(decay, monkeypatch
         generic = st.to_csc(items)
     assert np.array_equal(fast.indptr, generic.indptr) and np.array_equal(fast.indices, generic.indices)
     assert np.array_equal(fast.data, generic.data)
+
+
+def _assert_same_matrix(dev, host, fmt):
+    ptr, idx, val = ("rptr", "rcol", "rval") if fmt == "csr" else ("cptr", "crow", "cval")
+    assert np.array_equal(dev[ptr].numpy(), host.indptr)
+    assert np.array_equal(dev[idx].numpy(), host.indices)
+    assert np.array_equal(dev[val].numpy(), host.data)
+    assert dev[ptr].numpy().dtype == np.int32 and dev[idx].numpy().dtype == np.int32 and dev[val].numpy().dtype == np.float32
+
+
+@pytest.mark.parametrize("upsert", [False, True])
+def test_device_resident_store_tracks_the_host_store(upsert):
+    """utils/device_store.py (run here on CPU tensors): after any sequence of mini-batches the
+    resident sorted-COO copy yields exactly the host store's CSR / CSC exports, and partial(items)
+    exactly to_csc(items) / the CSR restricted to those columns -- through overwritten pairs, new
+    pairs, new users and items, duplicates inside a batch and a rebuild from a host export."""
+    import torch
+    from rtrec_amd.utils.device_store import DeviceInteractions
+    rng = np.random.default_rng(3)
+    st = UserItemInteractions(min_value=0, max_value=15)
+    mir = DeviceInteractions(torch, torch.device("cpu"))
+    U, I = 400, 90
+    csr = st.to_csr()
+    mir.load_csr(csr.indptr, csr.indices, csr.data, csr.shape[0], csr.shape[1], st.version)      # empty store
+    t = 1.7e9
+    for step in range(8):
+        m = 300 + 100 * step
+        u = rng.integers(0, U + 30 * step, m)
+        i = rng.zipf(1.4, m) % (I + 10 * step)
+        r = rng.integers(-2, 6, m).astype(float) if upsert else rng.integers(1, 6, m).astype(float)
+        st.add_interactions_batch(u, i, t + np.arange(m), r, upsert=upsert)
+        t += m
+        keys = np.unique(st._keys(u, i))
+        _, val, _ = st._lookup(keys)
+        if step == 4:            # fell behind: rebuilt from a full export instead
+            csr = st.to_csr()
+            mir.load_csr(csr.indptr, csr.indices, csr.data, csr.shape[0], csr.shape[1], st.version)
+        else:
+            mir.apply(keys >> 32, keys & 0xFFFFFFFF, val.astype(np.float32), st.shape[0], st.shape[1], st.version)
+        assert mir.version == st.version and (mir.n_users, mir.n_items) == st.shape and mir.nnz == st.nnz
+        full = mir.full()
+        _assert_same_matrix(full, st.to_csr(), "csr")
+        _assert_same_matrix(full, st.to_csc(), "csc")
+        assert np.array_equal(full["col_nnz"], np.diff(st.to_csc().indptr))
+        assert full["nonneg"] == bool(st.to_csc().data.min() >= 0)
+        items = np.unique(i).tolist() + [10 ** 6]
+        part = mir.partial(np.asarray(items))
+        host_csc = st.to_csc(items)
+        _assert_same_matrix(part, host_csc, "csc")
+        host_csr = host_csc.tocsr()
+        host_csr.sort_indices()
+        _assert_same_matrix(part, host_csr, "csr")
+        assert np.array_equal(part["col_nnz"], np.diff(host_csc.indptr))
+    # adopt(): the engine's uploaded arrays become the resident copy
+    full = mir.full()
+    other = DeviceInteractions(torch, torch.device("cpu"))
+    other.adopt(full, mir.n_users, mir.n_items, st.version)
+    _assert_same_matrix(other.full(), st.to_csr(), "csr")
+    _assert_same_matrix(other.full(), st.to_csc(), "csc")
