@@ -118,23 +118,39 @@ def _merge_blocks(old: _Block, new: _Block) -> _Block:
         nk, nv, nt = new.key[rest], new.val[rest], new.ts[rest]
     else:
         nk, nv, nt = new.key, new.val, new.ts
-    # two sorted runs: numpy's stable sort (timsort) merges them in one linear pass
-    key = np.concatenate([old.key, nk])
-    order = np.argsort(key, kind="stable")
-    return _Block(key[order], np.concatenate([old.val, nv])[order], np.concatenate([old.ts, nt])[order])
+    # two sorted runs with distinct keys: the destination of every new entry is its insertion point plus
+    # its rank, the old entries fill the remaining slots in order -- one binary search of the smaller run
+    # and three streaming scatters instead of a sort of n + m keys and three random gathers
+    n, m = len(old), nk.shape[0]
+    dst_new = np.searchsorted(old.key, nk) + np.arange(m, dtype=np.int64)
+    is_new = np.zeros(n + m, dtype=bool)
+    is_new[dst_new] = True
+    is_old = ~is_new
+    out = []
+    for a_old, a_new in ((old.key, nk), (old.val, nv), (old.ts, nt)):
+        o = np.empty(n + m, dtype=a_old.dtype)
+        o[is_old] = a_old
+        o[dst_new] = a_new
+        out.append(o)
+    return _Block(*out)
 
 
-def _stable_order(users: np.ndarray, items: np.ndarray, keys: np.ndarray) -> np.ndarray:
-    """argsort(keys, kind="stable").  When (user, item, arrival index) fit one int64 the composite is
-    VALUE-sorted instead (numpy's vectorised quicksort; the arrival index in the low bits both makes the
-    keys distinct -- so an unstable sort yields the stable order -- and is the permutation)."""
+def _stable_order(users: np.ndarray, items: np.ndarray, keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """(argsort(keys, kind="stable"), keys in that order).  When (user, item, arrival index) fit one int64
+    the composite is VALUE-sorted instead (numpy's vectorised quicksort; the arrival index in the low bits
+    both makes the keys distinct -- so an unstable sort yields the stable order -- and is the permutation),
+    and the sorted keys are unpacked from the composite instead of gathered through the permutation."""
     n = keys.shape[0]
     ib, xb = int(items.max()).bit_length(), max(1, (n - 1).bit_length())
     if n >= (1 << 12) and int(users.max()).bit_length() + ib + xb <= 63:
         comp = (users << (ib + xb)) | (items << xb) | np.arange(n, dtype=np.int64)
         comp.sort()
-        return comp & ((1 << xb) - 1)
-    return np.argsort(keys, kind="stable")
+        order = comp & ((1 << xb) - 1)
+        comp >>= xb
+        sk = ((comp >> ib) << _SHIFT) | (comp & ((1 << ib) - 1))
+        return order, sk
+    order = np.argsort(keys, kind="stable")
+    return order, keys[order]
 
 
 class UserItemInteractions:
@@ -258,19 +274,17 @@ class UserItemInteractions:
         seen = np.maximum.accumulate(np.concatenate(([self.max_timestamp], ts + 1.0)))[1:]
         keys = self._keys(users, items)
 
-        order = _stable_order(users, items, keys)
-        sk = keys[order]
+        order, sk = _stable_order(users, items, keys)
         first = np.ones(n, bool)
         first[1:] = sk[1:] != sk[:-1]
         if first.all():
-            rounds = [order]          # distinct pairs: one round, visited in key order (already sorted for the store)
+            rounds = [(order, sk)]    # distinct pairs: one round, visited in key order (already sorted for the store)
         else:   # occurrence rank of every interaction within its (user, item) group
             start = np.flatnonzero(first)
             grp = np.cumsum(first) - 1
             rank = np.arange(n) - start[grp]
-            rounds = [order[rank == r] for r in range(int(rank.max()) + 1)]
-        for idx in rounds:
-            k = keys[idx]
+            rounds = [(order[rank == r], sk[rank == r]) for r in range(int(rank.max()) + 1)]
+        for idx, k in rounds:
             if upsert:
                 new = dl[idx]
             else:

@@ -17,7 +17,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SHAPES = {"small": (20_000, 5_000, 500_000), "c2": (100_000, 50_000, 5_000_000), "c3": (138_493, 26_744, 26_000_000)}
+SHAPES = {"small": (20_000, 5_000, 500_000), "c2": (100_000, 50_000, 5_000_000), "c3": (138_493, 26_744, 26_000_000),
+          "c4": (1_000_000, 500_000, 100_000_000)}
 
 
 def main():
