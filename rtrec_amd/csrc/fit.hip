@@ -1499,7 +1499,7 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
 // R[r] <- (R[r] + x*w_old) - x*w_new over the column by all threads of the workgroup (element-wise,
 // order free).  Latency-bound like the producers: kUpdDepth entries per thread and round, and the
 // indices of the next round are requested before the gathers of this one are consumed.
-constexpr int kUpdDepth = 8;
+constexpr int kUpdDepth = 8;   // 16 shortens the update by 10 % and lengthens the fold by 3 % (register pressure): no gain
 __device__ void mw_update(const int *__restrict__ crow, const float *__restrict__ cval, float *R, int b, int e,
                           float w_old, float w_new, int tid) {
     int r[kUpdDepth], rn[kUpdDepth];

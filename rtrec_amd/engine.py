@@ -438,7 +438,7 @@ class SlimEngine:
             side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(be.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                heavy = launch(0, n_heavy, min(n_heavy, FIT_HEAVY_SLOTS), role="heavy")
+                heavy = launch(0, n_heavy, min(n_heavy, int(os.environ.get("RTREC_AMD_FIT_HEAVY_SLOTS", FIT_HEAVY_SLOTS))), role="heavy")
         for s in range(n_heavy, n, chunk):
             collect(launch(s, min(n, s + chunk), min(slots, max(1, min(n, s + chunk) - s))))
         if heavy is not None:
