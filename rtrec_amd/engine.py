@@ -157,6 +157,8 @@ class HipBackend:
         # belong here, next to the HIP context creation, not inside the first fit or recommend call
         w = torch.ones(1, dtype=torch.float32, device=self.device)
         self.ops.column_sqnorms(torch.tensor([0, 1], dtype=torch.int32, device=self.device), w, torch.empty_like(w))
+        from .utils.device_store import DeviceInteractions
+        DeviceInteractions(torch, self.device).warm_up()
 
     # -- helpers -------------------------------------------------------------------------
     def to_dev(self, a: np.ndarray):

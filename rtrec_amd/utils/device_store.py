@@ -70,6 +70,15 @@ class DeviceInteractions:
         self._ck, self._cv = (cols << _SHIFT) | X["crow"].to(i64), X["cval"].clone()
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
 
+    def warm_up(self) -> None:
+        """Run every tensor op of this class once on a four-entry matrix: the first use of a sort /
+        searchsorted / scatter kernel loads its code object (~0.1-0.3 s per process), which belongs to
+        backend construction, not to the first bulk_fit or mini-batch."""
+        self.load_csr(np.array([0, 2, 3]), np.array([0, 1, 1]), np.ones(3, np.float32), 2, 2, 0)
+        self.apply(np.array([0, 1]), np.array([1, 0]), np.ones(2, np.float32), 2, 2, 1)
+        self.adopt(self.full(), 2, 2, 2)
+        self.partial(np.array([1]))
+
     # ------------------------------------------------------------------ update
     def _merge(self, keys, vals, new_k, new_v):
         """Write (new_k, new_v) -- distinct keys, any order -- into the sorted (keys, vals): existing keys
