@@ -184,6 +184,19 @@ class SLIMElastic:
         self.item_similarity = self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), W_old, dtype)
         return self
 
+    def fit_device(self, X: Dict[str, Any], parallel: bool = False) -> "SLIMElastic":
+        """fit() for a matrix that is already resident on the device (DeviceInteractions.full() plus
+        n_users / n_items): serial mode starts from an empty float64 W, `parallel` merges into the
+        existing float32 one, exactly like fit / fit_in_parallel."""
+        targets = np.arange(int(X["n_items"]))
+        if parallel:
+            W_old = self.item_similarity
+            dtype = np.float32 if W_old is None else W_old.dtype
+            self.item_similarity = self._fit_targets(X, targets, W_old, dtype)
+        else:
+            self.item_similarity = self._fit_targets(X, targets, None, np.float64)
+        return self
+
     def partial_fit_items_device(self, X: Dict[str, Any], updated_items: List[int]) -> "SLIMElastic":
         """partial_fit_items for a matrix that is already resident on the device: `X` is the array set of
         DeviceInteractions.partial() plus n_users / n_items."""

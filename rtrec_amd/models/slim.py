@@ -102,13 +102,12 @@ class SLIM(BaseModel):
         return self
 
     def bulk_fit(self, parallel: bool = False, progress_bar: bool = True) -> "SLIM":
-        interaction_matrix = self.interactions.to_csc()
-        self.model.fit(interaction_matrix, parallel=parallel, progress_bar=progress_bar)
+        X = self._device_matrix(None)
+        if X is not None:        # resident X: CSR order from the host keys, CSC order by a sort on the device
+            self.model.fit_device(X, parallel=parallel)
+        else:
+            self.model.fit(self.interactions.to_csc(), parallel=parallel, progress_bar=progress_bar)
         self._x_on_device = None
-        mir = self._mirror()
-        if mir is not None:      # the full X the fit has just uploaded becomes the resident copy
-            eng = self.model.engine
-            mir.adopt(eng._X, eng.n_users, eng.n_items, self.interactions.version)
         return self
 
     # ------------------------------------------------------------ recommend
