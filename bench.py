@@ -205,8 +205,10 @@ def main() -> None:
     # WRITE_SIZE cannot be read from inside the process); the committed summary is attached when
     # it belongs to this workload.
     traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, "profiles", f"r01_{args.workload}_pmc_traffic.json")
-    if world == 1 and os.path.exists(tpath):
+    import glob
+    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc_traffic.json")))
+    tpath = tpaths[-1] if tpaths else ""          # the most recent round's summary
+    if world == 1 and tpath:
         try:
             traffic = json.load(open(tpath))["hbm_bytes_per_launch_corrected"]
             traffic_src = os.path.relpath(tpath, ROOT)

@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--batches", type=int, default=50)
     ap.add_argument("--batch-size", type=int, default=1000)
     ap.add_argument("--score-users", type=int, default=100)
+    ap.add_argument("--qps", type=float, default=0.0,
+                    help="fixed arrival rate in interactions/s (0 = back to back): mini-batch k is released at "
+                         "k * batch_size / qps; reports how far completion lags behind release")
+    ap.add_argument("--bulk-chunk", type=int, default=16_000_000, help="rows per vectorised bulk-ingest call")
     args = ap.parse_args()
     import torch
     from rtrec_amd import SLIM
@@ -45,8 +49,8 @@ def main():
 
     model = SLIM(min_value=0, max_value=15, nn_feature_selection=50)
     t0 = time.time()
-    for a in range(0, n_bulk, 1_000_000):          # vectorised bulk ingest
-        b = min(a + 1_000_000, n_bulk)
+    for a in range(0, n_bulk, args.bulk_chunk):    # vectorised bulk ingest
+        b = min(a + args.bulk_chunk, n_bulk)
         model.interactions.add_interactions_batch(model.user_ids.identify_many(u[a:b].astype(np.int64)),
                                                   model.item_ids.identify_many(i[a:b].astype(np.int64)), ts[a:b], r[a:b])
     t_ingest = time.time() - t0
@@ -58,15 +62,22 @@ def main():
     print(f"bulk: {n_bulk} interactions ingested in {t_ingest:.2f}s, fitted in {t_fit:.2f}s, "
           f"W nnz={model.model.item_similarity.nnz}", file=sys.stderr)
 
-    fit_ms, rec_ms, touched = [], [], []
+    fit_ms, rec_ms, touched, lag_ms = [], [], [], []
+    period = args.batch_size / args.qps if args.qps > 0 else 0.0
+    t_start = time.perf_counter()
     for k in range(args.batches):
         a = n_bulk + k * args.batch_size
         b = a + args.batch_size
         batch = list(zip(u[a:b].tolist(), i[a:b].tolist(), ts[a:b].tolist(), r[a:b].tolist()))
+        release = t_start + k * period
+        if period > 0.0:
+            while time.perf_counter() < release:      # the batch has not arrived yet
+                time.sleep(min(0.001, max(0.0, release - time.perf_counter())))
         t0 = time.perf_counter()
         model.fit(batch, progress_bar=False)
         torch.cuda.synchronize()
         fit_ms.append((time.perf_counter() - t0) * 1e3)
+        lag_ms.append((time.perf_counter() - release) * 1e3)          # completion behind release (queueing + service)
         touched.append(len(set(i[a:b].tolist())))
         users = rng.integers(0, U, args.score_users).tolist()
         t0 = time.perf_counter()
@@ -79,6 +90,12 @@ def main():
            "partial_fit_interactions_per_sec": float(args.batch_size / (np.mean(fit_ms) * 1e-3)),
            "recommend_ms_per_call": {"users": args.score_users, "p50": float(np.median(rec_ms)), "p95": float(np.quantile(rec_ms, 0.95))},
            "bulk_ingest_interactions_per_sec": float(n_bulk / t_ingest), "bulk_fit_seconds": t_fit}
+    if period > 0.0:
+        lag = np.array(lag_ms[2:])
+        out["fixed_qps"] = {"interactions_per_sec": args.qps, "batch_period_ms": period * 1e3,
+                            "completion_lag_ms": {"p50": float(np.median(lag)), "p95": float(np.quantile(lag, 0.95)),
+                                                  "max": float(lag.max())},
+                            "keeps_up": bool(lag[-1] <= lag[0] + period * 1e3)}
     print(json.dumps(out))
 
 
