@@ -29,6 +29,7 @@ from .lru import LRUFreqSet
 _SHIFT = 32
 _MASK = (1 << _SHIFT) - 1
 _DELTA_MERGE_MIN = 1 << 16
+_L0_MAX = 1 << 15              # recent writes: a mini-batch merges into at most this many entries
 
 
 class _Block:
@@ -168,6 +169,7 @@ class UserItemInteractions:
         self.max_timestamp = 0.0
         self._base = _Block()
         self._delta = _Block()
+        self._l0 = _Block()
         self.version = 0   # bumped on every mutation; device mirrors key their caches on it
 
     def __setstate__(self, state: Dict[str, Any]) -> None:
@@ -176,6 +178,7 @@ class UserItemInteractions:
         nested = state.get("interactions") if isinstance(state.get("interactions"), dict) else None
         if nested is None:
             self.__dict__.update(state)
+            self.__dict__.setdefault("_l0", _Block())
             return
         state = {k: v for k, v in state.items() if k != "interactions"}
         self.__dict__.update(state)
@@ -187,6 +190,7 @@ class UserItemInteractions:
         order = np.argsort(key, kind="stable")
         self._base = _Block(key[order], np.asarray(vals, dtype=np.float64)[order], np.asarray(tss, dtype=np.float64)[order])
         self._delta = _Block()
+        self._l0 = _Block()
         self.version = 0
 
     # ------------------------------------------------------------------ decay
@@ -214,7 +218,7 @@ class UserItemInteractions:
         return (users.astype(np.int64) << _SHIFT) | items.astype(np.int64)
 
     def _lookup(self, keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """(found, value, timestamp) per key; the delta block shadows the base block."""
+        """(found, value, timestamp) per key; newer levels shadow older ones (l0 > delta > base)."""
         val = np.zeros(keys.shape, np.float64)
         ts = np.zeros(keys.shape, np.float64)
         fb, pb = self._base.find(keys)
@@ -225,21 +229,47 @@ class UserItemInteractions:
         if fd.any():
             val[fd] = self._delta.val[pd_[fd]]
             ts[fd] = self._delta.ts[pd_[fd]]
-        return fb | fd, val, ts
+        fl, pl = self._l0.find(keys)
+        if fl.any():
+            val[fl] = self._l0.val[pl[fl]]
+            ts[fl] = self._l0.ts[pl[fl]]
+        return fb | fd | fl, val, ts
 
     def _write(self, keys: np.ndarray, val: np.ndarray, ts: np.ndarray, presorted: bool = False) -> None:
-        """Store unique keys (any order) into the delta block; merge down when it has grown."""
+        """Store unique keys (any order).  Three sorted levels, newest first: a small l0 that a
+        mini-batch merges into (so a 1k-interaction write never rewrites a multi-million-entry block),
+        the delta block l0 spills into, and the base block the delta is compacted into once it has
+        grown to an eighth of it."""
         if presorted:
             blk = _Block(keys, np.asarray(val, dtype=np.float64), np.asarray(ts, dtype=np.float64))
         else:
             order = np.argsort(keys, kind="stable")
             blk = _Block(keys[order], val[order].astype(np.float64), ts[order].astype(np.float64))
-        self._delta = _merge_blocks(self._delta, blk)
-        if len(self._delta) >= max(_DELTA_MERGE_MIN, len(self._base) // 8):
-            self._compact()
+        if len(blk) >= _L0_MAX // 2:          # a bulk chunk goes straight to the delta level (after what is newer than it)
+            self._flush_l0(check=False)
+            self._delta = _merge_blocks(self._delta, blk)
+            self._check_delta()
+        else:
+            self._l0 = _merge_blocks(self._l0, blk)
+            if len(self._l0) >= _L0_MAX:
+                self._flush_l0()
         self.version += 1
 
+    def _flush_l0(self, check: bool = True) -> None:
+        """Fold the recent-writes level into the delta block (every reader that walks the blocks does
+        this first; lookups by key do not need to)."""
+        if len(self._l0):
+            self._delta = _merge_blocks(self._delta, self._l0)
+            self._l0 = _Block()
+            if check:
+                self._check_delta()
+
+    def _check_delta(self) -> None:
+        if len(self._delta) >= max(_DELTA_MERGE_MIN, len(self._base) // 8):
+            self._compact()
+
     def _compact(self) -> _Block:
+        self._flush_l0(check=False)
         if len(self._delta):
             self._base = _merge_blocks(self._base, self._delta)
             self._delta = _Block()
@@ -307,6 +337,7 @@ class UserItemInteractions:
 
     # ------------------------------------------------------------------ queries
     def _user_entries(self, user_id: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        self._flush_l0()
         sb = self._select(self._base, np.array([user_id], np.int64), None)
         sd = self._select(self._delta, np.array([user_id], np.int64), None)
         if len(sd) == 0:
@@ -420,6 +451,7 @@ class UserItemInteractions:
             blk = self._compact()
             key, val, ts = blk.key, blk.val, blk.ts
         else:
+            self._flush_l0()
             sb = self._select(self._base, users, items)
             sd = self._select(self._delta, users, items)
             key = np.concatenate([self._delta.key[sd], self._base.key[sb]])     # delta first: it wins
@@ -461,6 +493,7 @@ class UserItemInteractions:
         entry or are inserted at their row position.  Same result as the generic path, ~6x less work."""
         n_u, n_i = self.shape
         static = self.decay_rate is None
+        self._flush_l0()
         iptr, rows_im, val_im, ts_im, d32_im = self._base.item_major(n_i, static)
         it = items[items < n_i]
         lo, hi = iptr[it], iptr[it + 1]

@@ -220,3 +220,27 @@ def test_streaming_through_the_device_resident_store_equals_host_exports(monkeyp
     for (Wd, rd), (Wh, rh) in zip(dev, host):
         assert same_matrix(Wd, Wh)
         assert rd == rh
+
+
+@pytest.mark.parametrize("parallel", [False, True])
+def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, monkeypatch):
+    """SLIM.bulk_fit takes X from the resident store (host CSR keys, CSC order by a device sort): same W
+    bits and dtype (float64 after a serial fit, float32 after a parallel one) as through to_csc()."""
+    from rtrec_amd import SLIM
+    rng = np.random.default_rng(5)
+    U, I, n = 900, 200, 20_000
+    rows = list(zip(rng.integers(0, U, n).tolist(), (rng.zipf(1.3, n) % I).tolist(),
+                    (1.7e9 + np.arange(n)).tolist(), (rng.integers(1, 6, n) * np.exp(-rng.random(n))).tolist()))
+
+    def run(device_store):
+        monkeypatch.setenv("RTREC_AMD_DEVICE_STORE", "1" if device_store else "0")
+        m = SLIM(min_value=0, max_value=15, nn_feature_selection=8)
+        m.add_interactions(rows)
+        m.bulk_fit(parallel=parallel, progress_bar=False)
+        return m.model.item_similarity, m.recommend_batch(list(range(0, 300, 7)), top_k=5)
+
+    (Wd, rd), (Wh, rh) = run(True), run(False)
+    assert Wd.dtype == Wh.dtype == (np.float32 if parallel else np.float64)
+    assert Wd.shape == Wh.shape and np.array_equal(Wd.indptr, Wh.indptr) and np.array_equal(Wd.indices, Wh.indices)
+    assert np.array_equal(Wd.data.view(np.uint8), Wh.data.view(np.uint8))
+    assert rd == rh

@@ -227,7 +227,7 @@ def test_store_selected_exports_use_indexes_and_match_full_export():
     s._compact()
     for a in range(100_000, n, 1000):          # mini-batches land in the delta block
         s.add_interactions_batch(u[a:a + 1000], i[a:a + 1000], ts[a:a + 1000], r[a:a + 1000])
-    assert len(s._delta) > 0 and len(s._base) > (1 << 15)
+    assert len(s._delta) + len(s._l0) > 0 and len(s._base) > (1 << 15)
     sel_items = [5, 17, 123, 899, 400]
     sel_users = [0, 7, 2999, 1500]
     part_c = s.to_csc(sel_items)
@@ -426,3 +426,42 @@ def test_device_resident_store_tracks_the_host_store(upsert):
     other.adopt(full, mir.n_users, mir.n_items, st.version)
     _assert_same_matrix(other.full(), st.to_csr(), "csr")
     _assert_same_matrix(other.full(), st.to_csc(), "csc")
+
+
+def test_store_levels_mini_batches_equal_one_bulk_write(monkeypatch):
+    """The store keeps three sorted levels (recent-writes l0 -> delta -> base).  Feeding the same
+    interactions as hundreds of mini-batches (l0 spills into the delta block several times, the delta
+    is compacted into the base block) must leave exactly the state of a few bulk writes: same exports,
+    same point lookups while entries still sit in l0."""
+    from rtrec_amd.utils import interactions as mod
+    monkeypatch.setattr(mod, "_L0_MAX", 1 << 12)
+    monkeypatch.setattr(mod, "_DELTA_MERGE_MIN", 1 << 13)
+    rng = np.random.default_rng(8)
+    n = 150_000
+    u, i = rng.integers(0, 4000, n), rng.zipf(1.3, n) % 1200
+    ts = 1.7e9 + np.arange(n, dtype=float)
+    r = rng.integers(1, 6, n).astype(float)
+    a_store = UserItemInteractions(min_value=0, max_value=12)
+    b_store = UserItemInteractions(min_value=0, max_value=12)
+    a_store.add_interactions_batch(u[:70_000], i[:70_000], ts[:70_000], r[:70_000])
+    b_store.add_interactions_batch(u[:70_000], i[:70_000], ts[:70_000], r[:70_000])
+    spills, compactions = 0, 0
+    for s in range(70_000, n, 500):
+        before, base_before = len(a_store._l0), len(a_store._base)
+        a_store.add_interactions_batch(u[s:s + 500], i[s:s + 500], ts[s:s + 500], r[s:s + 500])
+        spills += len(a_store._l0) < before
+        compactions += len(a_store._base) > base_before
+        if s % 20_000 == 0:                       # point lookups see l0 without flushing it
+            l0_before = len(a_store._l0)
+            for k in range(s, s + 500, 97):
+                assert a_store.has_interaction(int(u[k]), int(i[k]))
+            assert len(a_store._l0) == l0_before
+    assert spills >= 5 and compactions >= 2 and len(a_store._l0) < mod._L0_MAX
+    b_store.add_interactions_batch(u[70_000:], i[70_000:], ts[70_000:], r[70_000:])
+    for fmt in ("to_csr", "to_csc"):
+        A, B = getattr(a_store, fmt)(), getattr(b_store, fmt)()
+        assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices) and np.array_equal(A.data, B.data)
+    assert a_store.nnz == b_store.nnz and a_store.max_timestamp == b_store.max_timestamp
+    for k in range(0, n, 7919):
+        assert a_store.get_user_item_rating(int(u[k]), int(i[k])) == b_store.get_user_item_rating(int(u[k]), int(i[k]))
+    assert sorted(a_store.get_user_items(int(u[-1]))) == sorted(b_store.get_user_items(int(u[-1])))
