@@ -1267,6 +1267,10 @@ __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(Fit
 // element-wise residual update, the R = y materialisation and the scratch reset are split over
 // all threads.  Results are bit-identical to the single-wave kernel.
 // =============================================================================================
+#ifndef MW_FOLD_GROUP
+#define MW_FOLD_GROUP 4
+#endif
+constexpr int kFoldGroup = MW_FOLD_GROUP;   // chunks the consumer folds per loop iteration (power of two)
 constexpr int kMwWaves = 8;
 constexpr int kMwThreads = kMwWaves * 64;
 constexpr int kProducers = kMwWaves - 1;
@@ -1391,8 +1395,8 @@ __device__ __forceinline__ float chain64_dpp(float acc, const float4 &p) {
 template <int MODE>
 __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, const MwLds &M,
                          int b, int e, float w_old, int wave, int lane, int &seq) {
-    // padded to whole groups of four chunks: the extra products are +0.0 and never change the sum
-    const int n_chunks = (((e - b + 63) >> 6) + 3) & ~3;
+    // padded to whole groups of kFoldGroup chunks: the extra products are +0.0 and never change the sum
+    const int n_chunks = (((e - b + 63) >> 6) + kFoldGroup - 1) & ~(kFoldGroup - 1);
     float tmp = 0.0f;
     if (wave == 0) {
         // The chain of dependent v_add_f32 is the critical path of a popular target (~1e8 entries), so
@@ -1406,38 +1410,41 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
         // g+2 are requested before the 256 adds of group g, and `done` is published once per group.
         __builtin_amdgcn_s_setprio(3);
         if (n_chunks > 0 && lane < 16) {
+            constexpr int Gp = kFoldGroup;
             const float4 *ring4 = reinterpret_cast<const float4 *>(M.ring);
             auto slot_of = [&](int c) { return (seq + c) & (kRing - 1); };
-            float4 A[4], B[4];
-            int f[4];
+            float4 A[Gp], B[Gp];
+            int f[Gp];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < Gp; ++k) {
                 while (lds_load_acquire(&M.ready[slot_of(k)]) != seq + k + 1) __builtin_amdgcn_s_sleep(1);
                 A[k] = ring4[slot_of(k) * 16 + lane];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(4 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int c = 0; c < n_chunks; c += 4) {
-                if (c + 4 < n_chunks) {
-                    while ((f[0] != seq + c + 5) | (f[1] != seq + c + 6) | (f[2] != seq + c + 7) | (f[3] != seq + c + 8)) {
+            for (int k = 0; k < Gp; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            for (int c = 0; c < n_chunks; c += Gp) {
+                if (c + Gp < n_chunks) {
+                    for (;;) {
+                        bool bad = false;
+#pragma unroll
+                        for (int k = 0; k < Gp; ++k) bad |= (f[k] != seq + c + Gp + k + 1);
+                        if (!bad) break;
                         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            f[k] = __hip_atomic_load(&M.ready[slot_of(c + 4 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        for (int k = 0; k < Gp; ++k)
+                            f[k] = __hip_atomic_load(&M.ready[slot_of(c + Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-                for (int k = 0; k < 4; ++k) B[k] = ring4[slot_of(c + 4 + k) * 16 + lane];     // past the end: stale, unused
+                for (int k = 0; k < Gp; ++k) B[k] = ring4[slot_of(c + Gp + k) * 16 + lane];     // past the end: stale, unused
 #pragma unroll
-                for (int k = 0; k < 4; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(c + 8 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                tmp = chain64_dpp(tmp, A[0]);
-                tmp = chain64_dpp(tmp, A[1]);
-                tmp = chain64_dpp(tmp, A[2]);
-                tmp = chain64_dpp(tmp, A[3]);
+                for (int k = 0; k < Gp; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(c + 2 * Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) A[k] = B[k];
-                if (lane == 0) lds_store_release(M.done, seq + c + 4);
+                for (int k = 0; k < Gp; ++k) tmp = chain64_dpp(tmp, A[k]);
+#pragma unroll
+                for (int k = 0; k < Gp; ++k) A[k] = B[k];
+                if (lane == 0) lds_store_release(M.done, seq + c + Gp);
             }
         }
         tmp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tmp)));
