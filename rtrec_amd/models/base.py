@@ -103,10 +103,16 @@ class BaseModel(ABC):
             return
         uid = self.user_ids.identify_many(users)
         iid = self.item_ids.identify_many(items)
+        v0 = self.interactions.version
         self.interactions.add_interactions_batch(uid, iid, np.asarray(tstamps, dtype=np.float64),
                                                  np.asarray(ratings, dtype=np.float64), upsert=update_interaction)
+        self._stored(v0, uid, iid)
         if record_interactions:
             self._record_batch(uid, iid)
+
+    def _stored(self, version_before: int, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
+        """Hook: the interactions (user_ids, item_ids) have just been written to the store, which was at
+        `version_before`.  Models that mirror the store elsewhere (device-resident X) advance the mirror."""
 
     @staticmethod
     def _batch_is_homogeneous(objs: Tuple[Any, ...], ident: Identifier) -> bool:

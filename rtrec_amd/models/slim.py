@@ -47,19 +47,25 @@ class SLIM(BaseModel):
             mir.load_csr(csr.indptr, csr.indices, csr.data, csr.shape[0], csr.shape[1], self.interactions.version)
         return mir
 
+    _MIRROR_APPLY_MAX = 1 << 18     # larger writes (bulk chunks) leave the mirror stale: it is rebuilt on demand
+
     def _ingest(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool
                 ) -> Tuple[np.ndarray, np.ndarray]:
-        """Store a batch; a mirror that was in step with the store is advanced by the batch's distinct
-        (user, item) pairs -- their new values come from the host store, which owns the semantics."""
-        st = self.interactions
-        v0 = st.version
+        v0 = self.interactions.version
         uid, iid = super()._ingest(interactions, update_interaction)
-        mir = self._dev_x
-        if mir is not None and mir.version == v0 and st.decay_rate is None and st.version != v0:
-            keys = np.unique(st._keys(uid, iid))
-            _, val, _ = st._lookup(keys)
-            mir.apply(keys >> 32, keys & 0xFFFFFFFF, val.astype(np.float32), st.shape[0], st.shape[1], st.version)
+        self._stored(v0, uid, iid)
         return uid, iid
+
+    def _stored(self, version_before: int, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
+        """A mirror that was in step with the store is advanced by the batch's distinct (user, item)
+        pairs -- their new values come from the host store, which owns the semantics."""
+        st, mir = self.interactions, self._dev_x
+        if (mir is None or mir.version != version_before or st.decay_rate is not None or st.version == version_before
+                or len(user_ids) > self._MIRROR_APPLY_MAX):
+            return
+        keys = np.unique(st._keys(user_ids, item_ids))
+        _, val, _ = st._lookup(keys)
+        mir.apply(keys >> 32, keys & 0xFFFFFFFF, val.astype(np.float32), st.shape[0], st.shape[1], st.version)
 
     def _device_matrix(self, item_ids: Optional[List[int]]) -> Optional[Dict[str, Any]]:
         """X (or X with only `item_ids`' columns populated) as device arrays, or None -> host export."""

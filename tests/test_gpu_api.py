@@ -214,6 +214,21 @@ def test_streaming_through_the_device_resident_store_equals_host_exports(monkeyp
             if device_store:
                 assert m._dev_x.version == m.interactions.version and m._dev_x.nnz == m.interactions.nnz
             out.append((m.model.item_similarity.copy(), m.recommend_batch(list(range(0, 200, 3)), top_k=7)))
+        # incremental Recommender.fit on a numeric DataFrame: the columnar ingest advances the mirror too
+        import contextlib, io
+        import pandas as pd
+        from rtrec_amd import Recommender
+        df = pd.DataFrame({"user": u[:300] + 5, "item": i[:300], "tstamp": ts[-1] + 1.0 + np.arange(300), "rating": r[:300]})
+        loads = []
+        if device_store:
+            orig = m._dev_x.load_csr
+            m._dev_x.load_csr = lambda *a, **k: (loads.append(1), orig(*a, **k))[1]
+        with contextlib.redirect_stdout(io.StringIO()):
+            Recommender(m).fit(df)
+        assert not loads                                   # advanced incrementally, never rebuilt from a host export
+        if device_store:
+            assert m._dev_x.version == m.interactions.version and m._dev_x.nnz == m.interactions.nnz
+        out.append((m.model.item_similarity.copy(), m.recommend_batch(list(range(0, 200, 3)), top_k=7)))
         return out
 
     dev, host = run(True), run(False)
