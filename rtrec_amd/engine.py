@@ -370,7 +370,7 @@ class SlimEngine:
         if K > 0 and n > FIT_MW_MAX_TARGETS:
             want = int(os.environ.get("RTREC_AMD_FIT_HEAVY", FIT_HEAVY_TARGETS))
             nnz_sorted = X["col_nnz"][targets]
-            n_heavy = int(min(want, n - FIT_MW_MAX_TARGETS - 1, np.searchsorted(-nnz_sorted, -FIT_HEAVY_MIN_ROWS,
+            n_heavy = int(min(want, n - FIT_MW_MAX_TARGETS - 1, np.searchsorted(-nnz_sorted, -int(os.environ.get("RTREC_AMD_FIT_HEAVY_MIN_ROWS", FIT_HEAVY_MIN_ROWS)),
                                                                                  side="right")))
             n_heavy = max(n_heavy, 0)
 
