@@ -556,12 +556,14 @@ class SlimEngine:
         (or of the CSR batch `xb` = (ptr, col, val) device tensors).  `d_rows` may pass the row ids
         as a device tensor that is already resident (bench.py reuses it across steps).
 
-        Multi-GPU: every rank scores the rows against its own column shard; the per-shard lists are
-        packed into ONE int32 record per user -- [scores | ids | first-touch aux | count] (float64
-        scores in front when W is float64) -- so a step needs a single all-gather, and the rows are
-        processed in chunks whose all-gathers (RCCL, asynchronous on its own stream) overlap the
-        scoring kernel of the next chunk; merge_topk_kernel then reads the gathered block in place
-        through strides."""
+        Multi-GPU: every rank scores the rows against its own column shard and packs its per-shard lists
+        into ONE int32 record per user -- [scores | ids | first-touch aux | count] (float64 scores in
+        front when W is float64).  The exchange is sized for xGMI's point-to-point mesh rather than for
+        a switch: an ALL-TO-ALL hands rank r the records of ITS slice of the users from every shard
+        (B/G * 124 B from each peer instead of all B * 124 B of an all-gather), merge_topk_kernel merges
+        that slice in place through strides, and only the final k-lists (84 B per user) are all-gathered.
+        Rows are processed in chunks whose exchanges (RCCL, asynchronous on its own stream) overlap the
+        scoring kernel of the next chunk."""
         be = self.be
         if not self._W:
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
@@ -582,10 +584,12 @@ class SlimEngine:
         per = max(1, int(self.gather_chunk_rows))
         n_chunks = max(1, min(MAX_GATHER_CHUNKS, -(-n_rows // per)))
         per = -(-n_rows // n_chunks)
-        # record layout (int32 words): [2k float64 scores]? | k scores | k ids | k aux | count | pad to even
+        # exchanged record (int32 words): [2k float64 scores]? | k scores | k ids | k aux | count | pad to even
         o_sc = 2 * k if f64 else 0
         width = o_sc + 3 * k + 1
         width += width & 1
+        fwidth = 2 * k + 1          # final record: k scores | k ids | count | pad to even
+        fwidth += fwidth & 1
         o_ids = be.empty((n_rows, k), torch.int32)
         o_scs = be.empty((n_rows, k), torch.float32)
         o_cnt = be.empty((n_rows,), torch.int32)
@@ -600,20 +604,41 @@ class SlimEngine:
                                                                  cnt.view(m, 1)]
             if (o_sc + 3 * k + 1) & 1:
                 parts.append(torch.zeros((m, 1), dtype=torch.int32, device=ids.device))
-            packed = torch.cat(parts, dim=1)
-            g = be.empty((G * m, width), torch.int32)
-            work = dist.all_gather_into_tensor(g, packed, group=self.group, async_op=True)
-            pending.append((a, b, g, packed, work))
-        for a, b, g, packed, work in pending:
+            q = -(-m // G)                      # rows of this chunk each rank merges
+            if q * G == m:
+                packed = torch.cat(parts, dim=1)
+            else:                               # pad to G equal slices; padded rows carry count 0
+                packed = torch.zeros((q * G, width), dtype=torch.int32, device=ids.device)
+                packed[:m] = torch.cat(parts, dim=1)
+            recv = be.empty((G * q, width), torch.int32)
+            work = dist.all_to_all_single(recv, packed, group=self.group, async_op=True)
+            pending.append((a, b, q, recv, packed, work))
+        finals = []
+        for a, b, q, recv, packed, work in pending:
             work.wait()
-            m = b - a
-            g3 = g.view(G, m, width)
+            g3 = recv.view(G, q, width)         # [source shard, row of my slice, record]
             g_sc = g3[:, :, o_sc:o_sc + k].view(torch.float32)
             g_ids = g3[:, :, o_sc + k:o_sc + 2 * k]
             g_aux = g3[:, :, o_sc + 2 * k:o_sc + 3 * k]
             g_cnt = g3[:, :, o_sc + 3 * k]
-            g_sc64 = g.view(torch.float64).view(G, m, width // 2)[:, :, :k] if f64 else None
-            be.merge_topk(m, G, k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids[a:b], o_scs[a:b], o_cnt[a:b])
+            g_sc64 = recv.view(torch.float64).view(G, q, width // 2)[:, :, :k] if f64 else None
+            s_ids = be.empty((q, k), torch.int32)
+            s_sc = be.empty((q, k), torch.float32)
+            s_cnt = be.empty((q,), torch.int32)
+            be.merge_topk(q, G, k, g_ids, g_sc, g_sc64, g_aux, g_cnt, s_ids, s_sc, s_cnt)
+            fparts = [s_sc.view(torch.int32), s_ids, s_cnt.view(q, 1)]
+            if (2 * k + 1) & 1:
+                fparts.append(torch.zeros((q, 1), dtype=torch.int32, device=s_ids.device))
+            fin = torch.cat(fparts, dim=1)
+            out = be.empty((G * q, fwidth), torch.int32)
+            work2 = dist.all_gather_into_tensor(out, fin, group=self.group, async_op=True)
+            finals.append((a, b, out, fin, work2))
+        for a, b, out, fin, work2 in finals:
+            work2.wait()
+            m = b - a
+            o_scs[a:b] = out[:m, :k].view(torch.float32)
+            o_ids[a:b] = out[:m, k:2 * k]
+            o_cnt[a:b] = out[:m, 2 * k]
         return o_ids, o_scs, o_cnt
 
     def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
