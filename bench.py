@@ -59,6 +59,9 @@ def main() -> None:
     ap.add_argument("--tile-cols", type=int, default=4096)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--score-shard", default="columns", choices=["columns", "rows"],
+                    help="multi-GPU scoring: item-column shards of W + list exchange (BASELINE.json's configuration), or "
+                         "user-row shards with W replicated (for catalogues whose W is tiny, e.g. c4)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
     args = ap.parse_args()
 
@@ -95,7 +98,8 @@ def main() -> None:
     if rank == 0:
         log(f"[bench] workload {args.workload}: {U} x {I}, nnz={nnz} generated in {time.time() - t0:.1f}s")
 
-    eng = SlimEngine(device=f"cuda:{local_rank}", rank=rank, world_size=world, tile_cols=args.tile_cols)
+    eng = SlimEngine(device=f"cuda:{local_rank}", rank=rank, world_size=world, tile_cols=args.tile_cols,
+                     score_shard=args.score_shard)
     eng.set_interactions(Xc, X)
 
     # ------------------------------------------------------------------ fit (each rank: its own columns)
@@ -144,9 +148,10 @@ def main() -> None:
     xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
 
     def step():
-        # world == 1: one fused launch.  world > 1: the engine's sharded path -- local top-k per
-        # column shard in row chunks, one packed RCCL all-gather per chunk overlapped with the next
-        # chunk's kernel, strided merge (SlimEngine.score_topk_device).
+        # world == 1: one fused launch.  world > 1: the engine's sharded path (SlimEngine.score_topk_device)
+        # -- local top-k per column shard in row chunks, an all-to-all of the per-shard lists per chunk
+        # overlapped with the next chunk's kernel, strided merge of this rank's slice, all-gather of the
+        # final lists; or, with --score-shard rows, this rank's slice of the users against all of W.
         return eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
 
     for _ in range(args.warmup):
@@ -185,10 +190,18 @@ def main() -> None:
 
     # ------------------------------------------------------------------ roofline of score_tiles_kernel (this rank)
     Wr = W.tocsr()
-    shard_row_nnz = np.diff(Wr[:, lo:hi].tocsr().indptr).astype(np.float64) if hi > lo else np.zeros(I)
-    users_per_item = np.diff(Xc.indptr).astype(np.float64)
-    gathered_entries = float((users_per_item * shard_row_nnz).sum())
-    algo_bytes = 8.0 * nnz + 8.0 * gathered_entries + 8.0 * top_k * U + 4.0 * (U + 1)
+    if world > 1 and args.score_shard == "rows":      # this rank: its slice of the users against all of W
+        q_rows = -(-U // world)
+        ra, rb = min(U, rank * q_rows), min(U, (rank + 1) * q_rows)
+        row_nnz_w = np.diff(Wr.indptr).astype(np.float64)
+        Xs = X[ra:rb]
+        gathered_entries = float(row_nnz_w[Xs.indices].sum())
+        algo_bytes = 8.0 * Xs.nnz + 8.0 * gathered_entries + 8.0 * top_k * (rb - ra) + 4.0 * (rb - ra + 1)
+    else:
+        shard_row_nnz = np.diff(Wr[:, lo:hi].tocsr().indptr).astype(np.float64) if hi > lo else np.zeros(I)
+        users_per_item = np.diff(Xc.indptr).astype(np.float64)
+        gathered_entries = float((users_per_item * shard_row_nnz).sum())
+        algo_bytes = 8.0 * nnz + 8.0 * gathered_entries + 8.0 * top_k * U + 4.0 * (U + 1)
     kern_ms = tot_ms.value / max(n_launch.value, 1)
     achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
 
@@ -223,7 +236,8 @@ def main() -> None:
         "config": {"workload": f"{args.workload}: {wl['desc']}", "n_users": U, "n_items": I, "nnz": nnz,
                    "nn_feature_selection": K, "top_k": top_k, "tile_cols": lay["tile_cols"], "n_tiles": lay["n_tiles"],
                    "active_columns": lay["n_cols"],
-                   "parallelism": f"item-column shard x{world}" if world > 1 else "single GPU"},
+                   "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
+                                   else f"user-row shard x{world}, W replicated")},
         "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()),

@@ -254,8 +254,17 @@ class SlimEngine:
     """Fit / score / similar-items on one GPU (one shard of W)."""
 
     def __init__(self, device: Any = None, rank: int = 0, world_size: int = 1, process_group: Any = None,
-                 tile_cols: Optional[int] = None, backend: Any = None):
+                 tile_cols: Optional[int] = None, backend: Any = None, score_shard: Optional[str] = None):
         self.rank, self.world_size, self.group = rank, world_size, process_group
+        # How a multi-GPU scoring pass is divided.  "columns" (default; BASELINE.json's configuration): every
+        # rank scores all users against its item-column shard of W, lists are exchanged and merged.
+        # "rows": W is replicated (it is assembled on every rank after a fit anyway), every rank scores its
+        # 1/G slice of the users against all of W and only the final lists are all-gathered -- for
+        # catalogues whose W is so small that a pass is bound by reading the user rows (C4: 3.2k active
+        # columns), which column sharding does not divide.
+        self.score_shard = (score_shard or os.environ.get("RTREC_AMD_SCORE_SHARD", "columns")).lower()
+        if self.score_shard not in ("columns", "rows"):
+            raise ValueError(f"score_shard must be 'columns' or 'rows': {self.score_shard}")
         self.tile_cols = int(tile_cols or DEFAULT_TILE_COLS)
         self.be = backend if backend is not None else HipBackend(device)
         self.n_users = 0
@@ -481,7 +490,7 @@ class SlimEngine:
         a plain one for DENSE / CANDIDATES mode."""
         be = self.be
         n_items = W_csc.shape[1]
-        lo, hi = shard_bounds(n_items, self.world_size, self.rank)
+        lo, hi = (0, n_items) if self.score_shard == "rows" else shard_bounds(n_items, self.world_size, self.rank)
         W_csc = W_csc if W_csc.has_sorted_indices else W_csc.sorted_indices()
         W: Dict[str, Any] = {"n_items": n_items, "col_lo": lo, "col_hi": hi, "acc_f64": bool(acc_f64),
                              "host": W_csc, "layouts": {}}
@@ -581,6 +590,8 @@ class SlimEngine:
         f64 = bool(self._W["acc_f64"])
         if d_rows is None:
             d_rows = torch.arange(n_rows, dtype=torch.int32, device=xb[0].device)
+        if self.score_shard == "rows":
+            return self._score_row_sharded(d_rows, n_rows, xb, k, filter_interacted, mode, d_rank)
         per = max(1, int(self.gather_chunk_rows))
         n_chunks = max(1, min(MAX_GATHER_CHUNKS, -(-n_rows // per)))
         per = -(-n_rows // n_chunks)
@@ -641,6 +652,30 @@ class SlimEngine:
             o_cnt[a:b] = out[:m, 2 * k]
         return o_ids, o_scs, o_cnt
 
+    def _score_row_sharded(self, d_rows, n_rows: int, xb, k: int, filter_interacted: bool, mode: int, d_rank):
+        """score_shard == "rows": this rank scores rows [r*q, (r+1)*q) of the batch against the whole W (no
+        merge step: its lists are final) and the final records [k scores | k ids | count] of all ranks
+        are all-gathered, 84 B per user at k = 10."""
+        import torch.distributed as dist
+        be = self.be
+        torch = be.torch
+        G = self.world_size
+        q = -(-n_rows // G)
+        a = min(n_rows, self.rank * q)
+        b = min(n_rows, a + q)
+        m = b - a
+        fwidth = 2 * k + 1
+        fwidth += fwidth & 1
+        fin = torch.zeros((q, fwidth), dtype=torch.int32, device=d_rows.device)      # short / empty slices: count 0
+        if m > 0:
+            ids, sc, sc64, aux, cnt = self._local_topk(d_rows[a:b], m, xb, k, filter_interacted, mode, d_rank)
+            fin[:m, :k] = sc.view(torch.int32)
+            fin[:m, k:2 * k] = ids
+            fin[:m, 2 * k] = cnt
+        out = be.empty((G * q, fwidth), torch.int32)
+        dist.all_gather_into_tensor(out, fin, group=self.group)
+        return out[:n_rows, k:2 * k].contiguous(), out[:n_rows, :k].contiguous().view(torch.float32), out[:n_rows, 2 * k].contiguous()
+
     def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
                        mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None
                        ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -687,7 +722,7 @@ class SlimEngine:
         if lay is not None and B > 0:
             be.score_rows(B, None, xb, W["n_items"], W["col_lo"], lay, W["acc_f64"], out)
         block = out.cpu().numpy()[:, :n_local]
-        if self.world_size == 1:
+        if self.world_size == 1 or self.score_shard == "rows":      # rows mode: W is not sharded
             return block
         import torch.distributed as dist
         parts: List[Any] = [None] * self.world_size

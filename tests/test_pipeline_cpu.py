@@ -164,14 +164,14 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, score_shard="columns"):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         z = np.load(os.path.join(G, "models.npz"))
         X = load_csc(z, "X2")
-        eng = SlimEngine(backend=OracleBackend(), rank=rank, world_size=world)
+        eng = SlimEngine(backend=OracleBackend(), rank=rank, world_size=world, score_shard=score_shard)
         eng.gather_chunk_rows = 7          # several chunks -> several asynchronous all-gathers in flight
         m = SLIMElastic({"nn_feature_selection": 50}, engine=eng)
         m.partial_fit_items(X.copy(), list(range(400)))            # each rank fits its own column shard
@@ -192,16 +192,17 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_rank_column_sharding_gloo(world):
+@pytest.mark.parametrize("world,score_shard", [(2, "columns"), (3, "columns"), (2, "rows"), (3, "rows")])
+def test_two_rank_column_sharding_gloo(world, score_shard):
     """Column-sharded fit + scoring over gloo: per-shard lists travel by all-to-all (every rank merges
     its slice of the users; 7-row chunks do not divide by 2 or 3, so padded slices are exercised) and the
-    final lists by all-gather; results must equal the single-process reference goldens."""
+    final lists by all-gather; "rows" mode replicates W and shards the users instead.  Either way the
+    results must equal the single-process reference goldens."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, score_shard)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)

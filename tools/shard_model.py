@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Single-GPU model of the column-sharded scoring pass (what each rank of an N-GPU job runs).
+"""Single-GPU model of the sharded scoring pass (what each rank of an N-GPU job runs), for both ways
+of dividing it: item-column shards of W (default) and user-row shards with W replicated.
 
 For N in --worlds: build rank r's shard of W (r = 0..N-1) on cuda:0, time its local
 score_topk launch over ALL users, and report max-over-ranks (the compute part of one bench step
@@ -69,10 +70,35 @@ def main() -> None:
             lay = e._layout(True)
         worst = max(per_rank)
         base = base or worst
-        gather_bytes = N * U * (k * 12 + 4)      # ids + scores + aux per entry, count per row, from every rank
-        print(json.dumps({"world": N, "local_ms_max": worst, "local_ms_min": min(per_rank),
-                          "speedup_vs_1": base / worst, "allgather_bytes_per_rank_out": gather_bytes,
-                          "users_per_s_compute_only": U / (worst * 1e-3)}), flush=True)
+        rec = k * 12 + 4                          # scores + ids + aux per entry, count per row
+        # column shards: all-to-all of the per-shard lists (this rank receives its U/N slice from N-1 peers),
+        # then an all-gather of the final lists (k * 8 + 4 bytes per user)
+        exch_bytes = (N - 1) * (-(-U // N)) * rec + (N - 1) * (-(-U // N)) * (k * 8 + 4)
+        # row shards: W replicated, this rank scores U/N users; only the final lists travel
+        q = -(-U // N)
+        e = SlimEngine(device="cuda:0", score_shard="rows")
+        e._X = eng._X
+        e.n_users, e.n_items = U, I
+        e.set_weights(W)
+        rows_ms = []
+        for r in range(N):
+            d_slice = d_rows[min(U, r * q):min(U, (r + 1) * q)]
+            m = int(d_slice.shape[0])
+            if m == 0:
+                continue
+            e._local_topk(d_slice, m, xb, k, True, _native.TOPK_SPARSE, None)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                e._local_topk(d_slice, m, xb, k, True, _native.TOPK_SPARSE, None)
+            torch.cuda.synchronize()
+            rows_ms.append((time.perf_counter() - t0) / args.steps * 1e3)
+        print(json.dumps({"world": N, "column_shards": {"local_ms_max": worst, "local_ms_min": min(per_rank),
+                                                         "speedup_vs_1": base / worst, "bytes_received_per_rank": exch_bytes},
+                          "row_shards": {"local_ms_max": max(rows_ms), "speedup_vs_1": base / max(rows_ms),
+                                         "bytes_received_per_rank": (N - 1) * q * (k * 8 + 4)},
+                          "users_per_s_compute_only": {"columns": U / (worst * 1e-3), "rows": U / (max(rows_ms) * 1e-3)}}),
+              flush=True)
 
 
 if __name__ == "__main__":
