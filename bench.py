@@ -191,12 +191,10 @@ def main() -> None:
     # ------------------------------------------------------------------ roofline of score_tiles_kernel (this rank)
     Wr = W.tocsr()
     if world > 1 and args.score_shard == "rows":      # this rank: its slice of the users against all of W
-        q_rows = -(-U // world)
-        ra, rb = min(U, rank * q_rows), min(U, (rank + 1) * q_rows)
         row_nnz_w = np.diff(Wr.indptr).astype(np.float64)
-        Xs = X[ra:rb]
+        Xs = X[rank::world]
         gathered_entries = float(row_nnz_w[Xs.indices].sum())
-        algo_bytes = 8.0 * Xs.nnz + 8.0 * gathered_entries + 8.0 * top_k * (rb - ra) + 4.0 * (rb - ra + 1)
+        algo_bytes = 8.0 * Xs.nnz + 8.0 * gathered_entries + 8.0 * top_k * Xs.shape[0] + 4.0 * (Xs.shape[0] + 1)
     else:
         shard_row_nnz = np.diff(Wr[:, lo:hi].tocsr().indptr).astype(np.float64) if hi > lo else np.zeros(I)
         users_per_item = np.diff(Xc.indptr).astype(np.float64)

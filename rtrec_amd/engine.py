@@ -653,28 +653,29 @@ class SlimEngine:
         return o_ids, o_scs, o_cnt
 
     def _score_row_sharded(self, d_rows, n_rows: int, xb, k: int, filter_interacted: bool, mode: int, d_rank):
-        """score_shard == "rows": this rank scores rows [r*q, (r+1)*q) of the batch against the whole W (no
-        merge step: its lists are final) and the final records [k scores | k ids | count] of all ranks
-        are all-gathered, 84 B per user at k = 10."""
+        """score_shard == "rows": this rank scores rows r, r+G, r+2G, ... of the batch (strided, so that
+        every rank gets the same mix of heavy and light users whatever their order) against the whole W
+        -- no merge step: its lists are final -- and the final records [k scores | k ids | count] of all
+        ranks are all-gathered, 84 B per user at k = 10."""
         import torch.distributed as dist
         be = self.be
         torch = be.torch
         G = self.world_size
         q = -(-n_rows // G)
-        a = min(n_rows, self.rank * q)
-        b = min(n_rows, a + q)
-        m = b - a
+        mine = d_rows[self.rank::G].contiguous()
+        m = int(mine.shape[0])
         fwidth = 2 * k + 1
         fwidth += fwidth & 1
         fin = torch.zeros((q, fwidth), dtype=torch.int32, device=d_rows.device)      # short / empty slices: count 0
         if m > 0:
-            ids, sc, sc64, aux, cnt = self._local_topk(d_rows[a:b], m, xb, k, filter_interacted, mode, d_rank)
+            ids, sc, sc64, aux, cnt = self._local_topk(mine, m, xb, k, filter_interacted, mode, d_rank)
             fin[:m, :k] = sc.view(torch.int32)
             fin[:m, k:2 * k] = ids
             fin[:m, 2 * k] = cnt
         out = be.empty((G * q, fwidth), torch.int32)
         dist.all_gather_into_tensor(out, fin, group=self.group)
-        return out[:n_rows, k:2 * k].contiguous(), out[:n_rows, :k].contiguous().view(torch.float32), out[:n_rows, 2 * k].contiguous()
+        out = out.view(G, q, fwidth).transpose(0, 1).reshape(G * q, fwidth)[:n_rows]    # row i*G + p <- rank p, slot i
+        return out[:, k:2 * k].contiguous(), out[:, :k].contiguous().view(torch.float32), out[:, 2 * k].contiguous()
 
     def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
                        mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None

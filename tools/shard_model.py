@@ -82,7 +82,7 @@ def main() -> None:
         e.set_weights(W)
         rows_ms = []
         for r in range(N):
-            d_slice = d_rows[min(U, r * q):min(U, (r + 1) * q)]
+            d_slice = d_rows[r::N].contiguous()           # strided: every rank the same mix of heavy and light users
             m = int(d_slice.shape[0])
             if m == 0:
                 continue
