@@ -592,7 +592,9 @@ class SlimEngine:
             d_rows = torch.arange(n_rows, dtype=torch.int32, device=xb[0].device)
         if self.score_shard == "rows":
             return self._score_row_sharded(d_rows, n_rows, xb, k, filter_interacted, mode, d_rank)
-        per = max(1, int(self.gather_chunk_rows))
+        # a chunk's local kernel shrinks with the shard (1/G of W), its launch + exchange overhead does not:
+        # chunks grow with G so that one still amortises the other
+        per = max(1, int(self.gather_chunk_rows) * max(1, G // 2))
         n_chunks = max(1, min(MAX_GATHER_CHUNKS, -(-n_rows // per)))
         per = -(-n_rows // n_chunks)
         # exchanged record (int32 words): [2k float64 scores]? | k scores | k ids | k aux | count | pad to even
