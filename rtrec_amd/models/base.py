@@ -264,6 +264,26 @@ class BaseModel(ABC):
             return [(self.item_ids.get(i), s) for i, s in pairs]
         return [self.item_ids.get(i) for i, _ in pairs]
 
+    def similar_items_batch(self, query_items: List[Any], query_item_tags: Optional[List[str]] = None, top_k: int = 10,
+                            ret_scores: bool = False) -> List[Any]:
+        """[similar_items(q, ...) for q in query_items] in one pass.  Models that can answer many queries at
+        once override _similar_items_batch; the default loops."""
+        ids = [self.item_ids.identify(q) for q in query_items]       # same order and side effects as one call per query
+        known = [i for i in ids if i is not None]
+        answers = iter(self._similar_items_batch(known, query_item_tags=query_item_tags, top_k=top_k))
+        out: List[Any] = []
+        for i in ids:
+            if i is None:
+                out.append([])
+                continue
+            pairs = next(answers)
+            out.append([(self.item_ids.get(j), s) for j, s in pairs] if ret_scores else [self.item_ids.get(j) for j, _ in pairs])
+        return out
+
+    def _similar_items_batch(self, query_item_ids: List[int], query_item_tags: Optional[List[str]] = None,
+                             top_k: int = 10) -> List[List[Tuple[int, float]]]:
+        return [self._similar_items(i, query_item_tags=query_item_tags, top_k=top_k) for i in query_item_ids]
+
     def get_users_by_items(self, items: List[Any]) -> List[Any]:
         item_ids = [i for i in (self.item_ids.get_id(item) for item in items) if i is not None]
         if not item_ids:

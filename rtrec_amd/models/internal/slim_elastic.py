@@ -314,3 +314,21 @@ class SLIMElastic:
         if ret_ndarrays:
             return ids, sc
         return list(zip(ids.tolist(), sc.tolist()))
+
+    def similar_items_batch(self, item_ids: List[int], top_k: int = 10) -> List[List[Tuple[int, float]]]:
+        """[similar_items(i, top_k) for i in item_ids] with ONE launch of similar_topk_kernel and one
+        download (the reference answers item-to-item queries one column at a time, slim_elastic.py:820-857)."""
+        if self.item_similarity is None:
+            raise RuntimeError("Model must be fitted before calling similar_items.")
+        n_items = self.item_similarity.shape[1]
+        out: List[List[Tuple[int, float]]] = [[] for _ in item_ids]
+        valid = [p for p, i in enumerate(item_ids) if 0 <= i < n_items]
+        if not valid or top_k <= 0:
+            return out
+        self._sync_weights()
+        ids, sc, cnt = self.engine.similar_items([item_ids[p] for p in valid], top_k)
+        id_rows, sc_rows, cnts = ids.tolist(), sc.tolist(), cnt.tolist()
+        for r, p in enumerate(valid):
+            c = cnts[r]
+            out[p] = list(zip(id_rows[r][:c], sc_rows[r][:c]))
+        return out

@@ -168,6 +168,10 @@ class SLIM(BaseModel):
                        ) -> List[Tuple[int, float]]:
         return self.model.similar_items(query_item_id, top_k=top_k, ret_ndarrays=False)  # type: ignore
 
+    def _similar_items_batch(self, query_item_ids: List[int], query_item_tags: Optional[List[str]] = None,
+                             top_k: int = 10) -> List[List[Tuple[int, float]]]:
+        return self.model.similar_items_batch(query_item_ids, top_k=top_k)
+
     # ------------------------------------------------------------ persistence (slim.py:117-149)
     def _serialize(self) -> dict:
         return {"model": self.model, "interactions": self.interactions, "user_ids": self.user_ids,

@@ -98,6 +98,9 @@ class Recommender:
 
     def similar_items(self, query_items: List[Any], query_item_tags: Optional[List[str]] = None, top_k: int = 10,
                       ret_scores: bool = False):
+        batch = getattr(self.model, "similar_items_batch", None)
+        if batch is not None:        # one kernel launch for all queries instead of one per query
+            return batch(query_items, query_item_tags, top_k, ret_scores)
         return [self.model.similar_items(item, query_item_tags, top_k, ret_scores) for item in query_items]
 
     def evaluate(self, test_data: pd.DataFrame, user_tags: Optional[Dict[Any, List[str]]] = None,
