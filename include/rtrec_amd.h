@@ -271,6 +271,22 @@ int rtrec_slim_similar_topk(int32_t n_queries, const int32_t *d_queries,
                             int32_t *d_out_ids, float *d_out_scores, int32_t *d_out_count,
                             void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * INTERACTION STORE, host side  (replaces the per-interaction dict updates of
+ * rtrec/utils/interactions.py:81-119 for the columnar store of rtrec_amd/utils/interactions.py)
+ * HOST pointers.  Merge two sorted blocks (key = user << 32 | item, each with distinct keys) into
+ * out_* (room for n_a + n_b entries); on equal keys the entry of b wins.  Returns the number of
+ * entries written, or -1 on invalid arguments.  n_threads <= 0: up to 16 hardware threads.
+ * ------------------------------------------------------------------------------------- */
+int64_t rtrec_store_merge_sorted(const int64_t *a_key, const double *a_val, const double *a_ts, int64_t n_a,
+                                 const int64_t *b_key, const double *b_val, const double *b_ts, int64_t n_b,
+                                 int64_t *out_key, double *out_val, double *out_ts, int32_t n_threads);
+
+/* Positions of ASCENDING needles[m] in the sorted hay[n] (host pointers): pos[i] = lower bound of needles[i]
+ * clamped to n - 1, found[i] = (hay[pos[i]] == needles[i]).  0 on success, -1 on invalid arguments. */
+int rtrec_store_find_sorted(const int64_t *hay, int64_t n, const int64_t *needles, int64_t m,
+                            int64_t *pos, uint8_t *found, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,7 +18,7 @@ from .models.base import BaseModel
 from .utils.metrics import compute_scores
 
 _COLUMNS = ["user", "item", "tstamp", "rating"]
-_COLUMNAR_CHUNK = 1 << 24
+_COLUMNAR_CHUNK = 1 << 22
 
 
 class Recommender:

@@ -97,9 +97,60 @@ class _Block:
         """(found mask, position) of each key."""
         if len(self) == 0:
             return np.zeros(keys.shape, bool), np.zeros(keys.shape, np.int64)
+        if keys.shape[0] >= _NATIVE_FIND_MIN and len(self) >= _NATIVE_FIND_MIN and bool(np.all(keys[1:] >= keys[:-1])):
+            lib = _native_lib()                 # ascending needles: galloping search at memory speed
+            if lib is not None:
+                k = np.ascontiguousarray(keys, dtype=np.int64)
+                hay = np.ascontiguousarray(self.key)
+                pos = np.empty(k.shape[0], np.int64)
+                found = np.empty(k.shape[0], np.uint8)
+                if lib.rtrec_store_find_sorted(hay.ctypes.data, len(self), k.ctypes.data, k.shape[0],
+                                               pos.ctypes.data, found.ctypes.data, 0) != 0:
+                    raise RuntimeError("rtrec_store_find_sorted failed")
+                return found.view(bool), pos
         pos = np.searchsorted(self.key, keys)
         pos_c = np.minimum(pos, len(self) - 1)
         return self.key[pos_c] == keys, pos_c
+
+
+_NATIVE_MERGE_MIN = 1 << 15
+_NATIVE_FIND_MIN = 1 << 14
+_native_merge: Any = None          # False: the native library is not available (numpy merge instead)
+_native_handle: Any = None
+
+
+def _native_lib() -> Any:
+    """librtrec_amd.so (host routines of csrc/store_host.hip), or None when it has not been built."""
+    global _native_handle
+    if _native_handle is None:
+        try:
+            from .. import _native
+            _native_handle = _native.load()
+        except Exception:
+            _native_handle = False
+    return _native_handle or None
+
+
+def _merge_native(old: _Block, new: _Block) -> Optional[_Block]:
+    """Two-pointer merge by librtrec_amd.so's host routine (rtrec_store_merge_sorted: memory speed,
+    threaded), or None when the library has not been built."""
+    global _native_merge
+    if _native_merge is None:
+        try:
+            from .. import _native
+            _native_merge = _native.load().rtrec_store_merge_sorted
+        except Exception:
+            _native_merge = False
+    if _native_merge is False:
+        return None
+    n, m = len(old), len(new)
+    cols = [np.ascontiguousarray(a) for a in (old.key, old.val, old.ts, new.key, new.val, new.ts)]
+    ko, vo, to = np.empty(n + m, np.int64), np.empty(n + m, np.float64), np.empty(n + m, np.float64)
+    p = [a.ctypes.data for a in cols]
+    cnt = int(_native_merge(p[0], p[1], p[2], n, p[3], p[4], p[5], m, ko.ctypes.data, vo.ctypes.data, to.ctypes.data, 0))
+    if cnt < 0:
+        raise RuntimeError("rtrec_store_merge_sorted failed")
+    return _Block(ko[:cnt], vo[:cnt], to[:cnt]) if cnt == n + m else _Block(ko[:cnt].copy(), vo[:cnt].copy(), to[:cnt].copy())
 
 
 def _merge_blocks(old: _Block, new: _Block) -> _Block:
@@ -108,6 +159,10 @@ def _merge_blocks(old: _Block, new: _Block) -> _Block:
         return new
     if len(new) == 0:
         return old
+    if len(old) + len(new) >= _NATIVE_MERGE_MIN:
+        merged = _merge_native(old, new)
+        if merged is not None:
+            return merged
     found, pos = old.find(new.key)
     if found.any():   # overwrite in place, append the rest
         old.val[pos[found]] = new.val[found]

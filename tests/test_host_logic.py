@@ -465,3 +465,48 @@ def test_store_levels_mini_batches_equal_one_bulk_write(monkeypatch):
     for k in range(0, n, 7919):
         assert a_store.get_user_item_rating(int(u[k]), int(i[k])) == b_store.get_user_item_rating(int(u[k]), int(i[k]))
     assert sorted(a_store.get_user_items(int(u[-1]))) == sorted(b_store.get_user_items(int(u[-1])))
+
+
+def test_native_block_merge_equals_numpy_merge(monkeypatch):
+    """rtrec_store_merge_sorted (host routine of librtrec_amd.so, threaded two-pointer merge) against the
+    numpy merge of the store: overlapping keys (the new block wins), disjoint keys, one-sided tails."""
+    from rtrec_amd.utils import interactions as mod
+    rng = np.random.default_rng(12)
+
+    def block(keys):
+        keys = np.unique(keys.astype(np.int64))
+        return mod._Block(keys, rng.random(len(keys)), rng.random(len(keys)) * 1e9)
+
+    cases = [(rng.integers(0, 1 << 40, 200_000), rng.integers(0, 1 << 40, 150_000)),          # almost disjoint
+             (rng.integers(0, 300_000, 200_000), rng.integers(0, 300_000, 90_000)),            # heavy overlap
+             (np.arange(100_000), np.arange(100_000, 180_000)),                                # b entirely above a
+             (np.arange(50_000, 120_000), np.arange(0, 60_000))]                               # b below and into a
+    for ka, kb in cases:
+        a1, b1 = block(ka), block(kb)
+        a2 = mod._Block(a1.key.copy(), a1.val.copy(), a1.ts.copy())
+        native = mod._merge_blocks(a1, b1)
+        assert mod._native_merge not in (None, False), "librtrec_amd.so must export rtrec_store_merge_sorted"
+        with monkeypatch.context() as mp:
+            mp.setattr(mod, "_NATIVE_MERGE_MIN", 1 << 62)
+            plain = mod._merge_blocks(a2, b1)
+        assert np.array_equal(native.key, plain.key) and np.array_equal(native.val, plain.val)
+        assert np.array_equal(native.ts, plain.ts)
+        assert np.all(np.diff(native.key) > 0)
+
+
+def test_native_sorted_lookup_equals_searchsorted(monkeypatch):
+    """rtrec_store_find_sorted (galloping search for ascending needles) against numpy's searchsorted path
+    of _Block.find: hits, misses below / between / above the block, repeated needles."""
+    from rtrec_amd.utils import interactions as mod
+    rng = np.random.default_rng(13)
+    hay = np.unique(rng.integers(1000, 1 << 34, 300_000).astype(np.int64))
+    blk = mod._Block(hay, np.zeros(len(hay)), np.zeros(len(hay)))
+    for needles in (np.sort(np.concatenate([rng.choice(hay, 40_000), rng.integers(0, 1 << 35, 40_000)])).astype(np.int64),
+                    np.sort(rng.choice(hay[:5000], 30_000)).astype(np.int64),                       # dense repeats
+                    np.concatenate([np.arange(20_000), np.arange(1 << 36, (1 << 36) + 20_000)]).astype(np.int64)):
+        f1, p1 = blk.find(needles)
+        with monkeypatch.context() as mp:
+            mp.setattr(mod, "_NATIVE_FIND_MIN", 1 << 62)
+            f2, p2 = blk.find(needles)
+        assert mod._native_lib() is not None
+        assert np.array_equal(f1, f2) and np.array_equal(p1, p2) and f1.dtype == np.bool_

@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--qps", type=float, default=0.0,
                     help="fixed arrival rate in interactions/s (0 = back to back): mini-batch k is released at "
                          "k * batch_size / qps; reports how far completion lags behind release")
-    ap.add_argument("--bulk-chunk", type=int, default=16_000_000, help="rows per vectorised bulk-ingest call")
+    ap.add_argument("--bulk-chunk", type=int, default=4_000_000, help="rows per vectorised bulk-ingest call")
     args = ap.parse_args()
     import torch
     from rtrec_amd import SLIM

@@ -62,8 +62,8 @@ def main():
     n_bulk = n - args.batches * args.batch_size
 
     model = SLIM(min_value=0, max_value=15, nn_feature_selection=50)
-    for a in range(0, n_bulk, 16_000_000):
-        b = min(a + 16_000_000, n_bulk)
+    for a in range(0, n_bulk, 4_000_000):
+        b = min(a + 4_000_000, n_bulk)
         model.interactions.add_interactions_batch(model.user_ids.identify_many(u[a:b].astype(np.int64)),
                                                   model.item_ids.identify_many(i[a:b].astype(np.int64)), ts[a:b], r[a:b])
     model.bulk_fit(parallel=True, progress_bar=False)
