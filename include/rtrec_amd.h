@@ -287,6 +287,14 @@ int64_t rtrec_store_merge_sorted(const int64_t *a_key, const double *a_val, cons
 int rtrec_store_find_sorted(const int64_t *hay, int64_t n, const int64_t *needles, int64_t m,
                             int64_t *pos, uint8_t *found, int32_t n_threads);
 
+/* Hot-item bookkeeping (replaces one LRUFreqSet.add per interaction, rtrec/utils/lru.py:11-60): replay
+ * values[n] in order on a capacity-bounded recency list with hit counts.  The list comes in
+ * (state_keys/state_counts[n_state]) and goes out (out_keys/out_counts, room for `capacity`) oldest first;
+ * all keys are ids in [0, id_bound).  Returns the length of the list, or -1 on invalid arguments. */
+int64_t rtrec_lru_replay(const int64_t *state_keys, const int64_t *state_counts, int64_t n_state,
+                         const int64_t *values, int64_t n, int64_t capacity, int64_t id_bound,
+                         int64_t *out_keys, int64_t *out_counts);
+
 #ifdef __cplusplus
 }
 #endif

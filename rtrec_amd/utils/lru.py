@@ -32,7 +32,8 @@ class LRUFreqSet(MutableSet):
     def add_many(self, values: Iterable[Any]) -> None:
         """Same end state as calling add() for each value in order."""
         if isinstance(values, np.ndarray):
-            if values.dtype.kind in "iu" and values.ndim == 1 and len(values) > 64 and self._add_many_ints(values):
+            if values.dtype.kind in "iu" and values.ndim == 1 and len(values) > 64 and (
+                    self._add_many_ints(values) or self._replay_native(values)):
                 return
             values = values.tolist()       # python scalars: the keys are handed back to callers
         values = list(values)
@@ -81,6 +82,35 @@ class LRUFreqSet(MutableSet):
         for j in order.tolist():
             k = keys[j]
             data[k] = data.pop(k, 0) + cnt[j]
+        return True
+
+    _NATIVE_ID_BOUND = 1 << 26
+
+    def _replay_native(self, values: "np.ndarray") -> bool:
+        """add() for every value in order -- evictions included -- by librtrec_amd.so's host routine
+        (rtrec_lru_replay: an intrusive linked list over the ids).  For batches that overflow the capacity,
+        where the end state depends on the exact interleaving.  Returns False (nothing done) when the
+        library is missing or the keys are not small non-negative integers."""
+        try:
+            from .. import _native
+            lib = _native.load()
+        except Exception:
+            return False
+        data = self.data
+        if any(not isinstance(k, int) for k in data):
+            return False
+        vals = np.ascontiguousarray(values, dtype=np.int64)
+        bound = max(int(vals.max()), max(data, default=0)) + 1
+        if int(vals.min()) < 0 or (data and min(data) < 0) or bound > self._NATIVE_ID_BOUND:
+            return False
+        sk = np.fromiter(data.keys(), dtype=np.int64, count=len(data))
+        sc = np.fromiter(data.values(), dtype=np.int64, count=len(data))
+        ok, oc = np.empty(self.capacity, np.int64), np.empty(self.capacity, np.int64)
+        n_out = int(lib.rtrec_lru_replay(sk.ctypes.data, sc.ctypes.data, len(sk), vals.ctypes.data, len(vals),
+                                         self.capacity, bound, ok.ctypes.data, oc.ctypes.data))
+        if n_out < 0:
+            return False
+        self.data = OrderedDict(zip(ok[:n_out].tolist(), oc[:n_out].tolist()))
         return True
 
     def discard(self, value: Any) -> None:

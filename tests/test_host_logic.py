@@ -510,3 +510,20 @@ def test_native_sorted_lookup_equals_searchsorted(monkeypatch):
             f2, p2 = blk.find(needles)
         assert mod._native_lib() is not None
         assert np.array_equal(f1, f2) and np.array_equal(p1, p2) and f1.dtype == np.bool_
+
+
+def test_native_lru_replay_equals_sequential_adds():
+    """Batches that overflow the capacity are replayed by rtrec_lru_replay (host routine of
+    librtrec_amd.so); the end state -- keys, hit counts, recency order -- must be the one a loop of add()
+    leaves, across several batches on a warm set."""
+    rng = np.random.default_rng(21)
+    a, b = LRUFreqSet(capacity=500), LRUFreqSet(capacity=500)
+    for step in range(6):
+        vals = (rng.zipf(1.2, 5000) % 3000).astype(np.int64) if step % 2 == 0 else rng.integers(0, 3000, 4000)
+        for v in vals.tolist():
+            a.add(v)
+        b.add_many(vals)
+        assert list(a.data.items()) == list(b.data.items())
+        assert all(isinstance(k, int) for k in b.data)
+    assert len(b) == 500
+    assert list(a.get_freq_items(20)) == list(b.get_freq_items(20))
