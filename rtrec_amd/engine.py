@@ -265,6 +265,9 @@ class SlimEngine:
         self.score_shard = (score_shard or os.environ.get("RTREC_AMD_SCORE_SHARD", "columns")).lower()
         if self.score_shard not in ("columns", "rows"):
             raise ValueError(f"score_shard must be 'columns' or 'rows': {self.score_shard}")
+        # testing aid: run the multi-GPU exchange (collectives, strided merge) even with a single rank, so that
+        # the RCCL code path can be exercised on a one-GPU box through a 1-rank process group
+        self.force_exchange = os.environ.get("RTREC_AMD_FORCE_EXCHANGE") == "1"
         self.tile_cols = int(tile_cols or DEFAULT_TILE_COLS)
         self.be = backend if backend is not None else HipBackend(device)
         self.n_users = 0
@@ -581,7 +584,7 @@ class SlimEngine:
         if d_rows is None and row_ids is not None:
             d_rows = be.to_dev(np.asarray(row_ids, dtype=np.int32))
         d_rank = be.to_dev(np.asarray(col_rank, dtype=np.int32)) if col_rank is not None else None
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force_exchange:
             ids, sc, sc64, aux, cnt = self._local_topk(d_rows, n_rows, xb, top_k, filter_interacted, mode, d_rank)
             return ids, sc, cnt
         import torch.distributed as dist

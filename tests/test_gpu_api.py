@@ -259,3 +259,44 @@ def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, mo
     assert Wd.shape == Wh.shape and np.array_equal(Wd.indptr, Wh.indptr) and np.array_equal(Wd.indices, Wh.indices)
     assert np.array_equal(Wd.data.view(np.uint8), Wh.data.view(np.uint8))
     assert rd == rh
+
+
+_RCCL_ONE_RANK = r"""
+import os, sys, numpy as np, scipy.sparse as sp, torch, torch.distributed as dist
+G = sys.argv[1]
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+from rtrec_amd.engine import SlimEngine
+from rtrec_amd.models.internal.slim_elastic import SLIMElastic
+z, zs = np.load(os.path.join(G, "models.npz")), np.load(os.path.join(G, "scoring.npz"))
+load = lambda p: sp.csc_matrix((z[p + "_data"], z[p + "_indices"], z[p + "_indptr"]), shape=tuple(z[p + "_shape"]))
+X, users = load("X2").tocsr(), zs["users"].tolist()
+for mode in ("columns", "rows"):
+    eng = SlimEngine(device="cuda:0", rank=0, world_size=1, score_shard=mode)
+    eng.force_exchange = True
+    eng.gather_chunk_rows = 7                       # several chunks: several asynchronous exchanges in flight
+    m = SLIMElastic({"nn_feature_selection": 50}, engine=eng)
+    for dtype, tag in ((np.float32, "f32"), (np.float64, "f64")):
+        m.item_similarity = sp.csc_matrix(load("W2_k50"), dtype=dtype)
+        out = m.recommend_batch(users, X, top_k=10, filter_interacted=True, dense_output=False)
+        assert out == [[x for x in row.tolist() if x >= 0] for row in zs[f"ids_{tag}_sparse_filter"]], (mode, tag, "sparse")
+        out = m.recommend_batch(users, X, top_k=10, filter_interacted=False, dense_output=True)
+        assert out == [[x for x in row.tolist() if x >= 0] for row in zs[f"ids_{tag}_dense_nofilter"]], (mode, tag, "dense")
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL-EXCHANGE-OK")
+"""
+
+
+def test_exchange_path_over_rccl_with_one_rank():
+    """The multi-GPU exchange of the scoring path (all_to_all_single of per-shard lists, strided merge of the
+    received block, all_gather_into_tensor of the final lists; row-shard mode too) pushed through RCCL
+    itself: a 1-rank NCCL group on this box's GPU, in a child process, against the reference goldens."""
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, G], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "RCCL-EXCHANGE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
