@@ -191,12 +191,12 @@ def _merge_blocks(old: _Block, new: _Block) -> _Block:
     return _Block(*out)
 
 
-def _stable_order(users: np.ndarray, items: np.ndarray, keys: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+def _stable_order(users: np.ndarray, items: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
     """(argsort(keys, kind="stable"), keys in that order).  When (user, item, arrival index) fit one int64
     the composite is VALUE-sorted instead (numpy's vectorised quicksort; the arrival index in the low bits
     both makes the keys distinct -- so an unstable sort yields the stable order -- and is the permutation),
     and the sorted keys are unpacked from the composite instead of gathered through the permutation."""
-    n = keys.shape[0]
+    n = users.shape[0]
     ib, xb = int(items.max()).bit_length(), max(1, (n - 1).bit_length())
     if n >= (1 << 12) and int(users.max()).bit_length() + ib + xb <= 63:
         comp = (users << (ib + xb)) | (items << xb) | np.arange(n, dtype=np.int64)
@@ -205,6 +205,7 @@ def _stable_order(users: np.ndarray, items: np.ndarray, keys: np.ndarray) -> Tup
         comp >>= xb
         sk = ((comp >> ib) << _SHIFT) | (comp & ((1 << ib) - 1))
         return order, sk
+    keys = (users << _SHIFT) | items
     order = np.argsort(keys, kind="stable")
     return order, keys[order]
 
@@ -355,11 +356,12 @@ class UserItemInteractions:
         if late.any():
             logging.warning(f"{int(late.sum())} interaction timestamp(s) are in the future "
                             f"(max {float(ts.max())}, current time {now})")
-        # max_timestamp as each interaction sees it: running max of (tstamp + 1)
-        seen = np.maximum.accumulate(np.concatenate(([self.max_timestamp], ts + 1.0)))[1:]
-        keys = self._keys(users, items)
+        # max_timestamp as each interaction sees it (running max of tstamp + 1): only decay looks at it
+        decaying = self.decay_rate is not None and not upsert
+        seen = np.maximum.accumulate(np.concatenate(([self.max_timestamp], ts + 1.0)))[1:] if decaying else None
+        max_ts_after = float(seen[-1]) if decaying else max(self.max_timestamp, float(ts.max()) + 1.0)
 
-        order, sk = _stable_order(users, items, keys)
+        order, sk = _stable_order(users, items)
         first = np.ones(n, bool)
         first[1:] = sk[1:] != sk[:-1]
         if first.all():
@@ -374,11 +376,14 @@ class UserItemInteractions:
                 new = dl[idx]
             else:
                 found, old, old_ts = self._lookup(k)
-                cur = np.where(found & (old != 0.0), self._decay_array(old, old_ts, seen[idx]), 0.0)
+                if decaying:
+                    cur = np.where(found & (old != 0.0), self._decay_array(old, old_ts, seen[idx]), 0.0)
+                else:
+                    cur = old                 # 0.0 where the pair is new
                 new = np.clip(cur + dl[idx], self.min_value, self.max_value)
             self._write(k, new, ts[idx], presorted=True)     # every round is a subsequence of the key-sorted order
 
-        self.max_timestamp = float(seen[-1])
+        self.max_timestamp = max_ts_after
         i_hi = int(items.max())
         if i_hi <= max(4 * n, 1 << 22):
             self.all_item_ids.update(np.flatnonzero(np.bincount(items, minlength=i_hi + 1)).tolist())
