@@ -174,14 +174,30 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
                    : (a.mode == RTREC_TOPK_CANDIDATES ? static_cast<uint32_t>(a.col_rank[global_col(a, t0 + c)]) : 0u);
         return x;
     };
-    auto rank_and_store = [&](bool have, const Cand<ACC> &mine, int n_lanes) {
+    // Rank of every candidate = number of better ones; only lanes that HOLD a candidate are visited (a
+    // light user's touched list is mostly its own, excluded, items), and in SPARSE mode without
+    // first-touch tracking every aux is 0, so the comparison is (score, id) alone.  Selection is the
+    // per-user cost of a pass (C2: 43 % of it), and it is VALU-issue bound.
+    auto rank_and_store = [&](bool have, const Cand<ACC> &mine) {
+        const bool use_aux = FT || a.mode == RTREC_TOPK_CANDIDATES;
+        unsigned long long m = __ballot(have);
+        const int n_have = static_cast<int>(__builtin_popcountll(m));
         int rank = 0;
-        for (int t = 0; t < n_lanes; ++t) {
-            const Cand<ACC> o = cand_readlane<ACC>(mine, t);
-            rank += cand_better(o, mine) ? 1 : 0;
+        if (use_aux) {
+            for (; m; m &= m - 1) {
+                const Cand<ACC> o = cand_readlane<ACC>(mine, __builtin_ctzll(m));
+                rank += cand_better(o, mine) ? 1 : 0;
+            }
+        } else {
+            for (; m; m &= m - 1) {
+                const int t = __builtin_ctzll(m);
+                const ACC os = readlane_t(mine.score, t);
+                const int oi = readlane_i(mine.id, t);
+                rank += (os > mine.score || (os == mine.score && oi > mine.id)) ? 1 : 0;
+            }
         }
         if (have && rank < a.kk) { L.res_s[rank] = mine.score; L.res_i[rank] = mine.id; L.res_a[rank] = mine.aux; }
-        return min(static_cast<int>(__builtin_popcountll(__ballot(have))), a.kk);
+        return min(n_have, a.kk);
     };
 
     if (n_idx <= 64) {
@@ -191,7 +207,7 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
             const int c = idx(lane);
             if (sel_key(acc[c], zero_valid) != ninf) { mine = make_cand(c); have = true; }
         }
-        return rank_and_store(have, mine, n_idx);
+        return rank_and_store(have, mine);
     }
 
     if (a.kk > 64) {
@@ -236,7 +252,22 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
     // rank of this lane's best among the 64 lane bests (ties broken by lane id): pure VALU
     // (v_readlane + compare), no cross-lane LDS traffic
     ACC tau = ninf;
-    {
+    if (a.kk <= 16) {
+        // Any lower bound of the kk-th largest key serves (a looser one only admits a few more candidates to
+        // pass 2).  The kk-th largest of the 16 QUAD maxima is one -- kk quads hold a key >= it -- and costs 16
+        // rank steps instead of 64.
+        ACC q = best;
+        { const ACC o = shfl_xor_t(q, 1); q = o > q ? o : q; }
+        { const ACC o = shfl_xor_t(q, 2); q = o > q ? o : q; }
+        int rank = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const ACC o = readlane_t(q, 4 * t);
+            rank += (o > q || (o == q && t < (lane >> 2))) ? 1 : 0;
+        }
+        const unsigned long long at = __ballot(rank == a.kk - 1);
+        if (at) tau = readlane_t(q, __builtin_ctzll(at));
+    } else {
         int rank = 0;
 #pragma unroll
         for (int t = 0; t < 64; ++t) {
@@ -296,7 +327,7 @@ __device__ __forceinline__ int select_topk(const ScoreArgs &a, const TileLds<ACC
         Cand<ACC> mine; mine.id = -1; mine.score = ninf; mine.aux = 0u;
         const bool have = lane < cnt;
         if (have) mine = make_cand(L.clist[lane]);
-        return rank_and_store(have, mine, cnt);
+        return rank_and_store(have, mine);
     }
     int n_out = 0;
     if (cnt <= kListCap) {
