@@ -379,10 +379,17 @@ class SlimEngine:
         # the single-wave throughput kernel works through the rest; the C-ABI picks the kernel by
         # call size (<= FIT_MW_MAX_TARGETS targets -> multi-wave), so this is two plain calls.
         n_heavy = 0
+        heavy_slots = FIT_HEAVY_SLOTS
         if K > 0 and n > FIT_MW_MAX_TARGETS:
-            want = int(os.environ.get("RTREC_AMD_FIT_HEAVY", FIT_HEAVY_TARGETS))
+            # A call of a few thousand targets (one rank's share of a sharded fit, a large incremental fit)
+            # ends with its slowest target: more of it goes to the multi-wave kernel, two workgroups per CU
+            # (C3, an eighth of the targets: 0.77 -> 0.59 s; tools/fit_shard_model.py).
+            small_call = n <= 2 * FIT_MW_MAX_TARGETS
+            want = int(os.environ.get("RTREC_AMD_FIT_HEAVY", 4 * FIT_HEAVY_TARGETS if small_call else FIT_HEAVY_TARGETS))
+            heavy_slots = 2 * FIT_HEAVY_SLOTS if small_call else FIT_HEAVY_SLOTS
+            heavy_min_rows = FIT_HEAVY_MIN_ROWS // 8 if small_call else FIT_HEAVY_MIN_ROWS
             nnz_sorted = X["col_nnz"][targets]
-            n_heavy = int(min(want, n - FIT_MW_MAX_TARGETS - 1, np.searchsorted(-nnz_sorted, -int(os.environ.get("RTREC_AMD_FIT_HEAVY_MIN_ROWS", FIT_HEAVY_MIN_ROWS)),
+            n_heavy = int(min(want, n - FIT_MW_MAX_TARGETS - 1, np.searchsorted(-nnz_sorted, -int(os.environ.get("RTREC_AMD_FIT_HEAVY_MIN_ROWS", heavy_min_rows)),
                                                                                  side="right")))
             n_heavy = max(n_heavy, 0)
 
@@ -452,7 +459,7 @@ class SlimEngine:
             side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(be.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                heavy = launch(0, n_heavy, min(n_heavy, int(os.environ.get("RTREC_AMD_FIT_HEAVY_SLOTS", FIT_HEAVY_SLOTS))), role="heavy")
+                heavy = launch(0, n_heavy, min(n_heavy, int(os.environ.get("RTREC_AMD_FIT_HEAVY_SLOTS", heavy_slots))), role="heavy")
         for s in range(n_heavy, n, chunk):
             collect(launch(s, min(n, s + chunk), min(slots, max(1, min(n, s + chunk) - s))))
         if heavy is not None:
