@@ -295,6 +295,13 @@ int64_t rtrec_lru_replay(const int64_t *state_keys, const int64_t *state_counts,
                          const int64_t *values, int64_t n, int64_t capacity, int64_t id_bound,
                          int64_t *out_keys, int64_t *out_counts);
 
+/* One round of a batch on distinct (user, item) pairs, no time decay (rtrec/utils/interactions.py:81-119):
+ * out_val[k] = clip(old[k] + delta[order[k]], lo, hi) -- or delta[order[k]] when old is NULL (upsert) --
+ * and out_ts[k] = tstamp[order[k]].  Host pointers; 0 on success, -1 on invalid arguments. */
+int rtrec_store_apply_round(const int64_t *order, int64_t n, const double *delta, const double *tstamp,
+                            const double *old, double lo, double hi, double *out_val, double *out_ts,
+                            int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

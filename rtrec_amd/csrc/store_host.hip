@@ -154,3 +154,32 @@ extern "C" int64_t rtrec_lru_replay(const int64_t *state_keys, const int64_t *st
     for (int64_t k = head; k >= 0; k = next[k], ++o) { out_keys[o] = k; out_counts[o] = cnt[k]; }
     return o;
 }
+
+// One round of a batch of interactions on DISTINCT pairs without time decay (interactions.py:81-119):
+// interaction order[k] lands on the k-th key of the round; its value is clip(old[k] + delta, lo, hi) -- or
+// delta itself when `old` is NULL (upsert) -- and its timestamp the interaction's.  Two random gathers
+// and a clip, spread over threads.
+extern "C" int rtrec_store_apply_round(const int64_t *order, int64_t n, const double *delta, const double *tstamp,
+                                       const double *old, double lo, double hi, double *out_val, double *out_ts,
+                                       int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!order || !delta || !tstamp || !out_val || !out_ts))) return -1;
+    int T = n_threads > 0 ? n_threads : static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+    if (n < (1 << 16)) T = 1;
+    auto work = [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const int64_t i = order[k];
+            double v = delta[i];
+            if (old) { v += old[k]; v = v < lo ? lo : (v > hi ? hi : v); }      // numpy.clip: NaN passes through
+            out_val[k] = v;
+            out_ts[k] = tstamp[i];
+        }
+    };
+    if (T == 1) { work(0, n); return 0; }
+    std::vector<std::thread> th;
+    for (int p = 0; p < T; ++p) {
+        const int64_t k0 = n * p / T, k1 = n * (p + 1) / T;
+        if (k1 > k0) th.emplace_back(work, k0, k1);
+    }
+    for (auto &x : th) x.join();
+    return 0;
+}

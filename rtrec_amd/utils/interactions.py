@@ -115,6 +115,7 @@ class _Block:
 
 _NATIVE_MERGE_MIN = 1 << 15
 _NATIVE_FIND_MIN = 1 << 14
+_NATIVE_APPLY_MIN = 1 << 16
 _native_merge: Any = None          # False: the native library is not available (numpy merge instead)
 _native_handle: Any = None
 
@@ -344,8 +345,8 @@ class UserItemInteractions:
         (interactions.py:81-119), vectorised over the interactions that touch distinct pairs."""
         users = np.asarray(users, dtype=np.int64)
         items = np.asarray(items, dtype=np.int64)
-        ts = np.asarray(tstamps, dtype=np.float64)
-        dl = np.asarray(deltas, dtype=np.float64)
+        ts = np.ascontiguousarray(tstamps, dtype=np.float64)
+        dl = np.ascontiguousarray(deltas, dtype=np.float64)
         n = users.shape[0]
         if n == 0:
             return
@@ -371,7 +372,18 @@ class UserItemInteractions:
             grp = np.cumsum(first) - 1
             rank = np.arange(n) - start[grp]
             rounds = [(order[rank == r], sk[rank == r]) for r in range(int(rank.max()) + 1)]
+        lib = _native_lib() if (not decaying and n >= _NATIVE_APPLY_MIN) else None
         for idx, k in rounds:
+            if lib is not None:       # gather + add + clip in one threaded pass (rtrec_store_apply_round)
+                old = None if upsert else np.ascontiguousarray(self._lookup(k)[1])
+                idx_c = np.ascontiguousarray(idx, dtype=np.int64)
+                new, ts_k = np.empty(len(idx_c), np.float64), np.empty(len(idx_c), np.float64)
+                if lib.rtrec_store_apply_round(idx_c.ctypes.data, len(idx_c), dl.ctypes.data, ts.ctypes.data,
+                                               old.ctypes.data if old is not None else None, float(self.min_value),
+                                               float(self.max_value), new.ctypes.data, ts_k.ctypes.data, 0) != 0:
+                    raise RuntimeError("rtrec_store_apply_round failed")
+                self._write(k, new, ts_k, presorted=True)
+                continue
             if upsert:
                 new = dl[idx]
             else:

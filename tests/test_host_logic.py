@@ -527,3 +527,33 @@ def test_native_lru_replay_equals_sequential_adds():
         assert all(isinstance(k, int) for k in b.data)
     assert len(b) == 500
     assert list(a.get_freq_items(20)) == list(b.get_freq_items(20))
+
+
+@pytest.mark.parametrize("upsert", [False, True])
+def test_native_ingest_round_equals_numpy_round(upsert, monkeypatch):
+    """Large batches apply their rounds through rtrec_store_apply_round (gather + add + clip in one
+    threaded pass); the store must end up exactly as through the numpy expressions -- with repeated pairs
+    inside the batch (several rounds), clipping at both ends and values already in the store."""
+    from rtrec_amd.utils import interactions as mod
+    rng = np.random.default_rng(31)
+    n = 200_000
+    u, i = rng.integers(0, 3000, n), rng.zipf(1.3, n) % 500          # many repeated pairs
+    r = rng.integers(-4, 9, n).astype(float)
+    ts = 1.7e9 + np.arange(n, dtype=float)[::-1].copy()               # not monotone either
+    stores = []
+    for native in (True, False):
+        with monkeypatch.context() as mp:
+            if not native:
+                mp.setattr(mod, "_NATIVE_APPLY_MIN", 1 << 62)
+            st = UserItemInteractions(min_value=-3, max_value=10)
+            st.add_interactions_batch(u[:120_000], i[:120_000], ts[:120_000], r[:120_000], upsert=upsert)
+            st.add_interactions_batch(u[120_000:], i[120_000:], ts[120_000:], r[120_000:], upsert=upsert)
+            stores.append(st)
+    a, b = stores
+    A, B = a.to_csr(), b.to_csr()
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices) and np.array_equal(A.data, B.data)
+    blk_a, blk_b = a._compact(), b._compact()
+    assert np.array_equal(blk_a.val, blk_b.val) and np.array_equal(blk_a.ts, blk_b.ts)
+    assert a.max_timestamp == b.max_timestamp
+    if not upsert:          # an upsert stores the rating as it is
+        assert A.data.min() >= -3 and A.data.max() <= 10
