@@ -26,11 +26,19 @@ class SLIM(BaseModel):
         self._dev_x: Optional[DeviceInteractions] = None        # X resident in HBM (utils/device_store.py)
 
     # ------------------------------------------------------------ device-resident X
-    def _mirror(self) -> Optional[DeviceInteractions]:
-        """The device-resident copy of X, or None where it does not apply: a store with time decay
-        (every value is then a float64 `pow` of max_timestamp, which the host evaluates) or a backend
-        without device arrays.  RTREC_AMD_DEVICE_STORE=0 forces the host-export path."""
-        if self.interactions.decay_rate is not None or os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0":
+    def _store_tag(self) -> Any:
+        """What a device copy of X must match to be current: the store version, and with time decay also
+        max_timestamp (every value is a function of it)."""
+        st = self.interactions
+        return st.version if st.decay_rate is None else (st.version, st.max_timestamp)
+
+    def _mirror(self, full: bool = False) -> Optional[DeviceInteractions]:
+        """The device-resident copy of X, or None where it does not apply: a backend without device
+        arrays, or a store with time decay unless only the FULL matrix at the current max_timestamp is
+        wanted (bulk_fit, recommend) -- decayed values are float64 `pow`s the host evaluates, so such a
+        copy is rebuilt from a host export instead of advanced per mini-batch.
+        RTREC_AMD_DEVICE_STORE=0 forces the host-export path."""
+        if (self.interactions.decay_rate is not None and not full) or os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0":
             return None
         be = self.model.engine.be
         if not getattr(be, "supports_device_store", False):
@@ -39,12 +47,12 @@ class SLIM(BaseModel):
             self._dev_x = DeviceInteractions(be.torch, be.device)
         return self._dev_x
 
-    def _mirror_synced(self) -> Optional[DeviceInteractions]:
+    def _mirror_synced(self, full: bool = False) -> Optional[DeviceInteractions]:
         """The mirror, brought up to the host store's state (one full export if it has fallen behind)."""
-        mir = self._mirror()
-        if mir is not None and mir.version != self.interactions.version:
+        mir = self._mirror(full)
+        if mir is not None and mir.version != self._store_tag():
             csr = self.interactions.to_csr()
-            mir.load_csr(csr.indptr, csr.indices, csr.data, csr.shape[0], csr.shape[1], self.interactions.version)
+            mir.load_csr(csr.indptr, csr.indices, csr.data, csr.shape[0], csr.shape[1], self._store_tag())
         return mir
 
     _MIRROR_APPLY_MAX = 1 << 18     # larger writes (bulk chunks) leave the mirror stale: it is rebuilt on demand
@@ -69,7 +77,7 @@ class SLIM(BaseModel):
 
     def _device_matrix(self, item_ids: Optional[List[int]]) -> Optional[Dict[str, Any]]:
         """X (or X with only `item_ids`' columns populated) as device arrays, or None -> host export."""
-        mir = self._mirror_synced()
+        mir = self._mirror_synced(full=item_ids is None)
         if mir is None:
             return None
         X = dict(mir.full() if item_ids is None else mir.partial(np.asarray(item_ids, dtype=np.int64)))
@@ -121,8 +129,8 @@ class SLIM(BaseModel):
         """Make the GPU copy of X (CSR, decayed to the current max_timestamp) current."""
         stamp = (self.interactions.version, self.interactions.max_timestamp)
         if self._x_on_device != stamp:
-            mir = self._mirror()
-            if mir is not None and mir.version == self.interactions.version:
+            mir = self._mirror(full=True)
+            if mir is not None and mir.version == self._store_tag():
                 self.model.engine.set_interactions_device(mir.full(), mir.n_users, mir.n_items)
             else:
                 self.model.engine.set_interactions(None, self.interactions.to_csr(), need_csc=False)
@@ -143,7 +151,7 @@ class SLIM(BaseModel):
         dense_output = not self.item_ids.pass_through
         stamp = (self.interactions.version, self.interactions.max_timestamp)
         n_users = self.interactions.shape[0]
-        resident = self._dev_x is not None and self._dev_x.version == self.interactions.version
+        resident = self._dev_x is not None and self._dev_x.version == self._store_tag()
         if self._x_on_device == stamp or resident or len(user_ids) * 16 >= n_users:
             # bulk scoring: (re)upload all of X once and score it in place by row id
             self._sync_interactions()

@@ -237,10 +237,11 @@ def test_streaming_through_the_device_resident_store_equals_host_exports(monkeyp
         assert rd == rh
 
 
-@pytest.mark.parametrize("parallel", [False, True])
-def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, monkeypatch):
+@pytest.mark.parametrize("parallel,decay", [(False, None), (True, None), (True, 30)])
+def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, decay, monkeypatch):
     """SLIM.bulk_fit takes X from the resident store (host CSR keys, CSC order by a device sort): same W
-    bits and dtype (float64 after a serial fit, float32 after a parallel one) as through to_csc()."""
+    bits and dtype (float64 after a serial fit, float32 after a parallel one) as through to_csc() -- also for
+    a store with time decay, whose values the host evaluates at the current max_timestamp either way."""
     from rtrec_amd import SLIM
     rng = np.random.default_rng(5)
     U, I, n = 900, 200, 20_000
@@ -249,9 +250,12 @@ def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, mo
 
     def run(device_store):
         monkeypatch.setenv("RTREC_AMD_DEVICE_STORE", "1" if device_store else "0")
-        m = SLIM(min_value=0, max_value=15, nn_feature_selection=8)
+        kw = {"decay_in_days": decay} if decay else {}
+        m = SLIM(min_value=0, max_value=15, nn_feature_selection=8, **kw)
         m.add_interactions(rows)
         m.bulk_fit(parallel=parallel, progress_bar=False)
+        # with time decay the resident copy serves the full matrix (bulk_fit, recommend), never mini-batches
+        assert (m._dev_x is not None and m._dev_x.version == m._store_tag()) == device_store
         return m.model.item_similarity, m.recommend_batch(list(range(0, 300, 7)), top_k=5)
 
     (Wd, rd), (Wh, rh) = run(True), run(False)

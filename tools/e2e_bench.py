@@ -34,6 +34,7 @@ def main() -> None:
     ap.add_argument("--shape", default="ml1m", choices=sorted(SHAPES))
     ap.add_argument("--stream", type=int, default=1000, help="interactions held back for the partial_fit step")
     ap.add_argument("--profile", action="store_true", help="cProfile the bulk_fit call (host-side breakdown to stderr)")
+    ap.add_argument("--decay-days", type=int, default=0, help="SLIM(decay_in_days=...): BASELINE config 5 (0 = no time decay)")
     args = ap.parse_args()
     import torch
     from rtrec_amd import SLIM, Recommender
@@ -54,7 +55,8 @@ def main() -> None:
     from rtrec_amd.engine import HipBackend
     HipBackend()
 
-    rec = Recommender(SLIM(min_value=0, max_value=15, nn_feature_selection=K))
+    kw = {"decay_in_days": args.decay_days} if args.decay_days > 0 else {}
+    rec = Recommender(SLIM(min_value=0, max_value=15, nn_feature_selection=K, **kw))
     sink = io.StringIO()
     import cProfile
     import pstats
