@@ -302,6 +302,12 @@ int rtrec_store_apply_round(const int64_t *order, int64_t n, const double *delta
                             const double *old, double lo, double hi, double *out_val, double *out_ts,
                             int32_t n_threads);
 
+/* Time decay of stored values (rtrec/utils/interactions.py:62-79), host pointers:
+ * out[k] = val[k] * pow(rate, ((now_arr ? now_arr[k] : now) - ts[k]) / 86400.0) in float64 with libm's pow (what
+ * CPython's `**` calls); out64 and / or out32 (rounded to float32) may be NULL.  0 on success. */
+int rtrec_store_decay(const double *val, const double *ts, int64_t n, double rate, const double *now_arr,
+                      double now, double *out64, float *out32, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

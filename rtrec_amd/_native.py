@@ -23,7 +23,7 @@ EXPORTS = [
     "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_amd_score_timer", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
     "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_gram_workspace_bytes", "rtrec_slim_gram_matrix", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
-    "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round",
+    "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round", "rtrec_store_decay",
 ]
 
 
@@ -106,6 +106,8 @@ def load() -> C.CDLL:
     L.rtrec_lru_replay.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp]
     L.rtrec_store_apply_round.restype = C.c_int
     L.rtrec_store_apply_round.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, vp, vp, i32]
+    L.rtrec_store_decay.restype = C.c_int
+    L.rtrec_store_decay.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_double, vp, vp, i32]
     _lib = L
     return L
 

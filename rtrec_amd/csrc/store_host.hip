@@ -8,6 +8,7 @@
 #include "../../include/rtrec_amd.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <thread>
 #include <vector>
@@ -172,6 +173,33 @@ extern "C" int rtrec_store_apply_round(const int64_t *order, int64_t n, const do
             if (old) { v += old[k]; v = v < lo ? lo : (v > hi ? hi : v); }      // numpy.clip: NaN passes through
             out_val[k] = v;
             out_ts[k] = tstamp[i];
+        }
+    };
+    if (T == 1) { work(0, n); return 0; }
+    std::vector<std::thread> th;
+    for (int p = 0; p < T; ++p) {
+        const int64_t k0 = n * p / T, k1 = n * (p + 1) / T;
+        if (k1 > k0) th.emplace_back(work, k0, k1);
+    }
+    for (auto &x : th) x.join();
+    return 0;
+}
+
+// Time decay of stored values (rtrec/utils/interactions.py:62-79): out[k] = val[k] * rate ** ((now - ts[k]) / 86400)
+// in float64 with libm's pow() -- the function CPython's float ** float calls, so the result is the
+// reference's bit for bit (numpy's vectorised pow differs by an ulp now and then) -- `now` per entry
+// (now_arr) or one value.  out64 and/or out32 (the float32 the exports carry) may be NULL.
+extern "C" int rtrec_store_decay(const double *val, const double *ts, int64_t n, double rate, const double *now_arr,
+                                 double now, double *out64, float *out32, int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!val || !ts))) return -1;
+    int T = n_threads > 0 ? n_threads : static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())));
+    if (n < (1 << 14)) T = 1;
+    auto work = [&](int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const double elapsed_days = ((now_arr ? now_arr[k] : now) - ts[k]) / 86400.0;
+            const double v = val[k] * std::pow(rate, elapsed_days);
+            if (out64) out64[k] = v;
+            if (out32) out32[k] = static_cast<float>(v);
         }
     };
     if (T == 1) { work(0, n); return 0; }

@@ -116,6 +116,7 @@ class _Block:
 _NATIVE_MERGE_MIN = 1 << 15
 _NATIVE_FIND_MIN = 1 << 14
 _NATIVE_APPLY_MIN = 1 << 16
+_NATIVE_DECAY_MIN = 1
 _native_merge: Any = None          # False: the native library is not available (numpy merge instead)
 _native_handle: Any = None
 
@@ -267,6 +268,16 @@ class UserItemInteractions:
     def _decay_array(self, val: np.ndarray, ts: np.ndarray, now: Any) -> np.ndarray:
         if self.decay_rate is None:
             return val
+        lib = _native_lib() if val.shape[0] >= _NATIVE_DECAY_MIN else None
+        if lib is not None:       # libm pow, threaded: the reference's own arithmetic (float ** float), bit for bit
+            v, t = np.ascontiguousarray(val, dtype=np.float64), np.ascontiguousarray(ts, dtype=np.float64)
+            now_arr = None if np.ndim(now) == 0 else np.ascontiguousarray(now, dtype=np.float64)
+            out = np.empty(v.shape[0], np.float64)
+            if lib.rtrec_store_decay(v.ctypes.data, t.ctypes.data, v.shape[0], float(self.decay_rate),
+                                     now_arr.ctypes.data if now_arr is not None else None,
+                                     0.0 if now_arr is not None else float(now), out.ctypes.data, None, 0) != 0:
+                raise RuntimeError("rtrec_store_decay failed")
+            return out
         return val * np.power(self.decay_rate, (now - ts) / 86400.0)
 
     # ------------------------------------------------------------------ lookup

@@ -69,7 +69,8 @@ def test_reference_unit_test_scenarios():
     assert m2.recommend_batch([1, 2, 3, 4], top_k=3) == api["int_ids"]["top3"]
 
 
-@pytest.mark.parametrize("name,kw", [("k5", {"nn_feature_selection": 5}), ("all", {})])
+@pytest.mark.parametrize("name,kw", [("k5", {"nn_feature_selection": 5}), ("all", {}),
+                                     ("k5_decay", {"nn_feature_selection": 5, "decay_in_days": 30})])
 def test_incremental_fit_sequence_on_gpu(name, kw):
     from rtrec_amd import SLIM
     z = np.load(os.path.join(G, "partial_fit.npz"))
