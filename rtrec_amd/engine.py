@@ -284,6 +284,18 @@ class SlimEngine:
                          need_csc: bool = True) -> None:
         """Upload X (U x I).  Both orientations must have sorted indices (scipy canonical form)."""
         be = self.be
+        if X_csr is None and need_csc and getattr(be, "supports_device_store", False):
+            # only the CSC orientation comes from the host: the CSR one is a sort of the keys on the device
+            # (utils/device_store.py) instead of a scipy tocsr() here and a second upload
+            from .utils.device_store import DeviceInteractions
+            if not X_csc.has_sorted_indices:
+                X_csc = X_csc.sorted_indices()
+            if X_csc.nnz >= 2 ** 31:
+                raise ValueError("more than 2**31 interactions per GPU are not supported")
+            d = DeviceInteractions(be.torch, be.device)
+            d.load_csc(X_csc.indptr, X_csc.indices, X_csc.data, X_csc.shape[0], X_csc.shape[1], 0)
+            self.set_interactions_device(d.full(), X_csc.shape[0], X_csc.shape[1])
+            return
         if X_csr is None:
             X_csr = X_csc.tocsr()
         if not X_csr.has_sorted_indices:

@@ -59,6 +59,21 @@ class DeviceInteractions:
         self._cv = self._rv[order]
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
 
+    def load_csc(self, indptr: np.ndarray, indices: np.ndarray, data: np.ndarray, n_users: int, n_items: int,
+                 version: int) -> None:
+        """(Re)build from a host CSC export (sorted indices); the row-major copy is sorted on the device --
+        instead of a scipy tocsr() on the host and a second upload."""
+        torch = self.torch
+        cptr = self._dev(np.asarray(indptr, dtype=np.int64))
+        crow = self._dev(np.asarray(indices, dtype=np.int64))
+        self._cv = self._dev(np.asarray(data, dtype=np.float32))
+        cols = torch.repeat_interleave(torch.arange(n_items, device=self.device, dtype=torch.int64), cptr[1:] - cptr[:-1])
+        self._ck = (cols << _SHIFT) | crow
+        rk = (crow << _SHIFT) | cols
+        self._rk, order = torch.sort(rk)
+        self._rv = self._cv[order]
+        self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
+
     def adopt(self, X: Dict[str, Any], n_users: int, n_items: int, version: int) -> None:
         """Take over a full X the engine has already uploaded (bulk_fit): no host work at all."""
         torch = self.torch
@@ -78,6 +93,7 @@ class DeviceInteractions:
         self.apply(np.array([0, 1]), np.array([1, 0]), np.ones(2, np.float32), 2, 2, 1)
         self.adopt(self.full(), 2, 2, 2)
         self.partial(np.array([1]))
+        self.load_csc(np.array([0, 1, 3]), np.array([0, 0, 1]), np.ones(3, np.float32), 2, 2, 3)
 
     # ------------------------------------------------------------------ update
     def _merge(self, keys, vals, new_k, new_v):

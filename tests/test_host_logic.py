@@ -427,6 +427,12 @@ def test_device_resident_store_tracks_the_host_store(upsert):
     other.adopt(full, mir.n_users, mir.n_items, st.version)
     _assert_same_matrix(other.full(), st.to_csr(), "csr")
     _assert_same_matrix(other.full(), st.to_csc(), "csc")
+    # load_csc(): from a host CSC export (the engine's path for host-built matrices), CSR by a device sort
+    c = st.to_csc()
+    third = DeviceInteractions(torch, torch.device("cpu"))
+    third.load_csc(c.indptr, c.indices, c.data, c.shape[0], c.shape[1], st.version)
+    _assert_same_matrix(third.full(), st.to_csr(), "csr")
+    _assert_same_matrix(third.full(), c, "csc")
 
 
 def test_store_levels_mini_batches_equal_one_bulk_write(monkeypatch):
