@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A fresh checkout has no librtrec_amd.so (built artefacts stay out of the history): build it before
+    the first test needs it -- hipcc cross-compiles gfx950 without a GPU; the host routines of the interaction
+    store (merge / lookup / decay / LRU replay) live in the same library."""
+    try:
+        from rtrec_amd import build
+        if build.is_stale():
+            build.build_native()
+    except Exception as e:      # the tests that need the library then say so themselves
+        print(f"[conftest] could not build librtrec_amd.so: {e}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle import slim_oracle
