@@ -456,3 +456,105 @@ void slim_oracle_recommend_batch(int32_t n_rows, const int32_t *Xb_indptr, const
     }
     free(ov64); free(ov32); free(oi); free(pv64); free(pv32); free(pidx); free(next); free(acc64); free(acc32);
 }
+
+
+/* ---- multi-core variants for the CPU baseline ------------------------
+ * The reference's own parallel axis is the item column (slim_elastic.py:296-301, 358-366: a
+ * process pool over chunks of columns); users are independent in recommend_batch.  POSIX
+ * threads pull columns / row blocks from an atomic counter; every worker owns its scratch, so
+ * the per-column / per-row arithmetic is the single-threaded code above, unchanged.
+ * Fit output: fixed stride `cap` per column (out_idx/out_val[c * cap ...], out_cnt[c]). */
+#include <pthread.h>
+#include <stdatomic.h>
+
+typedef struct {
+    int32_t n_users, n_items;
+    const float *X_data; const int32_t *X_indices; const int32_t *X_indptr;
+    int32_t n_cols; const int32_t *cols;
+    double alpha, l1_ratio, tol; int32_t max_iter; uint32_t seed; int32_t positive, top_features;
+    int32_t cap; int32_t *out_cnt; int32_t *out_idx; float *out_val; int32_t *n_iter_out;
+    atomic_int next;
+} fit_mt_job;
+
+static void *fit_mt_worker(void *arg)
+{
+    fit_mt_job *J = (fit_mt_job *)arg;
+    for (;;) {
+        const int32_t c = atomic_fetch_add(&J->next, 1);
+        if (c >= J->n_cols) break;
+        int32_t it = 0; float gap = 0.0f;
+        J->out_cnt[c] = slim_oracle_fit_column(J->n_users, J->n_items, J->X_data, J->X_indices, J->X_indptr,
+                                               J->cols[c], J->alpha, J->l1_ratio, J->tol, J->max_iter, J->seed,
+                                               J->positive, J->top_features,
+                                               J->out_idx + (int64_t)c * J->cap, J->out_val + (int64_t)c * J->cap,
+                                               &it, &gap);
+        if (J->n_iter_out) J->n_iter_out[c] = it;
+    }
+    return NULL;
+}
+
+int32_t slim_oracle_fit_columns_mt(int32_t n_users, int32_t n_items,
+                                   const float *X_data, const int32_t *X_indices, const int32_t *X_indptr,
+                                   int32_t n_cols, const int32_t *cols,
+                                   double alpha, double l1_ratio, double tol,
+                                   int32_t max_iter, uint32_t seed, int32_t positive, int32_t top_features,
+                                   int32_t cap, int32_t *out_cnt, int32_t *out_idx, float *out_val,
+                                   int32_t *n_iter_out, int32_t n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    fit_mt_job J = { n_users, n_items, X_data, X_indices, X_indptr, n_cols, cols, alpha, l1_ratio, tol, max_iter,
+                     seed, positive, top_features, cap, out_cnt, out_idx, out_val, n_iter_out, 0 };
+    pthread_t th[256];
+    int32_t started = 0;
+    for (int32_t t = 0; t < n_threads - 1; t++)
+        if (pthread_create(&th[started], NULL, fit_mt_worker, &J) == 0) started++;
+    fit_mt_worker(&J);
+    for (int32_t t = 0; t < started; t++) pthread_join(th[t], NULL);
+    return started + 1;
+}
+
+typedef struct {
+    int32_t n_rows; const int32_t *Xb_indptr; const int32_t *Xb_indices; const float *Xb_data;
+    const int32_t *W_indptr; const int32_t *W_indices; const float *W_data;
+    int32_t n_cols, top_k, filter, dense, use_f64;
+    int32_t *ids; float *scores; int32_t *counts;
+    int32_t block;
+    atomic_int next;
+} rec_mt_job;
+
+static void *rec_mt_worker(void *arg)
+{
+    rec_mt_job *J = (rec_mt_job *)arg;
+    for (;;) {
+        const int32_t b = atomic_fetch_add(&J->next, 1);
+        const int64_t r0 = (int64_t)b * J->block;
+        if (r0 >= J->n_rows) break;
+        const int32_t n = (int32_t)((r0 + J->block <= J->n_rows) ? J->block : J->n_rows - r0);
+        /* rows [r0, r0 + n): the row pointers are absolute offsets into Xb_indices / Xb_data */
+        slim_oracle_recommend_batch(n, J->Xb_indptr + r0, J->Xb_indices, J->Xb_data, J->W_indptr, J->W_indices,
+                                    J->W_data, J->n_cols, J->top_k, J->filter, J->dense, J->use_f64,
+                                    J->ids + r0 * J->top_k, J->scores + r0 * J->top_k, J->counts + r0);
+    }
+    return NULL;
+}
+
+int32_t slim_oracle_recommend_batch_mt(int32_t n_rows, const int32_t *Xb_indptr, const int32_t *Xb_indices,
+                                       const float *Xb_data,
+                                       const int32_t *W_indptr, const int32_t *W_indices, const float *W_data,
+                                       int32_t n_cols, int32_t top_k, int32_t filter, int32_t dense,
+                                       int32_t use_f64,
+                                       int32_t *ids, float *scores, int32_t *counts, int32_t n_threads)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    rec_mt_job J = { n_rows, Xb_indptr, Xb_indices, Xb_data, W_indptr, W_indices, W_data, n_cols, top_k, filter,
+                     dense, use_f64, ids, scores, counts, 256, 0 };
+    pthread_t th[256];
+    int32_t started = 0;
+    for (int32_t t = 0; t < n_threads - 1; t++)
+        if (pthread_create(&th[started], NULL, rec_mt_worker, &J) == 0) started++;
+    rec_mt_worker(&J);
+    for (int32_t t = 0; t < started; t++) pthread_join(th[t], NULL);
+    return started + 1;
+}

@@ -138,6 +138,24 @@ void slim_oracle_recommend_batch(int32_t n_rows, const int32_t *Xb_indptr, const
                                  int32_t use_f64,
                                  int32_t *ids, float *scores, int32_t *counts);
 
+/* Multi-core variants for the CPU baseline (POSIX threads over item columns / blocks of user rows -- the
+ * reference's own parallel axis, slim_elastic.py:296-301,358-366).  Per-column and per-row arithmetic is the
+ * single-threaded code, so results are identical for every thread count.  Fit output has a fixed stride:
+ * column c's coefficients at out_idx/out_val[c * cap ...], out_cnt[c] of them.  Return the threads used. */
+int32_t slim_oracle_fit_columns_mt(int32_t n_users, int32_t n_items,
+                                   const float *X_data, const int32_t *X_indices, const int32_t *X_indptr,
+                                   int32_t n_cols, const int32_t *cols,
+                                   double alpha, double l1_ratio, double tol,
+                                   int32_t max_iter, uint32_t seed, int32_t positive, int32_t top_features,
+                                   int32_t cap, int32_t *out_cnt, int32_t *out_idx, float *out_val,
+                                   int32_t *n_iter_out, int32_t n_threads);
+int32_t slim_oracle_recommend_batch_mt(int32_t n_rows, const int32_t *Xb_indptr, const int32_t *Xb_indices,
+                                       const float *Xb_data,
+                                       const int32_t *W_indptr, const int32_t *W_indices, const float *W_data,
+                                       int32_t n_cols, int32_t top_k, int32_t filter, int32_t dense,
+                                       int32_t use_f64,
+                                       int32_t *ids, float *scores, int32_t *counts, int32_t n_threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,14 @@ def lib() -> C.CDLL:
         L.slim_oracle_recommend_batch.argtypes = [C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p,
                                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                   _i32p, _f32p, _i32p]
+        L.slim_oracle_fit_columns_mt.restype = C.c_int32
+        L.slim_oracle_fit_columns_mt.argtypes = [C.c_int32, C.c_int32, _f32p, _i32p, _i32p, C.c_int32, _i32p,
+                                                 C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32,
+                                                 C.c_int32, C.c_int32, C.c_int32, _i32p, _i32p, _f32p, _i32p, C.c_int32]
+        L.slim_oracle_recommend_batch_mt.restype = C.c_int32
+        L.slim_oracle_recommend_batch_mt.argtypes = [C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p,
+                                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                                     _i32p, _f32p, _i32p, C.c_int32]
         _lib = L
     return _lib
 
@@ -106,13 +114,26 @@ def cd(X_csc, y: np.ndarray, alpha=0.1, l1_ratio=0.1, tol=1e-4, max_iter=100,
 
 
 def fit_columns(X_csc, cols, alpha=0.1, l1_ratio=0.1, tol=1e-4, max_iter=100, random_state=43,
-                positive=True, nn_feature_selection=None):
-    """Per-column model.sparse_coef_ for each target column: (ptr, idx, val, n_iter)."""
+                positive=True, nn_feature_selection=None, n_threads=1):
+    """Per-column model.sparse_coef_ for each target column: (ptr, idx, val, n_iter).
+    n_threads > 1: POSIX threads over the columns (identical results)."""
     U, I = X_csc.shape
     d, i, p = _csc(X_csc)
     cols = np.ascontiguousarray(cols, dtype=np.int32)
     K = int(nn_feature_selection) if nn_feature_selection is not None else 0
     cap = min(K, I) if K > 0 else I
+    if n_threads > 1 and len(cols) > 0:
+        cnt = np.zeros(len(cols), dtype=np.int32)
+        idx2 = np.empty((len(cols), cap), dtype=np.int32)
+        val2 = np.empty((len(cols), cap), dtype=np.float32)
+        nit = np.zeros(len(cols), dtype=np.int32)
+        lib().slim_oracle_fit_columns_mt(U, I, d, i, p, len(cols), cols, alpha, l1_ratio, tol, max_iter,
+                                         sklearn_seed(random_state), int(bool(positive)), K, cap,
+                                         cnt, idx2.reshape(-1), val2.reshape(-1), nit, int(n_threads))
+        mask = np.arange(cap)[None, :] < cnt[:, None]
+        ptr = np.zeros(len(cols) + 1, dtype=np.int64)
+        np.cumsum(cnt, out=ptr[1:])
+        return ptr, idx2[mask], val2[mask], nit
     ptr = np.zeros(len(cols) + 1, dtype=np.int64)
     idx = np.empty(max(len(cols) * cap, 1), dtype=np.int32)
     val = np.empty(max(len(cols) * cap, 1), dtype=np.float32)
@@ -123,14 +144,17 @@ def fit_columns(X_csc, cols, alpha=0.1, l1_ratio=0.1, tol=1e-4, max_iter=100, ra
     return ptr, idx[:total], val[:total], nit[:len(cols)]
 
 
-def recommend_batch(Xb_csr, W_csr, top_k=10, filter_interacted=True, dense=False, use_f64=False):
-    """(ids[B,k], scores[B,k], counts[B]) following slim_elastic.py:674-741 + top-k helpers."""
+def recommend_batch(Xb_csr, W_csr, top_k=10, filter_interacted=True, dense=False, use_f64=False, n_threads=1):
+    """(ids[B,k], scores[B,k], counts[B]) following slim_elastic.py:674-741 + top-k helpers.
+    n_threads > 1: POSIX threads over blocks of rows (identical results)."""
     B = Xb_csr.shape[0]
     n_cols = W_csr.shape[1]
     ids = np.empty((B, top_k), dtype=np.int32)
     sc = np.empty((B, top_k), dtype=np.float32)
     cnt = np.empty(max(B, 1), dtype=np.int32)
-    lib().slim_oracle_recommend_batch(
+    fn = lib().slim_oracle_recommend_batch_mt if n_threads > 1 else lib().slim_oracle_recommend_batch
+    extra = (int(n_threads),) if n_threads > 1 else ()
+    fn(
         B, np.ascontiguousarray(Xb_csr.indptr, dtype=np.int32),
         np.ascontiguousarray(Xb_csr.indices, dtype=np.int32),
         np.ascontiguousarray(Xb_csr.data, dtype=np.float32),
@@ -138,7 +162,7 @@ def recommend_batch(Xb_csr, W_csr, top_k=10, filter_interacted=True, dense=False
         np.ascontiguousarray(W_csr.indices, dtype=np.int32),
         np.ascontiguousarray(W_csr.data, dtype=np.float32),
         n_cols, top_k, int(bool(filter_interacted)), int(bool(dense)), int(bool(use_f64)),
-        ids.reshape(-1) if B else np.empty(0, np.int32), sc.reshape(-1) if B else np.empty(0, np.float32), cnt)
+        ids.reshape(-1) if B else np.empty(0, np.int32), sc.reshape(-1) if B else np.empty(0, np.float32), cnt, *extra)
     return ids, sc, cnt[:B]
 
 

@@ -116,6 +116,7 @@ class _Block:
 _NATIVE_MERGE_MIN = 1 << 15
 _NATIVE_FIND_MIN = 1 << 14
 _NATIVE_APPLY_MIN = 1 << 16
+_MAX_ROUNDS = 32                   # occurrences of one (user, item) pair per batch that are applied as vectorised rounds
 _NATIVE_DECAY_MIN = 1
 _native_merge: Any = None          # False: the native library is not available (numpy merge instead)
 _native_handle: Any = None
@@ -374,6 +375,7 @@ class UserItemInteractions:
         max_ts_after = float(seen[-1]) if decaying else max(self.max_timestamp, float(ts.max()) + 1.0)
 
         order, sk = _stable_order(users, items)
+        tail_idx = tail_key = None
         first = np.ones(n, bool)
         first[1:] = sk[1:] != sk[:-1]
         if first.all():
@@ -382,7 +384,20 @@ class UserItemInteractions:
             start = np.flatnonzero(first)
             grp = np.cumsum(first) - 1
             rank = np.arange(n) - start[grp]
-            rounds = [(order[rank == r], sk[rank == r]) for r in range(int(rank.max()) + 1)]
+            # Round r = the r-th occurrence of every pair, vectorised over the pairs.  The rounds are cut out of
+            # ONE stable sort by rank (O(n log n) for the batch, not O(n) per round), and only the first
+            # _MAX_ROUNDS of them are run this way: a pair repeated more often than that (a bot, a replayed
+            # stream) has the rest of its sequence folded in one sequential pass below, so the cost of a
+            # batch stays O(n) however often one pair repeats (the reference's loop is O(n) too).
+            by_rank = np.argsort(rank, kind="stable")
+            bounds = np.concatenate(([0], np.cumsum(np.bincount(rank))))
+            n_rounds = min(len(bounds) - 1, _MAX_ROUNDS)
+            rounds = [(order[by_rank[bounds[r]:bounds[r + 1]]], sk[by_rank[bounds[r]:bounds[r + 1]]])
+                      for r in range(n_rounds)]
+            if len(bounds) - 1 > n_rounds:
+                tail = by_rank[bounds[n_rounds]:]
+                tail.sort()                               # back to (key, arrival) order
+                tail_idx, tail_key = order[tail], sk[tail]
         lib = _native_lib() if (not decaying and n >= _NATIVE_APPLY_MIN) else None
         for idx, k in rounds:
             if lib is not None:       # gather + add + clip in one threaded pass (rtrec_store_apply_round)
@@ -405,6 +420,8 @@ class UserItemInteractions:
                     cur = old                 # 0.0 where the pair is new
                 new = np.clip(cur + dl[idx], self.min_value, self.max_value)
             self._write(k, new, ts[idx], presorted=True)     # every round is a subsequence of the key-sorted order
+        if tail_idx is not None:
+            self._fold_tail(tail_idx, tail_key, ts, dl, seen, upsert)
 
         self.max_timestamp = max_ts_after
         i_hi = int(items.max())
@@ -417,6 +434,33 @@ class UserItemInteractions:
             self.hot_items.add_many(items[pos])
         self.max_user_id = max(self.max_user_id, int(users.max()))
         self.max_item_id = max(self.max_item_id, int(items.max()))
+
+    def _fold_tail(self, idx: np.ndarray, keys: np.ndarray, ts: np.ndarray, dl: np.ndarray,
+                   seen: Optional[np.ndarray], upsert: bool) -> None:
+        """Occurrences beyond the vectorised rounds, in (key, arrival) order: every pair's remaining sequence is
+        folded one interaction after the other with the reference's own scalar arithmetic (Python floats,
+        interactions.py:62-79,103-112), then the pairs are written once."""
+        cut = np.flatnonzero(np.concatenate(([True], keys[1:] != keys[:-1], [True])))
+        ukeys = keys[cut[:-1]]
+        if upsert:                       # the last occurrence wins
+            last = idx[cut[1:] - 1]
+            self._write(ukeys, dl[last], ts[last], presorted=True)
+            return
+        _, old, old_ts = self._lookup(ukeys)     # every such pair exists: its earlier occurrences were just stored
+        lo, hi, rate = self.min_value, self.max_value, self.decay_rate
+        dl_l, ts_l = dl[idx].tolist(), ts[idx].tolist()
+        seen_l = seen[idx].tolist() if seen is not None else None
+        out_v, out_t = old.tolist(), old_ts.tolist()
+        cuts = cut.tolist()
+        for g in range(len(ukeys)):
+            v, t = out_v[g], out_t[g]
+            for q in range(cuts[g], cuts[g + 1]):
+                if seen_l is not None and v != 0.0:
+                    v = v * rate ** ((seen_l[q] - t) / 86400.0)
+                v = max(lo, min(v + dl_l[q], hi))
+                t = ts_l[q]
+            out_v[g], out_t[g] = v, t
+        self._write(ukeys, np.asarray(out_v, np.float64), np.asarray(out_t, np.float64), presorted=True)
 
     # ------------------------------------------------------------------ queries
     def _user_entries(self, user_id: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

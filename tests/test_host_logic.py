@@ -564,3 +564,43 @@ def test_native_ingest_round_equals_numpy_round(upsert, monkeypatch):
     assert a.max_timestamp == b.max_timestamp
     if not upsert:          # an upsert stores the rating as it is
         assert A.data.min() >= -3 and A.data.max() <= 10
+
+
+@pytest.mark.parametrize("kw,upsert", [({}, False), ({"decay_in_days": 7}, False), ({}, True)])
+def test_heavily_repeated_pairs_fold_sequentially_and_stay_linear(kw, upsert):
+    """A pair repeated far more often than the vectorised rounds cover (a bot / a replayed stream): the
+    rest of its sequence is folded one interaction after the other, and the store must end up exactly as
+    if every interaction had been added on its own (the reference's loop, interactions.py:81-119) --
+    in time linear in the batch (the per-round masks made it O(n x repeats))."""
+    import time as _time
+    rng = np.random.default_rng(5)
+    n = 3000
+    u, i = rng.integers(0, 40, n), rng.integers(0, 30, n)
+    hot = rng.random(n) < 0.4
+    u[hot], i[hot] = 7, 3                                  # ~1200 occurrences of one pair
+    u[rng.random(n) < 0.1], i[rng.random(n) < 0.1] = 8, 4
+    r = rng.integers(-3, 6, n).astype(float)
+    ts = 1.7e9 + np.sort(rng.random(n)) * 40 * 86400.0
+    batch = UserItemInteractions(min_value=-2, max_value=9, **kw)
+    batch.add_interactions_batch(u[:100], i[:100], ts[:100], r[:100], upsert=upsert)
+    batch.add_interactions_batch(u[100:], i[100:], ts[100:], r[100:], upsert=upsert)
+    single = UserItemInteractions(min_value=-2, max_value=9, **kw)
+    for k in range(n):
+        single.add_interaction(int(u[k]), int(i[k]), float(ts[k]), float(r[k]), upsert=upsert)
+    a, b = batch._compact(), single._compact()
+    assert np.array_equal(a.key, b.key) and np.array_equal(a.ts, b.ts)
+    assert np.array_equal(bits64(a.val), bits64(b.val))
+    assert batch.max_timestamp == single.max_timestamp
+    # linear cost: one pair repeated 200,000 times in a 400,000-row batch
+    m = 400_000
+    uu, ii = rng.integers(0, 5000, m), rng.integers(0, 800, m)
+    uu[::2], ii[::2] = 1, 1
+    st = UserItemInteractions(min_value=-5, max_value=10)
+    t0 = _time.perf_counter()
+    st.add_interactions_batch(uu, ii, 1.7e9 + np.arange(m, dtype=float), np.ones(m))
+    assert _time.perf_counter() - t0 < 5.0
+    assert st.get_user_item_rating(1, 1) == 10.0
+
+
+def bits64(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
