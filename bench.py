@@ -65,24 +65,48 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
     args = ap.parse_args()
 
+    # `python3 bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
+    # driver's own torch.distributed.run command line) as a CHILD, before this process has touched the GPU,
+    # and leave with its exit code -- a bare `--gpus 8` must never silently measure one GPU.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}")
+        sys.exit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        log(f"error: WORLD_SIZE={world} but --gpus {args.gpus}: the launcher and the bench disagree about the number of ranks")
+        sys.exit(2)
     # RTREC_BENCH_SAME_GPU=1 (functional test only): every rank drives cuda:0 and the collectives
     # run over gloo, so the sharded path can be exercised on a single-GPU box.
     same_gpu = os.environ.get("RTREC_BENCH_SAME_GPU") == "1"
     if same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    ranks_seen, rank_devices, backend = 1, [f"cuda:{local_rank}"], None
     if world > 1:
         if same_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = dist.get_backend()
+        devs = [None] * world
+        dist.all_gather_object(devs, f"cuda:{local_rank}")
+        rank_devices = [d for d in devs if d is not None]
+        ranks_seen = len(rank_devices)
+        if ranks_seen != args.gpus:
+            log(f"error: {ranks_seen} ranks joined, --gpus {args.gpus}")
+            sys.exit(3)
 
     from rtrec_amd import _native
     from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients, shard_bounds
@@ -159,6 +183,9 @@ def main() -> None:
     lib = eng.be.lib
     tot_ms, n_launch = C.c_double(0), C.c_int64(0)
     torch.cuda.synchronize()
+    prof_fn = getattr(lib, "rtrec_amd_score_profile", None) if os.environ.get("RTREC_AMD_LIB") else None
+    if prof_fn is not None:          # diagnostic build (-DSCORE_PROFILE): per-phase clocks of the sparse kernel
+        prof_fn(None, 1)
     lib.rtrec_amd_score_timer(1, None, None)
     if world > 1:
         dist.barrier()
@@ -172,6 +199,15 @@ def main() -> None:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lib.rtrec_amd_score_timer(0, C.byref(tot_ms), C.byref(n_launch))
+    if prof_fn is not None and rank == 0:
+        buf = (C.c_uint64 * 16)()
+        prof_fn(buf, 0)
+        names = ["jobs", "rowptr", "hdr", "group", "dense", "sparse", "select", "emit", "reset", "queue",
+                 "n_dense", "n_sparse_rows", "n_sparse_chunks", "n_overflow", "total"]
+        v = dict(zip(names, [int(x) for x in buf]))
+        tot = max(v["total"], 1)
+        log("[score profile] " + json.dumps({k: (v[k] if k in ("jobs", "total") or k.startswith("n_") else round(v[k] / tot, 4))
+                                             for k in names}))
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -236,6 +272,7 @@ def main() -> None:
                    "active_columns": lay["n_cols"],
                    "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
                                    else f"user-row shard x{world}, W replicated")},
+        "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend,
         "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()),

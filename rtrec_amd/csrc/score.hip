@@ -68,6 +68,29 @@ struct ScoreArgs {
     int ablate;           // diagnostics: bit0 skip accumulate, bit1 skip select, bit2 skip reset, bit3 skip filter
 };
 
+// Diagnostic build (-DSCORE_PROFILE, tools/ab_build.sh): per-phase shader-clock totals of the sparse kernel,
+// summed over all waves in g_score_prof (read with rtrec_amd_score_profile; not part of the release ABI).
+#ifdef SCORE_PROFILE
+enum { PF_JOBS, PF_ROWPTR, PF_HDR, PF_GROUP, PF_DENSE, PF_SPARSE, PF_SELECT, PF_EMIT, PF_RESET, PF_QUEUE,
+       PF_N_DENSE, PF_N_SPARSE_ROWS, PF_N_SPARSE_CHUNKS, PF_N_OVERFLOW, PF_TOTAL, PF_COUNT };
+__device__ unsigned long long g_score_prof[16];
+#define PF_DECL unsigned long long pf_[16] = {0}; unsigned long long pf_t_ = __builtin_amdgcn_s_memtime();
+#define PF_MARK(slot) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pf_[slot] += n_ - pf_t_; pf_t_ = n_; }
+#define PF_ADD(slot, v) { pf_[slot] += (v); }
+#define PF_PARAMS , unsigned long long *pf_, unsigned long long &pf_t_
+#define PF_ARGS , pf_, pf_t_
+#define PF_NOARGS , pf_dummy_, pf_dummy_t_
+#define PF_DUMMY unsigned long long pf_dummy_[16]; unsigned long long pf_dummy_t_ = 0;
+#else
+#define PF_DECL
+#define PF_MARK(slot)
+#define PF_ADD(slot, v)
+#define PF_PARAMS
+#define PF_ARGS
+#define PF_NOARGS
+#define PF_DUMMY
+#endif
+
 #ifndef SCORE_LIST_CAP
 #define SCORE_LIST_CAP 256
 #endif
@@ -419,7 +442,7 @@ __device__ __forceinline__ void emit_result(const ScoreArgs &a, const TileLds<AC
 // accumulation; scores of the other columns are untouched.
 template <typename ACC, bool FT, bool TOUCH, bool PREFILTER = false>
 __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds<ACC> &L, int a0, int n_a, int tile,
-                                               int t0 = 0, int ncol = 0) {
+                                               int t0, int ncol PF_PARAMS) {
     const int lane = lane_id();
     ACC *acc = L.acc;
     const int *tp = a.tile_ptr + static_cast<size_t>(tile) * (a.n_items + 1);
@@ -473,6 +496,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
             push(first, lc);
         }
         unsigned long long live = __ballot(e > s || d >= 0);
+        PF_MARK(PF_HDR)
         if (TOUCH && track && __ballot(e - s >= kTouchCap / 4 || d >= 0)) { track = false; tcnt = kTouchCap + 1; }
         while (live) {
             // Take the next kRowGroup non-empty rows (ascending item order) and issue the loads of
@@ -497,6 +521,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                 cc[j] = -1; vv[j] = 0.0f;
                 if (ss[j] + lane < ee[j]) { cc[j] = a.w_col[ss[j] + lane]; vv[j] = a.w_val[ss[j] + lane]; }
             }
+            PF_MARK(PF_GROUP)
 #pragma unroll
             for (int j = 0; j < kRowGroup; ++j) {
                 if (dd[j] >= 0) {
@@ -534,6 +559,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                             }
                         }
                         for (; sidx < steps; ++sidx) acc4[64 * sidx] = acc4[64 * sidx] + dv4[64 * sidx] * xs;
+                        PF_MARK(PF_DENSE) PF_ADD(PF_N_DENSE, 1)
                         continue;
                     }
                     for (int c = lane * 4; c < a.tile_cols; c += 256) {
@@ -607,6 +633,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                     }
                     if (TOUCH) push(f2, c);
                 }
+                PF_MARK(PF_SPARSE) PF_ADD(PF_N_SPARSE_ROWS, 1) PF_ADD(PF_N_SPARSE_CHUNKS, (eej - ss[j] + 63) >> 6)
             }
         }
     }
@@ -637,7 +664,8 @@ __global__ __launch_bounds__(64) void score_tiles_dense_kernel(ScoreArgs a) {
     const int n_a = a.xb_ptr[xrow + 1] - a0;
 
     for (int c = lane * 4; c < S; c += 256) { L.acc[c] = ACC(0); L.acc[c + 1] = ACC(0); L.acc[c + 2] = ACC(0); L.acc[c + 3] = ACC(0); }
-    accumulate_tile<ACC, false, false>(a, L, a0, n_a, tile);
+    PF_DUMMY
+    accumulate_tile<ACC, false, false>(a, L, a0, n_a, tile, 0, 0 PF_NOARGS);
 
     if (a.mode == RTREC_TOPK_CANDIDATES) {
         for (int c = lane; c < ncol; c += 64)
@@ -674,7 +702,8 @@ __global__ __launch_bounds__(64) void score_rows_kernel(ScoreArgs a, ACC *out, l
     const int a0 = a.xb_ptr[xrow];
     const int n_a = a.xb_ptr[xrow + 1] - a0;
     for (int c = lane * 4; c < S; c += 256) { L.acc[c] = ACC(0); L.acc[c + 1] = ACC(0); L.acc[c + 2] = ACC(0); L.acc[c + 3] = ACC(0); }
-    accumulate_tile<ACC, false, false>(a, L, a0, n_a, tile);
+    PF_DUMMY
+    accumulate_tile<ACC, false, false>(a, L, a0, n_a, tile, 0, 0 PF_NOARGS);
     ACC *o = out + static_cast<long long>(row) * out_stride + t0;
     for (int c = lane; c < ncol; c += 64) o[c] = L.acc[c];
 }
@@ -694,6 +723,10 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
 
     const int n_rows = FT ? *a.row_list_len : a.n_rows;
     const int total = n_rows * a.n_tiles;
+    PF_DECL
+#ifdef SCORE_PROFILE
+    const unsigned long long pf_start_ = pf_t_;
+#endif
     // jobs are claimed kQueueChunk at a time: one device-scope counter serves only ~90 claims/us
     int w_next = 0, w_end = 0;
     for (;;) {
@@ -701,6 +734,7 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
             int w0 = 0;
             if (lane == 0) w0 = atomicAdd(a.queue, kQueueChunk);
             w_next = readfirst_i(w0);
+            PF_MARK(PF_QUEUE)
             if (w_next >= total) break;
             w_end = min(w_next + kQueueChunk, total);
         }
@@ -711,17 +745,21 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
         const int ncol = min(S, a.n_cols - t0);
         const int xrow = a.row_ids ? a.row_ids[row] : row;
         const int a0 = a.xb_ptr[xrow];
-        const int n_a = a.xb_ptr[xrow + 1] - a0;
+        const int n_a = readfirst_i(a.xb_ptr[xrow + 1] - a0);
+        PF_MARK(PF_ROWPTR) PF_ADD(PF_JOBS, 1)
 
         // interacted items leave the race inside accumulate_tile (PREFILTER)
-        const int tcnt = (a.ablate & 1) ? 0 : accumulate_tile<ACC, FT, true, true>(a, L, a0, n_a, tile, t0, ncol);
+        const int tcnt = (a.ablate & 1) ? 0 : accumulate_tile<ACC, FT, true, true>(a, L, a0, n_a, tile, t0, ncol PF_ARGS);
         const bool overflow = tcnt > kTouchCap;
+        PF_ADD(PF_N_OVERFLOW, overflow ? 1 : 0)
         int n_out = 0;
         if (tcnt > 0 && !(a.ablate & 2)) {
             if (!overflow) n_out = select_topk<ACC, FT>(a, L, IdxList{L.tlist}, tcnt, t0, /*zero_valid=*/false);
             else n_out = select_topk<ACC, FT>(a, L, IdxAll{}, ncol, t0, /*zero_valid=*/false);
         }
+        PF_MARK(PF_SELECT)
         emit_result<ACC>(a, L, row, tile, n_out);
+        PF_MARK(PF_EMIT)
 
         // restore the invariant
         if (a.ablate & 4) {
@@ -733,7 +771,14 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
                 if (FT) { L.ft[c] = 0xffffffffu; L.ft[c + 1] = 0xffffffffu; L.ft[c + 2] = 0xffffffffu; L.ft[c + 3] = 0xffffffffu; }
             }
         }
+        PF_MARK(PF_RESET)
     }
+#ifdef SCORE_PROFILE
+    if (!FT && lane == 0) {
+        pf_[PF_TOTAL] = __builtin_amdgcn_s_memtime() - pf_start_;
+        for (int q = 0; q < PF_COUNT; ++q) atomicAdd(&g_score_prof[q], pf_[q]);
+    }
+#endif
 }
 
 struct MergeArgs {
@@ -1038,6 +1083,14 @@ extern "C" int rtrec_amd_score_timer(int32_t enable, double *total_ms, int64_t *
     t.enabled = enable > 0;
     return RTREC_OK;
 }
+
+#ifdef SCORE_PROFILE
+extern "C" int rtrec_amd_score_profile(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(rtrec::g_score_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtrec::g_score_prof), z, sizeof(z)) != hipSuccess) return -4; }
+    return 0;
+}
+#endif
 
 extern "C" size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k) {
     if (n_rows < 0 || n_tiles <= 0 || top_k <= 0) return 0;

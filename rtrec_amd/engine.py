@@ -701,13 +701,54 @@ class SlimEngine:
         out = out.view(G, q, fwidth).transpose(0, 1).reshape(G * q, fwidth)[:n_rows]    # row i*G + p <- rank p, slot i
         return out[:, k:2 * k].contiguous(), out[:, :k].contiguous().view(torch.float32), out[:, 2 * k].contiguous()
 
+    MAX_TOP_K = 1023            # kMaxTopK of csrc/score.hip
+    MAX_MERGE_CANDIDATES = 1024  # per-tile lists of one row the merge kernel takes: n_tiles * (top_k + 1)
+
+    def topk_supported(self, top_k: int, mode: int) -> bool:
+        """Whether the fused score + top-k kernels serve this request (rtrec_slim_score_topk's limits);
+        callers fall back to score rows from the device + a host selection otherwise."""
+        if top_k > self.MAX_TOP_K:
+            return False
+        lay = self._layout(compact=(mode == _native.TOPK_SPARSE), top_k=top_k)
+        return lay is None or lay["n_tiles"] * (top_k + 1) <= self.MAX_MERGE_CANDIDATES
+
+    def _check_rows(self, row_ids: np.ndarray) -> None:
+        """Row ids index the resident X: anything outside [0, n_users) would be an out-of-bounds device read
+        (the reference's scipy indexing raises IndexError for it)."""
+        if len(row_ids) and (int(row_ids.min()) < 0 or int(row_ids.max()) >= self.n_users):
+            bad = row_ids[(row_ids < 0) | (row_ids >= self.n_users)]
+            raise IndexError(f"row index ({int(bad[0])}) out of range for the resident interaction matrix "
+                             f"with {self.n_users} rows")
+
+    def rows_csr(self, row_ids: Sequence[int]) -> sp.csr_matrix:
+        """Rows of the resident X as a host CSR (download of just those rows)."""
+        row_ids = np.asarray(row_ids, dtype=np.int64)
+        self._check_rows(row_ids)
+        torch = self.be.torch
+        X = self._X
+        d_rows = self.be.to_dev(row_ids)
+        beg, end = X["rptr"][d_rows].long(), X["rptr"][d_rows + 1].long()
+        cnt = end - beg
+        indptr = np.zeros(len(row_ids) + 1, dtype=np.int64)
+        indptr[1:] = np.cumsum(cnt.cpu().numpy())
+        total = int(indptr[-1])
+        if total:
+            off = torch.arange(total, device=d_rows.device) - torch.repeat_interleave(
+                torch.as_tensor(indptr[:-1], device=d_rows.device), cnt) + torch.repeat_interleave(beg, cnt)
+            cols, vals = X["rcol"][off].cpu().numpy(), X["rval"][off].cpu().numpy()
+        else:
+            cols, vals = np.empty(0, np.int32), np.empty(0, np.float32)
+        return sp.csr_matrix((vals, cols, indptr), shape=(len(row_ids), self.n_items))
+
     def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
                        mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None
                        ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """Top-k for rows of the resident X.  Returns numpy (ids[B,k], scores[B,k], counts[B])."""
-        row_ids = np.asarray(row_ids, dtype=np.int32)
+        row_ids = np.asarray(row_ids, dtype=np.int64)
         if len(row_ids) == 0:
             return (np.empty((0, top_k), np.int32), np.empty((0, top_k), np.float32), np.empty((0,), np.int32))
+        self._check_rows(row_ids)
+        row_ids = row_ids.astype(np.int32)
         ids, sc, cnt = self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank)
         return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
 

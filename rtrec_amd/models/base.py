@@ -57,18 +57,28 @@ class BaseModel(ABC):
             return np.empty(0, np.int64), np.empty(0, np.int64)
         try:
             users, items, tstamps, ratings = zip(*rows)
-            ts = np.asarray(tstamps, dtype=np.float64)
-            dl = np.asarray(ratings, dtype=np.float64)
+            ts, dl = np.asarray(tstamps), np.asarray(ratings)
+            # numeric columns only: np.asarray(..., dtype=float64) would silently PARSE "3.5", where the
+            # reference's `current + delta` raises and the row is skipped (interactions.py:103-105)
+            if ts.dtype.kind not in "fiub" or dl.dtype.kind not in "fiub":
+                raise ValueError("non-numeric timestamp or rating")
+            ts, dl = ts.astype(np.float64), dl.astype(np.float64)
             if ts.shape != (len(rows),) or dl.shape != (len(rows),):
                 raise ValueError("malformed interaction batch")
             clean = self._batch_is_homogeneous(users, self.user_ids) and self._batch_is_homogeneous(items, self.item_ids)
         except Exception:
             clean = False
         if clean:
-            uid = self.user_ids.identify_many(users)
-            iid = self.item_ids.identify_many(items)
-            self.interactions.add_interactions_batch(uid, iid, ts, dl, upsert=update_interaction)
-            return uid, iid
+            try:
+                uid = self.user_ids.identify_many(users)
+                iid = self.item_ids.identify_many(items)
+                self.interactions.add_interactions_batch(uid, iid, ts, dl, upsert=update_interaction)
+                return uid, iid
+            except Exception:
+                # nothing has been stored yet (the store validates before it writes) and identify() is
+                # idempotent, so the per-interaction path below redoes the batch row by row and skips the
+                # offending rows like the reference does
+                pass
         # per-interaction path with the reference's swallow-and-warn convention (base.py:86-94)
         u_out: List[int] = []
         i_out: List[int] = []
@@ -123,7 +133,14 @@ class BaseModel(ABC):
         if all_int:
             return ident.pass_through is not False and all(o >= 0 for o in objs)
         none_int = not any(isinstance(o, (int, np.integer)) for o in objs)
-        return none_int and ident.pass_through is not True
+        if not (none_int and ident.pass_through is not True):
+            return False
+        try:                       # an unhashable id (a JSON list, ...) raises in identify(): per-row path
+            for o in objs:
+                hash(o)
+        except TypeError:
+            return False
+        return True
 
     def add_interactions(self, interactions: Iterable[Tuple[Any, Any, float, float]],
                          update_interaction: bool = False, record_interactions: bool = False) -> None:

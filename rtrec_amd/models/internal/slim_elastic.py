@@ -230,12 +230,73 @@ class SLIMElastic:
         if top_k <= 0:
             B = Xb.shape[0] if row_ids is None else len(row_ids)
             return np.empty((B, 0), np.int32), np.empty((B, 0), np.float32), np.zeros(B, np.int32)
+        if not self.engine.topk_supported(top_k, mode):
+            # beyond what the fused kernel selects on the device (top_k > 1023, or a catalogue whose per-tile
+            # lists would not fit the merge): scores from the device (score_rows_kernel), selection on the host
+            if row_ids is not None:
+                Xb = self.engine.rows_csr(row_ids)
+            return self._topk_host(Xb, candidate_item_ids, top_k, filter_interacted, mode)
         if row_ids is not None:
             return self.engine.recommend_rows(row_ids, top_k, filter_interacted, mode, col_rank)
         if Xb.shape[1] != n_items:   # the reference would fail inside scipy on a shape mismatch
             Xb = Xb.copy()
             Xb.resize((Xb.shape[0], n_items))
         return self.engine.recommend_csr(Xb, top_k, filter_interacted, mode, col_rank)
+
+    def _topk_host(self, Xb: sp.csr_matrix, candidate_item_ids: Optional[List[int]], top_k: int,
+                   filter_interacted: bool, mode: int, chunk_rows: int = 256):
+        """Large-k path: the score rows come from the device (SlimEngine.predict_csr), the selection follows
+        slim_elastic.py:661-672 (candidates), :744-779 (dense) and :782-818 (sparse: stored non-zero products
+        only, stable sort over scipy's reverse-first-touch product order) in numpy.  Unspecified tie orders
+        (numpy's unstable argsort) follow the same canonical rule as the kernels."""
+        W = self._item_similarity
+        n_items = W.shape[1]
+        Xb = Xb.tocsr()
+        if Xb.shape[1] != n_items:
+            Xb = Xb.copy()
+            Xb.resize((Xb.shape[0], n_items))
+        if not Xb.has_sorted_indices:
+            Xb = Xb.sorted_indices()
+        B = Xb.shape[0]
+        dt = np.float64 if W.dtype == np.float64 else np.float32
+        ids = np.full((B, top_k), -1, dtype=np.int32)
+        scores = np.full((B, top_k), -np.inf, dtype=np.float32)
+        counts = np.zeros(B, dtype=np.int32)
+        Wr = W.tocsr() if mode == _native.TOPK_SPARSE else None
+        cand = np.asarray(candidate_item_ids, dtype=np.int64) if candidate_item_ids is not None else None
+        for r0 in range(0, B, chunk_rows):
+            S = np.asarray(self.engine.predict_csr(Xb[r0:r0 + chunk_rows]), dtype=dt)
+            for q in range(S.shape[0]):
+                r = r0 + q
+                own = Xb.indices[Xb.indptr[r]:Xb.indptr[r + 1]]
+                if cand is not None:
+                    sc = S[q, cand]
+                    top = np.argsort(sc, kind="stable")[-top_k:][::-1]
+                    sel, val = cand[top], sc[top]
+                elif mode == _native.TOPK_DENSE:
+                    sc = S[q].copy()
+                    if filter_interacted:
+                        sc[own] = -np.inf
+                    top = np.argsort(sc, kind="stable")[-top_k:][::-1]
+                    top = top[sc[top] != -np.inf]
+                    sel, val = top, sc[top]
+                else:
+                    sc = S[q]
+                    nz = sc != 0
+                    if filter_interacted:
+                        nz[own] = False
+                    cols = np.flatnonzero(nz)
+                    # first-touch position of every product column: W rows of the user's items in ascending item order
+                    seq = np.concatenate([Wr.indices[Wr.indptr[i]:Wr.indptr[i + 1]] for i in own.tolist()]
+                                         or [np.empty(0, np.int32)])
+                    ft = np.full(n_items, -1, dtype=np.int64)
+                    u, first = np.unique(seq, return_index=True)
+                    ft[u] = first
+                    order = np.lexsort((-ft[cols], -sc[cols]))[:top_k]
+                    sel, val = cols[order], sc[cols][order]
+                c = len(sel)
+                ids[r, :c], scores[r, :c], counts[r] = sel, val, c
+        return ids, scores, counts
 
     def recommend(self, user_id: int, interaction_matrix: sp.csr_matrix,
                   candidate_item_ids: Optional[List[int]] = None, top_k: int = 10, filter_interacted: bool = True,

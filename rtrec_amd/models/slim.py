@@ -151,6 +151,9 @@ class SLIM(BaseModel):
         dense_output = not self.item_ids.pass_through
         stamp = (self.interactions.version, self.interactions.max_timestamp)
         n_users = self.interactions.shape[0]
+        ids_arr = np.asarray(user_ids, dtype=np.int64)
+        if len(ids_arr) and (int(ids_arr.min()) < 0 or int(ids_arr.max()) >= n_users):
+            return self._recommend_odd_ids(ids_arr, n_users, candidate_item_ids, top_k, filter_interacted)
         resident = self._dev_x is not None and self._dev_x.version == self._store_tag()
         if self._x_on_device == stamp or resident or len(user_ids) * 16 >= n_users:
             # bulk scoring: (re)upload all of X once and score it in place by row id
@@ -171,6 +174,39 @@ class SLIM(BaseModel):
             ids, scores, counts = self.model._topk(Xb, candidate_item_ids, top_k, filter_interacted, dense_output)
             ids, scores, counts = ids[inverse], scores[inverse], counts[inverse]
         return self.model._format(ids, scores, counts, ret_scores=False)
+
+    def _recommend_odd_ids(self, ids: np.ndarray, n_users: int, candidate_item_ids: Optional[List[int]], top_k: int,
+                           filter_interacted: bool) -> List[List[int]]:
+        """Internal user ids outside [0, n_users) -- a negative integer user, or a user known only through
+        register_user_feature -- never reach the device.  They get what the reference's scipy row indexing
+        of to_csr(select_users=...) gives them (slim.py:93, slim_elastic.py:707): IndexError beyond the
+        matrix, and for a negative id the row it wraps around to, which is populated only if that user is
+        in the same batch."""
+        bad = ids[(ids >= n_users) | (ids < -n_users)]
+        if len(bad):
+            raise IndexError(f"index ({int(bad[0])}) out of range")
+        regular = set(ids[ids >= 0].tolist())
+        rows = np.where(ids < 0, ids + n_users, ids)
+        live = np.array([(i >= 0) or (int(w) in regular) for i, w in zip(ids.tolist(), rows.tolist())], dtype=bool)
+        out: List[List[int]] = [[] for _ in ids]
+        if live.any():
+            got = self._recommend_hot_batch(rows[live].tolist(), candidate_item_ids=candidate_item_ids, top_k=top_k,
+                                            filter_interacted=filter_interacted)
+            for p, row in zip(np.flatnonzero(live).tolist(), got):
+                out[p] = row
+        if candidate_item_ids is not None and not live.all():
+            # an all-zero row still ranks the candidates (scores 0): argsort(...)[-k:][::-1], slim_elastic.py:730-733
+            k = min(top_k, len(candidate_item_ids))
+            zero_row = [candidate_item_ids[j] for j in range(len(candidate_item_ids) - 1, len(candidate_item_ids) - 1 - k, -1)]
+            for p in np.flatnonzero(~live).tolist():
+                out[p] = list(zero_row)
+        elif not self.item_ids.pass_through and not live.all():
+            # dense mode ranks every item of an all-zero row too: highest ids first (stable-argsort rule, D1)
+            n_items = self.model.item_similarity.shape[1]
+            k = min(top_k, n_items)
+            for p in np.flatnonzero(~live).tolist():
+                out[p] = list(range(n_items - 1, n_items - 1 - k, -1))
+        return out
 
     def _similar_items(self, query_item_id: int, query_item_tags: Optional[List[str]] = None, top_k: int = 10
                        ) -> List[Tuple[int, float]]:

@@ -348,6 +348,9 @@ class UserItemInteractions:
     def add_interaction(self, user_id: int, item_id: int, tstamp: float, delta: float = 1.0,
                         upsert: bool = False) -> None:
         """One interaction: new = clip(decayed(old) + delta) or, with upsert, (delta, tstamp)."""
+        # the reference computes `tstamp > now + 180.0` and `current + delta` with the caller's objects: a
+        # numeric string raises TypeError there (numpy would parse it), and the caller skips the row
+        tstamp, delta = 0.0 + tstamp, (delta if upsert else 0.0 + delta)
         self.add_interactions_batch(np.array([user_id], np.int64), np.array([item_id], np.int64),
                                     np.array([tstamp], np.float64), np.array([delta], np.float64), upsert=upsert)
 

@@ -84,33 +84,36 @@ class LRUFreqSet(MutableSet):
             data[k] = data.pop(k, 0) + cnt[j]
         return True
 
-    _NATIVE_ID_BOUND = 1 << 26
-
     def _replay_native(self, values: "np.ndarray") -> bool:
         """add() for every value in order -- evictions included -- by librtrec_amd.so's host routine
-        (rtrec_lru_replay: an intrusive linked list over the ids).  For batches that overflow the capacity,
-        where the end state depends on the exact interleaving.  Returns False (nothing done) when the
-        library is missing or the keys are not small non-negative integers."""
+        (rtrec_lru_replay: an intrusive linked list over dense key indices).  For batches that overflow the
+        capacity, where the end state depends on the exact interleaving.  The keys of the state and of the
+        batch are first mapped to dense indices 0..D-1, so the routine's list nodes are sized by the number of
+        DISTINCT keys, not by the largest id (a sparse or large item-id space used to cost a 16 B x max-id
+        allocation per overflowing batch).  Returns False (nothing done) when the library is missing or the
+        keys are not integers."""
         try:
             from .. import _native
             lib = _native.load()
         except Exception:
             return False
         data = self.data
-        if any(not isinstance(k, int) for k in data):
-            return False
         vals = np.ascontiguousarray(values, dtype=np.int64)
-        bound = max(int(vals.max()), max(data, default=0)) + 1
-        if int(vals.min()) < 0 or (data and min(data) < 0) or bound > self._NATIVE_ID_BOUND:
+        try:
+            sk = np.fromiter(data.keys(), dtype=np.int64, count=len(data))
+        except (TypeError, ValueError, OverflowError):
             return False
-        sk = np.fromiter(data.keys(), dtype=np.int64, count=len(data))
+        if len(sk) and not all(isinstance(k, int) for k in data):       # e.g. 1.0 would have been cast silently
+            return False
         sc = np.fromiter(data.values(), dtype=np.int64, count=len(data))
+        uniq = np.unique(np.concatenate([sk, vals]))
+        sk_d, vals_d = np.searchsorted(uniq, sk), np.searchsorted(uniq, vals)
         ok, oc = np.empty(self.capacity, np.int64), np.empty(self.capacity, np.int64)
-        n_out = int(lib.rtrec_lru_replay(sk.ctypes.data, sc.ctypes.data, len(sk), vals.ctypes.data, len(vals),
-                                         self.capacity, bound, ok.ctypes.data, oc.ctypes.data))
+        n_out = int(lib.rtrec_lru_replay(sk_d.ctypes.data, sc.ctypes.data, len(sk_d), vals_d.ctypes.data, len(vals_d),
+                                         self.capacity, max(len(uniq), 1), ok.ctypes.data, oc.ctypes.data))
         if n_out < 0:
             return False
-        self.data = OrderedDict(zip(ok[:n_out].tolist(), oc[:n_out].tolist()))
+        self.data = OrderedDict(zip(uniq[ok[:n_out]].tolist(), oc[:n_out].tolist()))
         return True
 
     def discard(self, value: Any) -> None:

@@ -305,3 +305,79 @@ def test_exchange_path_over_rccl_with_one_rank():
                PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK, G], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "RCCL-EXCHANGE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def _small_int_model(n_users=300, n_items=1800, seed=9, **kw):
+    from rtrec_amd import SLIM
+    rng = np.random.default_rng(seed)
+    n = 12000
+    u, i = rng.integers(0, n_users, n), (rng.zipf(1.25, n) - 1) % n_items
+    r = rng.integers(1, 6, n).astype(float) + rng.random(n)
+    ts = 1.7e9 + np.arange(n, dtype=float)
+    m = SLIM(nn_feature_selection=20, **kw)
+    m.add_interactions(list(zip(u.tolist(), i.tolist(), ts.tolist(), r.tolist())))
+    m.bulk_fit(progress_bar=False)
+    return m
+
+
+def test_user_ids_outside_the_matrix_never_reach_the_device():
+    """internal user ids outside [0, n_users) used to be read out of bounds by the
+    resident-X kernels.  They now get the reference's scipy semantics (slim.py:93, slim_elastic.py:707):
+    IndexError beyond the matrix, and a negative id wraps to a row that is empty unless it is in the batch."""
+    from rtrec_amd.engine import SlimEngine
+    m = _small_int_model()
+    n_users = m.interactions.shape[0]
+    ok = m.recommend_batch([0, 1, 2], top_k=5)
+    assert m._recommend_hot_batch([0, -1, 2], top_k=5) == [ok[0], [], ok[2]]
+    last = m._recommend_hot_batch([n_users - 1], top_k=5)[0]
+    assert m._recommend_hot_batch([-1, n_users - 1], top_k=5) == [last, last]      # -1 IS the last row here
+    assert m.recommend(-1, top_k=5) == []
+    with pytest.raises(IndexError):
+        m._recommend_hot_batch([n_users], top_k=5)
+    with pytest.raises(IndexError):
+        m._recommend_hot_batch([-n_users - 1], top_k=5)
+    with pytest.raises(IndexError):
+        m.model.engine.recommend_rows([0, n_users], top_k=5)
+    with pytest.raises(IndexError):
+        m.model.engine.recommend_rows([-1], top_k=5)
+    # a user known only through register_user_feature has no row: string ids -> internal id >= n_users
+    from rtrec_amd import SLIM
+    s = SLIM()
+    s.fit([("a", "x", 1.7e9, 1.0), ("b", "y", 1.7e9, 2.0), ("a", "y", 1.7e9, 1.0)], progress_bar=False)
+    s.recommend_batch(["a", "b"], top_k=2)
+    s.register_user_feature("ghost", ["tag"])
+    with pytest.raises(IndexError):
+        s.recommend("ghost", top_k=2)
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_top_k_beyond_the_kernel_limit_is_served_from_device_scores(dense, oracle):
+    """top_k > 1023 (rtrec_slim_score_topk's limit; the reference accepts any top_k): score rows from the
+    device, selection on the host in the reference's orders -- equal to the oracle, and equal to the fused
+    kernel's answer on the prefix it can produce."""
+    from rtrec_amd.models.internal.slim_elastic import SLIMElastic
+    m = _small_int_model()
+    W = m.model.item_similarity
+    X = m.interactions.to_csr()
+    users = list(range(0, 300, 7))
+    el = SLIMElastic({"nn_feature_selection": 20})
+    el.item_similarity = W
+    big = el.recommend_batch(users, X, top_k=1500, dense_output=dense, ret_scores=True)
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[users], W.tocsr(), top_k=1500, dense=dense, use_f64=(W.dtype == np.float64))
+    for (ids, sc), oi, os_, oc in zip(big, o_ids, o_sc, o_cnt):
+        assert ids == oi[:oc].tolist()
+        assert np.array_equal(bits(sc), bits(os_[:oc]))
+    small = el.recommend_batch(users, X, top_k=50, dense_output=dense)
+    assert [ids[:50] for ids, _ in big] == small
+    # candidates: the whole candidate list, ranked
+    cands = list(range(5, 1700))
+    got = el.recommend_batch(users[:5], X, candidate_item_ids=cands, top_k=1400)
+    ref = el.recommend_batch(users[:5], X, candidate_item_ids=cands, top_k=1000)
+    assert [g[:1000] for g in got] == ref and all(len(g) == 1400 for g in got)
+
+
+def test_evaluate_matches_the_reference_end_to_end_on_gpu():
+    """N3: Recommender.fit + evaluate (ndcg@k, recall, map, auc ...) on the GPU path equal the reference's run."""
+    from rtrec_amd import SLIM
+    from tests.test_pipeline_cpu import _evaluate_against_golden
+    _evaluate_against_golden(SLIM)

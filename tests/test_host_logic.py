@@ -604,3 +604,36 @@ def test_heavily_repeated_pairs_fold_sequentially_and_stay_linear(kw, upsert):
 
 def bits64(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def test_bad_rows_in_an_otherwise_clean_batch_are_skipped_like_the_reference():
+    """base.py:86-94 of the reference: an interaction that raises is logged and skipped, the rest of
+    the batch is stored.  The vectorised batch path must not lose the batch: an unhashable
+    id and a numeric STRING rating (which numpy would happily parse) each cost one row."""
+    from rtrec_amd.models.slim import SLIM
+    m = SLIM()
+    rows = [("u1", "a", 1.7e9, 1.0), ("u2", ["x", "y"], 1.7e9, 2.0), ("u3", "b", 1.7e9, "3.5"), ("u1", "b", 1.7e9, 4.0)]
+    m.add_interactions(rows)
+    st = m.interactions
+    assert st.nnz == 2
+    assert m.user_ids.obj_to_id == {"u1": 0, "u2": 1, "u3": 2}        # registered in row order, like the reference
+    assert m.item_ids.obj_to_id == {"a": 0, "b": 1}
+    assert st.get_user_item_rating(0, 0) == 1.0 and st.get_user_item_rating(0, 1) == 4.0
+
+
+def test_ranking_metrics_match_reference_goldens():
+    """rtrec/utils/metrics.py:5-313 captured by tools/gen_golden.py (evaluate.json): every metric on 156
+    (ranked, truth) pairs incl. the empty-list corner cases at sizes 1 / 5 / 10, and compute_scores' means."""
+    g = json.load(open(os.path.join(G, "evaluate.json")))
+    pairs = [(r, t) for r, t in g["pairs"]]
+    for size in (1, 5, 10):
+        for (r, t), want in zip(pairs, g["per_pair"][str(size)]):
+            got = [float(getattr(metrics, nm)(r, t, size)) for nm in g["metric_names"]]
+            assert got == pytest.approx(want, rel=1e-12, abs=1e-15), (r, t, size)
+        agg = metrics.compute_scores(iter(pairs), size)
+        ref = g["aggregate"][str(size)]
+        assert set(agg) == set(ref) and agg["tp"] == ref["tp"]
+        for k in ref:
+            assert agg[k] == pytest.approx(ref[k], rel=1e-12), (k, size)
+    assert metrics.mrr([r for r, _ in pairs], [t for _, t in pairs], 5) == pytest.approx(g["aggregate"]["mrr_5"], rel=1e-12)
+    assert metrics.map_score([r for r, _ in pairs], [t for _, t in pairs], 5) == pytest.approx(g["aggregate"]["map_5"], rel=1e-12)

@@ -304,3 +304,57 @@ def test_batched_similar_items_equal_one_call_per_query(ids):
         assert batched == one_by_one
     assert any(len(x) > 0 for x in one_by_one)
     assert a.item_ids.get_id(conv(10 ** 6)) == b.item_ids.get_id(conv(10 ** 6))
+
+
+def test_odd_user_ids_and_large_top_k_on_the_host_paths():
+    """Host logic of two round-2 additions, on the stand-in backend: (1) internal user ids outside [0, n_users)
+    are resolved before anything is launched (IndexError / wrapped row), (2) top_k beyond the fused kernel's
+    limit is served by score rows + a host selection that equals the oracle's order."""
+    from oracle import slim_oracle as so
+    rng = np.random.default_rng(9)
+    n = 6000
+    u, i = rng.integers(0, 120, n), (rng.zipf(1.25, n) - 1) % 1300
+    r = rng.integers(1, 6, n).astype(float) + rng.random(n)
+    m = cpu_slim(nn_feature_selection=10)
+    m.add_interactions(list(zip(u.tolist(), i.tolist(), (1.7e9 + np.arange(n)).tolist(), r.tolist())))
+    m.bulk_fit(progress_bar=False)
+    n_users = m.interactions.shape[0]
+    ok = m.recommend_batch([0, 1, 2], top_k=5)
+    assert m._recommend_hot_batch([0, -1, 2], top_k=5) == [ok[0], [], ok[2]]
+    last = m._recommend_hot_batch([n_users - 1], top_k=5)[0]
+    assert m._recommend_hot_batch([-1, n_users - 1], top_k=5) == [last, last]
+    with pytest.raises(IndexError):
+        m._recommend_hot_batch([n_users], top_k=5)
+    with pytest.raises(IndexError):
+        m.model.engine.recommend_rows([-1], top_k=5)
+    W, X = m.model.item_similarity, m.interactions.to_csr()
+    users = list(range(0, 120, 5))
+    for dense in (False, True):
+        big = m.model.recommend_batch(users, X, top_k=1100, dense_output=dense, ret_scores=True)
+        o_ids, o_sc, o_cnt = so.recommend_batch(X[users], W.tocsr(), top_k=1100, dense=dense, use_f64=(W.dtype == np.float64))
+        for (ids, sc), oi, os_, oc in zip(big, o_ids, o_sc, o_cnt):
+            assert ids == oi[:oc].tolist() and np.array_equal(bits(sc), bits(os_[:oc]))
+
+
+def _evaluate_against_golden(make_model):
+    """Recommender(SLIM).fit(train) -> evaluate(test) / recommend_batch vs the reference's own run
+    (tests/golden/evaluate.json, tools/gen_golden.py: rtrec/recommender.py:39-82,163-200)."""
+    import json
+    import pandas as pd
+    g = json.load(open(os.path.join(G, "evaluate.json")))["e2e"]
+    cols = ("user", "item", "tstamp", "rating")
+    train = pd.DataFrame(dict(zip(cols, g["train"])))
+    test = pd.DataFrame(dict(zip(cols, g["test"])))
+    rec = Recommender(make_model(**g["model_kwargs"]))
+    rec.fit(train, batch_size=1000, parallel=False)
+    assert rec.recommend_batch(g["users"], top_k=10) == g["recommend_top10"]
+    for key, ref in g["evaluate"].items():
+        size, fi = key.split("_")
+        got = rec.evaluate(test, recommend_size=int(size), filter_interacted=bool(int(fi)))
+        assert set(got) == set(ref) and got["tp"] == ref["tp"]
+        for k in ref:
+            assert got[k] == pytest.approx(ref[k], rel=1e-12), (key, k)
+
+
+def test_evaluate_matches_the_reference_end_to_end():
+    _evaluate_against_golden(cpu_slim)

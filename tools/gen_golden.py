@@ -328,7 +328,51 @@ def gen_serving():
     json.dump(sessions, open(os.path.join(OUT, "serving.json"), "w"), indent=1)
 
 
+# ------------------------------------------------------------------ N3: ranking metrics + Recommender.evaluate
+def gen_evaluate():
+    """rtrec/utils/metrics.py:5-313 on seeded (ranked, truth) pairs incl. the empty / short-list corner cases,
+    and rtrec/recommender.py:39-82,163-200 end to end: Recommender(SLIM).fit(train) -> evaluate(test)."""
+    import pandas as pd
+    from rtrec.recommender import Recommender as RefRecommender
+    from rtrec.utils import metrics as M
+    rng = np.random.default_rng(77)
+    pairs = [([], []), ([], [1, 2]), ([3, 4], []), ([1], [1]), ([5, 6, 7], [7]), ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12], [11, 12, 1])]
+    for _ in range(150):
+        n_r, n_t = int(rng.integers(0, 14)), int(rng.integers(0, 9))
+        pairs.append((rng.permutation(30)[:n_r].tolist(), rng.permutation(30)[:n_t].tolist()))
+    names = ["precision", "recall", "f1_score", "ndcg", "hit", "reciprocal_rank", "auc", "true_positives", "average_precision"]
+    per_pair = {}
+    for size in (1, 5, 10):
+        per_pair[str(size)] = [[float(getattr(M, nm)(r, g, size)) for nm in names] for r, g in pairs]
+    agg = {str(size): M.compute_scores(iter(pairs), size) for size in (1, 5, 10)}
+    agg["mrr_5"] = M.mrr([r for r, _ in pairs], [g for _, g in pairs], 5)
+    agg["map_5"] = M.map_score([r for r, _ in pairs], [g for _, g in pairs], 5)
+
+    U, I, n = 300, 120, 7000
+    u = (rng.zipf(1.3, n) - 1) % U
+    i = (rng.zipf(1.2, n) - 1) % I
+    r = np.round(rng.integers(1, 6, n) + rng.random(n), 6)
+    ts = T0 + np.sort(rng.random(n)) * 30 * 86400.0
+    df = pd.DataFrame({"user": u.astype(int), "item": i.astype(int), "tstamp": ts, "rating": r})
+    train, test = df.iloc[:6000], df.iloc[6000:]
+    rec = RefRecommender(RefSLIM(nn_feature_selection=8, min_value=0, max_value=15))
+    rec.fit(train, batch_size=1000, parallel=False)
+    ev = {f"{size}_{int(fi)}": rec.evaluate(test, recommend_size=size, filter_interacted=fi)
+          for size in (5, 10) for fi in (True, False)}
+    users = sorted(set(test["user"].tolist()))
+    recs = rec.recommend_batch(users, top_k=10)
+    out = {"metric_names": names, "pairs": pairs, "per_pair": per_pair, "aggregate": agg,
+           "e2e": {"train": [train[c].tolist() for c in ("user", "item", "tstamp", "rating")],
+                   "test": [test[c].tolist() for c in ("user", "item", "tstamp", "rating")],
+                   "model_kwargs": {"nn_feature_selection": 8, "min_value": 0, "max_value": 15},
+                   "evaluate": ev, "users": users, "recommend_top10": [[int(x) for x in row] for row in recs]}}
+    json.dump(out, open(os.path.join(OUT, "evaluate.json"), "w"))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "evaluate":     # adds evaluate.json without touching the other fixtures
+        gen_evaluate()
+        sys.exit(0)
     gen_rng()
     gen_cd_columns()
     X, X2, model = gen_models()
@@ -338,5 +382,6 @@ if __name__ == "__main__":
     gen_api()
     gen_reference_pickles()
     gen_serving()
+    gen_evaluate()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
