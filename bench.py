@@ -181,12 +181,11 @@ def main() -> None:
     for _ in range(args.warmup):
         out = step()
     lib = eng.be.lib
-    tot_ms, n_launch = C.c_double(0), C.c_int64(0)
     torch.cuda.synchronize()
     prof_fn = getattr(lib, "rtrec_amd_score_profile", None) if os.environ.get("RTREC_AMD_LIB") else None
     if prof_fn is not None:          # diagnostic build (-DSCORE_PROFILE): per-phase clocks of the sparse kernel
         prof_fn(None, 1)
-    lib.rtrec_amd_score_timer(1, None, None)
+    eng.score_timer = eng.be.timer_create()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -198,7 +197,10 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    lib.rtrec_amd_score_timer(0, C.byref(tot_ms), C.byref(n_launch))
+    kern_total_ms, kern_launches = eng.be.timer_read(eng.score_timer)
+    tot_ms, n_launch = C.c_double(kern_total_ms), C.c_int64(kern_launches)
+    eng.be.timer_destroy(eng.score_timer)
+    eng.score_timer = 0
     if prof_fn is not None and rank == 0:
         buf = (C.c_uint64 * 16)()
         prof_fn(buf, 0)

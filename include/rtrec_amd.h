@@ -13,7 +13,10 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is
  *    enqueued on it and is stream-ordered.
  *  - Return value: 0 on success, negative rtrec_status otherwise.  No exceptions cross the
- *    boundary, no global mutable state, re-entrant.
+ *    boundary.  The library keeps no mutable state of its own and reads no environment variables:
+ *    everything a call depends on is in its arguments (optional ones in the rtrec_*_opts structs, a
+ *    timing bracket in a caller-owned rtrec_timer object), so calls on different streams / threads
+ *    are independent as long as they do not share buffers.
  *  - Index arrays are int32, values float32 (rtrec/utils/interactions.py:276,303 builds
  *    float32 matrices whose scipy index dtype is int32).
  */
@@ -181,11 +184,51 @@ typedef enum {
                                  interacted items are NOT filtered     (slim_elastic.py:661-672) */
 } rtrec_topk_mode;
 
-/* Measurement hook: HIP events on the launch stream around score_tiles_kernel (the dominant
- * kernel of rtrec_slim_score_topk).  enable > 0 starts (and zeroes) the accumulation, 0 stops it,
- * < 0 zeroes it; on return *total_ms / *launches hold the kernel time and count collected so
- * far (either may be NULL).  Not thread-safe; used by bench.py only. */
-int rtrec_amd_score_timer(int32_t enable, double *total_ms, int64_t *launches);
+/* Measurement hook (bench.py's roofline leg): a caller-owned pair of HIP events that a scoring call records on
+ * its launch stream around its dominant kernel when the object is passed in rtrec_score_opts.timer.
+ * rtrec_timer_read waits for the last recorded pair, adds it up and returns the total kernel time / the
+ * number of brackets collected so far (either pointer may be NULL); reset != 0 zeroes the totals afterwards. */
+int  rtrec_timer_create(void **out_timer);
+int  rtrec_timer_read(void *timer, double *total_ms, int64_t *launches, int32_t reset);
+void rtrec_timer_destroy(void *timer);
+
+/* Optional inputs of a scoring call. */
+typedef struct {
+    /* Rows of the CSR matrix d_xb_*: a job whose row id is outside [0, n_x_rows) scores as an EMPTY row
+     * instead of reading out of bounds.  <= 0: unknown, no check (the caller vouches for the ids). */
+    int32_t        n_x_rows;
+    /* "Feature-row" form of the shard (optional; used for SPARSE mode with float32 accumulation and
+     * top_k <= 15, ignored otherwise).  Only items that some column selected with a non-zero weight have a
+     * row in W; when those rows are few (fr_rows <= 128) the shard is also given as the dense matrix of
+     * those rows over the columns that hold a weight, in an order of the caller's choice:
+     *     d_fr_col_ids[n_cols]  layout column -> item id,   d_fr_col_map[n_items]  item id -> layout column or -1
+     * (n_cols as in the compacted tiled layout), cut into tiles of fr_tile_cols (256 or 128) columns:
+     *     d_fr_w[t * fr_slice_floats + f * fr_tile_cols + c] = W[item of row f, d_fr_col_ids[t * fr_tile_cols + c]]
+     * (0 where no weight is stored; fr_slice_floats = fr_rows * fr_tile_cols rounded up to a multiple of 256),
+     * d_fr_map[n_items] = row f of an item or -1, fr_n_tiles = ceil(n_cols / fr_tile_cols), and
+     * d_fr_tile_rows[t * 2 + h] bit f = 1 iff row 64 h + f holds a weight in tile t: blocks without one are
+     * skipped, so an order of the columns that clusters the rows' weights saves work without changing a sum.
+     * d_fr_scratch: rtrec_slim_score_fr_scratch_bytes() bytes of device scratch.  Scores and ids are identical to
+     * the tiled-CSR path; accumulators live in registers and the matrix is streamed through LDS
+     * (csrc/score.hip, score_frows_kernel). */
+    const int32_t *d_fr_map;
+    const int32_t *d_fr_col_ids;
+    const int32_t *d_fr_col_map;
+    const float   *d_fr_w;
+    const uint64_t *d_fr_tile_rows;
+    int32_t        fr_rows, fr_tile_cols, fr_n_tiles, fr_slice_floats;
+    void          *d_fr_scratch;
+    size_t         fr_scratch_bytes;
+    /* Optional work order for the feature-row kernel: a permutation of 0 .. n_rows-1; job position p scores row
+     * d_row_order[p] (outputs stay at row index d_row_order[p]).  Handing the rows over longest-first levels the
+     * kernel's waves and shortens its tail; results do not depend on it. */
+    const int32_t *d_row_order;
+    void          *timer;         /* rtrec_timer object or NULL */
+    int32_t        diagnostics;   /* ablation switches of tools/score_ablate.sh; honoured by diagnostic builds
+                                     (-DRTREC_DIAGNOSTICS) only, ignored by the release library */
+} rtrec_score_opts;
+
+size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols);
 
 /* Bytes of scratch for rtrec_slim_score_topk. */
 size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k);
@@ -223,6 +266,22 @@ int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                           int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,
                           uint32_t *d_out_aux, int32_t *d_out_count,
                           void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* rtrec_slim_score_topk with options; opts == NULL behaves exactly like rtrec_slim_score_topk. */
+int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_ids,
+                              const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
+                              int32_t n_items, int32_t n_cols, int32_t col_offset,
+                              const int32_t *d_col_ids, const int32_t *d_col_map,
+                              int32_t tile_cols, int32_t n_tiles,
+                              const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
+                              const int32_t *d_dense_idx, const float *d_dense_val,
+                              const int32_t *d_row_hdr,
+                              const int32_t *d_col_rank,
+                              int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
+                              int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,
+                              uint32_t *d_out_aux, int32_t *d_out_count,
+                              void *d_workspace, size_t workspace_bytes, void *stream,
+                              const rtrec_score_opts *opts);
 
 /* Score-vector export (replaces slim_elastic.py:566-626 predict / predict_selected / predict_all):
  * d_out[r * out_stride + c] = sum_i X[row_r, i] * W[i, col_offset + c] for the n_cols columns of a

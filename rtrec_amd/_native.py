@@ -20,7 +20,8 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
            -4: "kernel launch failed"}
 
 EXPORTS = [
-    "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_amd_score_timer", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
+    "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_timer_create", "rtrec_timer_read", "rtrec_timer_destroy",
+    "rtrec_slim_score_fr_scratch_bytes", "rtrec_slim_score_topk_opt", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
     "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_gram_workspace_bytes", "rtrec_slim_gram_matrix", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
     "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round", "rtrec_store_decay",
@@ -35,6 +36,14 @@ class FitCfg(C.Structure):
 class FitOpts(C.Structure):
     _fields_ = [("d_trace", C.c_void_p), ("d_gram", C.c_void_p), ("d_gram_index", C.c_void_p),
                 ("gram_n", C.c_int32), ("gram_rel_err", C.c_double)]
+
+
+class ScoreOpts(C.Structure):
+    _fields_ = [("n_x_rows", C.c_int32), ("d_fr_map", C.c_void_p), ("d_fr_col_ids", C.c_void_p),
+                ("d_fr_col_map", C.c_void_p), ("d_fr_w", C.c_void_p), ("d_fr_tile_rows", C.c_void_p),
+                ("fr_rows", C.c_int32), ("fr_tile_cols", C.c_int32), ("fr_n_tiles", C.c_int32),
+                ("fr_slice_floats", C.c_int32), ("d_fr_scratch", C.c_void_p), ("fr_scratch_bytes", C.c_size_t),
+                ("d_row_order", C.c_void_p), ("timer", C.c_void_p), ("diagnostics", C.c_int32)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -68,8 +77,14 @@ def load() -> C.CDLL:
     L.rtrec_amd_version.argtypes = []
     L.rtrec_amd_last_error.restype = C.c_char_p
     L.rtrec_amd_last_error.argtypes = []
-    L.rtrec_amd_score_timer.restype = C.c_int
-    L.rtrec_amd_score_timer.argtypes = [i32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.rtrec_timer_create.restype = C.c_int
+    L.rtrec_timer_create.argtypes = [C.POINTER(C.c_void_p)]
+    L.rtrec_timer_read.restype = C.c_int
+    L.rtrec_timer_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    L.rtrec_timer_destroy.restype = None
+    L.rtrec_timer_destroy.argtypes = [vp]
+    L.rtrec_slim_score_fr_scratch_bytes.restype = u64
+    L.rtrec_slim_score_fr_scratch_bytes.argtypes = [i32, i32]
     L.rtrec_slim_column_sqnorms.restype = C.c_int
     L.rtrec_slim_column_sqnorms.argtypes = [i32, vp, vp, vp, vp]
     L.rtrec_slim_fit_workspace_bytes.restype = u64
@@ -90,6 +105,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_score_topk.restype = C.c_int
     L.rtrec_slim_score_topk.argtypes = ([i32] + [vp] * 4 + [i32] * 3 + [vp] * 2 + [i32] * 2 + [vp] * 7
                                         + [i32] * 4 + [vp] * 5 + [vp, u64, vp])
+    L.rtrec_slim_score_topk_opt.restype = C.c_int
+    L.rtrec_slim_score_topk_opt.argtypes = L.rtrec_slim_score_topk.argtypes + [C.POINTER(ScoreOpts)]
     L.rtrec_slim_score_rows.restype = C.c_int
     L.rtrec_slim_score_rows.argtypes = [i32] + [vp] * 4 + [i32] * 5 + [vp] * 3 + [i32, vp, C.c_int64, vp]
     L.rtrec_slim_merge_topk.restype = C.c_int

@@ -20,11 +20,15 @@
 #include "common.hip.h"
 #include "../../include/rtrec_amd.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace rtrec {
 
 struct ScoreArgs {
     int n_rows;
     const int *row_ids;   // optional: job r scores CSR row row_ids[r]
+    int n_x_rows;         // rows of the CSR matrix: a row id outside [0, n_x_rows) scores as an empty row
     const int *xb_ptr;
     const int *xb_col;
     const float *xb_val;
@@ -660,8 +664,9 @@ __global__ __launch_bounds__(64) void score_tiles_dense_kernel(ScoreArgs a) {
     const int t0 = tile * S;
     const int ncol = min(S, a.n_cols - t0);
     const int xrow = a.row_ids ? a.row_ids[row] : row;
-    const int a0 = a.xb_ptr[xrow];
-    const int n_a = a.xb_ptr[xrow + 1] - a0;
+    const bool xok = xrow >= 0 && xrow < a.n_x_rows;       // anything else scores as an empty row
+    const int a0 = xok ? a.xb_ptr[xrow] : 0;
+    const int n_a = xok ? a.xb_ptr[xrow + 1] - a0 : 0;
 
     for (int c = lane * 4; c < S; c += 256) { L.acc[c] = ACC(0); L.acc[c + 1] = ACC(0); L.acc[c + 2] = ACC(0); L.acc[c + 3] = ACC(0); }
     PF_DUMMY
@@ -699,8 +704,9 @@ __global__ __launch_bounds__(64) void score_rows_kernel(ScoreArgs a, ACC *out, l
     const int t0 = tile * S;
     const int ncol = min(S, a.n_cols - t0);
     const int xrow = a.row_ids ? a.row_ids[row] : row;
-    const int a0 = a.xb_ptr[xrow];
-    const int n_a = a.xb_ptr[xrow + 1] - a0;
+    const bool xok = xrow >= 0 && xrow < a.n_x_rows;       // anything else scores as an empty row
+    const int a0 = xok ? a.xb_ptr[xrow] : 0;
+    const int n_a = xok ? a.xb_ptr[xrow + 1] - a0 : 0;
     for (int c = lane * 4; c < S; c += 256) { L.acc[c] = ACC(0); L.acc[c + 1] = ACC(0); L.acc[c + 2] = ACC(0); L.acc[c + 3] = ACC(0); }
     PF_DUMMY
     accumulate_tile<ACC, false, false>(a, L, a0, n_a, tile, 0, 0 PF_NOARGS);
@@ -744,8 +750,9 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
         const int t0 = tile * S;
         const int ncol = min(S, a.n_cols - t0);
         const int xrow = a.row_ids ? a.row_ids[row] : row;
-        const int a0 = a.xb_ptr[xrow];
-        const int n_a = readfirst_i(a.xb_ptr[xrow + 1] - a0);
+        const bool xok = xrow >= 0 && xrow < a.n_x_rows;   // anything else scores as an empty row
+        const int a0 = xok ? a.xb_ptr[xrow] : 0;
+        const int n_a = readfirst_i(xok ? a.xb_ptr[xrow + 1] - a0 : 0);
         PF_MARK(PF_ROWPTR) PF_ADD(PF_JOBS, 1)
 
         // interacted items leave the race inside accumulate_tile (PREFILTER)
@@ -916,6 +923,436 @@ __global__ __launch_bounds__(64) void similar_topk_kernel(int n_queries, const i
     }
 }
 
+
+// =============================================================================================
+// SPARSE mode, "feature-row" form (float32 W): the fast path when W has FEW non-empty rows.
+//
+// Only items that some target selected as a feature with a non-zero weight have a row in W.  Under
+// sklearn's alpha * n_samples scaling that set is small -- 61 rows on the 100k x 50k workload, 66 on the
+// ML-20M shape -- and those rows are long (a popular item is a feature of most targets).  The shard of
+// W is then a small dense R x n_cols matrix, and a user's score vector is the sum of its <= R rows
+// weighted by the user's ratings, added in ascending item order.  This kernel keeps the ACCUMULATORS IN
+// REGISTERS and streams that matrix through LDS:
+//   * a workgroup of 8 waves scores 128 users (16 per wave) against all column tiles, one tile
+//     (64 * REGS columns, R rows, one contiguous slice) at a time; slice t+1 is copied global -> LDS by
+//     LDS-DMA (global_load_lds_dwordx4, double buffered) while tile t is computed;
+//   * per tile every wave sweeps the rows its users own in ascending row order: one ds_read_b128 of the
+//     row serves all 16 users, a user that owns the row adds x * w with two v_pk_mul_f32 + two
+//     v_pk_add_f32 per 256 columns (one rounded product, one rounded add per column -- scipy's
+//     csr_matmat arithmetic and order; a stored zero is never added by scipy, and adding x * 0 = +-0
+//     here never changes a sum that started at +0);
+//   * the interacted filter is a bitmap: the user's own columns are marked once per job (built in LDS,
+//     parked in a per-wave scratch) and masked out of the candidates of each tile with scalar ops;
+//   * top-(k+1) per user is a sorted list in two registers (lane j = rank j) carried across the tiles:
+//     a column enters only if it beats the current (k+1)-th score, so after the first tiles a
+//     (user, tile) pair costs four compares.  The list is the row's final answer: no per-tile
+//     candidate lists, no merge kernel.
+// Exact score ties inside the leading k+1 are flagged and re-scored by score_sparse_kernel<ACC, true>
+// like before.  No LDS accumulators, no touched lists, no per-user reset.
+// =============================================================================================
+struct FrArgs {
+    int n_rows; const int *row_ids; int n_x_rows;
+    const int *order;       // optional [n_rows]: position p of the work list scores (and writes) row order[p]
+    const int *xb_ptr; const int *xb_col; const float *xb_val;
+    int n_items;
+    const int *fmap;        // [n_items] item -> row of the dense matrix, or -1
+    const int *col_map;     // [n_items] item -> layout column, or -1
+    const int *col_ids;     // [n_cols]  layout column -> item id (ascending)
+    int n_cols, R, n_tiles;
+    const float *wd;        // [n_tiles][slice_floats]: tile t, row f, column c at t * slice_floats + f * TC + c
+    const unsigned long long *tile_rows;   // [n_tiles][2]: bit f of word h set <=> row 64 h + f holds a weight in the tile
+    int slice_floats;       // R * TC rounded up to a multiple of 256 floats (1 KiB per LDS-DMA wave-instruction)
+    unsigned long long *mscratch;   // [gridDim.x][waves][users][n_tiles * REGS] interacted-column lane masks
+    int kk, top_k, filter;
+    int *out_id; float *out_score; uint32_t *out_aux; int *out_cnt;
+    int *flag_list; int *flag_len;
+    int *queue;
+};
+
+constexpr int kFrWaves = 16;                 // one workgroup per CU, four waves per SIMD
+constexpr int kFrUsers = 8;                  // users per wave
+constexpr int kFrWaveScratch = 4096;         // LDS bytes of setup scratch per wave (inside the second slice buffer)
+constexpr int kFrMaskWords = 416;            // 64-bit mask words per user the scratch holds (n_tiles * REGS)
+constexpr int kFrUserWords = 192;            // 32-bit words of global scratch per user: 128 ratings, 32 row words, pad
+constexpr int kFrMaxKk = 16;                 // top_k + 1 entries of a list fit one DPP row
+constexpr int kFrMaxRows = 128;
+
+// 64-bit words of global scratch per wave: kFrUserWords 32-bit words per user, then n_tiles * regs mask words per user
+__host__ __device__ constexpr size_t fr_wave_scratch_words(int n_tiles, int regs) {
+    return static_cast<size_t>(kFrUsers) * kFrUserWords / 2 + static_cast<size_t>(kFrUsers) * n_tiles * regs;
+}
+constexpr int kFrCandCap = 64;               // candidates a wave buffers per merge round (one per lane)
+__host__ __device__ constexpr size_t fr_slices_bytes(int slice_floats) {
+    const size_t sb = static_cast<size_t>(slice_floats) * 4;
+    return sb + (sb > static_cast<size_t>(kFrWaves) * kFrWaveScratch ? sb : static_cast<size_t>(kFrWaves) * kFrWaveScratch);
+}
+__host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
+__host__ __device__ constexpr size_t fr_lds_bytes(int slice_floats) {
+    return fr_slices_bytes(slice_floats) + kFrWaves * fr_wave_extra_bytes() + 16;
+}
+
+typedef __attribute__((address_space(3))) void fr_lds_void;
+typedef __attribute__((address_space(1))) const void fr_glb_void;
+
+template <int REGS> struct FrVec;
+template <> struct FrVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
+template <> struct FrVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+__device__ __forceinline__ float float_prev(float f) {       // largest float < f (f finite or +inf, not NaN)
+    const uint32_t b = __float_as_uint(f);
+    if ((b << 1) == 0u) return __uint_as_float(0x80000001u);
+    return __uint_as_float((b >> 31) ? b + 1u : b - 1u);
+}
+__device__ __forceinline__ float fr_shift_up(float v, float fill) {      // lane j <- lane j-1, lane 0 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int fr_shift_up(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float fr_row_shift_up(float v, float fill) {   // within each 16-lane row: lane j <- lane j-1
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x111, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int fr_row_shift_up(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, 0x111, 0xf, 0xf, false);
+}
+__device__ __forceinline__ float fr_shift_down(float v, float fill) {    // lane j <- lane j+1, lane 63 <- fill
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+
+// kk-th largest of the 64 per-lane values `best` (-inf = no value), or -inf when fewer than kk lanes hold
+// one: a LOWER BOUND of the kk-th largest element of any set whose per-lane maxima these are.  Uniform.
+__device__ __forceinline__ float fr_kth_lane_best(float best, int kk) {
+    const float ninf = -__builtin_huge_valf();
+    const int lane = lane_id();
+    float tau = ninf;
+    if (kk <= 16) {          // the kk-th largest of the 16 quad maxima is a bound as well, at a quarter of the steps
+        float q = best;
+        { const float o = shfl_xor_t(q, 1); q = o > q ? o : q; }
+        { const float o = shfl_xor_t(q, 2); q = o > q ? o : q; }
+        int rank = 0;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float o = readlane_f(q, 4 * t);
+            rank += (o > q || (o == q && t < (lane >> 2))) ? 1 : 0;
+        }
+        const unsigned long long at = __ballot(rank == kk - 1 && (lane & 3) == 0);
+        if (at) tau = readlane_f(q, __builtin_ctzll(at));
+    } else {
+        int rank = 0;
+#pragma unroll
+        for (int t = 0; t < 64; ++t) {
+            const float o = readlane_f(best, t);
+            rank += (o > best || (o == best && t < lane)) ? 1 : 0;
+        }
+        const unsigned long long at = __ballot(rank == kk - 1);
+        if (at) tau = readlane_f(best, __builtin_ctzll(at));
+    }
+    return tau;
+}
+
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  The per-user
+// register arrays of the kernel below are indexed with these constants only, so every element is a scalar
+// the register allocator sees from the start (a runtime-indexed array of this size would live in scratch).
+template <class F, int... I>
+__device__ __forceinline__ void fr_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void fr_static_for(F &&f) {
+    fr_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <int REGS, int XR>
+__global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef typename FrVec<REGS>::type vec;
+    constexpr int TC = 64 * REGS;
+    constexpr int UW = kFrUsers;
+    constexpr int NL = UW / 4;                              // list registers: four users per 64 lanes, 16 lanes each
+    const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
+    const int slice_bytes = a.slice_floats * 4;
+    const int kk = a.kk;                                    // <= 16
+    float *buf0 = reinterpret_cast<float *>(smem);
+    float *buf1 = reinterpret_cast<float *>(smem + slice_bytes);
+    // the second buffer doubles as the waves' setup scratch, so it is at least kFrWaves * kFrWaveScratch long;
+    // behind it every wave has a candidate buffer
+    unsigned char *extra = smem + fr_slices_bytes(a.slice_floats) + static_cast<size_t>(wave) * fr_wave_extra_bytes();
+    float *cv = reinterpret_cast<float *>(extra);                     // [kFrCandCap] candidate scores
+    int *cp = reinterpret_cast<int *>(cv + kFrCandCap);               // [kFrCandCap] column << 3 | user
+    int *s_job = reinterpret_cast<int *>(smem + fr_lds_bytes(a.slice_floats) - 16);
+    const int n_jobs = (a.n_rows + UW * kFrWaves - 1) / (UW * kFrWaves);
+    const int n_chunks = slice_bytes >> 10;                 // 1 KiB LDS-DMA pieces per slice
+    const float ninf = -__builtin_huge_valf();
+    const int mwords = a.n_tiles * REGS;
+    // per-wave global scratch: per user 192 words (ratings of its rows, compacted: 128; their row indices, four
+    // to a word: 32; pad), then the users' mask words
+    const size_t wave_words = fr_wave_scratch_words(a.n_tiles, REGS);
+    unsigned long long *sc_wave = a.mscratch + (static_cast<size_t>(blockIdx.x) * kFrWaves + wave) * wave_words;
+    uint32_t *xs_wave = reinterpret_cast<uint32_t *>(sc_wave);
+    unsigned long long *ms_wave = sc_wave + kFrUsers * kFrUserWords / 2;
+
+    auto load_slice = [&](int t, float *dst) {
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.wd + static_cast<size_t>(t) * a.slice_floats);
+        for (int c = wave; c < n_chunks; c += kFrWaves)
+            __builtin_amdgcn_global_load_lds((fr_glb_void *)(src + (static_cast<size_t>(c) << 10) + lane * 16),
+                                             (fr_lds_void *)(reinterpret_cast<unsigned char *>(dst) + (c << 10)),
+                                             16, 0, 0);
+    };
+
+    PF_DECL
+#ifdef SCORE_PROFILE
+    const unsigned long long pf_start_ = pf_t_;
+#endif
+    for (;;) {
+        __syncthreads();                                    // the previous job has left both slice buffers
+        PF_MARK(PF_QUEUE)
+        if (tid == 0) *s_job = atomicAdd(a.queue, 1);
+        __syncthreads();
+        const int job = *s_job;
+        if (job >= n_jobs) break;
+        load_slice(0, buf0);
+        // Row positions of this wave: position p of the job's 128 goes to wave p % 16, so that with rows handed
+        // over longest-first (a.order) every wave of the workgroup gets the same mix of long and short rows and
+        // the per-tile barriers find the waves level.
+        const int base = job * kFrWaves * UW + wave;
+
+        // ---- setup: per user its ratings of the R feature items (dense, lane = row of W) and the interacted-column
+        //      masks, built in LDS (the second slice buffer is free until tile 0 starts) and parked in the wave's
+        //      global scratch; the ratings come back into registers below ----
+        unsigned long long *Ml = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(buf1) + wave * kFrWaveScratch);
+        unsigned char *rowsb = reinterpret_cast<unsigned char *>(Ml + kFrMaskWords);      // [128] row index of entry j
+        float *xl = reinterpret_cast<float *>(rowsb + 256);                                // [128] floats
+        for (int u = 0; u < UW; ++u) {
+            const int p = base + u * kFrWaves;
+            int a0 = 0, n_a = 0;
+            if (p < a.n_rows) {
+                const int r = a.order ? a.order[p] : p;
+                const int xrow = a.row_ids ? a.row_ids[r] : r;
+                if (xrow >= 0 && xrow < a.n_x_rows) { a0 = a.xb_ptr[xrow]; n_a = a.xb_ptr[xrow + 1] - a0; }
+            }
+            a0 = readfirst_i(a0); n_a = readfirst_i(n_a);
+            for (int w = lane; w < mwords; w += 64) Ml[w] = 0ull;
+            fr_static_for<2>([&](auto H) { xl[H() * 64 + lane] = 0.0f; });
+            for (int b = 0; b < n_a; b += 64) {
+                const int q = b + lane;
+                if (q < n_a) {
+                    const int item = a.xb_col[a0 + q];
+                    if (item < a.n_items) {
+                        const int f = a.fmap[item];
+                        if (f >= 0) xl[f] = a.xb_val[a0 + q];             // the items of one row are distinct
+                        if (a.filter) {
+                            const int c = a.col_map[item];
+                            if (c >= 0) {
+                                const int cl = c & (TC - 1);
+                                atomicOr(&Ml[(c / TC) * REGS + (cl & (REGS - 1))], 1ull << (cl / REGS));
+                            }
+                        }
+                    }
+                }
+            }
+            uint32_t *xu = xs_wave + u * kFrUserWords;
+            fr_static_for<2>([&](auto H) { xu[H() * 64 + lane] = __float_as_uint(xl[H() * 64 + lane]); });
+            for (int w = lane; w < mwords; w += 64) ms_wave[static_cast<size_t>(u) * mwords + w] = Ml[w];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        float xr[UW][XR];          // lane f: the user's rating of the item of row 64 * h + f of W (0: not owned)
+        fr_static_for<UW>([&](auto Uc) {
+            constexpr int u = decltype(Uc)::value;
+            const uint32_t *xu = xs_wave + u * kFrUserWords;
+            fr_static_for<XR>([&](auto H) {
+                xr[u][H()] = __uint_as_float(__hip_atomic_load(&xu[H() * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            });
+        });
+        // running top-kk of every user, in registers: user u = lanes (u & 3) * 16 .. + kk - 1 of register u >> 2,
+        // lane offset j = rank j (a DPP row is 16 lanes, so a list shifts with row_shr:1)
+        float ls4[NL];
+        int lc4[NL];
+        fr_static_for<NL>([&](auto G) { ls4[G()] = ninf; lc4[G()] = -1; });
+
+        PF_MARK(PF_HDR) PF_ADD(PF_JOBS, 1)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice 0 has landed, the masks are in L2
+        __syncthreads();
+        PF_MARK(PF_GROUP)
+
+        const uint32_t lane16 = static_cast<uint32_t>(lane) * (REGS * 4);                  // byte offset of this lane in a row
+        for (int t = 0; t < a.n_tiles; ++t) {
+            const unsigned char *wb = reinterpret_cast<const unsigned char *>((t & 1) ? buf1 : buf0);
+            if (t + 1 < a.n_tiles) load_slice(t + 1, (t & 1) ? buf0 : buf1);
+            // interacted masks of this tile: lane j holds the word of (user j / REGS, register j % REGS)
+            unsigned long long mword = 0ull;
+            if (a.filter && lane < UW * REGS)
+                mword = __hip_atomic_load(&ms_wave[static_cast<size_t>(lane / REGS) * mwords + t * REGS + (lane % REGS)],
+                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t mw_lo = static_cast<uint32_t>(mword), mw_hi = static_cast<uint32_t>(mword >> 32);
+            unsigned long long nz[XR];        // rows of W that hold a weight in this tile
+            fr_static_for<XR>([&](auto H) { nz[H()] = a.tile_rows[t * 2 + H()]; });
+            vec acc[UW];
+
+            // ---- every user's rows of W, ascending: acc += x * w, one rounded product and one rounded add per
+            //      column (two v_pk_mul_f32 + two v_pk_add_f32 per 256 columns), four rows per step: their LDS
+            //      reads go out together, the applies follow.  Interacted columns start at -inf, which absorbs
+            //      every later addend, so they never show up as candidates. ----
+            fr_static_for<UW>([&](auto Uc) {
+                constexpr int u = decltype(Uc)::value;
+                fr_static_for<REGS>([&](auto Rc) {
+                    constexpr int r = decltype(Rc)::value;
+                    const unsigned int lo = readlane_u(mw_lo, u * REGS + r), hi = readlane_u(mw_hi, u * REGS + r);
+                    const unsigned long long ex = (static_cast<unsigned long long>(hi) << 32) | lo;
+                    float init;
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(init) : "v"(0.0f), "v"(ninf), "s"(ex));
+                    acc[u][r] = init;
+                });
+                fr_static_for<XR>([&](auto H) {
+                    constexpr int h = decltype(H)::value;
+                    // rows this user owns AND that hold a weight in this tile (the columns are ordered so that
+                    // most (row, tile) blocks are empty: skipping them skips additions of +-0 only)
+                    unsigned long long own = __ballot(xr[u][h] != 0.0f) & nz[h];
+                    const unsigned char *wh = wb + h * 64 * (TC * 4) + lane16;
+                    while (own) {
+                        int f[4];
+                        bool live[4];
+                        vec w[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            live[q] = own != 0ull;
+                            f[q] = live[q] ? __builtin_ctzll(own) : f[0];
+                            own &= own - 1;        // 0 stays 0
+                            w[q] = *reinterpret_cast<const vec *>(wh + f[q] * (TC * 4));
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float x = readlane_f(xr[u][h], f[q]);
+                            const float xs = live[q] ? x : 0.0f;       // a group that runs past the last row repeats one with x = 0
+                            acc[u] = acc[u] + w[q] * xs;
+                        }
+                        PF_ADD(PF_N_DENSE, 4)
+                    }
+                });
+            });
+            PF_MARK(PF_DENSE)
+
+            // ---- candidates: columns that beat the user's current kk-th score go to the wave's LDS buffer
+            //      (column << 3 | user); the buffer is then merged into the users' lists by one copy of the
+            //      insertion code per list register.  `resume` restarts the scan where a full buffer stopped it. ----
+            int resume = 0;
+            for (;;) {
+                int nc = 0, stop = UW * REGS;
+                fr_static_for<UW>([&](auto Uc) {
+                    constexpr int u = decltype(Uc)::value;
+                    if ((u + 1) * REGS <= resume || stop != UW * REGS) return;
+                    float thr = readlane_f(ls4[u >> 2], (u & 3) * 16 + kk - 1);
+                    float best = acc[u][0];
+                    fr_static_for<REGS>([&](auto Rc) { best = acc[u][Rc()] > best ? acc[u][Rc()] : best; });
+                    if (thr >= 0.0f) {
+                        if (!__ballot(best > thr)) return;      // the common case after the first tiles: nothing enters
+                    } else if (thr == ninf) {
+                        // The list is not full yet (first tile, or a user with few scored columns): everything
+                        // non-zero would pass.  Take the tile's own kk-th best candidate (a bound from the lane
+                        // maxima of the admissible columns) as the threshold instead.
+                        PF_ADD(PF_N_OVERFLOW, 1)
+                        float bm = ninf;
+                        fr_static_for<REGS>([&](auto Rc) {
+                            const float v = acc[u][Rc()];
+                            const float vm = (v != 0.0f) ? v : ninf;
+                            bm = vm > bm ? vm : bm;
+                        });
+                        const float t0 = fr_kth_lane_best(bm, kk);
+                        if (t0 != ninf) thr = float_prev(t0);       // candidates are the values >= t0
+                    }
+                    fr_static_for<REGS>([&](auto Rc) {
+                        constexpr int r = decltype(Rc)::value;
+                        if (u * REGS + r < resume || stop != UW * REGS) return;
+                        const float v = acc[u][r];
+                        // only non-zero sums compete (scipy keeps `!= 0`); -inf marks an interacted column
+                        const unsigned long long m = __ballot(v > thr && v != 0.0f);
+                        if (!m) return;
+                        const int cnt = static_cast<int>(__builtin_popcountll(m));
+                        if (nc + cnt > kFrCandCap) { stop = u * REGS + r; return; }
+                        if ((m >> lane) & 1ull) {
+                            const int pos = nc + lane_prefix(m);
+                            cv[pos] = v;
+                            cp[pos] = ((t * TC + lane * REGS + r) << 3) | u;
+                        }
+                        nc += cnt;
+                    });
+                });
+                if (nc > 0) {
+                    // merge the buffer into the lists; the whole buffer is read back in one LDS round trip
+                    const float myv = lane < nc ? cv[lane] : ninf;
+                    const int mypk = lane < nc ? cp[lane] : 0;
+                    for (int i = 0; i < nc; ++i) {
+                        const float v = readlane_f(myv, i);
+                        const int pk = readlane_i(mypk, i);
+                        const int u = pk & 7, col = pk >> 3;
+                        const int lb = (u & 3) * 16;
+                        const bool in = lane >= lb && lane < lb + kk;
+                        PF_ADD(PF_N_SPARSE_CHUNKS, 1)
+                        fr_static_for<NL>([&](auto G) {
+                            constexpr int g = decltype(G)::value;
+                            if ((u >> 2) != g) return;
+                            const float s = ls4[g];
+                            const int c = lc4[g];
+                            if (!(v > readlane_f(s, lb + kk - 1))) return;          // the threshold has risen meanwhile
+                            // ties inside the fast pass order by higher column; exact ties are re-scored anyway
+                            const bool better = in && ((s > v) || (s == v && c > col));
+                            const int pos = static_cast<int>(__builtin_popcountll(__ballot(better)));
+                            PF_ADD(PF_N_SPARSE_ROWS, 1)
+                            const float s_up = fr_row_shift_up(s, ninf);
+                            const int c_up = fr_row_shift_up(c, -1);
+                            const int rel = lane - lb;
+                            ls4[g] = !in || rel < pos ? s : (rel == pos ? v : s_up);
+                            lc4[g] = !in || rel < pos ? c : (rel == pos ? col : c_up);
+                        });
+                    }
+                }
+                if (stop == UW * REGS) break;
+                resume = stop;
+            }
+            PF_MARK(PF_SELECT)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice t+1 has landed ...
+            __syncthreads();                                    // ... and every wave has left slice t
+            PF_MARK(PF_GROUP)
+        }
+
+        // ---- the lists are the rows' answers ----
+        fr_static_for<UW>([&](auto Uc) {
+            constexpr int u = decltype(Uc)::value;
+            const int p = base + u * kFrWaves;
+            if (p >= a.n_rows) return;
+            const int r = a.order ? a.order[p] : p;
+            constexpr int lb = (u & 3) * 16;
+            const int rel = lane - lb;
+            const bool in = rel >= 0 && rel < kk;
+            const float s = ls4[u >> 2];
+            const int c = lc4[u >> 2];
+            const int n_valid = static_cast<int>(__builtin_popcountll(__ballot(in && c >= 0)));
+            const int n_fin = min(n_valid, a.top_k);
+            if (rel >= 0 && rel < a.top_k) {
+                const long long o = static_cast<long long>(r) * a.top_k + rel;
+                const bool ok = rel < n_fin;
+                a.out_id[o] = ok ? a.col_ids[c] : -1;
+                a.out_score[o] = ok ? s : ninf;
+                if (a.out_aux) a.out_aux[o] = 0u;
+            }
+            const float nxt = fr_shift_down(s, ninf);
+            const unsigned long long tie = __ballot(rel >= 0 && rel + 1 < n_valid && s == nxt);
+            if (lane == lb) {
+                a.out_cnt[r] = n_fin;
+                if (tie) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+            }
+        });
+        PF_MARK(PF_EMIT)
+    }
+#ifdef SCORE_PROFILE
+    if (lane == 0) {
+        pf_[PF_TOTAL] = __builtin_amdgcn_s_memtime() - pf_start_;
+        for (int q = 0; q < PF_COUNT; ++q) atomicAdd(&g_score_prof[q], pf_[q]);
+    }
+#endif
+}
+
 }  // namespace rtrec
 
 // ------------------------------------------------------------------------------------------
@@ -925,30 +1362,29 @@ using namespace rtrec;
 
 #include <cstdio>
 #include <cstdlib>
+#include <new>
 
 namespace {
-// RTREC_AMD_DEBUG=1: synchronise after every launch and report the stage (diagnostics only).
+// Diagnostic build only (-DRTREC_DEBUG_STAGES): synchronise after every launch and report the stage.
 inline void debug_stage(hipStream_t st, const char *what) {
-    static const bool on = std::getenv("RTREC_AMD_DEBUG") != nullptr;
-    if (!on) return;
+#ifdef RTREC_DEBUG_STAGES
     const hipError_t e = hipStreamSynchronize(st);
     std::fprintf(stderr, "[rtrec_amd] %s: %s\n", what, hipGetErrorString(e));
     std::fflush(stderr);
+#else
+    (void)st; (void)what;
+#endif
 }
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Optional HIP-event bracket around score_tiles_kernel (bench.py's roofline leg).
+// HIP-event bracket around the dominant kernel of a scoring call.  One object per caller (rtrec_timer_create):
+// the library itself keeps no state.
 struct KernelTimer {
-    bool enabled = false;
     hipEvent_t start = nullptr, stop = nullptr;
     double total_ms = 0.0;
     long long launches = 0;
     bool pending = false;
 };
-KernelTimer &score_timer() {
-    static KernelTimer t;
-    return t;
-}
 void timer_collect(KernelTimer &t) {
     if (!t.pending) return;
     float ms = 0.0f;
@@ -986,10 +1422,32 @@ unsigned persistent_grid(size_t lds_bytes, long long jobs) {
     return static_cast<unsigned>(jobs < g ? (jobs > 0 ? jobs : 1) : g);
 }
 
+// Feature-row form of the shard (rtrec_score_opts): usable for SPARSE mode with float32 accumulation.
+struct FrLayout {
+    const int *fmap = nullptr; const float *wd = nullptr; const int *order = nullptr;
+    const int *col_ids = nullptr; const int *col_map = nullptr; const unsigned long long *tile_rows = nullptr;
+    int rows = 0, tile_cols = 0, n_tiles = 0, slice_floats = 0;
+    unsigned long long *scratch = nullptr; size_t scratch_bytes = 0;
+};
+size_t fr_scratch_bytes(int n_tiles, int tile_cols) {
+    const int regs = tile_cols / 64;
+    return static_cast<size_t>(256) * kFrWaves * fr_wave_scratch_words(n_tiles, regs) * sizeof(unsigned long long);
+}
+bool fr_usable(const FrLayout &F, int kk) {
+    if (!F.fmap || !F.wd || !F.scratch || !F.col_ids || !F.col_map || !F.tile_rows) return false;
+    if (F.tile_cols != 256 && F.tile_cols != 128) return false;
+    const int regs = F.tile_cols / 64;
+    if (F.rows <= 0 || F.rows > kFrMaxRows || F.n_tiles <= 0 || F.n_tiles * regs > kFrMaskWords) return false;
+    if (F.slice_floats < F.rows * F.tile_cols || (F.slice_floats % 256) != 0) return false;
+    if (fr_lds_bytes(F.slice_floats) > 160u * 1024u) return false;
+    if (F.scratch_bytes < fr_scratch_bytes(F.n_tiles, F.tile_cols)) return false;
+    return kk >= 1 && kk <= kFrMaxKk;
+}
+
 template <typename ACC>
 int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_ids, float *d_out_scores,
                double *d_out_scores64, uint32_t *d_out_aux, int32_t *d_out_count,
-               unsigned char *ws, const ScoreWs &L, hipStream_t st) {
+               unsigned char *ws, const ScoreWs &L, hipStream_t st, KernelTimer *tmr, const FrLayout &FR, int n_x_rows) {
     ScoreArgs a = base;
     const bool sparse = (a.mode == RTREC_TOPK_SPARSE);
     const bool single = (a.n_tiles == 1);
@@ -1014,10 +1472,33 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     if (hipMemsetAsync(queue, 0, 8, st) != hipSuccess) return RTREC_ERR_LAUNCH;
 
     const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
-    KernelTimer &tm = score_timer();
     debug_stage(st, "score: begin");
-    if (tm.enabled) { timer_collect(tm); (void)hipEventRecord(tm.start, st); }
-    if (sparse) {
+    if (tmr) { timer_collect(*tmr); (void)hipEventRecord(tmr->start, st); }
+    bool fr_done = false;
+    if (sparse && sizeof(ACC) == 4 && fr_usable(FR, a.kk)) {
+        // few, long rows in W: accumulators in registers, the dense R x n_cols matrix streamed through LDS
+        FrArgs f{};
+        f.n_rows = a.n_rows; f.row_ids = a.row_ids; f.n_x_rows = n_x_rows; f.order = FR.order;
+        f.xb_ptr = a.xb_ptr; f.xb_col = a.xb_col; f.xb_val = a.xb_val; f.n_items = a.n_items;
+        f.fmap = FR.fmap; f.col_map = FR.col_map; f.col_ids = FR.col_ids; f.tile_rows = FR.tile_rows;
+        f.n_cols = a.n_cols; f.R = FR.rows; f.n_tiles = FR.n_tiles; f.wd = FR.wd; f.slice_floats = FR.slice_floats;
+        f.mscratch = FR.scratch;
+        f.kk = a.kk; f.top_k = top_k; f.filter = a.filter;
+        f.out_id = d_out_ids; f.out_score = d_out_scores; f.out_aux = d_out_aux; f.out_cnt = d_out_count;
+        f.flag_list = flag_list; f.flag_len = flag_len; f.queue = queue;
+        const int n_jobs = (a.n_rows + kFrUsers * kFrWaves - 1) / (kFrUsers * kFrWaves);
+        const unsigned grid = static_cast<unsigned>(n_jobs < 256 ? n_jobs : 256);
+        const size_t lds = fr_lds_bytes(FR.slice_floats);
+        const bool two = FR.rows > 64;
+        if (FR.tile_cols == 256) {
+            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 2>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 1>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
+        } else {
+            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 2>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 1>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
+        }
+        fr_done = true;
+    } else if (sparse) {
         const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true, a.kk);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, false>), dim3(persistent_grid(lds, total)), dim3(64),
                            lds, st, a);
@@ -1027,7 +1508,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_tiles_dense_kernel<ACC>), dim3(static_cast<unsigned>(per_xcd * 8)),
                            dim3(64), lds, st, a);
     }
-    if (tm.enabled) { (void)hipEventRecord(tm.stop, st); tm.pending = true; }
+    if (tmr) { (void)hipEventRecord(tmr->stop, st); tmr->pending = true; }
     debug_stage(st, "score tiles");
 
     MergeArgs m{};
@@ -1041,7 +1522,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     m.detect_ties = sparse ? 1 : 0;
     m.flag_list = flag_list; m.flag_len = flag_len;
     m.row_list = nullptr; m.row_list_len = nullptr;
-    if (!single) {
+    if (!single && !fr_done) {      // the feature-row kernel writes final lists itself
         hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, m);
         debug_stage(st, "merge_topk_kernel");
     }
@@ -1071,17 +1552,31 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
 }
 }  // namespace
 
-extern "C" int rtrec_amd_score_timer(int32_t enable, double *total_ms, int64_t *launches) {
-    KernelTimer &t = score_timer();
-    if (enable && !t.start) {
-        if (hipEventCreate(&t.start) != hipSuccess || hipEventCreate(&t.stop) != hipSuccess) return RTREC_ERR_LAUNCH;
-    }
+extern "C" int rtrec_timer_create(void **out_timer) {
+    if (!out_timer) return RTREC_ERR_INVALID_ARG;
+    KernelTimer *t = new (std::nothrow) KernelTimer();
+    if (!t) return RTREC_ERR_LAUNCH;
+    if (hipEventCreate(&t->start) != hipSuccess || hipEventCreate(&t->stop) != hipSuccess) { delete t; return RTREC_ERR_LAUNCH; }
+    *out_timer = t;
+    return RTREC_OK;
+}
+
+extern "C" int rtrec_timer_read(void *timer, double *total_ms, int64_t *launches, int32_t reset) {
+    if (!timer) return RTREC_ERR_INVALID_ARG;
+    KernelTimer &t = *static_cast<KernelTimer *>(timer);
     timer_collect(t);
     if (total_ms) *total_ms = t.total_ms;
     if (launches) *launches = t.launches;
-    if (enable < 0 || (enable && !t.enabled)) { t.total_ms = 0.0; t.launches = 0; }
-    t.enabled = enable > 0;
+    if (reset) { t.total_ms = 0.0; t.launches = 0; }
     return RTREC_OK;
+}
+
+extern "C" void rtrec_timer_destroy(void *timer) {
+    if (!timer) return;
+    KernelTimer *t = static_cast<KernelTimer *>(timer);
+    if (t->start) (void)hipEventDestroy(t->start);
+    if (t->stop) (void)hipEventDestroy(t->stop);
+    delete t;
 }
 
 #ifdef SCORE_PROFILE
@@ -1092,12 +1587,17 @@ extern "C" int rtrec_amd_score_profile(unsigned long long *out16, int reset) {
 }
 #endif
 
+extern "C" size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols) {
+    if (fr_n_tiles <= 0 || (fr_tile_cols != 256 && fr_tile_cols != 128)) return 0;
+    return fr_scratch_bytes(fr_n_tiles, fr_tile_cols);
+}
+
 extern "C" size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k) {
     if (n_rows < 0 || n_tiles <= 0 || top_k <= 0) return 0;
     return score_ws_layout(n_rows, n_tiles, top_k).total;
 }
 
-extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
+extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_ids,
                                      const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
                                      int32_t n_items, int32_t n_cols, int32_t col_offset,
                                      const int32_t *d_col_ids, const int32_t *d_col_map,
@@ -1109,7 +1609,8 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
                                      int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
                                      int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,
                                      uint32_t *d_out_aux, int32_t *d_out_count,
-                                     void *d_workspace, size_t workspace_bytes, void *stream) {
+                                     void *d_workspace, size_t workspace_bytes, void *stream,
+                                     const rtrec_score_opts *opts) {
     if (n_rows < 0 || n_items <= 0 || n_cols <= 0 || top_k <= 0) return RTREC_ERR_INVALID_ARG;
     if (d_row_hdr && (reinterpret_cast<uintptr_t>(d_row_hdr) & 15u)) return RTREC_ERR_INVALID_ARG;
     if (n_rows == 0) return RTREC_OK;
@@ -1136,12 +1637,50 @@ extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
     a.dense_idx = d_dense_idx; a.dense_val = d_dense_val;
     a.row_hdr = reinterpret_cast<const int4 *>(d_row_hdr);
     a.filter = filter_interacted; a.mode = mode;
-    { const char *ab = std::getenv("RTREC_AMD_ABLATE"); a.ablate = ab ? std::atoi(ab) : 0; }
+    a.n_x_rows = (opts && opts->n_x_rows > 0) ? opts->n_x_rows : 0x7fffffff;
+#ifdef RTREC_DIAGNOSTICS
+    a.ablate = opts ? opts->diagnostics : 0;       // tools/score_ablate.sh, diagnostic build only
+#else
+    a.ablate = 0;
+#endif
+    KernelTimer *tmr = opts ? static_cast<KernelTimer *>(opts->timer) : nullptr;
+    FrLayout FR;
+    if (opts && opts->d_fr_map && opts->d_fr_w) {
+        FR.fmap = opts->d_fr_map; FR.wd = opts->d_fr_w; FR.rows = opts->fr_rows; FR.tile_cols = opts->fr_tile_cols;
+        FR.n_tiles = opts->fr_n_tiles; FR.slice_floats = opts->fr_slice_floats;
+        FR.scratch = static_cast<unsigned long long *>(opts->d_fr_scratch); FR.scratch_bytes = opts->fr_scratch_bytes;
+        FR.order = opts->d_row_order;
+        FR.col_ids = opts->d_fr_col_ids; FR.col_map = opts->d_fr_col_map;
+        FR.tile_rows = reinterpret_cast<const unsigned long long *>(opts->d_fr_tile_rows);
+        if (FR.n_tiles != (n_cols + FR.tile_cols - 1) / (FR.tile_cols > 0 ? FR.tile_cols : 1)) return RTREC_ERR_INVALID_ARG;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned char *ws = static_cast<unsigned char *>(d_workspace);
     if (acc_f64)
-        return score_impl<double>(a, top_k, 8, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st);
-    return score_impl<float>(a, top_k, 4, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st);
+        return score_impl<double>(a, top_k, 8, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
+                                  tmr, FR, a.n_x_rows);
+    return score_impl<float>(a, top_k, 4, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
+                             tmr, FR, a.n_x_rows);
+}
+
+extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,
+                                     const int32_t *d_xb_ptr, const int32_t *d_xb_col, const float *d_xb_val,
+                                     int32_t n_items, int32_t n_cols, int32_t col_offset,
+                                     const int32_t *d_col_ids, const int32_t *d_col_map,
+                                     int32_t tile_cols, int32_t n_tiles,
+                                     const int32_t *d_tile_ptr, const uint16_t *d_w_col, const float *d_w_val,
+                                     const int32_t *d_dense_idx, const float *d_dense_val,
+                                     const int32_t *d_row_hdr,
+                                     const int32_t *d_col_rank,
+                                     int32_t top_k, int32_t filter_interacted, int32_t mode, int32_t acc_f64,
+                                     int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64,
+                                     uint32_t *d_out_aux, int32_t *d_out_count,
+                                     void *d_workspace, size_t workspace_bytes, void *stream) {
+    return rtrec_slim_score_topk_opt(n_rows, d_row_ids, d_xb_ptr, d_xb_col, d_xb_val, n_items, n_cols, col_offset,
+                                     d_col_ids, d_col_map, tile_cols, n_tiles, d_tile_ptr, d_w_col, d_w_val,
+                                     d_dense_idx, d_dense_val, d_row_hdr, d_col_rank, top_k, filter_interacted, mode,
+                                     acc_f64, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count,
+                                     d_workspace, workspace_bytes, stream, nullptr);
 }
 
 extern "C" int rtrec_slim_score_rows(int32_t n_rows, const int32_t *d_row_ids,
@@ -1159,6 +1698,7 @@ extern "C" int rtrec_slim_score_rows(int32_t n_rows, const int32_t *d_row_ids,
     a.n_rows = n_rows; a.row_ids = d_row_ids; a.xb_ptr = d_xb_ptr; a.xb_col = d_xb_col; a.xb_val = d_xb_val;
     a.n_items = n_items; a.n_cols = n_cols; a.col_offset = col_offset;
     a.tile_cols = tile_cols; a.n_tiles = n_tiles; a.tile_ptr = d_tile_ptr; a.w_col = d_w_col; a.w_val = d_w_val;
+    a.n_x_rows = 0x7fffffff;
     hipStream_t st = static_cast<hipStream_t>(stream);
     (void)hipGetLastError();
     const long long total = static_cast<long long>(n_rows) * n_tiles;

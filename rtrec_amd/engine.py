@@ -140,6 +140,57 @@ def row_header_table(T: TiledW) -> np.ndarray:
     return hdr
 
 
+FR_MAX_ROWS = 128           # kFrMaxRows of csrc/score.hip
+FR_MIN_FILL = 1.0 / 64.0    # the dense R x n_cols form pays when at least this share of it is stored weights
+
+
+def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: np.ndarray, col_map: np.ndarray
+                       ) -> Optional[Dict[str, Any]]:
+    """"Feature-row" form of columns [col_lo, col_hi) of W for score_frows_kernel (include/rtrec_amd.h,
+    rtrec_score_opts): only items that some column selected with a non-zero weight have a row in W; when
+    those rows are few the shard is the small dense matrix of those rows over the compacted columns, cut
+    into tiles of 256 (<= 66 rows) or 128 columns so that two slices fit LDS.  None when W does not have
+    that shape (many rows, or hardly filled): the tiled-CSR kernel serves it then."""
+    n_items = W_csc.shape[0]
+    indptr = np.asarray(W_csc.indptr, dtype=np.int64)
+    s, e = int(indptr[col_lo]), int(indptr[col_hi])
+    rows = np.asarray(W_csc.indices[s:e], dtype=np.int64)
+    vals = np.asarray(W_csc.data[s:e], dtype=np.float32)
+    cols = np.repeat(np.arange(col_lo, col_hi, dtype=np.int64), np.diff(indptr[col_lo:col_hi + 1]))
+    F = np.unique(rows)
+    R, n_cols = int(len(F)), int(len(col_ids))
+    if R == 0 or R > FR_MAX_ROWS or n_cols == 0 or len(vals) < FR_MIN_FILL * R * n_cols:
+        return None
+    tc = 256 if R <= 66 else 128
+    n_tiles = -(-n_cols // tc)
+    if n_tiles * (tc // 64) > 416:
+        return None
+    slice_floats = -(-(R * tc) // 256) * 256
+    fmap = np.full(n_items, -1, dtype=np.int32)
+    fmap[F] = np.arange(R, dtype=np.int32)
+    # Column order: the kernel skips (row, tile) blocks without a weight, so columns that use the same RARE rows
+    # should share tiles.  Sort the columns lexicographically by their row pattern, rarest row first (ML-20M
+    # shape: 35 % of the blocks a pass visits are non-empty instead of 94 % in item-id order).  Any order gives
+    # the same scores: a skipped block only ever added +-0.
+    f_of, c_of = fmap[rows].astype(np.int64), col_map[cols].astype(np.int64)
+    pattern = np.zeros((R, n_cols), dtype=bool)
+    pattern[f_of, c_of] = True
+    by_rarity = np.argsort(pattern.sum(axis=1), kind="stable")          # rarest row = primary key = last lexsort key
+    # ... descending, so that the columns with the most / rarest rows -- the high scorers -- come FIRST: the
+    # kernel's running top-k then settles within the first tiles (ascending, nearly every column displaces one)
+    order = np.lexsort(tuple(pattern[r] for r in by_rarity[::-1]))[::-1]     # layout position -> compacted column
+    fr_col_ids = np.asarray(col_ids, dtype=np.int32)[order]
+    fr_col_map = np.full(n_items, -1, dtype=np.int32)
+    fr_col_map[fr_col_ids] = np.arange(n_cols, dtype=np.int32)
+    lc = fr_col_map[cols].astype(np.int64)
+    wd = np.zeros(n_tiles * slice_floats, dtype=np.float32)
+    wd[(lc // tc) * slice_floats + f_of * tc + lc % tc] = vals
+    tile_rows = np.zeros((n_tiles, 2), dtype=np.uint64)
+    np.bitwise_or.at(tile_rows, (lc // tc, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
+    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=tile_rows.view(np.int64),
+                fr_rows=R, fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_slice_floats=slice_floats)
+
+
 class HipBackend:
     """Thin marshalling layer over librtrec_amd.so; all arrays are torch CUDA tensors."""
 
@@ -228,14 +279,33 @@ class HipBackend:
     def score_workspace_bytes(self, n_rows, n_tiles, top_k):
         return int(self.lib.rtrec_slim_score_workspace_bytes(n_rows, n_tiles, top_k))
 
+    supports_feature_rows = True
+
     def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
-                   acc_f64, ids, sc, sc64, aux, cnt, ws):
-        row_hdr = None if os.environ.get("RTREC_AMD_NO_ROWHDR") else lay.get("row_hdr")
+                   acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None):
+        fr = lay if (use_fr and lay.get("fr_w") is not None) else {}
         self.ops.score_topk(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo,
                             lay["col_ids"], lay["col_map"], lay["tile_cols"], lay["n_tiles"],
                             lay["tile_ptr"], lay["w_col"], lay["w_val"], lay.get("dense_idx"), lay.get("dense_val"),
-                            row_hdr, col_rank, top_k, bool(filter_interacted), int(mode), bool(acc_f64),
-                            ids, sc, sc64, aux, cnt, ws)
+                            lay.get("row_hdr"), col_rank, top_k, bool(filter_interacted), int(mode), bool(acc_f64),
+                            ids, sc, sc64, aux, cnt, ws,
+                            fr.get("fr_map"), fr.get("fr_col_ids"), fr.get("fr_col_map"), fr.get("fr_w"),
+                            fr.get("fr_tile_rows"), int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)),
+                            int(fr.get("fr_n_tiles", 0)), int(fr.get("fr_slice_floats", 0)), fr.get("fr_scratch"),
+                            row_order if fr else None, int(timer), int(diagnostics))
+
+    def timer_create(self) -> int:
+        h = C.c_void_p()
+        _native.check(self.lib.rtrec_timer_create(C.byref(h)), "rtrec_timer_create")
+        return int(h.value)
+
+    def timer_read(self, handle: int, reset: bool = False) -> Tuple[float, int]:
+        ms, n = C.c_double(0), C.c_int64(0)
+        _native.check(self.lib.rtrec_timer_read(C.c_void_p(handle), C.byref(ms), C.byref(n), int(reset)), "rtrec_timer_read")
+        return float(ms.value), int(n.value)
+
+    def timer_destroy(self, handle: int) -> None:
+        self.lib.rtrec_timer_destroy(C.c_void_p(handle))
 
     def score_rows(self, n_rows, row_ids, xb, n_items, col_lo, lay, acc_f64, out):
         self.ops.score_rows(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo, lay["tile_cols"],
@@ -278,6 +348,10 @@ class SlimEngine:
         self._score_ws = None
         self.gather_chunk_rows = GATHER_CHUNK_ROWS
         self.last_fit_stats: Dict[str, Any] = {}
+        self.score_timer = 0          # rtrec_timer handle (HipBackend.timer_create) bracketing the dominant score kernel
+        self.use_feature_rows = os.environ.get("RTREC_AMD_FEATURE_ROWS", "1") != "0"     # A/B switch of the score kernel
+        # ablation switches of tools/score_ablate.sh: only a diagnostic build of the library looks at them
+        self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0"))
 
     # ------------------------------------------------------------------------------ X
     def set_interactions(self, X_csc: sp.csc_matrix, X_csr: Optional[sp.csr_matrix] = None,
@@ -555,6 +629,16 @@ class SlimEngine:
                                row_hdr=be.to_dev(row_header_table(T)))
                     if compact:
                         W["n_active"] = T.n_cols
+                        if not W["acc_f64"] and getattr(be, "supports_feature_rows", False):
+                            fr = build_feature_rows(W["host"], W["col_lo"], W["col_hi"], T.col_ids, T.col_map)
+                            if fr is not None:
+                                nb = int(be.lib.rtrec_slim_score_fr_scratch_bytes(fr["fr_n_tiles"], fr["fr_tile_cols"]))
+                                lay.update(fr_map=be.to_dev(fr["fr_map"]), fr_w=be.to_dev(fr["fr_w"]),
+                                           fr_col_ids=be.to_dev(fr["fr_col_ids"]), fr_col_map=be.to_dev(fr["fr_col_map"]),
+                                           fr_tile_rows=be.to_dev(fr["fr_tile_rows"]),
+                                           fr_rows=fr["fr_rows"], fr_tile_cols=fr["fr_tile_cols"],
+                                           fr_n_tiles=fr["fr_n_tiles"], fr_slice_floats=fr["fr_slice_floats"],
+                                           fr_scratch=be.empty((nb,), be.torch.uint8))
             W["layouts"][key] = lay
         return W["layouts"][key]
 
@@ -577,9 +661,40 @@ class SlimEngine:
         need = be.score_workspace_bytes(n_rows, lay["n_tiles"], top_k)
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = be.empty((need,), torch.uint8)
-        be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
-                      mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws)
+        if isinstance(be, HipBackend):
+            use_fr = self.use_feature_rows and mode == _native.TOPK_SPARSE and lay.get("fr_w") is not None
+            order = self._row_order(d_row_ids, n_rows, xb) if use_fr else None
+            be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
+                          mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws, timer=self.score_timer,
+                          diagnostics=self.diagnostics, use_fr=use_fr, row_order=order)
+        else:
+            be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
+                          mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws)
         return ids, sc, sc64, aux, cnt
+
+    ROW_ORDER_MIN = 2048        # batches below this are one or two waves of jobs: nothing to level
+
+    def _row_order(self, d_row_ids, n_rows: int, xb):
+        """Work order for the feature-row kernel: the batch's rows by descending length (rtrec_score_opts.d_row_order).
+        A function of X and the row set only, so it is kept with the resident X and reused while the same row-id
+        tensor is scored again (bulk scoring, bench.py); small batches go in the order given."""
+        if n_rows < self.ROW_ORDER_MIN:
+            return None
+        torch = self.be.torch
+        resident = self._X.get("rptr") is xb[0]
+        key = (n_rows, None if d_row_ids is None else (d_row_ids.data_ptr(), d_row_ids._version))
+        if resident and self._X.get("_order_key") == key:
+            return self._X["_order"]
+        ptr = xb[0]
+        if d_row_ids is None:
+            lens = ptr[1:n_rows + 1] - ptr[:n_rows]
+        else:
+            rows = d_row_ids[:n_rows].long().clamp_(0, ptr.shape[0] - 2)
+            lens = ptr[rows + 1] - ptr[rows]
+        order = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
+        if resident:
+            self._X["_order_key"], self._X["_order"] = key, order
+        return order
 
     def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
                           mode: int, col_rank: Optional[np.ndarray] = None, xb=None, d_rows=None):

@@ -76,19 +76,30 @@ def fit_columns(cptr: Tensor, crow: Tensor, cval: Tensor, rptr: Tensor, rcol: Te
         cap, _p(ws), ws.numel(), n_slots, _p(queue), _stream(out_items), C.byref(opts)), "rtrec_slim_fit_columns_opt")
 
 
-@custom_op("rtrec_amd::score_topk", mutates_args=("ids", "scores", "scores64", "aux", "count", "ws"), device_types="cuda")
+@custom_op("rtrec_amd::score_topk", mutates_args=("ids", "scores", "scores64", "aux", "count", "ws", "fr_scratch"),
+           device_types="cuda")
 def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val: Tensor, n_rows: int,
                n_items: int, n_cols: int, col_offset: int, col_ids: Optional[Tensor], col_map: Optional[Tensor],
                tile_cols: int, n_tiles: int, tile_ptr: Tensor, w_col: Tensor, w_val: Tensor,
                dense_idx: Optional[Tensor], dense_val: Optional[Tensor], row_hdr: Optional[Tensor],
                col_rank: Optional[Tensor], top_k: int, filter_interacted: bool, mode: int, acc_f64: bool,
-               ids: Tensor, scores: Tensor, scores64: Optional[Tensor], aux: Tensor, count: Tensor, ws: Tensor) -> None:
+               ids: Tensor, scores: Tensor, scores64: Optional[Tensor], aux: Tensor, count: Tensor, ws: Tensor,
+               fr_map: Optional[Tensor], fr_col_ids: Optional[Tensor], fr_col_map: Optional[Tensor], fr_w: Optional[Tensor],
+               fr_tile_rows: Optional[Tensor], fr_rows: int, fr_tile_cols: int, fr_n_tiles: int,
+               fr_slice_floats: int, fr_scratch: Optional[Tensor], row_order: Optional[Tensor], timer: int,
+               diagnostics: int) -> None:
+    """rtrec_slim_score_topk_opt.  n_x_rows is taken from xb_ptr; fr_* is the optional feature-row form of the
+    shard; `timer` is an rtrec_timer handle (0 = none)."""
     lib = _native.load()
-    _native.check(lib.rtrec_slim_score_topk(
+    opts = _native.ScoreOpts(int(xb_ptr.shape[0]) - 1, _p(fr_map), _p(fr_col_ids), _p(fr_col_map), _p(fr_w),
+                             _p(fr_tile_rows), fr_rows, fr_tile_cols, fr_n_tiles,
+                             fr_slice_floats, _p(fr_scratch), fr_scratch.numel() if fr_scratch is not None else 0,
+                             _p(row_order), C.c_void_p(timer or None), diagnostics)
+    _native.check(lib.rtrec_slim_score_topk_opt(
         n_rows, _p(row_ids), _p(xb_ptr), _p(xb_col), _p(xb_val), n_items, n_cols, col_offset, _p(col_ids), _p(col_map),
         tile_cols, n_tiles, _p(tile_ptr), _p(w_col), _p(w_val), _p(dense_idx), _p(dense_val), _p(row_hdr), _p(col_rank),
         top_k, int(filter_interacted), mode, int(acc_f64), _p(ids), _p(scores), _p(scores64), _p(aux), _p(count),
-        _p(ws), ws.numel(), _stream(ids)), "rtrec_slim_score_topk")
+        _p(ws), ws.numel(), _stream(ids), C.byref(opts)), "rtrec_slim_score_topk_opt")
 
 
 @custom_op("rtrec_amd::score_rows", mutates_args=("out",), device_types="cuda")
