@@ -959,9 +959,13 @@ struct FrArgs {
     const int *col_map;     // [n_items] item -> layout column, or -1
     const int *col_ids;     // [n_cols]  layout column -> item id (ascending)
     int n_cols, R, n_tiles;
-    const float *wd;        // [n_tiles][slice_floats]: tile t, row f, column c at t * slice_floats + f * TC + c
+    const float *wd;        // the tiles' slices, super-tile after super-tile: per tile its rows that hold a weight, ascending
     const unsigned long long *tile_rows;   // [n_tiles][2]: bit f of word h set <=> row 64 h + f holds a weight in the tile
-    int slice_floats;       // R * TC rounded up to a multiple of 256 floats (1 KiB per LDS-DMA wave-instruction)
+    const int *tile_off;    // [n_tiles]: byte offset of the tile's slice inside its super-tile
+    const int *st_kb;       // [n_super + 1]: KiB offset of super-tile s in wd (one LDS-DMA wave-instruction moves 1 KiB)
+    const int *st_tile;     // [n_super + 1]: first tile of super-tile s (at most 32 tiles each)
+    int n_super;
+    int buf_bytes;          // bytes of one LDS buffer (>= the largest super-tile, >= the setup scratch)
     unsigned long long *mscratch;   // [gridDim.x][waves][users][n_tiles * REGS] interacted-column lane masks
     int kk, top_k, filter;
     int *out_id; float *out_score; uint32_t *out_aux; int *out_cnt;
@@ -982,13 +986,9 @@ __host__ __device__ constexpr size_t fr_wave_scratch_words(int n_tiles, int regs
     return static_cast<size_t>(kFrUsers) * kFrUserWords / 2 + static_cast<size_t>(kFrUsers) * n_tiles * regs;
 }
 constexpr int kFrCandCap = 64;               // candidates a wave buffers per merge round (one per lane)
-__host__ __device__ constexpr size_t fr_slices_bytes(int slice_floats) {
-    const size_t sb = static_cast<size_t>(slice_floats) * 4;
-    return sb + (sb > static_cast<size_t>(kFrWaves) * kFrWaveScratch ? sb : static_cast<size_t>(kFrWaves) * kFrWaveScratch);
-}
 __host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
-__host__ __device__ constexpr size_t fr_lds_bytes(int slice_floats) {
-    return fr_slices_bytes(slice_floats) + kFrWaves * fr_wave_extra_bytes() + 16;
+__host__ __device__ constexpr size_t fr_lds_bytes(int buf_bytes) {
+    return 2 * static_cast<size_t>(buf_bytes) + kFrWaves * fr_wave_extra_bytes() + 16;
 }
 
 typedef __attribute__((address_space(3))) void fr_lds_void;
@@ -1026,7 +1026,16 @@ __device__ __forceinline__ float fr_kth_lane_best(float best, int kk) {
     const float ninf = -__builtin_huge_valf();
     const int lane = lane_id();
     float tau = ninf;
-    if (kk <= 16) {          // the kk-th largest of the 16 quad maxima is a bound as well, at a quarter of the steps
+    if (kk > 64) {           // kk - 64: over the 64 lane values themselves
+        kk -= 64;
+        int rank = 0;
+        for (int t = 0; t < 64; ++t) {
+            const float o = readlane_f(best, t);
+            rank += (o > best || (o == best && t < lane)) ? 1 : 0;
+        }
+        const unsigned long long at = __ballot(rank == kk - 1);
+        if (at) tau = readlane_f(best, __builtin_ctzll(at));
+    } else if (kk <= 16) {   // the kk-th largest of the 16 quad maxima is a bound as well, at a quarter of the steps
         float q = best;
         { const float o = shfl_xor_t(q, 1); q = o > q ? o : q; }
         { const float o = shfl_xor_t(q, 2); q = o > q ? o : q; }
@@ -1063,41 +1072,41 @@ __device__ __forceinline__ void fr_static_for(F &&f) {
     fr_static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
 }
 
+typedef const __attribute__((address_space(4))) unsigned long long fr_const_u64;
+
 template <int REGS, int XR>
 __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename FrVec<REGS>::type vec;
     constexpr int TC = 64 * REGS;
+    constexpr int ROWB = TC * 4;                            // bytes of one row of a tile
     constexpr int UW = kFrUsers;
     constexpr int NL = UW / 4;                              // list registers: four users per 64 lanes, 16 lanes each
     const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
-    const int slice_bytes = a.slice_floats * 4;
     const int kk = a.kk;                                    // <= 16
-    float *buf0 = reinterpret_cast<float *>(smem);
-    float *buf1 = reinterpret_cast<float *>(smem + slice_bytes);
-    // the second buffer doubles as the waves' setup scratch, so it is at least kFrWaves * kFrWaveScratch long;
-    // behind it every wave has a candidate buffer
-    unsigned char *extra = smem + fr_slices_bytes(a.slice_floats) + static_cast<size_t>(wave) * fr_wave_extra_bytes();
-    float *cv = reinterpret_cast<float *>(extra);                     // [kFrCandCap] candidate scores
-    int *cp = reinterpret_cast<int *>(cv + kFrCandCap);               // [kFrCandCap] column << 3 | user
-    int *s_job = reinterpret_cast<int *>(smem + fr_lds_bytes(a.slice_floats) - 16);
+    unsigned char *buf0 = smem;
+    unsigned char *buf1 = smem + a.buf_bytes;               // >= kFrWaves * kFrWaveScratch: doubles as setup scratch
+    unsigned char *extra = smem + 2 * static_cast<size_t>(a.buf_bytes) + static_cast<size_t>(wave) * fr_wave_extra_bytes();
+    float *cv = reinterpret_cast<float *>(extra);                     // [kFrCandCap] candidate scores of one user
+    int *cp = reinterpret_cast<int *>(cv + kFrCandCap);               // [kFrCandCap] their layout columns
+    int *s_job = reinterpret_cast<int *>(smem + fr_lds_bytes(a.buf_bytes) - 16);
     const int n_jobs = (a.n_rows + UW * kFrWaves - 1) / (UW * kFrWaves);
-    const int n_chunks = slice_bytes >> 10;                 // 1 KiB LDS-DMA pieces per slice
     const float ninf = -__builtin_huge_valf();
     const int mwords = a.n_tiles * REGS;
-    // per-wave global scratch: per user 192 words (ratings of its rows, compacted: 128; their row indices, four
-    // to a word: 32; pad), then the users' mask words
+    // per-wave global scratch: per user 192 words (its ratings by row of W: 128; pad), then the users' mask words
     const size_t wave_words = fr_wave_scratch_words(a.n_tiles, REGS);
     unsigned long long *sc_wave = a.mscratch + (static_cast<size_t>(blockIdx.x) * kFrWaves + wave) * wave_words;
     uint32_t *xs_wave = reinterpret_cast<uint32_t *>(sc_wave);
     unsigned long long *ms_wave = sc_wave + kFrUsers * kFrUserWords / 2;
+    const uint32_t lane16 = static_cast<uint32_t>(lane) * (REGS * 4);         // byte offset of this lane in a row
 
-    auto load_slice = [&](int t, float *dst) {
-        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.wd + static_cast<size_t>(t) * a.slice_floats);
-        for (int c = wave; c < n_chunks; c += kFrWaves)
+    // super-tile s = tiles [st_tile[s], st_tile[s + 1]): their rows that hold a weight, tile after tile, st_kb[s + 1] - st_kb[s] KiB
+    auto load_super = [&](int sidx, unsigned char *dst) {
+        const int kb0 = a.st_kb[sidx], kb1 = a.st_kb[sidx + 1];
+        const unsigned char *src = reinterpret_cast<const unsigned char *>(a.wd) + (static_cast<size_t>(kb0) << 10);
+        for (int c = wave; c < kb1 - kb0; c += kFrWaves)
             __builtin_amdgcn_global_load_lds((fr_glb_void *)(src + (static_cast<size_t>(c) << 10) + lane * 16),
-                                             (fr_lds_void *)(reinterpret_cast<unsigned char *>(dst) + (c << 10)),
-                                             16, 0, 0);
+                                             (fr_lds_void *)(dst + (c << 10)), 16, 0, 0);
     };
 
     PF_DECL
@@ -1105,24 +1114,23 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
     const unsigned long long pf_start_ = pf_t_;
 #endif
     for (;;) {
-        __syncthreads();                                    // the previous job has left both slice buffers
+        __syncthreads();                                    // the previous job has left both buffers
         PF_MARK(PF_QUEUE)
         if (tid == 0) *s_job = atomicAdd(a.queue, 1);
         __syncthreads();
         const int job = *s_job;
         if (job >= n_jobs) break;
-        load_slice(0, buf0);
+        load_super(0, buf0);
         // Row positions of this wave: position p of the job's 128 goes to wave p % 16, so that with rows handed
         // over longest-first (a.order) every wave of the workgroup gets the same mix of long and short rows and
-        // the per-tile barriers find the waves level.
+        // the barriers find the waves level.
         const int base = job * kFrWaves * UW + wave;
 
         // ---- setup: per user its ratings of the R feature items (dense, lane = row of W) and the interacted-column
-        //      masks, built in LDS (the second slice buffer is free until tile 0 starts) and parked in the wave's
+        //      masks, built in LDS (the second buffer is free until super-tile 0 starts) and parked in the wave's
         //      global scratch; the ratings come back into registers below ----
-        unsigned long long *Ml = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(buf1) + wave * kFrWaveScratch);
-        unsigned char *rowsb = reinterpret_cast<unsigned char *>(Ml + kFrMaskWords);      // [128] row index of entry j
-        float *xl = reinterpret_cast<float *>(rowsb + 256);                                // [128] floats
+        unsigned long long *Ml = reinterpret_cast<unsigned long long *>(buf1 + wave * kFrWaveScratch);
+        float *xl = reinterpret_cast<float *>(Ml + kFrMaskWords) + 64;                     // [128] floats
         for (int u = 0; u < UW; ++u) {
             const int p = base + u * kFrWaves;
             int a0 = 0, n_a = 0;
@@ -1156,6 +1164,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             for (int w = lane; w < mwords; w += 64) ms_wave[static_cast<size_t>(u) * mwords + w] = Ml[w];
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_dcache_inv();                   // the masks are read back through the scalar cache
         float xr[UW][XR];          // lane f: the user's rating of the item of row 64 * h + f of W (0: not owned)
         fr_static_for<UW>([&](auto Uc) {
             constexpr int u = decltype(Uc)::value;
@@ -1168,160 +1177,166 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         // lane offset j = rank j (a DPP row is 16 lanes, so a list shifts with row_shr:1)
         float ls4[NL];
         int lc4[NL];
-        fr_static_for<NL>([&](auto G) { ls4[G()] = ninf; lc4[G()] = -1; });
+        fr_static_for<NL>([&](auto G4) { ls4[G4()] = ninf; lc4[G4()] = -1; });
+        uint32_t spilled = 0u;     // bit u: user u's candidates overflowed the buffer -> its row goes to the exact-tie pass
 
         PF_MARK(PF_HDR) PF_ADD(PF_JOBS, 1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice 0 has landed, the masks are in L2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // super-tile 0 has landed
         __syncthreads();
         PF_MARK(PF_GROUP)
 
-        const uint32_t lane16 = static_cast<uint32_t>(lane) * (REGS * 4);                  // byte offset of this lane in a row
-        for (int t = 0; t < a.n_tiles; ++t) {
-            const unsigned char *wb = reinterpret_cast<const unsigned char *>((t & 1) ? buf1 : buf0);
-            if (t + 1 < a.n_tiles) load_slice(t + 1, (t & 1) ? buf0 : buf1);
-            // interacted masks of this tile: lane j holds the word of (user j / REGS, register j % REGS)
-            unsigned long long mword = 0ull;
-            if (a.filter && lane < UW * REGS)
-                mword = __hip_atomic_load(&ms_wave[static_cast<size_t>(lane / REGS) * mwords + t * REGS + (lane % REGS)],
-                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t mw_lo = static_cast<uint32_t>(mword), mw_hi = static_cast<uint32_t>(mword >> 32);
-            unsigned long long nz[XR];        // rows of W that hold a weight in this tile
-            fr_static_for<XR>([&](auto H) { nz[H()] = a.tile_rows[t * 2 + H()]; });
-            vec acc[UW];
+        for (int sidx = 0; sidx < a.n_super; ++sidx) {
+            const unsigned char *wb = (sidx & 1) ? buf1 : buf0;
+            if (sidx + 1 < a.n_super) load_super(sidx + 1, (sidx & 1) ? buf0 : buf1);
+            const int t_lo = a.st_tile[sidx], t_hi = a.st_tile[sidx + 1];
+            // the tiles' row masks and slice offsets, lane tt = tile t_lo + tt: one load per super-tile, read back
+            // with v_readlane below (no memory latency inside the user loops)
+            unsigned long long nzv[2] = {0ull, 0ull};
+            int toffv = 0;
+            if (lane < t_hi - t_lo) {
+                nzv[0] = a.tile_rows[(t_lo + lane) * 2];
+                nzv[1] = a.tile_rows[(t_lo + lane) * 2 + 1];
+                toffv = a.tile_off[t_lo + lane];
+            }
 
-            // ---- every user's rows of W, ascending: acc += x * w, one rounded product and one rounded add per
-            //      column (two v_pk_mul_f32 + two v_pk_add_f32 per 256 columns), four rows per step: their LDS
-            //      reads go out together, the applies follow.  Interacted columns start at -inf, which absorbs
-            //      every later addend, so they never show up as candidates. ----
             fr_static_for<UW>([&](auto Uc) {
                 constexpr int u = decltype(Uc)::value;
-                fr_static_for<REGS>([&](auto Rc) {
-                    constexpr int r = decltype(Rc)::value;
-                    const unsigned int lo = readlane_u(mw_lo, u * REGS + r), hi = readlane_u(mw_hi, u * REGS + r);
-                    const unsigned long long ex = (static_cast<unsigned long long>(hi) << 32) | lo;
-                    float init;
-                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(init) : "v"(0.0f), "v"(ninf), "s"(ex));
-                    acc[u][r] = init;
-                });
-                fr_static_for<XR>([&](auto H) {
-                    constexpr int h = decltype(H)::value;
-                    // rows this user owns AND that hold a weight in this tile (the columns are ordered so that
-                    // most (row, tile) blocks are empty: skipping them skips additions of +-0 only)
-                    unsigned long long own = __ballot(xr[u][h] != 0.0f) & nz[h];
-                    const unsigned char *wh = wb + h * 64 * (TC * 4) + lane16;
-                    while (own) {
-                        int f[4];
-                        bool live[4];
-                        vec w[4];
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            live[q] = own != 0ull;
-                            f[q] = live[q] ? __builtin_ctzll(own) : f[0];
-                            own &= own - 1;        // 0 stays 0
-                            w[q] = *reinterpret_cast<const vec *>(wh + f[q] * (TC * 4));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float x = readlane_f(xr[u][h], f[q]);
-                            const float xs = live[q] ? x : 0.0f;       // a group that runs past the last row repeats one with x = 0
-                            acc[u] = acc[u] + w[q] * xs;
-                        }
-                        PF_ADD(PF_N_DENSE, 4)
-                    }
-                });
-            });
-            PF_MARK(PF_DENSE)
+                constexpr int g = u >> 2, lb = (u & 3) * 16;
+                fr_const_u64 *mc = (fr_const_u64 *)(ms_wave + static_cast<size_t>(u) * mwords);
+                float thr = readlane_f(ls4[g], lb + kk - 1);      // the user's current kk-th best score
+                int nc = 0;
 
-            // ---- candidates: columns that beat the user's current kk-th score go to the wave's LDS buffer
-            //      (column << 3 | user); the buffer is then merged into the users' lists by one copy of the
-            //      insertion code per list register.  `resume` restarts the scan where a full buffer stopped it. ----
-            int resume = 0;
-            for (;;) {
-                int nc = 0, stop = UW * REGS;
-                fr_static_for<UW>([&](auto Uc) {
-                    constexpr int u = decltype(Uc)::value;
-                    if ((u + 1) * REGS <= resume || stop != UW * REGS) return;
-                    float thr = readlane_f(ls4[u >> 2], (u & 3) * 16 + kk - 1);
-                    float best = acc[u][0];
-                    fr_static_for<REGS>([&](auto Rc) { best = acc[u][Rc()] > best ? acc[u][Rc()] : best; });
+                // merge the user's buffered candidates into its list (lane lb + j = rank j)
+                auto merge = [&]() {
+                    const float myv = lane < nc ? cv[lane] : ninf;
+                    const int mycol = lane < nc ? cp[lane] : 0;
+                    const int rel = lane - lb;
+                    const bool in = rel >= 0 && rel < kk;
+                    for (int i = 0; i < nc; ++i) {
+                        const float v = readlane_f(myv, i);
+                        const int col = readlane_i(mycol, i);
+                        const float s = ls4[g];
+                        const int c = lc4[g];
+                        PF_ADD(PF_N_SPARSE_CHUNKS, 1)
+                        if (!(v > readlane_f(s, lb + kk - 1))) continue;            // the threshold has risen meanwhile
+                        // ties inside the fast pass order by higher column; exact ties are re-scored anyway
+                        const bool better = in && ((s > v) || (s == v && c > col));
+                        const int pos = static_cast<int>(__builtin_popcountll(__ballot(better)));
+                        PF_ADD(PF_N_SPARSE_ROWS, 1)
+                        const float s_up = fr_row_shift_up(s, ninf);
+                        const int c_up = fr_row_shift_up(c, -1);
+                        ls4[g] = !in || rel < pos ? s : (rel == pos ? v : s_up);
+                        lc4[g] = !in || rel < pos ? c : (rel == pos ? col : c_up);
+                    }
+                    nc = 0;
+                    thr = readlane_f(ls4[g], lb + kk - 1);
+                };
+
+                for (int t = t_lo; t < t_hi; ++t) {
+                    // ---- the user's rows of W that hold a weight in this tile, ascending: acc += x * w, one rounded
+                    //      product and one rounded add per column (two v_pk_mul_f32 + two v_pk_add_f32 per 256
+                    //      columns), four rows per step: their LDS reads go out together, the applies follow; a
+                    //      step that runs past the last row repeats one with x = 0 (x * w = +-0 changes no sum).
+                    //      Blocks of W without a weight are skipped: they would only add +-0 as well. ----
+                    vec acc = vec(0.0f);
+                    const int toff = readlane_i(toffv, t - t_lo);
+                    int below = 0;                               // rows of this tile's slice before half h
+                    fr_static_for<XR>([&](auto H) {
+                        constexpr int h = decltype(H)::value;
+                        const unsigned long long nz =
+                            (static_cast<unsigned long long>(readlane_u(static_cast<uint32_t>(nzv[h] >> 32), t - t_lo)) << 32) |
+                            readlane_u(static_cast<uint32_t>(nzv[h]), t - t_lo);
+                        unsigned long long own = __ballot(xr[u][h] != 0.0f) & nz;
+                        // lane f: byte offset of row 64 h + f in the buffer (rows without a weight are not stored)
+                        const int offv = toff + (below + lane_prefix(nz)) * ROWB;
+                        below += static_cast<int>(__builtin_popcountll(nz));
+                        while (own) {
+                            int f[4];
+                            bool live[4];
+                            vec w[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                live[q] = own != 0ull;
+                                f[q] = live[q] ? __builtin_ctzll(own) : f[0];
+                                own &= own - 1;        // 0 stays 0
+                                w[q] = *reinterpret_cast<const vec *>(wb + readlane_i(offv, f[q]) + lane16);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float x = readlane_f(xr[u][h], f[q]);
+                                const float xs = live[q] ? x : 0.0f;
+                                acc = acc + w[q] * xs;
+                            }
+                            PF_ADD(PF_N_DENSE, 4)
+                        }
+                    });
+
+                    // ---- candidates: columns that beat the user's kk-th score and are not interacted ----
+                    float best = acc[0];
+                    fr_static_for<REGS>([&](auto Rc) { best = acc[Rc()] > best ? acc[Rc()] : best; });
+                    float tcut = thr;
                     if (thr >= 0.0f) {
-                        if (!__ballot(best > thr)) return;      // the common case after the first tiles: nothing enters
+                        if (!__ballot(best > thr)) continue;      // the common case after the first tiles: nothing enters
                     } else if (thr == ninf) {
                         // The list is not full yet (first tile, or a user with few scored columns): everything
-                        // non-zero would pass.  Take the tile's own kk-th best candidate (a bound from the lane
-                        // maxima of the admissible columns) as the threshold instead.
+                        // non-zero would pass.  Take the tile's own kk-th best admissible score (a bound from the
+                        // lane maxima) as the cut instead.
                         PF_ADD(PF_N_OVERFLOW, 1)
                         float bm = ninf;
                         fr_static_for<REGS>([&](auto Rc) {
-                            const float v = acc[u][Rc()];
-                            const float vm = (v != 0.0f) ? v : ninf;
+                            constexpr int r = decltype(Rc)::value;
+                            const unsigned long long ex = a.filter ? mc[t * REGS + r] : 0ull;
+                            const float v = acc[r];
+                            const float vm = (v != 0.0f && !((ex >> lane) & 1ull)) ? v : ninf;
                             bm = vm > bm ? vm : bm;
                         });
-                        const float t0 = fr_kth_lane_best(bm, kk);
-                        if (t0 != ninf) thr = float_prev(t0);       // candidates are the values >= t0
+                        // kk-th largest of the 64 lane maxima (the 16 quad maxima would do as a bound, but a loose one:
+                        // half the tile can lie above it); -inf: fewer than kk lanes hold a score, and everything
+                        // they hold (< kk * REGS <= kFrCandCap) fits the buffer
+                        const float t0 = fr_kth_lane_best(bm, 64 + kk);
+                        if (t0 != ninf) tcut = float_prev(t0);      // candidates are the values >= t0
                     }
                     fr_static_for<REGS>([&](auto Rc) {
                         constexpr int r = decltype(Rc)::value;
-                        if (u * REGS + r < resume || stop != UW * REGS) return;
-                        const float v = acc[u][r];
-                        // only non-zero sums compete (scipy keeps `!= 0`); -inf marks an interacted column
-                        const unsigned long long m = __ballot(v > thr && v != 0.0f);
+                        const float v = acc[r];
+                        // only non-zero sums compete (scipy keeps `!= 0`)
+                        unsigned long long m = __ballot(v > tcut && v != 0.0f);
+                        if (!m) return;
+                        if (a.filter) m &= ~mc[t * REGS + r];
                         if (!m) return;
                         const int cnt = static_cast<int>(__builtin_popcountll(m));
-                        if (nc + cnt > kFrCandCap) { stop = u * REGS + r; return; }
+                        if (nc + cnt > kFrCandCap) { spilled |= 1u << u; return; }
                         if ((m >> lane) & 1ull) {
                             const int pos = nc + lane_prefix(m);
                             cv[pos] = v;
-                            cp[pos] = ((t * TC + lane * REGS + r) << 3) | u;
+                            cp[pos] = t * TC + lane * REGS + r;
                         }
                         nc += cnt;
                     });
-                });
-                if (nc > 0) {
-                    // merge the buffer into the lists; the whole buffer is read back in one LDS round trip
-                    const float myv = lane < nc ? cv[lane] : ninf;
-                    const int mypk = lane < nc ? cp[lane] : 0;
-                    for (int i = 0; i < nc; ++i) {
-                        const float v = readlane_f(myv, i);
-                        const int pk = readlane_i(mypk, i);
-                        const int u = pk & 7, col = pk >> 3;
-                        const int lb = (u & 3) * 16;
-                        const bool in = lane >= lb && lane < lb + kk;
-                        PF_ADD(PF_N_SPARSE_CHUNKS, 1)
-                        fr_static_for<NL>([&](auto G) {
-                            constexpr int g = decltype(G)::value;
-                            if ((u >> 2) != g) return;
-                            const float s = ls4[g];
-                            const int c = lc4[g];
-                            if (!(v > readlane_f(s, lb + kk - 1))) return;          // the threshold has risen meanwhile
-                            // ties inside the fast pass order by higher column; exact ties are re-scored anyway
-                            const bool better = in && ((s > v) || (s == v && c > col));
-                            const int pos = static_cast<int>(__builtin_popcountll(__ballot(better)));
-                            PF_ADD(PF_N_SPARSE_ROWS, 1)
-                            const float s_up = fr_row_shift_up(s, ninf);
-                            const int c_up = fr_row_shift_up(c, -1);
-                            const int rel = lane - lb;
-                            ls4[g] = !in || rel < pos ? s : (rel == pos ? v : s_up);
-                            lc4[g] = !in || rel < pos ? c : (rel == pos ? col : c_up);
-                        });
-                    }
+                    // while the list is filling up merge after every tile (the cut of the next tile needs it),
+                    // later only when the buffer runs full or the user's tiles of this super-tile are done
+                    if (nc > 0 && (thr == ninf || nc > kFrCandCap / 2)) merge();
                 }
-                if (stop == UW * REGS) break;
-                resume = stop;
-            }
-            PF_MARK(PF_SELECT)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slice t+1 has landed ...
-            __syncthreads();                                    // ... and every wave has left slice t
+                if (nc > 0) merge();
+            });
+            PF_MARK(PF_DENSE)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // super-tile s+1 has landed ...
+            __syncthreads();                                    // ... and every wave has left super-tile s
             PF_MARK(PF_GROUP)
         }
 
-        // ---- the lists are the rows' answers ----
+        // ---- the lists are the rows' answers: lane lb + j of list register g = rank j of user 4 g + lb / 16 ----
+        int gid[NL], orow = 0;
+        fr_static_for<NL>([&](auto G4) { gid[G4()] = lc4[G4()] >= 0 ? a.col_ids[lc4[G4()]] : -1; });    // all gathers in flight together
+        if (lane < UW) {
+            const int p = base + lane * kFrWaves;
+            orow = p < a.n_rows ? (a.order ? a.order[p] : p) : -1;
+        }
         fr_static_for<UW>([&](auto Uc) {
             constexpr int u = decltype(Uc)::value;
-            const int p = base + u * kFrWaves;
-            if (p >= a.n_rows) return;
-            const int r = a.order ? a.order[p] : p;
+            const int r = readlane_i(orow, u);
+            if (r < 0) return;
             constexpr int lb = (u & 3) * 16;
             const int rel = lane - lb;
             const bool in = rel >= 0 && rel < kk;
@@ -1332,7 +1347,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             if (rel >= 0 && rel < a.top_k) {
                 const long long o = static_cast<long long>(r) * a.top_k + rel;
                 const bool ok = rel < n_fin;
-                a.out_id[o] = ok ? a.col_ids[c] : -1;
+                a.out_id[o] = ok ? gid[u >> 2] : -1;
                 a.out_score[o] = ok ? s : ninf;
                 if (a.out_aux) a.out_aux[o] = 0u;
             }
@@ -1340,7 +1355,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             const unsigned long long tie = __ballot(rel >= 0 && rel + 1 < n_valid && s == nxt);
             if (lane == lb) {
                 a.out_cnt[r] = n_fin;
-                if (tie) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+                if (tie || ((spilled >> u) & 1u)) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
             }
         });
         PF_MARK(PF_EMIT)
@@ -1426,7 +1441,8 @@ unsigned persistent_grid(size_t lds_bytes, long long jobs) {
 struct FrLayout {
     const int *fmap = nullptr; const float *wd = nullptr; const int *order = nullptr;
     const int *col_ids = nullptr; const int *col_map = nullptr; const unsigned long long *tile_rows = nullptr;
-    int rows = 0, tile_cols = 0, n_tiles = 0, slice_floats = 0;
+    int rows = 0, tile_cols = 0, n_tiles = 0, n_super = 0, buf_bytes = 0;
+    const int *tile_off = nullptr; const int *st_kb = nullptr; const int *st_tile = nullptr;
     unsigned long long *scratch = nullptr; size_t scratch_bytes = 0;
 };
 size_t fr_scratch_bytes(int n_tiles, int tile_cols) {
@@ -1434,12 +1450,12 @@ size_t fr_scratch_bytes(int n_tiles, int tile_cols) {
     return static_cast<size_t>(256) * kFrWaves * fr_wave_scratch_words(n_tiles, regs) * sizeof(unsigned long long);
 }
 bool fr_usable(const FrLayout &F, int kk) {
-    if (!F.fmap || !F.wd || !F.scratch || !F.col_ids || !F.col_map || !F.tile_rows) return false;
+    if (!F.fmap || !F.wd || !F.scratch || !F.col_ids || !F.col_map || !F.tile_rows || !F.tile_off || !F.st_kb || !F.st_tile) return false;
     if (F.tile_cols != 256 && F.tile_cols != 128) return false;
     const int regs = F.tile_cols / 64;
     if (F.rows <= 0 || F.rows > kFrMaxRows || F.n_tiles <= 0 || F.n_tiles * regs > kFrMaskWords) return false;
-    if (F.slice_floats < F.rows * F.tile_cols || (F.slice_floats % 256) != 0) return false;
-    if (fr_lds_bytes(F.slice_floats) > 160u * 1024u) return false;
+    if (F.n_super <= 0 || F.n_super > F.n_tiles) return false;
+    if (F.buf_bytes < kFrWaves * kFrWaveScratch || (F.buf_bytes & 1023) || fr_lds_bytes(F.buf_bytes) > 160u * 1024u) return false;
     if (F.scratch_bytes < fr_scratch_bytes(F.n_tiles, F.tile_cols)) return false;
     return kk >= 1 && kk <= kFrMaxKk;
 }
@@ -1481,14 +1497,15 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.n_rows = a.n_rows; f.row_ids = a.row_ids; f.n_x_rows = n_x_rows; f.order = FR.order;
         f.xb_ptr = a.xb_ptr; f.xb_col = a.xb_col; f.xb_val = a.xb_val; f.n_items = a.n_items;
         f.fmap = FR.fmap; f.col_map = FR.col_map; f.col_ids = FR.col_ids; f.tile_rows = FR.tile_rows;
-        f.n_cols = a.n_cols; f.R = FR.rows; f.n_tiles = FR.n_tiles; f.wd = FR.wd; f.slice_floats = FR.slice_floats;
+        f.n_cols = a.n_cols; f.R = FR.rows; f.n_tiles = FR.n_tiles; f.wd = FR.wd;
+        f.tile_off = FR.tile_off; f.st_kb = FR.st_kb; f.st_tile = FR.st_tile; f.n_super = FR.n_super; f.buf_bytes = FR.buf_bytes;
         f.mscratch = FR.scratch;
         f.kk = a.kk; f.top_k = top_k; f.filter = a.filter;
         f.out_id = d_out_ids; f.out_score = d_out_scores; f.out_aux = d_out_aux; f.out_cnt = d_out_count;
         f.flag_list = flag_list; f.flag_len = flag_len; f.queue = queue;
         const int n_jobs = (a.n_rows + kFrUsers * kFrWaves - 1) / (kFrUsers * kFrWaves);
         const unsigned grid = static_cast<unsigned>(n_jobs < 256 ? n_jobs : 256);
-        const size_t lds = fr_lds_bytes(FR.slice_floats);
+        const size_t lds = fr_lds_bytes(FR.buf_bytes);
         const bool two = FR.rows > 64;
         if (FR.tile_cols == 256) {
             if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 2>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
@@ -1647,7 +1664,9 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
     FrLayout FR;
     if (opts && opts->d_fr_map && opts->d_fr_w) {
         FR.fmap = opts->d_fr_map; FR.wd = opts->d_fr_w; FR.rows = opts->fr_rows; FR.tile_cols = opts->fr_tile_cols;
-        FR.n_tiles = opts->fr_n_tiles; FR.slice_floats = opts->fr_slice_floats;
+        FR.n_tiles = opts->fr_n_tiles; FR.n_super = opts->fr_n_super;
+        FR.buf_bytes = opts->fr_buf_bytes; FR.tile_off = opts->d_fr_tile_off; FR.st_kb = opts->d_fr_super_kb;
+        FR.st_tile = opts->d_fr_super_tile;
         FR.scratch = static_cast<unsigned long long *>(opts->d_fr_scratch); FR.scratch_bytes = opts->fr_scratch_bytes;
         FR.order = opts->d_row_order;
         FR.col_ids = opts->d_fr_col_ids; FR.col_map = opts->d_fr_col_map;

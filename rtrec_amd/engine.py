@@ -165,7 +165,6 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     n_tiles = -(-n_cols // tc)
     if n_tiles * (tc // 64) > 416:
         return None
-    slice_floats = -(-(R * tc) // 256) * 256
     fmap = np.full(n_items, -1, dtype=np.int32)
     fmap[F] = np.arange(R, dtype=np.int32)
     # Column order: the kernel skips (row, tile) blocks without a weight, so columns that use the same RARE rows
@@ -183,12 +182,44 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     fr_col_map = np.full(n_items, -1, dtype=np.int32)
     fr_col_map[fr_col_ids] = np.arange(n_cols, dtype=np.int32)
     lc = fr_col_map[cols].astype(np.int64)
-    wd = np.zeros(n_tiles * slice_floats, dtype=np.float32)
-    wd[(lc // tc) * slice_floats + f_of * tc + lc % tc] = vals
+    t_of = lc // tc
+    present = np.zeros((n_tiles, R), dtype=bool)            # (tile, row) blocks that hold a weight
+    present[t_of, f_of] = True
+    n_rows_t = present.sum(axis=1)
+    local = np.cumsum(present, axis=1) - 1                  # row -> index inside the tile's compact slice
+    # super-tiles: consecutive tiles staged in LDS as one piece (one barrier per super-tile), packed greedily into
+    # one buffer; at most 32 tiles each
+    buf_cap = (160 * 1024 - 16 * 512 - 16) // 2 // 1024 * 1024
+    row_bytes = tc * 4
+    if int(n_rows_t.max()) * row_bytes > buf_cap:
+        return None
+    st_tile = [0]
+    used = 0
+    for t in range(n_tiles):
+        need = int(n_rows_t[t]) * row_bytes
+        if t > st_tile[-1] and (used + need > buf_cap or t - st_tile[-1] >= 32):
+            st_tile.append(t)
+            used = 0
+        used += need
+    st_tile.append(n_tiles)
+    st_tile = np.asarray(st_tile, dtype=np.int64)
+    n_super = len(st_tile) - 1
+    super_of = np.repeat(np.arange(n_super), np.diff(st_tile))
+    super_rows = np.add.reduceat(n_rows_t, st_tile[:-1])
+    super_kb = np.zeros(n_super + 1, dtype=np.int64)
+    super_kb[1:] = np.cumsum(-(-(super_rows * row_bytes) // 1024))
+    first = np.cumsum(n_rows_t) - n_rows_t                  # rows stored before tile t ...
+    first = first - first[st_tile[:-1]][super_of]           # ... inside its super-tile
+    tile_off = (first * row_bytes).astype(np.int32)
+    wd = np.zeros(max(int(super_kb[-1]) * 256, 256), dtype=np.float32)
+    base = super_kb[super_of[t_of]] * 256 + first[t_of] * tc
+    wd[base + local[t_of, f_of] * tc + lc % tc] = vals
     tile_rows = np.zeros((n_tiles, 2), dtype=np.uint64)
-    np.bitwise_or.at(tile_rows, (lc // tc, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
+    np.bitwise_or.at(tile_rows, (t_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
+    buf_bytes = max(64 * 1024, int(-(-(int(super_rows.max()) * row_bytes) // 1024) * 1024))
     return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=tile_rows.view(np.int64),
-                fr_rows=R, fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_slice_floats=slice_floats)
+                fr_tile_off=tile_off, fr_super_kb=super_kb.astype(np.int32), fr_super_tile=st_tile.astype(np.int32), fr_rows=R,
+                fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_super=n_super, fr_buf_bytes=buf_bytes)
 
 
 class HipBackend:
@@ -290,8 +321,10 @@ class HipBackend:
                             lay.get("row_hdr"), col_rank, top_k, bool(filter_interacted), int(mode), bool(acc_f64),
                             ids, sc, sc64, aux, cnt, ws,
                             fr.get("fr_map"), fr.get("fr_col_ids"), fr.get("fr_col_map"), fr.get("fr_w"),
-                            fr.get("fr_tile_rows"), int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)),
-                            int(fr.get("fr_n_tiles", 0)), int(fr.get("fr_slice_floats", 0)), fr.get("fr_scratch"),
+                            fr.get("fr_tile_rows"), fr.get("fr_tile_off"), fr.get("fr_super_kb"), fr.get("fr_super_tile"),
+                            int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)), int(fr.get("fr_n_tiles", 0)),
+                            int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
+                            fr.get("fr_scratch"),
                             row_order if fr else None, int(timer), int(diagnostics))
 
     def timer_create(self) -> int:
@@ -636,8 +669,11 @@ class SlimEngine:
                                 lay.update(fr_map=be.to_dev(fr["fr_map"]), fr_w=be.to_dev(fr["fr_w"]),
                                            fr_col_ids=be.to_dev(fr["fr_col_ids"]), fr_col_map=be.to_dev(fr["fr_col_map"]),
                                            fr_tile_rows=be.to_dev(fr["fr_tile_rows"]),
+                                           fr_tile_off=be.to_dev(fr["fr_tile_off"]), fr_super_kb=be.to_dev(fr["fr_super_kb"]),
+                                           fr_super_tile=be.to_dev(fr["fr_super_tile"]),
                                            fr_rows=fr["fr_rows"], fr_tile_cols=fr["fr_tile_cols"],
-                                           fr_n_tiles=fr["fr_n_tiles"], fr_slice_floats=fr["fr_slice_floats"],
+                                           fr_n_tiles=fr["fr_n_tiles"], fr_n_super=fr["fr_n_super"],
+                                           fr_buf_bytes=fr["fr_buf_bytes"],
                                            fr_scratch=be.empty((nb,), be.torch.uint8))
             W["layouts"][key] = lay
         return W["layouts"][key]
