@@ -92,12 +92,16 @@ def make_model(oracle, U=1500, I=700, draws=40000, K=20, seed=3):
     return X, W
 
 
+@pytest.mark.parametrize("feature_rows", [True, False])     # False: the tiled-CSR kernel also where the feature-row one applies
 @pytest.mark.parametrize("tile_cols", [256, 8192])
 @pytest.mark.parametrize("mode,filt", [("sparse", True), ("sparse", False), ("dense", True), ("dense", False)])
 @pytest.mark.parametrize("f64", [False, True])
-def test_score_topk_bit_exact(oracle, mode, filt, f64, tile_cols):
+def test_score_topk_bit_exact(oracle, mode, filt, f64, tile_cols, feature_rows):
+    if not feature_rows and (mode == "dense" or f64):
+        pytest.skip("the feature-row kernel serves SPARSE mode with float32 accumulation only")
     X, W = make_model(oracle)
     eng = SlimEngine(device="cuda:0", tile_cols=tile_cols)
+    eng.use_feature_rows = feature_rows
     eng.set_interactions(None, X, need_csc=False)
     eng.set_weights(W.astype(np.float64) if f64 else W, acc_f64=f64)
     rows = np.arange(0, X.shape[0], 3)
@@ -120,8 +124,9 @@ def test_score_exact_ties_follow_reference_order(oracle):
     W = sp.csc_matrix(base[:, pick])          # every column is a copy of one of 40 -> many exact ties
     W.sort_indices()
     X = interaction_matrix(300, I, 6000, seed=9)
-    for tile in (256, 1024):
+    for tile, feature_rows in ((256, True), (1024, True), (256, False), (1024, False)):
         eng = SlimEngine(device="cuda:0", tile_cols=tile)
+        eng.use_feature_rows = feature_rows
         eng.set_interactions(None, X, need_csc=False)
         eng.set_weights(W)
         rows = np.arange(X.shape[0])
@@ -393,3 +398,60 @@ def test_fit_every_item_output_overflow_is_refitted(engine, oracle, monkeypatch)
         c = count[t]
         assert np.array_equal(items[t, :c], idx[ptr[t]:ptr[t + 1]])
         assert np.array_equal(bits(coef[t, :c]), bits(val[ptr[t]:ptr[t + 1]]))
+
+
+@pytest.mark.parametrize("R,n_cols,per_col", [(5, 40, 3), (64, 700, 12), (66, 3000, 20), (100, 900, 25), (128, 2600, 30),
+                                               (30, 9000, 6)])
+@pytest.mark.parametrize("integer_ratings", [False, True])
+def test_feature_row_kernel_shapes(oracle, R, n_cols, per_col, integer_ratings):
+    """score_frows_kernel over the shapes it specialises on: <= 64 / 65-66 / <= 128 rows of W (one or two
+    rating registers, 256- or 128-column tiles), one tile to dozens (several super-tiles), negative ratings,
+    integer ratings (exact score ties -> the exact-tie pass), users without any feature item, empty users,
+    row subsets in any order, top_k 1 .. 15, with and without the interacted filter -- against the oracle,
+    and against the tiled-CSR kernel."""
+    rng = np.random.default_rng(R * 1000 + n_cols)
+    I, U = max(n_cols + 200, 400), 700
+    feat = np.sort(rng.choice(I, R, replace=False))
+    cols = np.sort(rng.choice(I, n_cols, replace=False))
+    pop = 1.0 / np.arange(1, R + 1) ** 0.9
+    rr, cc = [], []
+    for c in cols:
+        k = min(R, max(1, int(rng.integers(1, per_col + 1))))
+        rr.append(rng.choice(feat, k, replace=False, p=pop / pop.sum()))
+        cc.append(np.full(k, c))
+    rr, cc = np.concatenate(rr), np.concatenate(cc)
+    vals = (rng.random(len(rr)).astype(np.float32) + 0.05) * np.where(rng.random(len(rr)) < 0.1, -1, 1).astype(np.float32)
+    if integer_ratings:
+        vals = np.round(vals * 4).astype(np.float32)
+        vals[vals == 0] = 1.0
+    W = sp.csc_matrix((vals, (rr, cc)), shape=(I, I), dtype=np.float32)
+    W.sum_duplicates(); W.eliminate_zeros(); W.sort_indices()
+    n_items = rng.integers(0, 60, U)
+    n_items[:20] = 0                                             # users without interactions
+    ur = np.repeat(np.arange(U), n_items)
+    # half of every user's items are feature items, the rest anything (incl. scored columns -> the filter matters)
+    ui = np.where(rng.random(len(ur)) < 0.5, rng.choice(feat, len(ur)), rng.integers(0, I, len(ur)))
+    xv = rng.integers(1, 6, len(ur)).astype(np.float32) if integer_ratings else (rng.random(len(ur)).astype(np.float32) * 5 - 0.5)
+    X = sp.csr_matrix((xv, (ur, ui)), shape=(U, I), dtype=np.float32)
+    X.sum_duplicates(); X.eliminate_zeros(); X.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    lay = eng._layout(True)
+    assert lay.get("fr_w") is not None and lay["fr_rows"] == len(np.unique(W.tocoo().row))
+    Wr = W.tocsr()
+    for rows in (np.arange(U), rng.permutation(U)[:333]):
+        for top_k, filt in ((10, True), (1, True), (15, False), (7, False)):
+            ids, sc, cnt = eng.recommend_rows(rows, top_k=top_k, filter_interacted=filt)
+            o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt)
+            assert np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc)), \
+                (len(rows), top_k, filt)
+    eng.use_feature_rows = False
+    ids2, sc2, cnt2 = eng.recommend_rows(np.arange(U), top_k=10)
+    eng.use_feature_rows = True
+    ids1, sc1, cnt1 = eng.recommend_rows(np.arange(U), top_k=10)
+    assert np.array_equal(ids1, ids2) and np.array_equal(bits(sc1), bits(sc2)) and np.array_equal(cnt1, cnt2)
+    # a batch large enough for the longest-first work order (ROW_ORDER_MIN) and several jobs per workgroup
+    big = rng.integers(0, U, 5000)
+    ids3, sc3, cnt3 = eng.recommend_rows(big, top_k=10)
+    assert np.array_equal(ids3, ids1[big]) and np.array_equal(bits(sc3), bits(sc1[big])) and np.array_equal(cnt3, cnt1[big])
