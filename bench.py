@@ -9,11 +9,13 @@ Contract (one JSON line on rank 0):
   N > 1   W is sharded by item column over the ranks (each rank also fits only its own columns);
           every rank scores all users against its shard, the per-shard top-k lists are
           all-gathered over RCCL and merged -> total work is fixed: "scaling": "strong".
-  roofline  algorithmic bytes of score_tiles_kernel (user row ids+vals,
-          gathered W row ids+vals, top-k output; 8 B per entry) / its mean launch time measured
-          with HIP events on the launch stream, against the 8 TB/s HBM peak.
-  cpu_baseline  the C oracle (bit-checked restatement of the reference's scipy/sklearn path)
-          timed single-threaded on this host on a bounded sample of the same workload.
+  roofline  the dominant score kernel against the limits that can bind it -- vector-ALU issue (the sums
+          are unfused float32 multiply + add), LDS reads, L2 -> LDS staging -- and its compulsory HBM
+          bytes; mean launch time from HIP events on the launch stream (a caller-owned rtrec_timer).
+          SURVEY 8d's "algorithmic bytes" (8 B per gathered W entry) are kept as `algorithmic`: W never
+          leaves L2 / LDS, so they are not a fraction of any hardware limit.
+  cpu_baseline  the C oracle (bit-checked restatement of the reference's scipy/sklearn path) timed on this
+          host with one thread and with all cores, on bounded samples of the same workload.
 """
 from __future__ import annotations
 
@@ -62,7 +64,7 @@ def main() -> None:
     ap.add_argument("--score-shard", default="columns", choices=["columns", "rows"],
                     help="multi-GPU scoring: item-column shards of W + list exchange (BASELINE.json's configuration), or "
                          "user-row shards with W replicated (for catalogues whose W is tiny, e.g. c4)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU time budget per cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget per cpu_baseline leg (4 legs)")
     args = ap.parse_args()
 
     # `python3 bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
@@ -77,7 +79,14 @@ def main() -> None:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         log(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}")
-        sys.exit(subprocess.call(cmd))
+        proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+        for out_line in proc.stdout:            # stdout carries exactly the JSON line; library chatter goes to stderr
+            if out_line.lstrip().startswith("{"):
+                sys.stdout.write(out_line)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write(out_line)
+        sys.exit(proc.wait())
 
     import torch
     import torch.distributed as dist
@@ -226,22 +235,72 @@ def main() -> None:
         eng.recommend_csr(X, top_k=top_k, filter_interacted=True, mode=_native.TOPK_SPARSE)
         pcie_users_per_s = U / (time.perf_counter() - t1)
 
-    # ------------------------------------------------------------------ roofline of score_tiles_kernel (this rank)
+    # ------------------------------------------------------------------ what bounds the dominant score kernel (this rank)
+    # SURVEY 8d prices the path in "algorithmic bytes" (8 B per gathered W entry), but W is ~1 MB and never
+    # leaves L2 / LDS: that figure is kept as `algorithmic`, and the kernel is priced against the bounds that
+    # can bind -- vector-ALU issue, LDS reads, L2 -> LDS staging -- plus its compulsory HBM bytes.
     Wr = W.tocsr()
     if world > 1 and args.score_shard == "rows":      # this rank: its slice of the users against all of W
         row_nnz_w = np.diff(Wr.indptr).astype(np.float64)
         Xs = X[rank::world]
         gathered_entries = float(row_nnz_w[Xs.indices].sum())
         algo_bytes = 8.0 * Xs.nnz + 8.0 * gathered_entries + 8.0 * top_k * Xs.shape[0] + 4.0 * (Xs.shape[0] + 1)
+        users_per_item = np.bincount(Xs.indices, minlength=I).astype(np.float64)
+        n_scored = Xs.shape[0]
     else:
         shard_row_nnz = np.diff(Wr[:, lo:hi].tocsr().indptr).astype(np.float64) if hi > lo else np.zeros(I)
         users_per_item = np.diff(Xc.indptr).astype(np.float64)
         gathered_entries = float((users_per_item * shard_row_nnz).sum())
         algo_bytes = 8.0 * nnz + 8.0 * gathered_entries + 8.0 * top_k * U + 4.0 * (U + 1)
+        n_scored = U
     kern_ms = tot_ms.value / max(n_launch.value, 1)
-    achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-
+    kern_s = kern_ms * 1e-3
     lay = eng._layout(True) or {"tile_cols": None, "n_tiles": 0, "n_cols": 0}
+    VALU_PEAK_TFLOPS = 78.6        # 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz, one flop per lane-op: the sums are NOT fused
+                                   # (x * w is rounded before it is added, like scipy's) so FMA's factor 2 does not apply
+    LDS_READ_PEAK_GBS = 150_000.0  # MI355X_MICROARCH.md: ~150 TB/s aggregate for ds_read_b64/b128
+    L2_PEAK_GBS = 34_500.0         # MI355X_MICROARCH.md: ~34.5 TB/s
+    bounds, kernel_name, bound = {}, "score_sparse_kernel<float,false>", "l2"
+    compulsory_hbm = 8.0 * (nnz if n_scored == U else int(Xs.nnz)) + 4.0 * (n_scored + 1) + (8.0 * top_k + 4.0) * n_scored
+    fr = lay.get("fr_host")
+    if fr is not None and eng.use_feature_rows:
+        tc, R = fr["fr_tile_cols"], fr["fr_rows"]
+        kernel_name = f"score_frows_kernel<{tc // 64},{2 if R > 64 else 1}>"
+        tr = fr["fr_tile_rows"].view(np.uint64).reshape(-1, 2)
+        feat_items = np.flatnonzero(fr["fr_map"] >= 0)
+        tiles_of_row = np.array([sum(((int(tr[t, f // 64]) >> (f % 64)) & 1) for t in range(tr.shape[0])) for f in range(R)],
+                                dtype=np.float64)
+        blocks = float((users_per_item[feat_items] * tiles_of_row).sum())      # (user, row, tile) blocks that hold a weight
+        flops = 2.0 * blocks * tc                                               # one rounded multiply + one rounded add per column
+        lds_bytes = blocks * tc * 4.0
+        n_jobs = -(-n_scored // 128)
+        l2_bytes = float(n_jobs) * float(fr["fr_super_kb"][-1]) * 1024.0 + 8.0 * (nnz if n_scored == U else int(Xs.nnz))
+        bounds = {"valu": {"achieved": flops / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": flops / kern_s / 1e12 / VALU_PEAK_TFLOPS, "flops_per_launch": flops,
+                           "useful_flops_per_launch": 2.0 * gathered_entries,
+                           "note": "unfused float32 multiply + add over every (user, row of W, tile) block that holds a "
+                                   "weight (zeros inside a block included); peak = vector f32 lane-ops/s without FMA"},
+                  "lds": {"achieved": lds_bytes / kern_s / 1e9, "peak": LDS_READ_PEAK_GBS, "unit": "GB/s",
+                          "frac": lds_bytes / kern_s / 1e9 / LDS_READ_PEAK_GBS, "bytes_per_launch": lds_bytes},
+                  "l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                         "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes,
+                         "note": "W slices staged into LDS once per 128-user job + the user rows"}}
+        bound = "valu"
+    else:
+        l2_bytes = 6.0 * gathered_entries + 24.0 * (nnz if n_scored == U else int(Xs.nnz)) * max(lay["n_tiles"], 1)
+        lds_bytes = 8.0 * gathered_entries
+        bounds = {"l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                         "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes},
+                  "lds": {"achieved": lds_bytes / kern_s / 1e9, "peak": 44_000.0, "unit": "GB/s",
+                          "frac": lds_bytes / kern_s / 1e9 / 44_000.0, "bytes_per_launch": lds_bytes,
+                          "note": "read-modify-write of the LDS accumulators, priced at the LDS write rate"}}
+    bounds["hbm"] = {"achieved": compulsory_hbm / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": compulsory_hbm / kern_s / 1e9 / HBM_PEAK_GBS, "compulsory_bytes_per_launch": compulsory_hbm,
+                     "note": "user rows + outputs: the only bytes that must come from / go to HBM"}
+    algorithmic = {"bytes_per_launch": algo_bytes, "GBps": algo_bytes / kern_s / 1e9,
+                   "note": "SURVEY 8d figure (8 B per gathered W entry); it prices W entries that never reach DRAM, so it "
+                           "is NOT a fraction of any hardware limit and is kept for continuity with round 1 only"}
+
     import zlib
     # same value for every --gpus N: the sharded path returns the unsharded answer
     topk_crc = zlib.crc32(out[0].cpu().numpy().tobytes()) if rank == 0 else 0
@@ -250,20 +309,38 @@ def main() -> None:
             dist.destroy_process_group()
         return
 
-    # HBM traffic of the dominant kernel comes from a separate rocprofv3 --pmc run (FETCH_SIZE /
-    # WRITE_SIZE cannot be read from inside the process); the committed summary is attached when
-    # it belongs to this workload.
-    traffic, traffic_src = None, None
+    # Counter-backed figures come from separate rocprofv3 --pmc runs of this same command (they cannot be read
+    # from inside the process); the committed summaries of the most recent round are attached.
     import glob
-    tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.workload}_pmc_traffic.json")))
-    tpath = tpaths[-1] if tpaths else ""          # the most recent round's summary
+
+    def latest(pattern):
+        paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+        return paths[-1] if paths else None
+
+    traffic, traffic_src, counters = None, None, None
+    tpath = latest(f"r*_{args.workload}_pmc_traffic.json")
     if world == 1 and tpath:
         try:
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch_corrected"]
-            traffic_src = os.path.relpath(tpath, ROOT)
+            tj = json.load(open(tpath))
+            if tj.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
+                traffic, traffic_src = tj["hbm_bytes_per_launch_corrected"], os.path.relpath(tpath, ROOT)
         except Exception:
             traffic = None
+    cpath = latest(f"r*_{args.workload}_score_counters.json")
+    if world == 1 and cpath:
+        try:
+            counters = dict(json.load(open(cpath)), source=os.path.relpath(cpath, ROOT))
+        except Exception:
+            counters = None
+    fpath = latest(f"r*_{args.workload}_fit_pmc.json")
+    fit_traffic = None
+    if world == 1 and fpath:
+        try:
+            fit_traffic = dict(json.load(open(fpath)), source=os.path.relpath(fpath, ROOT))
+        except Exception:
+            fit_traffic = None
 
+    best = bounds[bound]
     line = {
         "metric": "users-scored/sec top-10 (SLIM recommend, int ids, filter_interacted) + fit interactions/sec in `fit`",
         "value": value, "unit": "users/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -271,7 +348,7 @@ def main() -> None:
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "n_users": U, "n_items": I, "nnz": nnz,
                    "nn_feature_selection": K, "top_k": top_k, "tile_cols": lay["tile_cols"], "n_tiles": lay["n_tiles"],
-                   "active_columns": lay["n_cols"],
+                   "active_columns": lay["n_cols"], "w_rows": (fr["fr_rows"] if fr is not None else None),
                    "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
                                    else f"user-row shard x{world}, W replicated")},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend,
@@ -281,51 +358,75 @@ def main() -> None:
                 "roofline": {"kernel": "fit_columns_kernel<false> (+ fit_columns_mw_kernel for the heaviest targets)",
                              "bound": "hbm", "achieved": fit_algo_bytes / fit_local / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": fit_algo_bytes / fit_local / 1e9 / HBM_PEAK_GBS,
-                             "algorithmic_bytes": fit_algo_bytes, "seconds": fit_local,
-                             "note": "rank 0's columns; the coordinate-descent sweeps re-read the K feature columns "
-                                     "and the residual (not counted): measured fabric traffic is ~10 TB on c3 "
-                                     "(profiles/r01_c3_fit_pmc.json), i.e. the kernel is bound by random 64-B sector "
-                                     "traffic at ~3 TB/s, not by its compulsory bytes"}},
-        "roofline": {"kernel": "score_sparse_kernel<float,false>", "bound": "hbm", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": algo_bytes,
-                     "kernel_ms_avg": kern_ms, "launches": int(n_launch.value)},
+                             "algorithmic_bytes": fit_algo_bytes, "seconds": fit_local, "traffic": fit_traffic,
+                             "note": "rank 0's columns; compulsory bytes only (SURVEY 8d): the coordinate-descent sweeps "
+                                     "re-read the K feature columns and stream the per-target residual, which is what "
+                                     "`traffic` (PMC, profiles/) measures"}},
+        "roofline": {"kernel": kernel_name, "bound": bound, "achieved": best["achieved"], "peak": best["peak"],
+                     "unit": best["unit"], "frac": best["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel_ms_avg": kern_ms, "launches": int(n_launch.value), "bounds": bounds,
+                     "algorithmic": algorithmic, "counters": counters},
     }
 
-    # ------------------------------------------------------------------ cpu_baseline (oracle, 1 thread, bounded sample)
+    # ------------------------------------------------------------------ cpu_baseline: the C oracle on this host,
+    # one thread and all cores (POSIX threads over users / item columns: the reference's own parallel axis,
+    # slim_elastic.py:296-301,358-366), bounded samples of the same workload
     if world == 1 and not args.no_cpu_baseline:
         from oracle import slim_oracle as so
         so.lib()
+        # threads of the multi-core legs: the host's share for one GPU is 16 cores (the affinity mask of a GPU box
+        # shows the whole machine); `cores` reports the threads actually used
+        n_cores = max(1, min(16, len(os.sched_getaffinity(0))))
         rng = np.random.default_rng(7)
-        sample = rng.permutation(U)
-        n, done, spent = 64, 0, 0.0
-        ok = True
         ids_gpu = out[0].cpu().numpy()
-        while spent < args.cpu_seconds and done < U:
-            rows_s = np.sort(sample[done:done + n])
-            t1 = time.perf_counter()
-            o_ids, _, _ = so.recommend_batch(X[rows_s], Wr, top_k=top_k)
-            spent += time.perf_counter() - t1
-            ok = ok and np.array_equal(o_ids, ids_gpu[rows_s])
-            done += len(rows_s)
-            n = min(n * 2, 8192)
-        line["cpu_baseline"] = {"value": done / spent, "unit": "users/s", "cores": 1, "kind": "port",
-                                "sample": f"{done} random users of the same workload scored with the C oracle in "
-                                          f"{spent:.1f}s (top-k ids identical to the GPU: {ok})"}
-        # fit leg: random columns until the budget is spent
-        perm = rng.permutation(I)
-        spent_f, nnz_f, ncol_f = 0.0, 0, 0
+        sample = rng.permutation(U)
+
+        def score_leg(threads, budget, start):
+            n, done, spent, ok = 64 * threads, 0, 0.0, True
+            while spent < budget and start + done < U:
+                rows_s = np.sort(sample[start + done:start + done + n])
+                t1 = time.perf_counter()
+                o_ids, _, _ = so.recommend_batch(X[rows_s], Wr, top_k=top_k, n_threads=threads)
+                spent += time.perf_counter() - t1
+                ok = ok and np.array_equal(o_ids, ids_gpu[rows_s])
+                done += len(rows_s)
+                n = min(n * 2, 8192 * threads)
+            return {"value": done / spent, "unit": "users/s", "cores": threads, "kind": "port",
+                    "sample": f"{done} random users of the same workload scored with the C oracle in {spent:.1f}s "
+                              f"(top-k ids identical to the GPU: {ok})"}, done
+
+        leg1, used = score_leg(1, args.cpu_seconds / 2, 0)
+        legn, _ = score_leg(n_cores, args.cpu_seconds / 2, used)
+        line["cpu_baseline"] = dict(leg1, all_cores=legn)
+
+        # fit: a STRATIFIED sample of target columns (by column length: the top 1 %, the next 19 %, the tail), each
+        # stratum's mean time scaled to its size -> an estimate of the whole catalogue's fit time on this host,
+        # comparable with the GPU's whole-catalogue interactions/s (400 random columns are nearly all tail)
         col_nnz = np.diff(Xc.indptr)
-        while spent_f < args.cpu_seconds and ncol_f < I:
-            c = perm[ncol_f:ncol_f + 1]
-            t1 = time.perf_counter()
-            so.fit_columns(Xc, c, nn_feature_selection=K)
-            spent_f += time.perf_counter() - t1
-            nnz_f += int(col_nnz[c[0]])
-            ncol_f += 1
-        line["fit"]["cpu_baseline"] = {"value": nnz_f / spent_f, "unit": "interactions/s", "cores": 1, "kind": "port",
-                                       "sample": f"{ncol_f} random item columns ({nnz_f} interactions) fitted with the "
-                                                 f"C oracle in {spent_f:.1f}s"}
+        by_len = np.argsort(-col_nnz, kind="stable")
+        strata = [("top 1 %", by_len[:max(1, I // 100)]), ("next 19 %", by_len[max(1, I // 100):I // 5]), ("tail 80 %", by_len[I // 5:])]
+
+        def fit_leg(threads, budget):
+            est, parts = 0.0, []
+            for (name, cols_s), share in zip(strata, (0.5, 0.3, 0.2)):
+                pick = rng.permutation(cols_s)
+                done, spent, n = 0, 0.0, max(2, threads)
+                while spent < budget * share and done < len(pick):
+                    c = np.sort(pick[done:done + n]).astype(np.int32)
+                    t1 = time.perf_counter()
+                    so.fit_columns(Xc, c, nn_feature_selection=K, n_threads=threads)
+                    spent += time.perf_counter() - t1
+                    done += len(c)
+                    n = min(n * 2, 64 * threads)
+                est += spent / max(done, 1) * len(cols_s)
+                parts.append(f"{done} of {len(cols_s)} columns of the {name} in {spent:.1f}s")
+            return {"value": nnz / est, "unit": "interactions/s", "cores": threads, "kind": "port",
+                    "estimated_full_fit_seconds": est,
+                    "sample": "stratified by column length, each stratum's mean time scaled to its size: " + "; ".join(parts)}
+
+        f1 = fit_leg(1, args.cpu_seconds)
+        fn = fit_leg(n_cores, args.cpu_seconds)
+        line["fit"]["cpu_baseline"] = dict(f1, all_cores=fn)
     print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -666,6 +666,7 @@ class SlimEngine:
                             fr = build_feature_rows(W["host"], W["col_lo"], W["col_hi"], T.col_ids, T.col_map)
                             if fr is not None:
                                 nb = int(be.lib.rtrec_slim_score_fr_scratch_bytes(fr["fr_n_tiles"], fr["fr_tile_cols"]))
+                                lay["fr_host"] = fr      # host copy: bench.py prices the kernel's work from it
                                 lay.update(fr_map=be.to_dev(fr["fr_map"]), fr_w=be.to_dev(fr["fr_w"]),
                                            fr_col_ids=be.to_dev(fr["fr_col_ids"]), fr_col_map=be.to_dev(fr["fr_col_map"]),
                                            fr_tile_rows=be.to_dev(fr["fr_tile_rows"]),

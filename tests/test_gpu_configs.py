@@ -22,7 +22,7 @@ from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coeffici
 from rtrec_amd.synth import interaction_matrix, zipf_pairs
 
 pytestmark = pytest.mark.gpu
-CPU_THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+CPU_THREADS = max(1, min(16, len(os.sched_getaffinity(0))))       # the host share of one GPU
 T0 = 1_700_000_000.0
 
 
