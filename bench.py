@@ -61,6 +61,7 @@ def main() -> None:
     ap.add_argument("--tile-cols", type=int, default=4096)
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-fit", action="store_true", help="skip the second (tolerance-mode) fit")
     ap.add_argument("--score-shard", default="columns", choices=["columns", "rows"],
                     help="multi-GPU scoring: item-column shards of W + list exchange (BASELINE.json's configuration), or "
                          "user-row shards with W replicated (for catalogues whose W is tiny, e.g. c4)")
@@ -171,9 +172,41 @@ def main() -> None:
         fit_s = fit_local
     W = merge_coefficients(None, I, rows, cols, vals)
     eng.set_weights(W)
-    if rank == 0:
-        log(f"[bench] fit: {fit_s:.2f}s ({nnz / fit_s:,.0f} interactions/s), W nnz={W.nnz}, "
-            f"sweeps mean={n_iter.mean():.1f} max={n_iter.max()}")
+    # the same fit in the tolerance mode (exact=False: Gram-form CD / tree-reduced dots), timed beside the exact one;
+    # the scored W is the exact one
+    fit_fast = None
+    if not args.no_fast_fit:
+        We = merge_coefficients(None, I, *coefficients_to_updates(tg, items, coef, count))
+        fit_fast = {"note": "rank 0's columns, same call as the exact fit with mode=... (rtrec_fit_opts.fast): same features, "
+                            "coordinate sequence and stopping rules, dot products not in scikit-learn's left-to-right order"}
+        for mode_name in ("shuffle", "gram"):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.time()
+            tg_f, items_f, coef_f, count_f, n_iter_f = eng.fit_columns(mine, nn_feature_selection=K, mode=mode_name)
+            torch.cuda.synchronize()
+            fast_s = time.time() - t0
+            if world > 1:
+                t = torch.tensor([fast_s], device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                fast_s = float(t.item())
+            Wf = merge_coefficients(None, I, *coefficients_to_updates(tg_f, items_f, coef_f, count_f))
+            diff = abs(Wf - We)
+            same = n_iter_f[np.argsort(tg_f)] == n_iter[np.argsort(tg)]
+            col_same = np.zeros(I, bool)
+            col_same[np.sort(tg)[same]] = True
+            dcoo = diff.tocoo()
+            d_same = float(dcoo.data[col_same[dcoo.col]].max()) if dcoo.nnz and col_same[dcoo.col].any() else 0.0
+            fit_fast[mode_name] = {"seconds": fast_s, "interactions_per_sec": nnz / fast_s, "speedup_vs_exact": fit_s / fast_s,
+                                   "max_coef": float(abs(We).max()) if We.nnz else 0.0,
+                                   "max_abs_coef_diff_vs_exact": float(diff.max()) if diff.nnz else 0.0,
+                                   "max_abs_coef_diff_where_sweeps_agree": d_same,
+                                   "targets_with_other_sweep_count": int((~same).sum()), "targets": int(len(tg))}
+            if rank == 0:
+                log(f"[bench] fit ({mode_name}): {fast_s:.2f}s ({nnz / fast_s:,.0f} interactions/s), max |dW| = "
+                    f"{fit_fast[mode_name]['max_abs_coef_diff_vs_exact']:.3g} ({d_same:.3g} where the sweep counts agree: "
+                    f"{int(same.sum())} of {len(tg)}) of {fit_fast[mode_name]['max_coef']:.3g}")
 
     # ------------------------------------------------------------------ score: K timed steps
     row_ids = np.arange(U, dtype=np.int32)
@@ -354,7 +387,7 @@ def main() -> None:
         "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend,
         "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
-                "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()),
+                "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()), "mode": "exact", "tolerance_modes": fit_fast,
                 "roofline": {"kernel": "fit_columns_kernel<false> (+ fit_columns_mw_kernel for the heaviest targets)",
                              "bound": "hbm", "achieved": fit_algo_bytes / fit_local / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": fit_algo_bytes / fit_local / 1e9 / HBM_PEAK_GBS,

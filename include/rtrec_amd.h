@@ -136,6 +136,28 @@ typedef struct {
     const int32_t *d_gram_index;
     int32_t        gram_n;
     double         gram_rel_err;
+    /* Tolerance mode (0 = exact, the default).  The exact mode folds every dot product in the reference's
+     * left-to-right float32 order: coefficients and n_iter_ are bit-identical to scikit-learn's.  The tolerance
+     * modes keep the algorithm (same X^T y and feature selection, same coordinate sequence, same stopping rules)
+     * but let go of that order:
+     *   1  the dot products are tree-reduced (64 lane partial sums + a shuffle tree); the float32 residual is
+     *      updated exactly as the reference updates it.  Coefficients agree to ~1e-6 relative.
+     *   2  in addition a target whose features all have a row in d_gram is solved in Gram form (float64 state,
+     *      no residual: sklearn's `precompute` solver).  The float32 reference itself carries ~1e-5 of
+     *      accumulated rounding in its residual, so this mode agrees with it to a few 1e-5 relative.
+     * In either mode a stopping test that flips by a rounding can cost a target one sweep (a change of the order
+     * of the solver's own tolerance `tol`). */
+    int32_t        fast;
+    /* Tuning / test knobs; 0 selects the built-in default.
+     *   kernel            1: one wave per target (throughput), 2: one 8-wave workgroup per target (latency);
+     *                     default: latency mode for calls of <= 2048 targets
+     *   colwalk_min_rows  latency kernel: targets with at least this many users take the column-walk X^T y
+     *   screen_min        columns with at least this many entries are screened before an ordered fold
+     *   lane_max          every-item path: columns up to this length are folded one per lane (< 0: none) */
+    int32_t        kernel;
+    int32_t        colwalk_min_rows;
+    int32_t        screen_min;
+    int32_t        lane_max;
 } rtrec_fit_opts;
 
 /* rtrec_slim_fit_columns with options; opts == NULL behaves exactly like rtrec_slim_fit_columns. */

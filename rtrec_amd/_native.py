@@ -35,7 +35,8 @@ class FitCfg(C.Structure):
 
 class FitOpts(C.Structure):
     _fields_ = [("d_trace", C.c_void_p), ("d_gram", C.c_void_p), ("d_gram_index", C.c_void_p),
-                ("gram_n", C.c_int32), ("gram_rel_err", C.c_double)]
+                ("gram_n", C.c_int32), ("gram_rel_err", C.c_double), ("fast", C.c_int32), ("kernel", C.c_int32),
+                ("colwalk_min_rows", C.c_int32), ("screen_min", C.c_int32), ("lane_max", C.c_int32)]
 
 
 class ScoreOpts(C.Structure):

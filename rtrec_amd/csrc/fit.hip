@@ -24,8 +24,6 @@
 #include "common.hip.h"
 #include "../../include/rtrec_amd.h"
 
-#include <cstdlib>
-
 namespace rtrec {
 
 constexpr int kRowUnroll = 8;   // 64-item chunks of one user row updated together in the X^T y step
@@ -63,6 +61,7 @@ struct FitArgs {
     const int *gram_index;    // optional [I]: item -> row of `gram`, or -1
     int gram_n;
     double gram_rel_err;      // |gram - exact| <= gram_rel_err * exact
+    int fast;                 // tolerance mode (rtrec_fit_opts.fast): 1 tree-reduced dots, 2 also Gram-form CD (fit_gram_cd)
 };
 
 __device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, float nrm, int positive) {
@@ -343,6 +342,7 @@ __device__ __forceinline__ void screen_xta_interval(const Screen &S, float bw, i
 // ---------------------------------------------------------------------------------------------
 constexpr double kU = 0x1p-24;
 
+
 struct GramLane {   // per-lane state, lane p = feature p
     double c, r, a;
     int g;          // row of the Gram matrix, -1: not tracked
@@ -365,6 +365,126 @@ __device__ __forceinline__ FeatLds carve_feat(unsigned char *smem, int K) {
     F.f_ever = reinterpret_cast<int *>(F.f_s + K);
     F.hist = F.f_ever + K;
     return F;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tolerance mode (rtrec_fit_opts.fast): the same coordinate descent -- same features (X^T y and the
+// top-K selection stay exact), same xorshift coordinate sequence, same stopping rules -- but the dot
+// products are no longer folded in the reference's left-to-right float32 order:
+//   * par_dot: one order-free pass, 64 lanes + a shuffle tree (the wavefront partial sums of the brief);
+//   * fit_gram_cd: when all of a target's features are rows of the shared Gram matrix the residual is
+//     never formed at all.  With c_p = X_p . R the update of feature p by dw changes every c_q by
+//     -dw G_pq, so a sweep costs K^2 multiply-adds on a K x K block of G held in LDS instead of K passes
+//     over columns of tens of thousands of entries (sklearn's own `precompute` Gram solver,
+//     _cd_fast.pyx enet_coordinate_descent_gram; rtrec asks for it, slim_elastic.py:201, but sklearn
+//     ignores it for sparse X).  State in float64.
+// Coefficients agree with the exact mode to ~1e-6 relative (a stopping test that flips by a rounding
+// can cost one sweep on a rare target); DESIGN.md section 3.4, tests/test_gpu_kernels.py.
+// ---------------------------------------------------------------------------------------------
+__device__ float par_dot(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
+                         int b, int e, float w_old) {
+    const int lane = lane_id();
+    const bool add_back = (w_old != 0.0f);
+    float s0 = 0.0f;
+    int o = b;
+    for (; o + 512 <= e; o += 512) {
+        int r[8];
+        float x[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { r[u] = crow[o + u * 64 + lane]; x[u] = cval[o + u * 64 + lane]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = R[r[u]];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float vv = v[u];
+            if (add_back) vv = __fadd_rn(vv, __fmul_rn(x[u], w_old));
+            s0 = __fadd_rn(s0, __fmul_rn(vv, x[u]));
+        }
+    }
+    for (o += lane; o < e; o += 64) {
+        const float x = cval[o];
+        float vv = R[crow[o]];
+        if (add_back) vv = __fadd_rn(vv, __fmul_rn(x, w_old));
+        s0 = __fadd_rn(s0, __fmul_rn(vv, x));
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s0 = __fadd_rn(s0, shfl_xor_t(s0, m));
+    return s0;
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_t(v, m);
+    return v;
+}
+
+// Gram-form coordinate descent for one target whose Kc <= 64 features (lane p = feature p) all have a row in
+// a.gram.  Inputs in LDS: f_id, f_s (= X_p . y, the exact float X^T y entries), f_nrm.  gs: Kc x 64 floats of
+// LDS for the feature block of G.  Writes f_w (float32 coefficients) and returns sklearn's n_iter_.
+__device__ int fit_gram_cd(const FitArgs &a, int Kc, const FeatLds &F, float *gs, float yy, float tol_s, int g_lane) {
+    const int lane = lane_id();
+    const double alpha = a.cfg.l1_reg, beta = a.cfg.l2_reg;
+    const int positive = a.cfg.positive;
+    // feature block of the Gram matrix: row p of gs = G[g_p][g_q] for lane q
+    for (int p = 0; p < Kc; ++p) {
+        const int gp = readlane_i(g_lane, p);
+        float v = 0.0f;
+        if (lane < Kc && gp >= 0 && g_lane >= 0) v = static_cast<float>(a.gram[static_cast<size_t>(gp) * a.gram_n + g_lane]);
+        gs[p * 64 + lane] = v;
+    }
+    const bool live = lane < Kc && F.f_nrm[lane < Kc ? lane : 0] != 0.0f;
+    const double q = live ? static_cast<double>(F.f_s[lane]) : 0.0;       // X_q . y
+    const double nrm = live ? static_cast<double>(F.f_nrm[lane]) : 0.0;
+    double c = q, w = 0.0;                                                // c = X_q . R,  R = y - sum_p w_p X_p
+    uint32_t rng = a.cfg.seed;
+    const int max_iter = a.cfg.max_iter;
+    const double tol = a.cfg.tol;
+    int n_iter = 0;
+    for (; n_iter < max_iter; ++n_iter) {
+        double w_max = 0.0, d_w_max = 0.0;
+        for (int f = 0; f < Kc; ++f) {
+            const int p = static_cast<int>(rand_int(static_cast<uint32_t>(Kc), rng));
+            const double nrm_p = readlane_d(nrm, p);
+            if (nrm_p == 0.0) continue;
+            const double w_old = readlane_d(w, p);
+            const double tmp = readlane_d(c, p) + w_old * nrm_p;           // X_p . (R + w_p X_p)
+            double w_new;
+            if (positive && tmp < 0.0) w_new = 0.0;
+            else {
+                const double mag = fabs(tmp) - alpha;
+                w_new = (tmp > 0.0 ? 1.0 : (tmp < 0.0 ? -1.0 : 0.0)) * (mag > 0.0 ? mag : 0.0) / (nrm_p + beta);
+            }
+            if (w_new != w_old) {
+                c -= (w_new - w_old) * static_cast<double>(gs[p * 64 + lane]);
+                if (lane == p) w = w_new;
+            }
+            const double d = fabs(w_new - w_old);
+            d_w_max = d > d_w_max ? d : d_w_max;
+            const double aw = fabs(w_new);
+            w_max = aw > w_max ? aw : w_max;
+        }
+        if (w_max == 0.0 || d_w_max / w_max < tol || n_iter == max_iter - 1) {
+            // duality gap (_cd_fast.pyx:499-546) from the Gram state: XtA_q = c_q - beta w_q,
+            // R.R = y.y - w.q - w.c (G w = q - c),  R.y = y.y - w.q
+            double xta = live ? c - beta * w : 0.0;
+            xta = positive ? xta : fabs(xta);
+            double dn = live ? xta : (positive ? -1e300 : 0.0);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const double o = shfl_xor_t(dn, m); dn = o > dn ? o : dn; }
+            const double wq = wave_sum_d(w * q), wc = wave_sum_d(w * c), ww = wave_sum_d(w * w), l1 = wave_sum_d(fabs(w));
+            // features with a zero column (the target itself) have XtA = 0 exactly like the reference
+            const unsigned long long dead = __ballot(lane < Kc && !live);
+            if (dead && dn < 0.0) dn = 0.0;
+            const double R_norm2 = static_cast<double>(yy) - wq - wc, Ry = static_cast<double>(yy) - wq;
+            double cst, gap;
+            if (dn > alpha) { cst = alpha / dn; gap = 0.5 * (R_norm2 + R_norm2 * cst * cst); }
+            else { cst = 1.0; gap = R_norm2; }
+            gap += alpha * l1 - cst * Ry + 0.5 * beta * (1.0 + cst * cst) * ww;
+            if (gap < static_cast<double>(tol_s)) break;
+        }
+    }
+    if (lane < Kc) F.f_w[lane] = static_cast<float>(w);
+    return (n_iter < max_iter ? n_iter : max_iter - 1) + 1;
 }
 
 struct Prep {
@@ -668,6 +788,21 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
         }
     };
 
+    // ---- tolerance mode, all features in the Gram matrix: Gram-form coordinate descent, no residual ----
+    bool gram_done = false;
+    int gram_iters = 0;
+    if (!ALLF && a.fast >= 2 && a.gram != nullptr && Kc > 0 && Kc <= 64 && ny > 0) {
+        int g_lane = -1;
+        if (lane < Kc) g_lane = a.gram_index[f_id[lane]];
+        const unsigned long long missing = __ballot(lane < Kc && f_nrm[lane] != 0.0f && g_lane < 0);
+        if (!missing) {
+            float *gs = reinterpret_cast<float *>(smem + kFoldBufBytes + ((feat_lds_bytes(K) + 15) / 16) * 16);
+            gram_iters = fit_gram_cd(a, Kc, F, gs, P.yy, P.tol_s, g_lane);
+            gram_done = true;
+        }
+    }
+    if (a.fast) gram_on = false;   // the tracking screens serve the ordered folds only
+
     // ---- 3. coordinate descent (_cd_fast.pyx:428-548) ----
     bool dirty = false;            // false while every w is still 0, i.e. R == y
     int n_ever = 0;                // ALL path: features whose w was ever non-zero
@@ -675,8 +810,9 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
     uint32_t rng = a.cfg.seed;
     int n_iter = 0;
     const int max_iter = a.cfg.max_iter;
-    const bool skip_cd = (ny == 0) || (nf == 0);   // y == 0: all coefficients stay 0, max_iter sweeps
+    const bool skip_cd = (ny == 0) || (nf == 0) || gram_done;   // y == 0: all coefficients stay 0, max_iter sweeps
     if (skip_cd) n_iter = max_iter > 0 ? max_iter - 1 : 0;
+    if (gram_done) n_iter = gram_iters - 1;
 
     auto s_value = [&](int p) -> float {
         const float v = s[p];
@@ -705,7 +841,9 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
             bool screened = false;
             if (!dirty) tmp = ALLF ? s_value(p) : f_s[p];
             else {
-                if (w_old == 0.0f) {
+                if (a.fast) {
+                    tmp = par_dot(a.crow, a.cval, R, b, e, w_old);
+                } else if (w_old == 0.0f) {
                     Screen S;
                     if (!ALLF && gram_interval(p, e - b, S)) screened = screen_stays_zero(S, alpha, positive, w_new);
                     if (!screened && e - b >= a.screen_min && e - b <= kScreenMaxLen) {
@@ -714,7 +852,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                         screened = screen_stays_zero(screen_interval(ps, pa, e - b), alpha, positive, w_new);
                     }
                 }
-                if (!screened) { tmp = dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf); tr_folded += e - b; }
+                if (!screened && !a.fast) { tmp = dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf); tr_folded += e - b; }
             }
             if (!screened) w_new = cd_update(tmp, alpha, beta, nrm, positive);
             if (w_old != 0.0f || w_new != 0.0f) {
@@ -782,7 +920,10 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                         const int b = f_b[p], e = f_e[p];
                         const float bw = __fmul_rn(beta, f_w[p]);
                         Screen S;
-                        if (gram_interval(p, e - b, S)) {
+                        if (a.fast) {
+                            const float xta = __fsub_rn(par_dot(a.crow, a.cval, R, b, e, 0.0f), bw);
+                            lo = hi = positive ? xta : fabsf(xta);
+                        } else if (gram_interval(p, e - b, S)) {
                             screen_xta_interval(S, bw, positive, lo, hi);
                         } else if (e - b >= a.screen_min && e - b <= kScreenMaxLen) {
                             float ps, pa;
@@ -814,6 +955,13 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
             if (!dirty) { R_norm2 = yy; Ry = yy; }
             else {
                 R_norm2 = 0.0f;
+                if (a.fast) {
+                    float acc = 0.0f;
+                    for (int o = lane; o < U; o += 64) { const float v = R[o]; acc = __fadd_rn(acc, __fmul_rn(v, v)); }
+#pragma unroll
+                    for (int m = 32; m >= 1; m >>= 1) acc = __fadd_rn(acc, shfl_xor_t(acc, m));
+                    R_norm2 = acc;
+                } else
                 for (int o = 0; o < U; o += 64) {
                     float prod = 0.0f;
                     if (o + lane < U) { const float v = R[o + lane]; prod = __fmul_rn(v, v); }
@@ -2083,23 +2231,29 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
             a.gram = opts->d_gram; a.gram_index = opts->d_gram_index; a.gram_n = opts->gram_n;
             a.gram_rel_err = opts->gram_rel_err;
         }
+        a.fast = opts->fast < 0 ? 0 : (opts->fast > 2 ? 2 : opts->fast);
     }
-    { const char *cw = std::getenv("RTREC_AMD_COLWALK_MIN"); a.colwalk_min_rows = cw ? std::atoi(cw) : kColWalkMinRows; }
-    { const char *sm = std::getenv("RTREC_AMD_SCREEN_MIN"); a.screen_min = sm ? std::atoi(sm) : kScreenMinDefault; }
-    { const char *lm = std::getenv("RTREC_AMD_LANE_MAX"); a.lane_max = lm ? std::atoi(lm) : kLaneMaxDefault; }
+    // tuning / test knobs arrive in rtrec_fit_opts (0 = the built-in default); the library reads no environment
+    a.colwalk_min_rows = (opts && opts->colwalk_min_rows > 0) ? opts->colwalk_min_rows : kColWalkMinRows;
+    a.screen_min = (opts && opts->screen_min > 0) ? opts->screen_min : kScreenMinDefault;
+    a.lane_max = (opts && opts->lane_max != 0) ? (opts->lane_max < 0 ? 0 : opts->lane_max) : kLaneMaxDefault;
     (void)hipGetLastError();
     if (hipMemsetAsync(d_queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const int grid = n_slots < n_targets ? n_slots : n_targets;
     if (allf) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true>), dim3(grid), dim3(64), kFoldBufBytes + 16, st, a);
     } else {
-        // few targets (online partial_fit): the heaviest target is the critical path -> latency mode
-        const char *force = std::getenv("RTREC_AMD_FIT_MODE");            // "mw" / "sw": A/B switch
-        const bool latency_mode = force ? (force[0] == 'm') : (n_targets <= kMwMaxTargets);
+        // few targets (online partial_fit): the heaviest target is the critical path -> latency mode (multi-wave
+        // kernel); opts->kernel forces one of the two (A/B runs, tests).  The tolerance mode has no ordered fold to
+        // feed, so it always takes the one-wave-per-target kernel.
+        const int force = opts ? opts->kernel : 0;
+        const bool latency_mode = !a.fast && (force == 2 || (force == 0 && n_targets <= kMwMaxTargets));
         if (latency_mode) {
             hipLaunchKernelGGL(fit_columns_mw_kernel, dim3(grid), dim3(kMwThreads), mw_lds_bytes(K), st, a);
         } else {
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), kFoldBufBytes + feat_lds_bytes(K), st, a);
+            size_t lds = kFoldBufBytes + feat_lds_bytes(K);
+            if (a.fast >= 2 && a.gram && K <= 64) lds = kFoldBufBytes + ((feat_lds_bytes(K) + 15) / 16) * 16 + static_cast<size_t>(K) * 64 * 4;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), lds, st, a);
         }
     }
     return rtrec::launch_status();

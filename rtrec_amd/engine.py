@@ -278,14 +278,27 @@ class HipBackend:
     supports_gram = True
     supports_device_store = True     # X can stay resident as sorted COO (utils/device_store.py)
 
+    @staticmethod
+    def fit_knobs() -> Dict[str, int]:
+        """Tuning / test knobs of rtrec_fit_opts, read from the environment HERE (the library itself reads none):
+        RTREC_AMD_FIT_MODE=sw|mw, RTREC_AMD_COLWALK_MIN, RTREC_AMD_SCREEN_MIN, RTREC_AMD_LANE_MAX."""
+        mode = os.environ.get("RTREC_AMD_FIT_MODE", "")
+        lane_max = os.environ.get("RTREC_AMD_LANE_MAX")
+        return dict(kernel=2 if mode.startswith("m") else 1 if mode.startswith("s") else 0,
+                    colwalk_min_rows=int(os.environ.get("RTREC_AMD_COLWALK_MIN", 0)),
+                    screen_min=int(os.environ.get("RTREC_AMD_SCREEN_MIN", 0)),
+                    lane_max=0 if lane_max is None else (-1 if int(lane_max) == 0 else int(lane_max)))
+
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
-                    ws, queue, slots, trace=None, gram=None):
+                    ws, queue, slots, trace=None, gram=None, fast=False):
         g = gram or {}
+        k = self.fit_knobs()
         self.ops.fit_columns(X["cptr"], X["crow"], X["cval"], X["rptr"], X["rcol"], X["rval"], X["sqn"], targets,
                              n_users, n_items, float(cfg.l1_reg), float(cfg.l2_reg), float(cfg.tol), int(cfg.max_iter),
                              int(cfg.seed), bool(cfg.positive), int(cfg.top_features),
                              out_items, out_coef, out_count, out_niter, cap, ws, slots, queue, trace,
-                             g.get("G"), g.get("index"), int(g.get("n", 0)), float(g.get("rel_err", 0.0)))
+                             g.get("G"), g.get("index"), int(g.get("n", 0)), float(g.get("rel_err", 0.0)),
+                             int(fast), k["kernel"], k["colwalk_min_rows"], k["screen_min"], k["lane_max"])
 
     def gram_matrix(self, X, n_users, n_items, n_top):
         """Gram matrix X_P^T X_P of the n_top most popular items in float64 for the fit kernel's Gram
@@ -455,9 +468,11 @@ class SlimEngine:
     def fit_columns(self, targets: Sequence[int], alpha: float = 0.1, l1_ratio: float = 0.1,
                     positive: bool = True, max_iter: int = 100, tol: float = 1e-4, random_state: Optional[int] = 43,
                     nn_feature_selection: Optional[int] = None, n_slots: Optional[int] = None,
-                    trace: bool = False
+                    trace: bool = False, exact: bool = True, mode: Optional[str] = None
                     ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
-        """Fit the given target columns on this GPU.
+        """Fit the given target columns on this GPU.  mode: "exact" (default; bit-identical to scikit-learn),
+        "gram" (Gram-form coordinate descent where all features are in the Gram matrix, tree-reduced dots elsewhere;
+        a few 1e-5 relative; what exact=False selects) or "shuffle" (tree-reduced dots only) -- rtrec_fit_opts.fast.
 
         Returns (targets_in_processing_order, items[n, cap], coef[n, cap], count[n], n_iter[n]);
         row t describes model.sparse_coef_ of target t (see rtrec_slim_fit_columns).
@@ -515,9 +530,16 @@ class SlimEngine:
         # Gram tracking (csrc/fit.hip): bulk calls on a non-negative X get the Gram matrix of the most
         # popular items, which lets the kernel decide most zero coordinates without a pass over memory.
         gram = None
-        mode = os.environ.get("RTREC_AMD_GRAM", "auto")
-        if (K > 0 and min(K, I) <= 64 and X.get("nonneg") and getattr(be, "supports_gram", False) and mode != "0"
-                and (n > FIT_MW_MAX_TARGETS or mode == "force")):
+        gmode = os.environ.get("RTREC_AMD_GRAM", "auto")
+        mode_ = mode or ("exact" if exact else "gram")
+        if mode_ not in ("exact", "shuffle", "gram"):
+            raise ValueError(f"fit mode must be 'exact', 'shuffle' or 'gram': {mode_}")
+        fast = {"exact": 0, "shuffle": 1, "gram": 2}[mode_] if K > 0 else 0
+        if fast:
+            n_heavy = 0            # no ordered folds, no latency kernel: one launch
+        # exact mode: Gram TRACKING needs a non-negative X and pays on bulk calls; tolerance mode: Gram-form CD, any X
+        if (K > 0 and min(K, I) <= 64 and getattr(be, "supports_gram", False) and gmode != "0"
+                and (fast == 2 or (fast == 0 and X.get("nonneg") and (n > FIT_MW_MAX_TARGETS or gmode == "force")))):
             n_top = min(I, int(os.environ.get("RTREC_AMD_GRAM_ITEMS", GRAM_ITEMS)))
             if X.get("gram_n") != n_top:
                 X["gram"], X["gram_n"] = be.gram_matrix(X, U, I, n_top), n_top
@@ -559,8 +581,12 @@ class SlimEngine:
                      coef=be.empty((m, cap), torch.float32), count=be.empty((m,), torch.int32),
                      niter=be.empty((m,), torch.int32), trace=be.zeros((m, 8), torch.int64) if trace else None,
                      ws=(ws, queue))   # keeps the scratch alive while the kernel runs
-            be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
-                           ws_slots, d["trace"], gram)
+            if isinstance(be, HipBackend):
+                be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
+                               ws_slots, d["trace"], gram, fast=fast)
+            else:
+                be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
+                               ws_slots, d["trace"], gram)
             return d
 
         def collect(d):
