@@ -396,6 +396,14 @@ int rtrec_store_apply_round(const int64_t *order, int64_t n, const double *delta
 int rtrec_store_decay(const double *val, const double *ts, int64_t n, double rate, const double *now_arr,
                       double now, double *out64, float *out32, int32_t n_threads);
 
+/* The same decay for a RESIDENT matrix (device pointers): d_out32[k] = (float)(d_val[k] * pow(rate, (now - d_ts[k]) / 86400.0)).
+ * The device pow is not libm's bit for bit; a float64 product still rounds to the reference's float32 unless it lies
+ * within the pow's error of a float32 rounding boundary.  Entries closer than 4096 float64 ulps to one are listed in
+ * d_unsafe_idx (first `cap` of them; *d_unsafe_count = how many there were, ~n * 2^-17): the caller re-evaluates those
+ * with rtrec_store_decay and patches them, every other value is provably the reference's (csrc/store_device.hip). */
+int rtrec_store_decay_device(const double *d_val, const double *d_ts, int64_t n, double rate, double now,
+                             float *d_out32, int32_t *d_unsafe_idx, int32_t *d_unsafe_count, int32_t cap, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,6 +25,7 @@ EXPORTS = [
     "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_gram_workspace_bytes", "rtrec_slim_gram_matrix", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
     "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round", "rtrec_store_decay",
+    "rtrec_store_decay_device",
 ]
 
 
@@ -127,6 +128,8 @@ def load() -> C.CDLL:
     L.rtrec_store_apply_round.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, vp, vp, i32]
     L.rtrec_store_decay.restype = C.c_int
     L.rtrec_store_decay.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_double, vp, vp, i32]
+    L.rtrec_store_decay_device.restype = C.c_int
+    L.rtrec_store_decay_device.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_double, vp, vp, vp, i32, vp]
     _lib = L
     return L
 

@@ -340,6 +340,31 @@ class HipBackend:
                             fr.get("fr_scratch"),
                             row_order if fr else None, int(timer), int(diagnostics))
 
+    def decay_f32(self, raw, ts, rate: float, now: float):
+        """float32(raw * rate ** ((now - ts) / 86400)) for resident arrays: rtrec_store_decay_device, plus the host's libm
+        for the handful of entries the kernel flags as too close to a float32 rounding boundary (csrc/store_device.hip)."""
+        torch = self.torch
+        n = int(raw.shape[0])
+        out = self.empty((n,), torch.float32)
+        if n == 0:
+            return out
+        cap = max(1024, n >> 10)
+        idx = self.empty((cap,), torch.int32)
+        cnt = self.zeros((1,), torch.int32)
+        _native.check(self.lib.rtrec_store_decay_device(self.ptr(raw), self.ptr(ts), n, float(rate), float(now), self.ptr(out),
+                                                        self.ptr(idx), self.ptr(cnt), cap, self.stream()),
+                      "rtrec_store_decay_device")
+        k = int(cnt.item())
+        sel = idx[:k].long() if k <= cap else torch.arange(n, device=raw.device)        # overflow: let the host do them all
+        if sel.numel():
+            v, t = raw[sel].cpu().numpy(), ts[sel].cpu().numpy()
+            fix = np.empty(v.shape[0], np.float32)
+            if self.lib.rtrec_store_decay(v.ctypes.data, t.ctypes.data, v.shape[0], float(rate), None, float(now), None,
+                                          fix.ctypes.data, 0) != 0:
+                raise _native.NativeLibraryError("rtrec_store_decay failed")
+            out[sel] = torch.from_numpy(fix).to(out.device)
+        return out
+
     def timer_create(self) -> int:
         h = C.c_void_p()
         _native.check(self.lib.rtrec_timer_create(C.byref(h)), "rtrec_timer_create")

@@ -113,16 +113,20 @@ class BaseModel(ABC):
             return
         uid = self.user_ids.identify_many(users)
         iid = self.item_ids.identify_many(items)
-        v0 = self.interactions.version
+        tag0 = self._store_tag()
         self.interactions.add_interactions_batch(uid, iid, np.asarray(tstamps, dtype=np.float64),
                                                  np.asarray(ratings, dtype=np.float64), upsert=update_interaction)
-        self._stored(v0, uid, iid)
+        self._stored(tag0, uid, iid)
         if record_interactions:
             self._record_batch(uid, iid)
 
-    def _stored(self, version_before: int, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
-        """Hook: the interactions (user_ids, item_ids) have just been written to the store, which was at
-        `version_before`.  Models that mirror the store elsewhere (device-resident X) advance the mirror."""
+    def _store_tag(self) -> Any:
+        """What a copy of the store must match to be current (models with time decay add max_timestamp)."""
+        return self.interactions.version
+
+    def _stored(self, tag_before: Any, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
+        """Hook: the interactions (user_ids, item_ids) have just been written to the store, whose _store_tag() was
+        `tag_before`.  Models that mirror the store elsewhere (device-resident X) advance the mirror."""
 
     @staticmethod
     def _batch_is_homogeneous(objs: Tuple[Any, ...], ident: Identifier) -> bool:

@@ -33,47 +33,53 @@ class SLIM(BaseModel):
         return st.version if st.decay_rate is None else (st.version, st.max_timestamp)
 
     def _mirror(self, full: bool = False) -> Optional[DeviceInteractions]:
-        """The device-resident copy of X, or None where it does not apply: a backend without device
-        arrays, or a store with time decay unless only the FULL matrix at the current max_timestamp is
-        wanted (bulk_fit, recommend) -- decayed values are float64 `pow`s the host evaluates, so such a
-        copy is rebuilt from a host export instead of advanced per mini-batch.
-        RTREC_AMD_DEVICE_STORE=0 forces the host-export path."""
-        if (self.interactions.decay_rate is not None and not full) or os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0":
+        """The device-resident copy of X, or None where it does not apply (a backend without device arrays).
+        Stores with time decay keep their raw values and timestamps resident too and are re-valued on the device
+        at every new max_timestamp (utils/device_store.py).  RTREC_AMD_DEVICE_STORE=0 forces the host-export path."""
+        if os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0":
             return None
         be = self.model.engine.be
         if not getattr(be, "supports_device_store", False):
             return None
         if self._dev_x is None:
             self._dev_x = DeviceInteractions(be.torch, be.device)
+            self._dev_x.decay_fn = getattr(be, "decay_f32", None)
         return self._dev_x
 
     def _mirror_synced(self, full: bool = False) -> Optional[DeviceInteractions]:
-        """The mirror, brought up to the host store's state (one full export if it has fallen behind)."""
+        """The mirror, brought up to the host store's state (one upload of the store's compacted block -- keys, raw
+        values, timestamps -- if it has fallen behind; values are cast / decayed on the device)."""
         mir = self._mirror(full)
         if mir is not None and mir.version != self._store_tag():
-            csr = self.interactions.to_csr()
-            mir.load_csr(csr.indptr, csr.indices, csr.data, csr.shape[0], csr.shape[1], self._store_tag())
+            st = self.interactions
+            blk = st._compact()
+            mir.load_store(blk.key, blk.val, blk.ts if st.decay_rate is not None else None, st.shape[0], st.shape[1],
+                           self._store_tag(), rate=st.decay_rate, now=st.max_timestamp)
         return mir
 
     _MIRROR_APPLY_MAX = 1 << 18     # larger writes (bulk chunks) leave the mirror stale: it is rebuilt on demand
 
     def _ingest(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool
                 ) -> Tuple[np.ndarray, np.ndarray]:
-        v0 = self.interactions.version
+        tag0 = self._store_tag()
         uid, iid = super()._ingest(interactions, update_interaction)
-        self._stored(v0, uid, iid)
+        self._stored(tag0, uid, iid)
         return uid, iid
 
-    def _stored(self, version_before: int, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
+    def _stored(self, tag_before: Any, user_ids: np.ndarray, item_ids: np.ndarray) -> None:
         """A mirror that was in step with the store is advanced by the batch's distinct (user, item)
-        pairs -- their new values come from the host store, which owns the semantics."""
+        pairs -- their new (raw) values and timestamps come from the host store, which owns the semantics."""
         st, mir = self.interactions, self._dev_x
-        if (mir is None or mir.version != version_before or st.decay_rate is not None or st.version == version_before
-                or len(user_ids) > self._MIRROR_APPLY_MAX):
+        if (mir is None or mir.version != tag_before or self._store_tag() == tag_before
+                or len(user_ids) > self._MIRROR_APPLY_MAX or os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0"):
             return
         keys = np.unique(st._keys(user_ids, item_ids))
-        _, val, _ = st._lookup(keys)
-        mir.apply(keys >> 32, keys & 0xFFFFFFFF, val.astype(np.float32), st.shape[0], st.shape[1], st.version)
+        _, val, ts = st._lookup(keys)
+        if st.decay_rate is None:
+            mir.apply(keys >> 32, keys & 0xFFFFFFFF, val.astype(np.float32), st.shape[0], st.shape[1], self._store_tag())
+        else:
+            mir.apply(keys >> 32, keys & 0xFFFFFFFF, val, st.shape[0], st.shape[1], self._store_tag(), tstamps=ts,
+                      now=st.max_timestamp)
 
     def _device_matrix(self, item_ids: Optional[List[int]]) -> Optional[Dict[str, Any]]:
         """X (or X with only `item_ids`' columns populated) as device arrays, or None -> host export."""

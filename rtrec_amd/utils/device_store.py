@@ -14,8 +14,11 @@ sequential-duplicate semantics stay in one place).  CSR / CSC pointers are binar
 keys, and the touched-columns matrix is a gather of contiguous column slices plus a mask-compaction
 of the row-major copy: a few passes over HBM, no host export, no upload.
 
-Only for stores WITHOUT time decay (decay makes every value a function of max_timestamp in float64
-`pow`, which the host evaluates); the model falls back to host exports otherwise.
+Stores WITH time decay (every value is `raw * rate ** ((max_timestamp - tstamp) / 86400)` in float64,
+rtrec/utils/interactions.py:62-79) keep the raw float64 values and timestamps resident as well, and the
+float32 matrix is re-evaluated on the device whenever max_timestamp has moved -- one pass of the hand-written
+decay kernel (csrc/store_device.hip) whose float32 results are provably the reference's except for the few
+entries it flags as too close to a rounding boundary, which the host re-evaluates with libm and patches.
 
 PyTorch tensor ops are the plumbing here (sort / searchsorted / scatter on the resident arrays); the
 arrays feed the hand-written fit and score kernels through the same C-ABI as host-built matrices.
@@ -40,6 +43,13 @@ class DeviceInteractions:
         self.n_items = 0
         self._rk = self._rv = self._ck = self._cv = None      # sorted keys + values, both orientations
         self._full: Optional[Dict[str, Any]] = None
+        # time decay: raw float64 values and timestamps in both orientations, the rate, the max_timestamp the float32
+        # values were last evaluated at (None = stale) and the max_timestamp they are wanted at
+        self.rate: Optional[float] = None
+        self._rraw = self._rts = self._craw = self._cts = None
+        self._now: Optional[float] = None
+        self._valued_at: Optional[float] = None
+        self.decay_fn: Any = None           # (raw, ts, rate, now) -> float32 tensor; the GPU backend installs the HIP kernel
 
     # ------------------------------------------------------------------ build
     def _dev(self, a: np.ndarray):
@@ -57,6 +67,7 @@ class DeviceInteractions:
         ck = (rcol << _SHIFT) | rows
         self._ck, order = torch.sort(ck)            # keys are distinct: any sort yields the CSC order
         self._cv = self._rv[order]
+        self.rate = self._rraw = self._rts = self._craw = self._cts = self._now = self._valued_at = None
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
 
     def load_csc(self, indptr: np.ndarray, indices: np.ndarray, data: np.ndarray, n_users: int, n_items: int,
@@ -72,7 +83,54 @@ class DeviceInteractions:
         rk = (crow << _SHIFT) | cols
         self._rk, order = torch.sort(rk)
         self._rv = self._cv[order]
+        self.rate = self._rraw = self._rts = self._craw = self._cts = self._now = self._valued_at = None
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
+
+    def load_store(self, keys: np.ndarray, raw: np.ndarray, ts: Optional[np.ndarray], n_users: int, n_items: int,
+                   version: Any, rate: Optional[float] = None, now: Optional[float] = None) -> None:
+        """(Re)build from the host store's compacted block: row-major keys (user << 32 | item, ascending), the RAW
+        stored values and -- for a store with time decay (rate, now = max_timestamp) -- the timestamps.  No host
+        export: the values are cast (or decayed) on the device, the column-major copy is a device sort."""
+        torch = self.torch
+        self._rk = self._dev(np.asarray(keys, dtype=np.int64))
+        ck = ((self._rk & _MASK) << _SHIFT) | (self._rk >> _SHIFT)
+        self._ck, order = torch.sort(ck)
+        self.rate = None if rate is None else float(rate)
+        if self.rate is None:
+            self._rv = self._dev(np.asarray(raw, dtype=np.float32))
+            self._cv = self._rv[order]
+            self._rraw = self._rts = self._craw = self._cts = None
+            self._now = self._valued_at = None
+        else:
+            self._rraw, self._rts = self._dev(np.asarray(raw, dtype=np.float64)), self._dev(np.asarray(ts, dtype=np.float64))
+            self._craw, self._cts = self._rraw[order], self._rts[order]
+            self._rv = self._cv = None
+            self._now, self._valued_at = float(now), None
+        self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
+
+    def _host_decay(self, raw, ts, rate: float, now: float):
+        """decay_fn fallback (CPU tensors, tests): libm pow through the host routine, the reference's own arithmetic."""
+        from .interactions import _native_lib
+        lib = _native_lib()
+        v, t = raw.cpu().numpy(), ts.cpu().numpy()
+        out = np.empty(v.shape[0], np.float32)
+        if lib is not None and v.shape[0]:
+            if lib.rtrec_store_decay(v.ctypes.data, t.ctypes.data, v.shape[0], float(rate), None, float(now), None,
+                                     out.ctypes.data, 0) != 0:
+                raise RuntimeError("rtrec_store_decay failed")
+        elif v.shape[0]:
+            out = (v * rate ** ((now - t) / 86400.0)).astype(np.float32)
+        return self.torch.from_numpy(out).to(self.device)
+
+    def _revalue(self) -> None:
+        """Time decay: bring the float32 values of both orientations to the current max_timestamp."""
+        if self.rate is None or self._valued_at == self._now:
+            return
+        fn = self.decay_fn or self._host_decay
+        self._rv = fn(self._rraw, self._rts, self.rate, self._now)
+        self._cv = fn(self._craw, self._cts, self.rate, self._now)
+        self._valued_at = self._now
+        self._full = None
 
     def adopt(self, X: Dict[str, Any], n_users: int, n_items: int, version: int) -> None:
         """Take over a full X the engine has already uploaded (bulk_fit): no host work at all."""
@@ -83,6 +141,7 @@ class DeviceInteractions:
         cols = torch.repeat_interleave(torch.arange(n_items, device=self.device, dtype=i64), cptr[1:] - cptr[:-1])
         self._rk, self._rv = (rows << _SHIFT) | X["rcol"].to(i64), X["rval"].clone()
         self._ck, self._cv = (cols << _SHIFT) | X["crow"].to(i64), X["cval"].clone()
+        self.rate = self._rraw = self._rts = self._craw = self._cts = self._now = self._valued_at = None
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
 
     def warm_up(self) -> None:
@@ -94,46 +153,63 @@ class DeviceInteractions:
         self.adopt(self.full(), 2, 2, 2)
         self.partial(np.array([1]))
         self.load_csc(np.array([0, 1, 3]), np.array([0, 0, 1]), np.ones(3, np.float32), 2, 2, 3)
+        self.load_store(np.array([0, 1, (1 << 32) | 1]), np.ones(3), np.zeros(3), 2, 2, 4, rate=0.99, now=86400.0)
+        self.apply(np.array([0]), np.array([1]), np.ones(1), 2, 2, 5, tstamps=np.zeros(1), now=2 * 86400.0)
+        self.full()
 
     # ------------------------------------------------------------------ update
     def _merge(self, keys, vals, new_k, new_v):
         """Write (new_k, new_v) -- distinct keys, any order -- into the sorted (keys, vals): existing keys
-        are overwritten in place, new ones are inserted at their sorted position."""
+        are overwritten in place, new ones are inserted at their sorted position.  `vals` / `new_v` are lists of
+        value arrays that travel with the keys (one float32 array, or raw values + timestamps)."""
         torch = self.torch
         new_k, order = torch.sort(new_k)
-        new_v = new_v[order]
+        new_v = [v[order] for v in new_v]
         n = keys.shape[0]
         pos = torch.searchsorted(keys, new_k)
         if n:
             hit = keys[pos.clamp(max=n - 1)] == new_k
-            vals[pos[hit]] = new_v[hit]
+            for v, nv in zip(vals, new_v):
+                v[pos[hit]] = nv[hit]
         else:
             hit = torch.zeros_like(new_k, dtype=torch.bool)
         miss = ~hit
         m = int(miss.sum())
         if m == 0:
             return keys, vals
-        ins_k, ins_v, ins_pos = new_k[miss], new_v[miss], pos[miss]
+        ins_k, ins_pos = new_k[miss], pos[miss]
         out_k = torch.empty(n + m, dtype=keys.dtype, device=keys.device)
-        out_v = torch.empty(n + m, dtype=vals.dtype, device=vals.device)
         dst_new = ins_pos + torch.arange(m, device=keys.device, dtype=ins_pos.dtype)
         dst_old = torch.arange(n, device=keys.device, dtype=torch.int64) + torch.searchsorted(ins_k, keys)
         out_k[dst_old] = keys
-        out_v[dst_old] = vals
         out_k[dst_new] = ins_k
-        out_v[dst_new] = ins_v
-        return out_k, out_v
+        out_vals = []
+        for v, nv in zip(vals, new_v):
+            out_v = torch.empty(n + m, dtype=v.dtype, device=v.device)
+            out_v[dst_old] = v
+            out_v[dst_new] = nv[miss]
+            out_vals.append(out_v)
+        return out_k, out_vals
 
     def apply(self, users: np.ndarray, items: np.ndarray, values: np.ndarray, n_users: int, n_items: int,
-              version: int) -> None:
+              version: Any, tstamps: Optional[np.ndarray] = None, now: Optional[float] = None) -> None:
         """Set X[users[k], items[k]] = values[k] for distinct pairs (the state the host store holds after a
-        mini-batch) and grow the shape to (n_users, n_items)."""
+        mini-batch) and grow the shape to (n_users, n_items).  With time decay `values` are the RAW stored values,
+        `tstamps` their timestamps and `now` the store's max_timestamp after the batch."""
         u = self._dev(np.asarray(users, dtype=np.int64))
         i = self._dev(np.asarray(items, dtype=np.int64))
-        v = self._dev(np.asarray(values, dtype=np.float32))
-        if u.shape[0]:
-            self._rk, self._rv = self._merge(self._rk, self._rv, (u << _SHIFT) | i, v)
-            self._ck, self._cv = self._merge(self._ck, self._cv, (i << _SHIFT) | u, v)
+        if self.rate is None:
+            v = self._dev(np.asarray(values, dtype=np.float32))
+            if u.shape[0]:
+                self._rk, (self._rv,) = self._merge(self._rk, [self._rv], (u << _SHIFT) | i, [v])
+                self._ck, (self._cv,) = self._merge(self._ck, [self._cv], (i << _SHIFT) | u, [v])
+        else:
+            v = self._dev(np.asarray(values, dtype=np.float64))
+            t = self._dev(np.asarray(tstamps, dtype=np.float64))
+            if u.shape[0]:
+                self._rk, (self._rraw, self._rts) = self._merge(self._rk, [self._rraw, self._rts], (u << _SHIFT) | i, [v, t])
+                self._ck, (self._craw, self._cts) = self._merge(self._ck, [self._craw, self._cts], (i << _SHIFT) | u, [v, t])
+            self._now, self._valued_at = float(now), None      # every value is a function of max_timestamp
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
 
     # ------------------------------------------------------------------ views
@@ -148,6 +224,7 @@ class DeviceInteractions:
 
     def full(self) -> Dict[str, Any]:
         """X as the engine's array set (rptr/rcol/rval + cptr/crow/cval [+ col_nnz, nonneg])."""
+        self._revalue()
         if self._full is None:
             torch = self.torch
             cptr = self._pointers(self._ck, self.n_items)

@@ -188,32 +188,34 @@ def test_large_top_k_through_the_api():
         assert got == [o_ids[r, :o_cnt[r]].tolist() for r in range(len(users))]
 
 
-def test_streaming_through_the_device_resident_store_equals_host_exports(monkeypatch):
+@pytest.mark.parametrize("decay", [None, 30])
+def test_streaming_through_the_device_resident_store_equals_host_exports(decay, monkeypatch):
     """SLIM.fit mini-batches served from the device-resident X (utils/device_store.py: bulk_fit's upload
     adopted, every batch merged on the GPU, touched-columns matrix gathered there) give the same W,
     bit for bit, and the same recommendations as the host-export path (RTREC_AMD_DEVICE_STORE=0),
-    including new users / items and re-rated pairs."""
+    including new users / items and re-rated pairs -- also for a store with time decay, whose every value moves
+    with max_timestamp at every batch and is re-evaluated by the device decay kernel."""
     from rtrec_amd import SLIM
     rng = np.random.default_rng(11)
     U, I, n = 1500, 300, 40_000
     u, i = rng.integers(0, U, n), rng.zipf(1.3, n) % I
     r = (rng.integers(1, 6, n) * np.exp(-rng.random(n))).astype(float)
-    ts = 1.7e9 + np.arange(n, dtype=float)
+    ts = 1.7e9 + np.arange(n, dtype=float) * (600.0 if decay else 1.0)          # with decay: ~9 months of history
     n_bulk = n - 6 * 400
 
     def run(device_store):
         monkeypatch.setenv("RTREC_AMD_DEVICE_STORE", "1" if device_store else "0")
-        m = SLIM(min_value=0, max_value=15, nn_feature_selection=8)
+        m = SLIM(min_value=0, max_value=15, nn_feature_selection=8, **({"decay_in_days": decay} if decay else {}))
         m.add_interactions(list(zip(u[:n_bulk].tolist(), i[:n_bulk].tolist(), ts[:n_bulk].tolist(), r[:n_bulk].tolist())))
         m.bulk_fit(parallel=True, progress_bar=False)
-        assert (m._dev_x is not None and m._dev_x.version == m.interactions.version) == device_store
+        assert (m._dev_x is not None and m._dev_x.version == m._store_tag()) == device_store
         out = []
         for k in range(6):
             a = n_bulk + 400 * k
             uu, ii = u[a:a + 400] + (30 * k if k % 2 else 0), i[a:a + 400] + (7 * k if k % 3 == 0 else 0)   # some new ids
             m.fit(list(zip(uu.tolist(), ii.tolist(), ts[a:a + 400].tolist(), r[a:a + 400].tolist())), progress_bar=False)
             if device_store:
-                assert m._dev_x.version == m.interactions.version and m._dev_x.nnz == m.interactions.nnz
+                assert m._dev_x.version == m._store_tag() and m._dev_x.nnz == m.interactions.nnz
             out.append((m.model.item_similarity.copy(), m.recommend_batch(list(range(0, 200, 3)), top_k=7)))
         # incremental Recommender.fit on a numeric DataFrame: the columnar ingest advances the mirror too
         import contextlib, io
@@ -222,13 +224,13 @@ def test_streaming_through_the_device_resident_store_equals_host_exports(monkeyp
         df = pd.DataFrame({"user": u[:300] + 5, "item": i[:300], "tstamp": ts[-1] + 1.0 + np.arange(300), "rating": r[:300]})
         loads = []
         if device_store:
-            orig = m._dev_x.load_csr
-            m._dev_x.load_csr = lambda *a, **k: (loads.append(1), orig(*a, **k))[1]
+            orig = m._dev_x.load_store
+            m._dev_x.load_store = lambda *a, **k: (loads.append(1), orig(*a, **k))[1]
         with contextlib.redirect_stdout(io.StringIO()):
             Recommender(m).fit(df)
         assert not loads                                   # advanced incrementally, never rebuilt from a host export
         if device_store:
-            assert m._dev_x.version == m.interactions.version and m._dev_x.nnz == m.interactions.nnz
+            assert m._dev_x.version == m._store_tag() and m._dev_x.nnz == m.interactions.nnz
         out.append((m.model.item_similarity.copy(), m.recommend_batch(list(range(0, 200, 3)), top_k=7)))
         return out
 
@@ -242,7 +244,7 @@ def test_streaming_through_the_device_resident_store_equals_host_exports(monkeyp
 def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, decay, monkeypatch):
     """SLIM.bulk_fit takes X from the resident store (host CSR keys, CSC order by a device sort): same W
     bits and dtype (float64 after a serial fit, float32 after a parallel one) as through to_csc() -- also for
-    a store with time decay, whose values the host evaluates at the current max_timestamp either way."""
+    a store with time decay, whose resident values are re-evaluated on the device (csrc/store_device.hip)."""
     from rtrec_amd import SLIM
     rng = np.random.default_rng(5)
     U, I, n = 900, 200, 20_000
@@ -255,7 +257,6 @@ def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, de
         m = SLIM(min_value=0, max_value=15, nn_feature_selection=8, **kw)
         m.add_interactions(rows)
         m.bulk_fit(parallel=parallel, progress_bar=False)
-        # with time decay the resident copy serves the full matrix (bulk_fit, recommend), never mini-batches
         assert (m._dev_x is not None and m._dev_x.version == m._store_tag()) == device_store
         return m.model.item_similarity, m.recommend_batch(list(range(0, 300, 7)), top_k=5)
 

@@ -637,3 +637,40 @@ def test_ranking_metrics_match_reference_goldens():
             assert agg[k] == pytest.approx(ref[k], rel=1e-12), (k, size)
     assert metrics.mrr([r for r, _ in pairs], [t for _, t in pairs], 5) == pytest.approx(g["aggregate"]["mrr_5"], rel=1e-12)
     assert metrics.map_score([r for r, _ in pairs], [t for _, t in pairs], 5) == pytest.approx(g["aggregate"]["map_5"], rel=1e-12)
+
+
+def test_device_resident_store_with_time_decay_tracks_the_host_store():
+    """The resident store keeps raw values + timestamps for a store with time decay and re-values X whenever
+    max_timestamp moves (here on CPU tensors, through the host's libm routine): after every mini-batch its CSR / CSC
+    and the touched-columns matrix equal the host exports bit for bit -- also across a rebuild from the store block."""
+    import torch
+    from rtrec_amd.utils.device_store import DeviceInteractions
+    rng = np.random.default_rng(8)
+    st = UserItemInteractions(min_value=0, max_value=15, decay_in_days=30)
+    mir = DeviceInteractions(torch, torch.device("cpu"))
+    blk = st._compact()
+    mir.load_store(blk.key, blk.val, blk.ts, st.shape[0], st.shape[1], (st.version, st.max_timestamp), rate=st.decay_rate,
+                   now=st.max_timestamp)
+    t = 1.7e9
+    for step in range(7):
+        m = 300 + 80 * step
+        u = rng.integers(0, 300 + 30 * step, m)
+        i = rng.zipf(1.4, m) % (80 + 10 * step)
+        r = rng.integers(1, 6, m).astype(float)
+        st.add_interactions_batch(u, i, t + np.sort(rng.random(m)) * 5 * 86400.0, r)
+        t += 5 * 86400.0
+        keys = np.unique(st._keys(u, i))
+        _, val, ts = st._lookup(keys)
+        tag = (st.version, st.max_timestamp)
+        if step == 3:
+            blk = st._compact()
+            mir.load_store(blk.key, blk.val, blk.ts, st.shape[0], st.shape[1], tag, rate=st.decay_rate, now=st.max_timestamp)
+        else:
+            mir.apply(keys >> 32, keys & 0xFFFFFFFF, val, st.shape[0], st.shape[1], tag, tstamps=ts, now=st.max_timestamp)
+        assert mir.version == tag and mir.nnz == st.nnz
+        full = mir.full()
+        _assert_same_matrix(full, st.to_csr(), "csr")
+        _assert_same_matrix(full, st.to_csc(), "csc")
+        items = np.unique(i).tolist()
+        part = mir.partial(np.asarray(items))
+        _assert_same_matrix(part, st.to_csc(items), "csc")
