@@ -143,10 +143,21 @@ def main() -> None:
         dist.barrier()
     t0 = time.time()
     mine = eng.owned_columns(np.arange(I))       # this rank's fit targets, balanced by column length
-    tg, items, coef, count, n_iter = eng.fit_columns(mine, nn_feature_selection=K)
+    d_tg, d_items, d_coef, d_count, n_iter = eng.fit_columns(mine, nn_feature_selection=K, device_out=True)
     torch.cuda.synchronize()
     fit_local = time.time() - t0
-    rows, cols, vals = coefficients_to_updates(tg, items, coef, count)
+    # W stays on the device: the write-back (and, with several ranks, the exchange of the triples) and the score
+    # layouts are tensor ops there; the host copies below only feed this script's bookkeeping
+    t1 = time.time()
+    eng.set_weights(eng.merge_fit(None, I, False, d_tg, d_items, d_coef, d_count))
+    torch.cuda.synchronize()
+    merge_s = time.time() - t1
+    t1 = time.time()
+    eng._layout(compact=True, top_k=top_k)
+    torch.cuda.synchronize()
+    layout_s = time.time() - t1
+    tg, items, coef, count = (t.cpu().numpy() for t in (d_tg, d_items, d_coef, d_count))
+    tg = tg.astype(np.int64)
     # algorithmic bytes of this rank's fit (every datum once per target column):
     # y (8 nnz_j) + the co-occurring user rows that form X^T y (8 |I_u| per u in U_j) + the K selected
     # feature columns (8 nnz(c)) + the written coefficients (8 |S_j|)
@@ -160,18 +171,15 @@ def main() -> None:
     feat = float(col_nnz_all[items[sel_mask]].sum())
     fit_algo_bytes = 8.0 * float(col_nnz_all[mine].sum()) + 8.0 * cooc + 8.0 * feat + 8.0 * float(count.sum())
     if world > 1:
-        parts = [None] * world
-        dist.all_gather_object(parts, (rows, cols, vals))
-        rows = np.concatenate([p[0] for p in parts])
-        cols = np.concatenate([p[1] for p in parts])
-        vals = np.concatenate([p[2] for p in parts])
         t = torch.tensor([fit_local], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         fit_s = float(t.item())
     else:
         fit_s = fit_local
-    W = merge_coefficients(None, I, rows, cols, vals)
-    eng.set_weights(W)
+    W = eng.weights.to_csc(torch)
+    if rank == 0:
+        log(f"[bench] W write-back on the device {merge_s * 1e3:.1f} ms, score layouts built on the device {layout_s * 1e3:.1f} ms "
+            f"(W nnz={W.nnz})")
     # the same fit in the tolerance mode (exact=False: Gram-form CD / tree-reduced dots), timed beside the exact one;
     # the scored W is the exact one
     fit_fast = None
@@ -388,6 +396,9 @@ def main() -> None:
         "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()), "mode": "exact", "tolerance_modes": fit_fast,
+                "to_score": {"write_back_ms": merge_s * 1e3, "layouts_ms": layout_s * 1e3,
+                             "note": "fit output -> W merge -> score layouts, all on the device (engine.merge_fit, "
+                                     "build_tiled_w_device / build_feature_rows_device); no host copy of W is on this path"},
                 "roofline": {"kernel": "fit_columns_kernel<false> (+ fit_columns_mw_kernel for the heaviest targets)",
                              "bound": "hbm", "achieved": fit_algo_bytes / fit_local / 1e9, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": fit_algo_bytes / fit_local / 1e9 / HBM_PEAK_GBS,

@@ -725,10 +725,11 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
     const TileLds<ACC> L = carve_lds<ACC>(smem, S, FT, true, a.kk);
     const ACC ninf = NegInf<ACC>::value();
     const ACC unt = untouched_value(ACC(0));
-    for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
-
     const int n_rows = FT ? *a.row_list_len : a.n_rows;
     const int total = n_rows * a.n_tiles;
+    if (total == 0) return;              // the exact-tie pass usually has nothing to do: leave before touching LDS
+    for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
+
     PF_DECL
 #ifdef SCORE_PROFILE
     const unsigned long long pf_start_ = pf_t_;
@@ -817,13 +818,12 @@ struct MergeArgs {
 template <typename ACC>
 __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs m) {
     const int lane = lane_id();
-    int row = blockIdx.x;
-    if (m.row_list) {
-        if (row >= *m.row_list_len) return;
-        row = m.row_list[row];
-    }
     const ACC *sc = reinterpret_cast<const ACC *>(m.in_score);
     const ACC ninf = NegInf<ACC>::value();
+    // with a row list (the exact-tie pass) a small grid walks the list, which is usually empty; otherwise block = row
+    const int n_work = m.row_list ? *m.row_list_len : m.n_rows;
+    for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
+    const int row = m.row_list ? m.row_list[work] : work;
     constexpr int kMaxPerLane = 16;   // n_lists * kk <= 1024
     Cand<ACC> mine[kMaxPerLane];
     const int total = m.n_lists * m.kk;
@@ -885,6 +885,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs m) {
             const int slot = atomicAdd(m.flag_len, 1);
             m.flag_list[slot] = row;
         }
+    }
     }
 }
 
@@ -1561,7 +1562,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
             mf.s_list_stride = mf.list_stride; mf.s_row_stride = mf.row_stride;
             mf.detect_ties = 0;
             mf.row_list = flag_list; mf.row_list_len = flag_len;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, mf);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows < 2048 ? a.n_rows : 2048), dim3(64), 0, st, mf);
             debug_stage(st, "merge_topk_kernel (exact ties)");
         }
     }

@@ -187,14 +187,33 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     present[t_of, f_of] = True
     n_rows_t = present.sum(axis=1)
     local = np.cumsum(present, axis=1) - 1                  # row -> index inside the tile's compact slice
-    # super-tiles: consecutive tiles staged in LDS as one piece (one barrier per super-tile), packed greedily into
-    # one buffer; at most 32 tiles each
+    packed = _pack_super_tiles(n_rows_t.astype(np.int64), tc)     # consecutive tiles staged in LDS as one piece
+    if packed is None:
+        return None
+    st_tile, super_of, super_kb, first, buf_bytes = packed
+    n_super = len(st_tile) - 1
+    row_bytes = tc * 4
+    tile_off = (first * row_bytes).astype(np.int32)
+    wd = np.zeros(max(int(super_kb[-1]) * 256, 256), dtype=np.float32)
+    base = super_kb[super_of[t_of]] * 256 + first[t_of] * tc
+    wd[base + local[t_of, f_of] * tc + lc % tc] = vals
+    tile_rows = np.zeros((n_tiles, 2), dtype=np.uint64)
+    np.bitwise_or.at(tile_rows, (t_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
+    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=tile_rows.view(np.int64),
+                fr_tile_off=tile_off, fr_super_kb=super_kb.astype(np.int32), fr_super_tile=st_tile.astype(np.int32), fr_rows=R,
+                fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_super=n_super, fr_buf_bytes=buf_bytes)
+
+
+
+def _pack_super_tiles(n_rows_t: np.ndarray, tc: int):
+    """Greedy packing of consecutive tiles into LDS-sized super-tiles (shared by the host and device builders of the
+    feature-row layout).  None when one tile alone does not fit."""
     buf_cap = (160 * 1024 - 16 * 512 - 16) // 2 // 1024 * 1024
     row_bytes = tc * 4
+    n_tiles = len(n_rows_t)
     if int(n_rows_t.max()) * row_bytes > buf_cap:
         return None
-    st_tile = [0]
-    used = 0
+    st_tile, used = [0], 0
     for t in range(n_tiles):
         need = int(n_rows_t[t]) * row_bytes
         if t > st_tile[-1] and (used + need > buf_cap or t - st_tile[-1] >= 32):
@@ -208,18 +227,174 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     super_rows = np.add.reduceat(n_rows_t, st_tile[:-1])
     super_kb = np.zeros(n_super + 1, dtype=np.int64)
     super_kb[1:] = np.cumsum(-(-(super_rows * row_bytes) // 1024))
-    first = np.cumsum(n_rows_t) - n_rows_t                  # rows stored before tile t ...
-    first = first - first[st_tile[:-1]][super_of]           # ... inside its super-tile
-    tile_off = (first * row_bytes).astype(np.int32)
-    wd = np.zeros(max(int(super_kb[-1]) * 256, 256), dtype=np.float32)
-    base = super_kb[super_of[t_of]] * 256 + first[t_of] * tc
-    wd[base + local[t_of, f_of] * tc + lc % tc] = vals
-    tile_rows = np.zeros((n_tiles, 2), dtype=np.uint64)
-    np.bitwise_or.at(tile_rows, (t_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
+    first = np.cumsum(n_rows_t) - n_rows_t
+    first = first - first[st_tile[:-1]][super_of]
     buf_bytes = max(64 * 1024, int(-(-(int(super_rows.max()) * row_bytes) // 1024) * 1024))
-    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=tile_rows.view(np.int64),
-                fr_tile_off=tile_off, fr_super_kb=super_kb.astype(np.int32), fr_super_tile=st_tile.astype(np.int32), fr_rows=R,
-                fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_super=n_super, fr_buf_bytes=buf_bytes)
+    return st_tile, super_of, super_kb, first, buf_bytes
+
+
+def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int) -> Optional[Dict[str, Any]]:
+    """build_feature_rows for a W that is resident on the device as COO triples (int64 rows / cols sorted by (col, row),
+    float32 vals): the same layout, built with tensor ops -- only the per-tile row counts (a few dozen integers) visit
+    the host for the super-tile packing.  Returns device tensors (plus the scalars and, for bench.py, small host copies)."""
+    sel = (cols >= col_lo) & (cols < col_hi)
+    r, c, v = rows[sel], cols[sel], vals[sel]
+    if r.numel() == 0:
+        return None
+    F = torch.unique(r)
+    col_ids_sorted = torch.unique(c)
+    R, n_cols = int(F.numel()), int(col_ids_sorted.numel())
+    if R > FR_MAX_ROWS or r.numel() < FR_MIN_FILL * R * n_cols:
+        return None
+    tc = 256 if R <= 66 else 128
+    n_tiles = -(-n_cols // tc)
+    if n_tiles * (tc // 64) > 416:
+        return None
+    dev = r.device
+    i64 = torch.int64
+    fmap = torch.full((n_items,), -1, dtype=torch.int32, device=dev)
+    fmap[F] = torch.arange(R, dtype=torch.int32, device=dev)
+    f_of = fmap[r].to(i64)
+    c_of = torch.searchsorted(col_ids_sorted, c)
+    # column order: lexicographic by row pattern, rarest row most significant, descending (see build_feature_rows)
+    counts = torch.bincount(f_of, minlength=R)
+    by_rarity = torch.argsort(counts, stable=True)
+    rank = torch.empty(R, dtype=i64, device=dev)
+    rank[by_rarity] = torch.arange(R, dtype=i64, device=dev)
+    sig = (R - 1) - rank[f_of]                                  # bit significance of the entry's row: rarest = highest
+    n_words = -(-R // 60)
+    order = torch.arange(n_cols, dtype=i64, device=dev).flip(0)  # ties: descending column position, like the host builder
+    for w in range(n_words):                                     # least significant word first, stable sorts
+        inw = (sig // 60) == w
+        word = torch.zeros(n_cols, dtype=i64, device=dev)
+        word.index_add_(0, c_of[inw], torch.ones_like(sig[inw]) << (sig[inw] % 60))
+        order = order[torch.argsort(word[order], descending=True, stable=True)]
+    fr_col_ids = col_ids_sorted[order].to(torch.int32)
+    fr_col_map = torch.full((n_items,), -1, dtype=torch.int32, device=dev)
+    fr_col_map[fr_col_ids.to(i64)] = torch.arange(n_cols, dtype=torch.int32, device=dev)
+    lc = fr_col_map[c].to(i64)
+    t_of = lc // tc
+    present = torch.zeros((n_tiles, R), dtype=torch.bool, device=dev)
+    present[t_of, f_of] = True
+    n_rows_t = present.sum(dim=1).cpu().numpy().astype(np.int64)
+    packed = _pack_super_tiles(n_rows_t, tc)
+    if packed is None:
+        return None
+    st_tile, super_of, super_kb, first, buf_bytes = packed
+    local = torch.cumsum(present.to(i64), dim=1) - 1
+    d_super_kb = torch.from_numpy(super_kb).to(dev)
+    d_super_of = torch.from_numpy(super_of).to(dev)
+    d_first = torch.from_numpy(first).to(dev)
+    wd = torch.zeros(max(int(super_kb[-1]) * 256, 256), dtype=torch.float32, device=dev)
+    base = d_super_kb[d_super_of[t_of]] * 256 + d_first[t_of] * tc
+    wd[base + local[t_of, f_of] * tc + lc % tc] = v
+    # one bit per (row, tile) block that holds a weight
+    blk = torch.zeros((n_tiles, 2), dtype=i64, device=dev)
+    pt, pf = torch.nonzero(present, as_tuple=True)
+    blk.view(-1).index_add_(0, pt * 2 + pf // 64, torch.ones_like(pf) << (pf % 64))
+    fmap_host = fmap.cpu().numpy()
+    host = dict(fr_map=fmap_host, fr_tile_rows=blk.cpu().numpy(), fr_super_kb=super_kb.astype(np.int32), fr_rows=R,
+                fr_tile_cols=tc)
+    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=blk,
+                fr_tile_off=torch.from_numpy((first * tc * 4).astype(np.int32)).to(dev),
+                fr_super_kb=torch.from_numpy(super_kb.astype(np.int32)).to(dev),
+                fr_super_tile=torch.from_numpy(st_tile.astype(np.int32)).to(dev), fr_rows=R, fr_tile_cols=tc,
+                fr_n_tiles=n_tiles, fr_n_super=len(st_tile) - 1, fr_buf_bytes=buf_bytes, fr_host=host,
+                col_ids_sorted=col_ids_sorted)
+
+
+def build_tiled_w_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int, tile_cols: int,
+                         compact: bool = False, dense_fill: Optional[float] = None) -> Optional[Dict[str, Any]]:
+    """build_tiled_w + row_header_table for a W that is resident on the device (COO triples sorted by (col, row)):
+    the same arrays, as device tensors, built with tensor ops."""
+    sel = (cols >= col_lo) & (cols < col_hi)
+    r, c, v = rows[sel], cols[sel], vals[sel]
+    dev, i64 = rows.device, torch.int64
+    col_ids = col_map = None
+    if compact:
+        col_ids = torch.unique(c)
+        n_cols = int(col_ids.numel())
+        kloc = torch.searchsorted(col_ids, c)
+        col_map = torch.full((n_items,), -1, dtype=torch.int32, device=dev)
+        col_map[col_ids] = torch.arange(n_cols, dtype=torch.int32, device=dev)
+    else:
+        n_cols = col_hi - col_lo
+        kloc = c - col_lo
+    if n_cols <= 0:
+        return None
+    S = max(256, min(int(tile_cols), -(-max(n_cols, 1) // 256) * 256))
+    n_tiles = max(1, -(-n_cols // S))
+    seg = (kloc // S) * n_items + r                                # (tile, row) segment of every weight
+    order = torch.argsort(seg * S + kloc % S)                      # by tile, row, column
+    seg, kl, vl = seg[order], kloc[order] % S, v[order]
+    cnt = torch.bincount(seg, minlength=n_tiles * n_items)
+    dense_idx = dense_val = None
+    if dense_fill is not None:
+        dense_keys = torch.nonzero(cnt >= max(64, int(dense_fill * S))).view(-1)
+        if dense_keys.numel():
+            dense_idx = torch.full((n_tiles * n_items,), -1, dtype=torch.int32, device=dev)
+            dense_idx[dense_keys] = torch.arange(dense_keys.numel(), dtype=torch.int32, device=dev)
+            is_dense = dense_idx[seg] >= 0
+            dense_val = torch.zeros(int(dense_keys.numel()) * S, dtype=torch.float32, device=dev)
+            dense_val[dense_idx[seg[is_dense]].to(i64) * S + kl[is_dense]] = vl[is_dense]
+            seg, kl, vl = seg[~is_dense], kl[~is_dense], vl[~is_dense]
+            cnt = torch.bincount(seg, minlength=n_tiles * n_items)
+    starts = torch.zeros(n_tiles * n_items + 1, dtype=i64, device=dev)
+    torch.cumsum(cnt, 0, out=starts[1:])
+    if int(starts[-1]) >= 2 ** 31:
+        raise ValueError("W shard has more than 2**31 stored weights")
+    tile_ptr = torch.empty((n_tiles, n_items + 1), dtype=torch.int32, device=dev)
+    tile_ptr[:, :-1] = starts[:-1].view(n_tiles, n_items).to(torch.int32)
+    tile_ptr[:, -1] = starts[torch.arange(1, n_tiles + 1, device=dev) * n_items].to(torch.int32)
+    hdr = torch.empty((n_tiles, n_items, 4), dtype=torch.int32, device=dev)
+    hdr[:, :, 0] = tile_ptr[:, :-1]
+    hdr[:, :, 1] = tile_ptr[:, 1:]
+    hdr[:, :, 2] = dense_idx.view(n_tiles, n_items) if dense_idx is not None else -1
+    loc = col_map.to(i64) if col_map is not None else torch.arange(n_items, dtype=i64, device=dev) - col_lo
+    loc = torch.where((loc >= 0) & (loc < n_cols), loc, torch.full_like(loc, -1))
+    for t in range(n_tiles):
+        l = loc - t * S
+        hdr[t, :, 3] = torch.where((loc >= 0) & (l >= 0) & (l < S), l, torch.full_like(l, -1)).to(torch.int32)
+    return dict(n_cols=n_cols, tile_cols=S, n_tiles=n_tiles, nnz=int(vl.numel()), dense_idx=dense_idx, dense_val=dense_val,
+                n_dense=0 if dense_idx is None else int(dense_val.numel() // S),
+                tile_ptr=tile_ptr.view(-1), w_col=kl.to(torch.int16), w_val=vl.contiguous(),
+                col_ids=None if col_ids is None else col_ids.to(torch.int32), col_map=col_map, row_hdr=hdr)
+
+
+class DeviceWeights:
+    """W (I x I) resident on the device: COO triples sorted by (column, row) -- int64 rows / cols, float32 vals, no
+    explicit zeros.  It is what a fit writes (SlimEngine.merge_fit), what the score layouts are built from
+    (SlimEngine._layout) and what `item_similarity` is materialised from when the host asks for it (to_csc); `f64`
+    records that the host-visible matrix is float64 (serial fit, slim_elastic.py:252), which selects the float64
+    accumulator of the score kernels."""
+
+    __slots__ = ("rows", "cols", "vals", "n_items", "f64", "lossy", "_host", "_csc")
+
+    def __init__(self, rows, cols, vals, n_items: int, f64: bool, host: Optional[sp.csc_matrix] = None, lossy: bool = False):
+        self.rows, self.cols, self.vals, self.n_items, self.f64 = rows, cols, vals, int(n_items), bool(f64)
+        self.lossy = bool(lossy)       # uploaded from a float64 host matrix whose values are not float32 numbers
+        self._host = host
+        self._csc = None
+
+    @property
+    def nnz(self) -> int:
+        return int(self.vals.numel())
+
+    def csc_arrays(self, torch):
+        """(ptr, row, val) int32 / int32 / float32 device tensors: the CSC view the item-to-item kernel reads."""
+        if self._csc is None:
+            ptr = torch.searchsorted(self.cols, torch.arange(self.n_items + 1, dtype=torch.int64, device=self.cols.device))
+            self._csc = (ptr.to(torch.int32), self.rows.to(torch.int32), self.vals)
+        return self._csc
+
+    def to_csc(self, torch) -> sp.csc_matrix:
+        """The host matrix (sorted indices), downloaded once."""
+        if self._host is None:
+            ptr, row, val = self.csc_arrays(torch)
+            dt = np.float64 if self.f64 else np.float32
+            self._host = sp.csc_matrix((val.cpu().numpy().astype(dt), row.cpu().numpy(), ptr.cpu().numpy()),
+                                       shape=(self.n_items, self.n_items))
+        return self._host
 
 
 class HipBackend:
@@ -493,14 +668,16 @@ class SlimEngine:
     def fit_columns(self, targets: Sequence[int], alpha: float = 0.1, l1_ratio: float = 0.1,
                     positive: bool = True, max_iter: int = 100, tol: float = 1e-4, random_state: Optional[int] = 43,
                     nn_feature_selection: Optional[int] = None, n_slots: Optional[int] = None,
-                    trace: bool = False, exact: bool = True, mode: Optional[str] = None
-                    ) -> Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+                    trace: bool = False, exact: bool = True, mode: Optional[str] = None, device_out: bool = False
+                    ) -> Tuple[Any, Any, Any, Any, np.ndarray]:
         """Fit the given target columns on this GPU.  mode: "exact" (default; bit-identical to scikit-learn),
         "gram" (Gram-form coordinate descent where all features are in the Gram matrix, tree-reduced dots elsewhere;
         a few 1e-5 relative; what exact=False selects) or "shuffle" (tree-reduced dots only) -- rtrec_fit_opts.fast.
 
         Returns (targets_in_processing_order, items[n, cap], coef[n, cap], count[n], n_iter[n]);
-        row t describes model.sparse_coef_ of target t (see rtrec_slim_fit_columns).
+        row t describes model.sparse_coef_ of target t (see rtrec_slim_fit_columns).  device_out=True (feature
+        selection only) leaves the first four on the device -- int32 targets, the kernels' output blocks -- for
+        merge_fit(); only n_iter (one int per target) is downloaded.
         """
         be, X = self.be, self._X
         if "cptr" not in X:
@@ -592,8 +769,11 @@ class SlimEngine:
 
         # chunk so that the output block stays below ~1 GiB (matters for K=None, cap = I)
         chunk = max(1, min(n, int((1 << 30) // max(cap * 8, 1)))) if n else 1
-        items_out = np.empty((n, cap), dtype=np.int32)
-        coef_out = np.empty((n, cap), dtype=np.float32)
+        if device_out and K <= 0:
+            raise ValueError("device_out needs nn_feature_selection (the all-features output block is host-sized)")
+        kept: List[Dict[str, Any]] = []
+        items_out = np.empty((0 if device_out else n, cap), dtype=np.int32)
+        coef_out = np.empty((0 if device_out else n, cap), dtype=np.float32)
         count_out = np.empty((n,), dtype=np.int32)
         niter_out = np.empty((n,), dtype=np.int32)
         trace_out = np.zeros((n, 8), dtype=np.int64) if trace else None
@@ -616,6 +796,9 @@ class SlimEngine:
 
         def collect(d):
             lo_, hi_ = d["lo"], d["hi"]
+            if device_out:
+                kept.append(d)
+                return
             items_out[lo_:hi_] = d["items"].cpu().numpy()
             coef_out[lo_:hi_] = d["coef"].cpu().numpy()
             count_out[lo_:hi_] = d["count"].cpu().numpy()
@@ -646,6 +829,12 @@ class SlimEngine:
                 niter_out[over] = full[3]
                 items_out, coef_out = items_w, coef_w
         self.last_fit_stats = {"n_targets": n, "slots": slots, "cap": cap, "trace": trace_out, "n_heavy": n_heavy}
+        if device_out:
+            kept.sort(key=lambda d: d["lo"])
+            cat = (lambda k, shape, dt: torch.cat([d[k] for d in kept]) if kept else be.empty(shape, dt))
+            d_niter = cat("niter", (0,), torch.int32)
+            return (cat("t", (0,), torch.int32), cat("items", (0, cap), torch.int32), cat("coef", (0, cap), torch.float32),
+                    cat("count", (0,), torch.int32), d_niter.cpu().numpy())
         return targets, items_out, coef_out, count_out, niter_out
 
     def _fit_overflow(self, targets: np.ndarray, cfg, U: int, I: int, slots: int):
@@ -664,21 +853,72 @@ class SlimEngine:
         return items.cpu().numpy(), coef.cpu().numpy(), count.cpu().numpy(), niter.cpu().numpy()
 
     # ------------------------------------------------------------------------------ W
-    def set_weights(self, W_csc: sp.csc_matrix, acc_f64: bool = False) -> None:
-        """Register W (I x I, CSC).  The tiled layouts of this rank's column shard are built and
-        uploaded on first use: a compacted one (columns with at least one weight) for SPARSE mode,
-        a plain one for DENSE / CANDIDATES mode."""
-        be = self.be
-        n_items = W_csc.shape[1]
-        lo, hi = (0, n_items) if self.score_shard == "rows" else shard_bounds(n_items, self.world_size, self.rank)
+    def upload_weights(self, W_csc: sp.csc_matrix, acc_f64: Optional[bool] = None) -> DeviceWeights:
+        """Host W (I x I, CSC) -> DeviceWeights (weights are float32 on the device, like every layout built from them)."""
+        be, torch = self.be, self.be.torch
         W_csc = W_csc if W_csc.has_sorted_indices else W_csc.sorted_indices()
-        W: Dict[str, Any] = {"n_items": n_items, "col_lo": lo, "col_hi": hi, "acc_f64": bool(acc_f64),
-                             "host": W_csc, "layouts": {}}
-        # CSC copy for similar_items (whole matrix is small: <= K entries per column)
-        W["cptr"] = be.to_dev(np.asarray(W_csc.indptr, dtype=np.int32))
-        W["crow"] = be.to_dev(np.asarray(W_csc.indices, dtype=np.int32))
-        W["cval"] = be.to_dev(np.asarray(W_csc.data, dtype=np.float32))
-        self._W = W
+        n_items = W_csc.shape[1]
+        data = np.asarray(W_csc.data)
+        nz = data != 0
+        cols = np.repeat(np.arange(n_items, dtype=np.int64), np.diff(W_csc.indptr))
+        f64 = bool(W_csc.dtype == np.float64) if acc_f64 is None else bool(acc_f64)
+        d32 = data[nz].astype(np.float32)
+        lossy = bool(data.dtype != np.float32 and not np.array_equal(d32.astype(data.dtype), data[nz]))
+        return DeviceWeights(be.to_dev(np.asarray(W_csc.indices, dtype=np.int64)[nz]), be.to_dev(cols[nz]), be.to_dev(d32),
+                             n_items, f64, host=W_csc if nz.all() else None, lossy=lossy)
+
+    def set_weights(self, W: Any, acc_f64: Optional[bool] = None) -> None:
+        """Register W: a host scipy CSC matrix (uploaded) or a DeviceWeights (what merge_fit returns: nothing moves).
+        The layouts of this rank's column shard are built ON THE DEVICE on first use: a compacted one (columns with
+        at least one weight) plus the feature-row form for SPARSE mode, a plain one for DENSE / CANDIDATES mode."""
+        dw = W if isinstance(W, DeviceWeights) else self.upload_weights(W, acc_f64)
+        if acc_f64 is not None:
+            dw.f64 = bool(acc_f64)
+        n_items = dw.n_items
+        lo, hi = (0, n_items) if self.score_shard == "rows" else shard_bounds(n_items, self.world_size, self.rank)
+        self._W = {"n_items": n_items, "col_lo": lo, "col_hi": hi, "acc_f64": dw.f64, "dw": dw, "layouts": {}}
+
+    @property
+    def weights(self) -> Optional[DeviceWeights]:
+        return self._W.get("dw") if self._W else None
+
+    def merge_fit(self, old: Optional[DeviceWeights], n_items: int, f64: bool, d_targets, d_items, d_coef, d_count
+                  ) -> DeviceWeights:
+        """The LIL write-back of slim_elastic.py:271-274 / 371-374 / 554-557 on the device: start from `old`, then for
+        every fitted (i, j) a non-zero value overwrites W[i, j] and an explicit zero deletes it; entries of column j
+        that the new solution does not mention survive.  The arguments are this rank's
+        fit_columns(device_out=True) tensors; with several ranks the triples are exchanged with all_gather_into_tensor
+        (int64 keys + float32 values, padded to the longest part) -- nothing is pickled and nothing visits the host."""
+        torch = self.be.torch
+        n, cap = d_items.shape
+        mask = torch.arange(cap, device=d_items.device)[None, :] < d_count[:, None]
+        key = (d_targets.to(torch.int64)[:, None] * n_items + d_items.to(torch.int64))[mask]
+        val = d_coef[mask]
+        if self.world_size > 1:
+            import torch.distributed as dist
+            sizes = torch.zeros(self.world_size, dtype=torch.int64, device=key.device)
+            dist.all_gather_into_tensor(sizes, torch.tensor([key.numel()], dtype=torch.int64, device=key.device), group=self.group)
+            sizes = sizes.cpu().tolist()
+            m = max(max(sizes), 1)
+            kp = torch.zeros(m, dtype=torch.int64, device=key.device); kp[:key.numel()] = key
+            vp = torch.zeros(m, dtype=torch.float32, device=key.device); vp[:val.numel()] = val
+            ka = torch.empty(m * self.world_size, dtype=torch.int64, device=key.device)
+            va = torch.empty(m * self.world_size, dtype=torch.float32, device=key.device)
+            dist.all_gather_into_tensor(ka, kp, group=self.group)
+            dist.all_gather_into_tensor(va, vp, group=self.group)
+            key = torch.cat([ka[r * m:r * m + s] for r, s in enumerate(sizes)])
+            val = torch.cat([va[r * m:r * m + s] for r, s in enumerate(sizes)])
+        if old is not None and old.nnz:
+            inside = (old.rows < n_items) & (old.cols < n_items)
+            o_key = (old.cols * n_items + old.rows)[inside]
+            keep = ~torch.isin(o_key, key)
+            key = torch.cat([o_key[keep], key])
+            val = torch.cat([old.vals[inside][keep], val])
+        nz = val != 0
+        key, val = key[nz], val[nz]
+        order = torch.argsort(key)
+        key = key[order]
+        return DeviceWeights(key % n_items, key // n_items, val[order].contiguous(), n_items, f64)
 
     def _layout(self, compact: bool, top_k: int = 10) -> Optional[Dict[str, Any]]:
         """Tiled layout of this rank's shard.  The tile width is self.tile_cols unless the merge of the
@@ -698,35 +938,20 @@ class SlimEngine:
         key = (compact, tile)
         if key not in W["layouts"]:
             lay = None
+            dw: DeviceWeights = W["dw"]
+            torch = be.torch
             if W["col_hi"] > W["col_lo"]:
-                T = build_tiled_w(W["host"], W["col_lo"], W["col_hi"], tile, compact=compact,
-                                  dense_fill=DENSE_ROW_FILL if compact else None)
-                if T.n_cols > 0:
-                    lay = dict(n_cols=T.n_cols, tile_cols=T.tile_cols, n_tiles=T.n_tiles, nnz=int(T.w_val.shape[0]),
-                               dense_idx=be.to_dev(T.dense_idx) if T.dense_idx is not None else None,
-                               dense_val=be.to_dev(T.dense_val) if T.dense_val is not None else None,
-                               n_dense=0 if T.dense_idx is None else int(T.dense_val.shape[0] // T.tile_cols),
-                               tile_ptr=be.to_dev(T.tile_ptr), w_col=be.to_dev(T.w_col.view(np.int16)),
-                               w_val=be.to_dev(T.w_val),
-                               col_ids=be.to_dev(T.col_ids) if T.col_ids is not None else None,
-                               col_map=be.to_dev(T.col_map) if T.col_map is not None else None,
-                               row_hdr=be.to_dev(row_header_table(T)))
-                    if compact:
-                        W["n_active"] = T.n_cols
-                        if not W["acc_f64"] and getattr(be, "supports_feature_rows", False):
-                            fr = build_feature_rows(W["host"], W["col_lo"], W["col_hi"], T.col_ids, T.col_map)
-                            if fr is not None:
-                                nb = int(be.lib.rtrec_slim_score_fr_scratch_bytes(fr["fr_n_tiles"], fr["fr_tile_cols"]))
-                                lay["fr_host"] = fr      # host copy: bench.py prices the kernel's work from it
-                                lay.update(fr_map=be.to_dev(fr["fr_map"]), fr_w=be.to_dev(fr["fr_w"]),
-                                           fr_col_ids=be.to_dev(fr["fr_col_ids"]), fr_col_map=be.to_dev(fr["fr_col_map"]),
-                                           fr_tile_rows=be.to_dev(fr["fr_tile_rows"]),
-                                           fr_tile_off=be.to_dev(fr["fr_tile_off"]), fr_super_kb=be.to_dev(fr["fr_super_kb"]),
-                                           fr_super_tile=be.to_dev(fr["fr_super_tile"]),
-                                           fr_rows=fr["fr_rows"], fr_tile_cols=fr["fr_tile_cols"],
-                                           fr_n_tiles=fr["fr_n_tiles"], fr_n_super=fr["fr_n_super"],
-                                           fr_buf_bytes=fr["fr_buf_bytes"],
-                                           fr_scratch=be.empty((nb,), be.torch.uint8))
+                lay = build_tiled_w_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], tile,
+                                           compact=compact, dense_fill=DENSE_ROW_FILL if compact else None)
+                if lay is not None and compact:
+                    W["n_active"] = lay["n_cols"]
+                    if not W["acc_f64"] and getattr(be, "supports_feature_rows", False):
+                        fr = build_feature_rows_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"])
+                        if fr is not None:
+                            nb = int(be.lib.rtrec_slim_score_fr_scratch_bytes(fr["fr_n_tiles"], fr["fr_tile_cols"]))
+                            fr.pop("col_ids_sorted")
+                            lay.update(fr)           # fr_host: small host copies bench.py prices the kernel's work from
+                            lay["fr_scratch"] = be.empty((nb,), torch.uint8)
             W["layouts"][key] = lay
         return W["layouts"][key]
 
@@ -1012,7 +1237,8 @@ class SlimEngine:
         ids = be.empty((n, top_k), torch.int32)
         sc = be.empty((n, top_k), torch.float32)
         cnt = be.empty((n,), torch.int32)
-        be.similar_topk(d_q, W, top_k, ids, sc, cnt)
+        cptr, crow, cval = W["dw"].csc_arrays(torch)
+        be.similar_topk(d_q, {"cptr": cptr, "crow": crow, "cval": cval}, top_k, ids, sc, cnt)
         return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
 
 

@@ -7,8 +7,10 @@ arguments, same return types, same error messages -- so callers written against 
 calling scikit-learn's ElasticNet and over users calling scipy/numpy/sorted(), this class uploads
 the matrices once and calls the HIP kernels (rtrec_amd/csrc) through rtrec_amd.engine.
 
-`item_similarity` stays a host scipy.sparse.csc_matrix (public attribute, pickled, read by
-HybridSlimFM); the GPU keeps its own tiled copy that is rebuilt whenever the attribute changes.
+W lives on the device between fit and score (engine.DeviceWeights: the fit kernels' output is merged into it and
+the score layouts are built from it there).  `item_similarity` is still the reference's public attribute -- a host
+scipy.sparse.csc_matrix, pickled, read by HybridSlimFM -- but it is materialised from the device copy only when
+somebody reads it; assigning to it replaces the device copy.
 """
 from __future__ import annotations
 
@@ -20,7 +22,7 @@ import scipy.sparse as sp
 from numpy import ndarray
 
 from ... import _native
-from ...engine import SlimEngine, coefficients_to_updates, merge_coefficients
+from ...engine import DeviceWeights, SlimEngine, coefficients_to_updates, merge_coefficients
 
 
 def _default_engine() -> SlimEngine:
@@ -57,20 +59,34 @@ class SLIMElastic:
         # "gram" (Gram-form coordinate descent: a few 1e-5 relative, several times faster on dense catalogues; also
         # selected by exact=False) or "shuffle" (tree-reduced dot products on the float32 residual) -- DESIGN.md 3.4
         self.fit_mode = config.get("fit_mode", "exact" if config.get("exact", True) else "gram")
-        self._item_similarity: Optional[sp.csc_matrix] = None
+        self._item_similarity: Optional[sp.csc_matrix] = None    # host copy of W (None while only the device holds it)
+        self._w_dev: Optional[DeviceWeights] = None              # device copy of W (None until first needed)
         self._engine = engine
-        self._w_on_device: Optional[int] = None      # id() of the matrix the GPU copy was built from
         self.n_iter_: Optional[np.ndarray] = None    # sweeps per fitted column of the last fit
 
     # ---------------------------------------------------------------- state
     @property
     def item_similarity(self) -> Optional[sp.csc_matrix]:
+        if self._item_similarity is None and self._w_dev is not None:
+            self._item_similarity = self._w_dev.to_csc(self.engine.be.torch)     # one download, on demand
         return self._item_similarity
 
     @item_similarity.setter
     def item_similarity(self, W: Optional[sp.csc_matrix]) -> None:
         self._item_similarity = W
-        self._w_on_device = None
+        self._w_dev = None
+
+    @property
+    def is_fitted(self) -> bool:
+        return self._item_similarity is not None or self._w_dev is not None
+
+    @property
+    def n_items_fitted(self) -> int:
+        """Number of item columns of W (item_similarity.shape[1]) without materialising the host matrix."""
+        return self._w_dev.n_items if self._w_dev is not None else self._item_similarity.shape[1]
+
+    def _w_is_f64(self) -> bool:
+        return self._w_dev.f64 if self._w_dev is not None else self._item_similarity.dtype == np.float64
 
     @property
     def engine(self) -> SlimEngine:
@@ -80,8 +96,9 @@ class SLIMElastic:
 
     def __getstate__(self) -> Dict[str, Any]:
         state = dict(self.__dict__)
+        state["_item_similarity"] = self.item_similarity      # the host matrix is what is pickled
         state["_engine"] = None
-        state["_w_on_device"] = None
+        state["_w_dev"] = None
         return state
 
     def __setstate__(self, state: Dict[str, Any]) -> None:
@@ -92,7 +109,8 @@ class SLIMElastic:
         self.__dict__.update(state)
         self.__dict__.setdefault("_item_similarity", None)
         self._engine = None
-        self._w_on_device = None
+        self._w_dev = None
+        self.__dict__.pop("_w_on_device", None)
         self.__dict__.setdefault("n_iter_", None)
 
     def _check_optim(self) -> None:
@@ -104,9 +122,10 @@ class SLIMElastic:
         raise ValueError(f"Invalid Optimizer name: {self.optim_name}")
 
     # ---------------------------------------------------------------- fit
-    def _fit_targets(self, X_csc: sp.csc_matrix, targets: np.ndarray, W_old: Optional[sp.csc_matrix],
-                     dtype) -> sp.csc_matrix:
-        """Fit `targets` on the GPU(s) and write the coefficients back like the reference's LIL loop."""
+    def _fit_targets(self, X_csc: sp.csc_matrix, targets: np.ndarray, keep_old: bool, f64: bool) -> None:
+        """Fit `targets` on the GPU(s) and write the coefficients back like the reference's LIL loop: into the existing
+        W (`keep_old`) or into an empty one.  With feature selection the whole write-back happens on the device
+        (SlimEngine.merge_fit) and the host matrix is only built when `item_similarity` is read."""
         self._check_optim()
         eng = self.engine
         if isinstance(X_csc, dict):       # already resident on the device (utils/device_store.py)
@@ -115,11 +134,26 @@ class SLIMElastic:
         else:
             n_items = X_csc.shape[1]
             eng.set_interactions(X_csc)
+        targets = np.unique(np.asarray(targets, dtype=np.int64))     # a column listed twice is fitted once
         mine = eng.owned_columns(targets)
-        tg, items, coef, count, n_iter = eng.fit_columns(
-            mine, alpha=self.alpha, l1_ratio=self.l1_ratio, positive=self.positive_only, max_iter=self.max_iter,
-            tol=self.tol, random_state=self.random_state, nn_feature_selection=self.nn_feature_selection,
-            **({} if getattr(self, "fit_mode", "exact") == "exact" else {"mode": self.fit_mode}))
+        kw = dict(alpha=self.alpha, l1_ratio=self.l1_ratio, positive=self.positive_only, max_iter=self.max_iter,
+                  tol=self.tol, random_state=self.random_state, nn_feature_selection=self.nn_feature_selection,
+                  **({} if getattr(self, "fit_mode", "exact") == "exact" else {"mode": self.fit_mode}))
+        old_dev: Optional[DeviceWeights] = None
+        if keep_old and self.is_fitted:
+            if self._w_dev is None:
+                W = self._item_similarity
+                self._w_dev = eng.upload_weights(W if isinstance(W, sp.csc_matrix) else sp.csc_matrix(W))
+            old_dev = self._w_dev
+        if self.nn_feature_selection is not None and (old_dev is None or not old_dev.lossy):
+            d_t, d_items, d_coef, d_count, n_iter = eng.fit_columns(mine, device_out=True, **kw)
+            self.n_iter_ = n_iter
+            self._w_dev = eng.merge_fit(old_dev, n_items, f64, d_t, d_items, d_coef, d_count)
+            self._item_similarity = None
+            eng.set_weights(self._w_dev)
+            return
+        # all-features fits (output block sized for the host) and float64 matrices that float32 cannot hold
+        tg, items, coef, count, n_iter = eng.fit_columns(mine, **kw)
         rows, cols, vals = coefficients_to_updates(tg, items, coef, count)
         self.n_iter_ = n_iter
         if eng.world_size > 1:
@@ -129,10 +163,15 @@ class SLIMElastic:
             rows = np.concatenate([p[0] for p in parts])
             cols = np.concatenate([p[1] for p in parts])
             vals = np.concatenate([p[2] for p in parts])
+        W_old = self.item_similarity if keep_old else None
         if W_old is not None and W_old.shape[0] != n_items:
             W_old = W_old.copy()
             W_old.resize((n_items, n_items))
-        return merge_coefficients(W_old, n_items, rows, cols, vals, dtype=dtype)
+        self.item_similarity = merge_coefficients(W_old, n_items, rows, cols, vals, dtype=np.float64 if f64 else np.float32)
+
+    def _merge_dtype_f64(self) -> bool:
+        """dtype of a merge into the existing matrix: float32 when there is none yet (slim_elastic.py:322-327)."""
+        return self._w_is_f64() if self.is_fitted else False
 
     @staticmethod
     def _as_csc(interaction_matrix: Any, err: str) -> sp.csc_matrix:
@@ -152,7 +191,7 @@ class SLIMElastic:
             logging.warning("Multiprocessing is only supported for CSC format. Fitting in single process.")
         X = self._as_csc(interaction_matrix,
                          "Interaction matrix must be a scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
-        self.item_similarity = self._fit_targets(X, np.arange(X.shape[1]), None, np.float64)
+        self._fit_targets(X, np.arange(X.shape[1]), False, True)
         return self
 
     def fit_in_parallel(self, interaction_matrix: sp.csc_matrix, item_ids: Optional[ndarray] = None,
@@ -164,9 +203,7 @@ class SLIMElastic:
             raise ValueError("Interaction matrix must be in CSC format for parallel processing.")
         n_items = interaction_matrix.shape[1]
         targets = np.arange(n_items) if item_ids is None else np.asarray(item_ids, dtype=np.int64)
-        W_old = self.item_similarity
-        dtype = np.float32 if W_old is None else W_old.dtype
-        self.item_similarity = self._fit_targets(interaction_matrix, targets, W_old, dtype)
+        self._fit_targets(interaction_matrix, targets, True, self._merge_dtype_f64())
         return self
 
     def partial_fit(self, interaction_matrix: sp.csr_matrix, user_ids: List[int], parallel: bool = False,
@@ -184,9 +221,7 @@ class SLIMElastic:
             return self.fit_in_parallel(interaction_matrix, item_ids=np.array(updated_items), progress_bar=progress_bar)
         X = self._as_csc(interaction_matrix,
                          "Interaction matrix must be a scipy.sparse.csr_matrix or scipy.sparse.csc_matrix.")
-        W_old = self.item_similarity
-        dtype = np.float32 if W_old is None else W_old.dtype
-        self.item_similarity = self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), W_old, dtype)
+        self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), True, self._merge_dtype_f64())
         return self
 
     def fit_device(self, X: Dict[str, Any], parallel: bool = False) -> "SLIMElastic":
@@ -195,34 +230,32 @@ class SLIMElastic:
         existing float32 one, exactly like fit / fit_in_parallel."""
         targets = np.arange(int(X["n_items"]))
         if parallel:
-            W_old = self.item_similarity
-            dtype = np.float32 if W_old is None else W_old.dtype
-            self.item_similarity = self._fit_targets(X, targets, W_old, dtype)
+            self._fit_targets(X, targets, True, self._merge_dtype_f64())
         else:
-            self.item_similarity = self._fit_targets(X, targets, None, np.float64)
+            self._fit_targets(X, targets, False, True)
         return self
 
     def partial_fit_items_device(self, X: Dict[str, Any], updated_items: List[int]) -> "SLIMElastic":
         """partial_fit_items for a matrix that is already resident on the device: `X` is the array set of
         DeviceInteractions.partial() plus n_users / n_items."""
-        W_old = self.item_similarity
-        dtype = np.float32 if W_old is None else W_old.dtype
-        self.item_similarity = self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), W_old, dtype)
+        self._fit_targets(X, np.asarray(list(updated_items), dtype=np.int64), True, self._merge_dtype_f64())
         return self
 
     # ---------------------------------------------------------------- score
     def _sync_weights(self) -> None:
-        W = self._item_similarity
-        if self._w_on_device != id(W):
+        """Make the engine score with this model's W (a no-op while it already does)."""
+        if self._w_dev is None:
+            W = self._item_similarity
             Wc = W if isinstance(W, sp.csc_matrix) else sp.csc_matrix(W)
-            self.engine.set_weights(Wc, acc_f64=(Wc.dtype == np.float64))
-            self._w_on_device = id(W)
+            self._w_dev = self.engine.upload_weights(Wc, acc_f64=(Wc.dtype == np.float64))
+        if self.engine.weights is not self._w_dev:
+            self.engine.set_weights(self._w_dev)
 
     def _topk(self, Xb: sp.csr_matrix, candidate_item_ids: Optional[List[int]], top_k: int, filter_interacted: bool,
               dense_output: bool, row_ids: Optional[Sequence[int]] = None):
         """(ids[B,k], scores[B,k], counts[B]) for the rows of Xb (or rows `row_ids` of the resident X)."""
         self._sync_weights()
-        n_items = self._item_similarity.shape[1]
+        n_items = self.n_items_fitted
         col_rank = None
         if candidate_item_ids is not None:
             mode = _native.TOPK_CANDIDATES
@@ -254,7 +287,7 @@ class SLIMElastic:
         slim_elastic.py:661-672 (candidates), :744-779 (dense) and :782-818 (sparse: stored non-zero products
         only, stable sort over scipy's reverse-first-touch product order) in numpy.  Unspecified tie orders
         (numpy's unstable argsort) follow the same canonical rule as the kernels."""
-        W = self._item_similarity
+        W = self.item_similarity
         n_items = W.shape[1]
         Xb = Xb.tocsr()
         if Xb.shape[1] != n_items:
@@ -306,7 +339,7 @@ class SLIMElastic:
     def recommend(self, user_id: int, interaction_matrix: sp.csr_matrix,
                   candidate_item_ids: Optional[List[int]] = None, top_k: int = 10, filter_interacted: bool = True,
                   dense_output: bool = True, ret_scores: bool = False) -> List[int] | Tuple[List[int], ndarray]:
-        if self.item_similarity is None:
+        if not self.is_fitted:
             raise RuntimeError("Model must be fitted before calling predict.")
         out = self.recommend_batch([user_id], interaction_matrix, candidate_item_ids, top_k, filter_interacted,
                                    dense_output, ret_scores)
@@ -316,7 +349,7 @@ class SLIMElastic:
                         candidate_item_ids: Optional[List[int]] = None, top_k: int = 10,
                         filter_interacted: bool = True, dense_output: bool = True, ret_scores: bool = False
                         ) -> List[List[int]] | List[Tuple[List[int], ndarray]]:
-        if self.item_similarity is None:
+        if not self.is_fitted:
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
         if len(user_ids) == 0:
             return []
@@ -333,14 +366,14 @@ class SLIMElastic:
 
     # ---------------------------------------------------------------- predict (dense / sparse score rows)
     def _not_fitted(self, what: str) -> None:
-        if self.item_similarity is None:
+        if not self.is_fitted:
             raise RuntimeError(f"Model must be fitted before calling {what}.")
 
     def _predict_rows(self, Xb: sp.csr_matrix, dense_output: bool):
         """Xb . W as the reference's safe_sparse_dot returns it: ndarray if dense_output, else a CSR
         (canonical: sorted indices, exact zeros dropped -- scipy's unsorted product order is not kept)."""
         self._sync_weights()
-        n_items = self._item_similarity.shape[1]
+        n_items = self.n_items_fitted
         Xb = Xb.tocsr()
         if Xb.shape[1] != n_items:
             Xb = Xb.copy()
@@ -368,9 +401,9 @@ class SLIMElastic:
     # ---------------------------------------------------------------- item-to-item
     def similar_items(self, item_id: int, top_k: int = 10, ret_ndarrays: bool = False
                       ) -> List[Tuple[int, float]] | Tuple[ndarray, ndarray]:
-        if self.item_similarity is None:
+        if not self.is_fitted:
             raise RuntimeError("Model must be fitted before calling similar_items.")
-        n_items = self.item_similarity.shape[1]
+        n_items = self.n_items_fitted
         if not 0 <= item_id < n_items or top_k <= 0:
             ids, sc = np.empty(0, np.int32), np.empty(0, np.float32)
         else:
@@ -384,9 +417,9 @@ class SLIMElastic:
     def similar_items_batch(self, item_ids: List[int], top_k: int = 10) -> List[List[Tuple[int, float]]]:
         """[similar_items(i, top_k) for i in item_ids] with ONE launch of similar_topk_kernel and one
         download (the reference answers item-to-item queries one column at a time, slim_elastic.py:820-857)."""
-        if self.item_similarity is None:
+        if not self.is_fitted:
             raise RuntimeError("Model must be fitted before calling similar_items.")
-        n_items = self.item_similarity.shape[1]
+        n_items = self.n_items_fitted
         out: List[List[Tuple[int, float]]] = [[] for _ in item_ids]
         valid = [p for p, i in enumerate(item_ids) if 0 <= i < n_items]
         if not valid or top_k <= 0:

@@ -150,7 +150,7 @@ class SLIM(BaseModel):
     def _recommend_hot_batch(self, user_ids: List[int], candidate_item_ids: Optional[List[int]] = None,
                              users_tags: Optional[List[List[str]]] = None, top_k: int = 10,
                              filter_interacted: bool = True) -> List[List[int]]:
-        if self.model.item_similarity is None:
+        if not self.model.is_fitted:
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
         if len(user_ids) == 0:
             return []
@@ -208,7 +208,7 @@ class SLIM(BaseModel):
                 out[p] = list(zero_row)
         elif not self.item_ids.pass_through and not live.all():
             # dense mode ranks every item of an all-zero row too: highest ids first (stable-argsort rule, D1)
-            n_items = self.model.item_similarity.shape[1]
+            n_items = self.model.n_items_fitted
             k = min(top_k, n_items)
             for p in np.flatnonzero(~live).tolist():
                 out[p] = list(range(n_items - 1, n_items - 1 - k, -1))

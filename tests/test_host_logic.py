@@ -12,7 +12,9 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from rtrec_amd.engine import build_tiled_w, coefficients_to_updates, merge_coefficients, shard_bounds, sklearn_seed
+from rtrec_amd.engine import (DENSE_ROW_FILL, DeviceWeights, SlimEngine, build_feature_rows, build_feature_rows_device, build_tiled_w,
+                              build_tiled_w_device, coefficients_to_updates, merge_coefficients, row_header_table, shard_bounds,
+                              sklearn_seed)
 from rtrec_amd.utils.identifiers import Identifier, IdentifierError
 from rtrec_amd.utils.interactions import UserItemInteractions
 from rtrec_amd.utils.lru import LRUFreqSet
@@ -185,6 +187,87 @@ def test_merge_coefficients_stale_entry_semantics():
     t, it, co, cnt = np.array([2, 0]), np.array([[1, 0, 9], [2, 9, 9]]), np.array([[.1, .2, 9], [.3, 9, 9]], np.float32), np.array([2, 1])
     r, c, v = coefficients_to_updates(t, it, co, cnt)
     assert r.tolist() == [1, 0, 2] and c.tolist() == [2, 2, 0] and np.allclose(v, [.1, .2, .3])
+
+
+def _device_coo(W):
+    import torch
+    coo = W.tocoo()
+    o = np.lexsort((coo.row, coo.col))
+    return (torch, torch.from_numpy(coo.row[o].astype(np.int64)), torch.from_numpy(coo.col[o].astype(np.int64)),
+            torch.from_numpy(coo.data[o].astype(np.float32)))
+
+
+def _feature_row_w(n_items=700, n_feat=40, seed=5):
+    """A W whose weights sit in a few rows (what top-K feature selection on a popularity-skewed catalogue gives)."""
+    rng = np.random.default_rng(seed)
+    feat = np.sort(rng.choice(n_items, n_feat, replace=False))
+    M = np.zeros((n_items, n_items), dtype=np.float32)
+    for j in rng.choice(n_items, int(n_items * 0.8), replace=False):
+        rows = feat[rng.random(n_feat) < rng.uniform(0.05, 0.6)]
+        M[rows, j] = rng.uniform(0.01, 1.0, len(rows)).astype(np.float32)
+    np.fill_diagonal(M, 0)
+    return sp.csc_matrix(M)
+
+
+@pytest.mark.parametrize("shard", [(0, None), (1, 3)])
+def test_device_layout_builders_equal_the_host_builders(shard):
+    """The score layouts are built on the device from the resident W (engine.build_*_device); the numpy builders are
+    their specification: every array must come out identical (tensor ops on CPU tensors here, the same code on the GPU)."""
+    for W in (_feature_row_w(), sp.random(900, 900, density=0.03, random_state=2, format="csc", dtype=np.float32)):
+        W.sort_indices()
+        I = W.shape[0]
+        lo, hi = (0, I) if shard[1] is None else shard_bounds(I, shard[1], shard[0])
+        torch, r, c, v = _device_coo(W)
+        for compact, tile in ((True, 256), (True, 4096), (False, 256)):
+            T = build_tiled_w(W, lo, hi, tile, compact=compact, dense_fill=DENSE_ROW_FILL if compact else None)
+            D = build_tiled_w_device(torch, r, c, v, I, lo, hi, tile, compact=compact, dense_fill=DENSE_ROW_FILL if compact else None)
+            assert (D["n_cols"], D["tile_cols"], D["n_tiles"]) == (T.n_cols, T.tile_cols, T.n_tiles)
+            assert np.array_equal(D["tile_ptr"].numpy(), T.tile_ptr) and np.array_equal(D["w_val"].numpy(), T.w_val)
+            assert np.array_equal(D["w_col"].numpy().view(np.uint16), T.w_col)
+            assert np.array_equal(D["row_hdr"].numpy(), row_header_table(T))
+            assert (D["dense_idx"] is None) == (T.dense_idx is None)
+            if T.dense_idx is not None:
+                assert np.array_equal(D["dense_idx"].numpy(), T.dense_idx) and np.array_equal(D["dense_val"].numpy(), T.dense_val)
+            if compact:
+                assert np.array_equal(D["col_ids"].numpy(), T.col_ids) and np.array_equal(D["col_map"].numpy(), T.col_map)
+                H = build_feature_rows(W, lo, hi, T.col_ids, T.col_map)
+                F = build_feature_rows_device(torch, r, c, v, I, lo, hi)
+                assert (H is None) == (F is None)
+                if H is not None:
+                    for k in ("fr_map", "fr_col_ids", "fr_col_map", "fr_w", "fr_tile_rows", "fr_tile_off", "fr_super_kb", "fr_super_tile"):
+                        assert np.array_equal(F[k].numpy().ravel(), np.asarray(H[k]).ravel()), k
+                    for k in ("fr_rows", "fr_tile_cols", "fr_n_tiles", "fr_n_super", "fr_buf_bytes"):
+                        assert F[k] == H[k], k
+    assert build_feature_rows_device(*_device_coo(_feature_row_w()), 700, 0, 700) is not None     # the dense form was exercised
+
+
+def test_device_merge_equals_the_host_write_back():
+    """SlimEngine.merge_fit (device tensors) == merge_coefficients (the LIL write-back restated in numpy): overwrite,
+    delete on explicit zero, keep unmentioned entries, grow with the catalogue; and DeviceWeights round-trips to the host."""
+    import torch
+    from tests.cpu_backend import OracleBackend
+    eng = SlimEngine(backend=OracleBackend())
+    rng = np.random.default_rng(11)
+    W_host, dw, I = None, None, 50
+    for step in range(4):
+        I += 7 * step                                            # new items appear between fits
+        tg = np.sort(rng.choice(I, 12, replace=False)).astype(np.int64)
+        cap = 6
+        items = np.stack([rng.choice(I, cap, replace=False) for _ in tg]).astype(np.int32)
+        coef = rng.uniform(-1, 1, (len(tg), cap)).astype(np.float32)
+        coef[rng.random(coef.shape) < 0.4] = 0.0                 # explicit zeros delete
+        count = rng.integers(0, cap + 1, len(tg)).astype(np.int32)
+        if W_host is not None and W_host.shape[0] != I:
+            W_host = W_host.copy(); W_host.resize((I, I))
+        W_host = merge_coefficients(W_host, I, *coefficients_to_updates(tg, items, coef, count))
+        dw = eng.merge_fit(dw, I, False, torch.from_numpy(tg.astype(np.int32)), torch.from_numpy(items), torch.from_numpy(coef),
+                           torch.from_numpy(count))
+        got = dw.to_csc(torch)
+        assert got.dtype == np.float32 and got.has_sorted_indices and (got != W_host).nnz == 0 and got.nnz == W_host.nnz
+        assert np.array_equal(got.indptr, W_host.indptr) and np.array_equal(got.indices, W_host.indices)
+    up = eng.upload_weights(W_host)
+    assert not up.lossy and up.to_csc(torch) is W_host and np.array_equal(up.vals.numpy(), dw.vals.numpy())
+    assert eng.upload_weights(sp.csc_matrix(W_host, dtype=np.float64) * (1.0 / 3.0)).lossy
 
 
 @pytest.mark.parametrize("compact", [False, True])

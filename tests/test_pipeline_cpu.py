@@ -9,6 +9,7 @@ The HIP kernels themselves are covered by the -m gpu tests.
 import io
 import json
 import os
+import pickle
 import socket
 
 import numpy as np
@@ -65,6 +66,29 @@ def test_incremental_fit_sequence_matches_reference(name, kw):
     ref = z[f"rec_{name}"]
     for r, row in enumerate(recs):
         assert row == [x for x in ref[r].tolist() if x >= 0]
+
+
+def test_w_stays_on_the_device_between_fit_and_recommend():
+    """A streaming fit -> recommend sequence never builds the host matrix: the fit output is merged into the resident W
+    and the score layouts are built from it (engine.merge_fit / build_*_device); `item_similarity` is materialised only
+    when somebody reads it, and then equals the reference's matrix."""
+    z = np.load(os.path.join(G, "partial_fit.npz"))
+    u, i, v, ts = z["u"], z["i"], z["v"], z["ts"]
+    m = cpu_slim(min_value=0, max_value=15, nn_feature_selection=5)
+    host = cpu_slim(min_value=0, max_value=15, nn_feature_selection=5)      # re-uploads a host matrix before every recommend
+    for key in ("A", "B", "C"):
+        a, b = z[key]
+        batch = [(int(x), int(y), float(t), float(r)) for x, y, t, r in zip(u[a:b], i[a:b], ts[a:b], v[a:b])]
+        m.fit(batch, progress_bar=False)
+        host.fit(batch, progress_bar=False)
+        host.model.item_similarity = host.model.item_similarity.copy()
+        users = z["rec_users_k5"].tolist()
+        assert m.recommend_batch(users, top_k=5) == host.recommend_batch(users, top_k=5)
+        assert m.model._item_similarity is None and m.model.is_fitted and m.model._w_dev is m.model.engine.weights
+    assert same_matrix(m.model.item_similarity, load_csc(z, "W_k5_C_add"))       # first read: one download
+    assert m.model.item_similarity is m.model._item_similarity
+    m2 = pickle.loads(pickle.dumps(m.model))
+    assert same_matrix(m2.item_similarity, m.model.item_similarity) and m2._w_dev is None
 
 
 def test_slimelastic_facade_dtypes_and_errors():

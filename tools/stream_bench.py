@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--qps", type=float, default=0.0,
                     help="fixed arrival rate in interactions/s (0 = back to back): mini-batch k is released at "
                          "k * batch_size / qps; reports how far completion lags behind release")
+    ap.add_argument("--fit-mode", default="exact", choices=["exact", "gram", "shuffle"],
+                    help="SLIMElastic fit_mode: exact (bit-identical to scikit-learn) or a tolerance mode (DESIGN.md 3.4)")
     ap.add_argument("--bulk-chunk", type=int, default=4_000_000, help="rows per vectorised bulk-ingest call")
     args = ap.parse_args()
     import torch
@@ -47,7 +49,7 @@ def main():
     n_stream = args.batches * args.batch_size
     n_bulk = n - n_stream
 
-    model = SLIM(min_value=0, max_value=15, nn_feature_selection=50)
+    model = SLIM(min_value=0, max_value=15, nn_feature_selection=50, fit_mode=args.fit_mode)
     t0 = time.time()
     for a in range(0, n_bulk, args.bulk_chunk):    # vectorised bulk ingest
         b = min(a + args.bulk_chunk, n_bulk)
@@ -60,7 +62,7 @@ def main():
     t_fit = time.time() - t0
     model.recommend_batch(list(range(args.score_users)), top_k=10)          # warm the scoring path
     print(f"bulk: {n_bulk} interactions ingested in {t_ingest:.2f}s, fitted in {t_fit:.2f}s, "
-          f"W nnz={model.model.item_similarity.nnz}", file=sys.stderr)
+          f"W nnz={model.model._w_dev.nnz if model.model._w_dev is not None else model.model.item_similarity.nnz}", file=sys.stderr)
 
     fit_ms, rec_ms, touched, lag_ms = [], [], [], []
     period = args.batch_size / args.qps if args.qps > 0 else 0.0
@@ -84,7 +86,7 @@ def main():
         model.recommend_batch(users, top_k=10)
         rec_ms.append((time.perf_counter() - t0) * 1e3)
     fit_ms, rec_ms = np.array(fit_ms[2:]), np.array(rec_ms[2:])      # first two include allocation / layout warm-up
-    out = {"workload": args.workload, "n_users": U, "n_items": I, "bulk_interactions": int(n_bulk),
+    out = {"workload": args.workload, "fit_mode": args.fit_mode, "w_host_copies": int(model.model._item_similarity is not None), "n_users": U, "n_items": I, "bulk_interactions": int(n_bulk),
            "batch_size": args.batch_size, "batches": args.batches, "items_touched_per_batch": float(np.mean(touched)),
            "partial_fit_ms": {"p50": float(np.median(fit_ms)), "p95": float(np.quantile(fit_ms, 0.95)), "max": float(fit_ms.max())},
            "partial_fit_interactions_per_sec": float(args.batch_size / (np.mean(fit_ms) * 1e-3)),
