@@ -10,6 +10,7 @@ import io
 import json
 import os
 import pickle
+import time
 import socket
 
 import numpy as np
@@ -301,6 +302,62 @@ def test_serving_shell_replays_the_reference_transcript(session):
     assert r.status_code == 200
     assert r.json()["recommendations"] == [s["response"]["recommendations"] for s in steps
                                            if s["path"] == "/recommend" and s["status"] == 200][-4:-1]
+
+
+@pytest.mark.parametrize("ids", ["int", "str"])
+def test_concurrent_recommend_requests_are_coalesced_into_shared_launches(ids):
+    """serving.app.RecommendCoalescer: concurrent /recommend requests share recommend_batch launches, every caller
+    gets exactly the answer of its own model.recommend call (known, unknown and failing users alike), and a request
+    arriving alone is answered without company."""
+    import threading
+    from rtrec_amd.serving.app import ModelGate
+    z = np.load(os.path.join(G, "partial_fit.npz"))
+    a, b = z["A"]
+    conv = (lambda x: f"id{int(x)}") if ids == "str" else int
+    m = cpu_slim(min_value=0, max_value=15, nn_feature_selection=5)
+    m.fit([(conv(x), conv(y), float(t), float(r)) for x, y, t, r in zip(z["u"][a:b], z["i"][a:b], z["ts"][a:b], z["v"][a:b])],
+          progress_bar=False)
+    users = [conv(x) for x in sorted(set(z["u"][a:b].tolist()))[:40]] + [conv(10 ** 6), conv(10 ** 6 + 1)]     # two unknown
+    want = {(u, k, f): m.recommend(user=u, top_k=k, filter_interacted=f) for u in users for k, f in ((5, True), (3, False))}
+    calls = {"batch": 0, "single": 0}
+    rb, r1 = m.recommend_batch, m.recommend
+    m.recommend_batch = lambda *a_, **k_: (calls.__setitem__("batch", calls["batch"] + 1), rb(*a_, **k_))[1]
+    m.recommend = lambda *a_, **k_: (calls.__setitem__("single", calls["single"] + 1), r1(*a_, **k_))[1]
+    gate = ModelGate(m, coalesce_ms=50)
+    got, errs = {}, []
+
+    def client(u, k, f):
+        try:
+            got[(u, k, f)] = gate.recommend(u, k, f)
+        except Exception as exc:        # pragma: no cover
+            errs.append(exc)
+
+    with gate._lock:                    # the model is busy (a /fit): the requests queue up behind it
+        threads = [threading.Thread(target=client, args=key) for key in want]
+        for t in threads:
+            t.start()
+        time.sleep(0.2)
+    for t in threads:
+        t.join(timeout=60)
+    assert not errs and got == want
+    assert gate.coalescer.requests == len(want) and not gate.coalescer._leading and not gate.coalescer._queue
+    assert calls["batch"] <= 4 and calls["single"] <= 4 + 1, calls      # two option groups (+ a first round that may be small)
+    # alone: answered by a plain recommend call after the bounded wait
+    calls.update(batch=0, single=0)
+    assert gate.recommend(users[0], 5, True) == want[(users[0], 5, True)] and calls == {"batch": 0, "single": 1}
+    # a failing shared launch falls back to one call per request; a failing request is a 500 for that caller only
+    m.recommend_batch = lambda *a_, **k_: (_ for _ in ()).throw(RuntimeError("boom"))
+    m.recommend = lambda user, **k_: (_ for _ in ()).throw(RuntimeError("bad user")) if user == users[1] else r1(user=user, **k_)
+    got.clear()
+    with gate._lock:
+        threads = [threading.Thread(target=client, args=(u, 5, True)) for u in users[:6]]
+        for t in threads:
+            t.start()
+        time.sleep(0.2)
+    for t in threads:
+        t.join(timeout=60)
+    assert len(errs) == 1 and getattr(errs[0], "status_code", None) == 500
+    assert got == {(u, 5, True): want[(u, 5, True)] for u in users[:6] if u != users[1]}
 
 
 @pytest.mark.parametrize("ids", ["int", "str"])
