@@ -62,6 +62,9 @@ def main() -> None:
     ap.add_argument("--top-k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-fit", action="store_true", help="skip the second (tolerance-mode) fit")
+    ap.add_argument("--stream-batches", type=int, default=8,
+                    help="streaming leg (N = 1 only): this many 1,000-interaction SLIM.fit mini-batches per fit mode, each "
+                         "followed by a 100-user recommend_batch, on a model bulk-fitted at the same workload shape (0 = skip)")
     ap.add_argument("--score-shard", default="columns", choices=["columns", "rows"],
                     help="multi-GPU scoring: item-column shards of W + list exchange (BASELINE.json's configuration), or "
                          "user-row shards with W replicated (for catalogues whose W is tiny, e.g. c4)")
@@ -411,6 +414,13 @@ def main() -> None:
                      "kernel_ms_avg": kern_ms, "launches": int(n_launch.value), "bounds": bounds,
                      "algorithmic": algorithmic, "counters": counters},
     }
+
+    # ------------------------------------------------------------------ streaming leg (SURVEY 8 row S1 / BASELINE config 4 pattern)
+    if world == 1 and args.stream_batches > 0:
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+        from stream_bench import SHAPES, run_stream
+        if args.workload in ("c2", "c3") and args.workload in SHAPES:      # the c4 bulk load alone takes minutes
+            line["streaming"] = run_stream(args.workload, batches=args.stream_batches, fit_modes=("exact", "gram"), log=log)
 
     # ------------------------------------------------------------------ cpu_baseline: the C oracle on this host,
     # one thread and all cores (POSIX threads over users / item columns: the reference's own parallel axis,

@@ -1818,13 +1818,35 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     const int tc = M.bc_i[0], Kc = M.bc_i[1];
     const int nf = Kc;
 
+    // tolerance mode (rtrec_fit_opts.fast = 2), all features in the Gram matrix: wave 0 runs the Gram-form
+    // coordinate descent (fit_gram_cd: K^2 multiply-adds per sweep, no residual); X^T y and the selection above
+    // were exact and multi-wave, which is what a popular target of a small call needs.  Otherwise the ordered
+    // folds below run as in exact mode (trivially within the tolerance).
+    bool gram_done = false;
+    if (a.fast >= 2 && a.gram != nullptr && Kc > 0 && Kc <= 64 && ny > 0) {
+        if (wave == 0) {
+            int g_lane = -1;
+            if (lane < Kc) g_lane = a.gram_index[f_id[lane]];
+            const unsigned long long missing = __ballot(lane < Kc && f_nrm[lane] != 0.0f && g_lane < 0);
+            int iters = -1;
+            if (!missing) {
+                float *gs = reinterpret_cast<float *>(smem + ((mw_lds_bytes(K) + 15) / 16) * 16);
+                iters = fit_gram_cd(a, Kc, F, gs, yy, tol_s, g_lane);
+            }
+            if (lane == 0) M.bc_i[3] = iters;
+        }
+        __syncthreads();
+        gram_done = M.bc_i[3] >= 0;
+    }
+
     bool dirty = false;
     bool r_is_y = col_walk;     // R already holds y (column walk): nothing to materialise later
     float gap = __fadd_rn(a.cfg.tol, 1.0f);
     uint32_t rng = a.cfg.seed;
     const int max_iter = a.cfg.max_iter;
-    const bool skip_cd = (ny == 0) || (nf == 0);
+    const bool skip_cd = (ny == 0) || (nf == 0) || gram_done;
     int n_iter = skip_cd ? (max_iter > 0 ? max_iter - 1 : 0) : 0;
+    if (gram_done) n_iter = M.bc_i[3] - 1;
     int upd = 0;   // parity of the broadcast slot
 
     for (; !skip_cd && n_iter < max_iter; ++n_iter) {
@@ -2247,9 +2269,12 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
         // kernel); opts->kernel forces one of the two (A/B runs, tests).  The tolerance mode has no ordered fold to
         // feed, so it always takes the one-wave-per-target kernel.
         const int force = opts ? opts->kernel : 0;
-        const bool latency_mode = !a.fast && (force == 2 || (force == 0 && n_targets <= kMwMaxTargets));
+        // tolerance mode: the multi-wave kernel serves Gram-form CD only (fast = 2); tree-reduced dots are single-wave
+        const bool latency_mode = a.fast != 1 && (force == 2 || (force == 0 && n_targets <= kMwMaxTargets));
         if (latency_mode) {
-            hipLaunchKernelGGL(fit_columns_mw_kernel, dim3(grid), dim3(kMwThreads), mw_lds_bytes(K), st, a);
+            size_t mw_lds = mw_lds_bytes(K);
+            if (a.fast >= 2 && a.gram && K <= 64) mw_lds = ((mw_lds + 15) / 16) * 16 + static_cast<size_t>(K) * 64 * 4;
+            hipLaunchKernelGGL(fit_columns_mw_kernel, dim3(grid), dim3(kMwThreads), mw_lds, st, a);
         } else {
             size_t lds = kFoldBufBytes + feat_lds_bytes(K);
             if (a.fast >= 2 && a.gram && K <= 64) lds = kFoldBufBytes + ((feat_lds_bytes(K) + 15) / 16) * 16 + static_cast<size_t>(K) * 64 * 4;

@@ -737,8 +737,8 @@ class SlimEngine:
         if mode_ not in ("exact", "shuffle", "gram"):
             raise ValueError(f"fit mode must be 'exact', 'shuffle' or 'gram': {mode_}")
         fast = {"exact": 0, "shuffle": 1, "gram": 2}[mode_] if K > 0 else 0
-        if fast:
-            n_heavy = 0            # no ordered folds, no latency kernel: one launch
+        if fast == 1:
+            n_heavy = 0            # tree-reduced dots: single-wave kernel only, one launch
         # exact mode: Gram TRACKING needs a non-negative X and pays on bulk calls; tolerance mode: Gram-form CD, any X
         if (K > 0 and min(K, I) <= 64 and getattr(be, "supports_gram", False) and gmode != "0"
                 and (fast == 2 or (fast == 0 and X.get("nonneg") and (n > FIT_MW_MAX_TARGETS or gmode == "force")))):

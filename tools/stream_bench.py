@@ -21,6 +21,85 @@ SHAPES = {"small": (20_000, 5_000, 500_000), "c2": (100_000, 50_000, 5_000_000),
           "c4": (1_000_000, 500_000, 100_000_000)}
 
 
+def run_stream(workload="c2", batches=50, batch_size=1000, score_users=100, qps=0.0, fit_modes=("exact",),
+               bulk_chunk=4_000_000, log=lambda msg: print(msg, file=sys.stderr)):
+    """Bulk-load + fit, then `batches` mini-batches per fit mode through SLIM.fit / recommend_batch.  Returns the report
+    (one entry per fit mode under "modes"; the first mode's figures are also at the top level)."""
+    import torch
+    from rtrec_amd import SLIM
+    from rtrec_amd.synth import zipf_pairs
+
+    U, I, draws = SHAPES[workload]
+    rng = np.random.default_rng(5)
+    u, i = zipf_pairs(U, I, draws, seed=20251003)
+    n = len(u)
+    order = rng.permutation(n)
+    u, i = u[order], i[order]
+    r = (rng.integers(1, 6, n) * np.exp(-rng.random(n) * 0.7)).astype(np.float64)
+    ts = 1.7e9 + np.arange(n, dtype=np.float64)
+    n_stream = batches * batch_size * len(fit_modes)
+    n_bulk = n - n_stream
+
+    model = SLIM(min_value=0, max_value=15, nn_feature_selection=50, fit_mode=fit_modes[0])
+    t0 = time.time()
+    for a in range(0, n_bulk, bulk_chunk):    # vectorised bulk ingest
+        b = min(a + bulk_chunk, n_bulk)
+        model.interactions.add_interactions_batch(model.user_ids.identify_many(u[a:b].astype(np.int64)),
+                                                  model.item_ids.identify_many(i[a:b].astype(np.int64)), ts[a:b], r[a:b])
+    t_ingest = time.time() - t0
+    t0 = time.time()
+    model.bulk_fit(parallel=True, progress_bar=False)
+    torch.cuda.synchronize()
+    t_fit = time.time() - t0
+    model.recommend_batch(list(range(score_users)), top_k=10)          # warm the scoring path
+    log(f"[stream] bulk: {n_bulk} interactions ingested in {t_ingest:.2f}s, fitted in {t_fit:.2f}s, W nnz={model.model._w_dev.nnz}")
+    out = {"workload": workload, "n_users": U, "n_items": I, "bulk_interactions": int(n_bulk), "batch_size": batch_size,
+           "batches": batches, "bulk_ingest_interactions_per_sec": float(n_bulk / t_ingest), "bulk_fit_seconds": t_fit, "modes": {}}
+    period = batch_size / qps if qps > 0 else 0.0
+    for mi, mode in enumerate(fit_modes):
+        model.model.fit_mode = mode
+        fit_ms, rec_ms, touched, lag_ms = [], [], [], []
+        t_start = time.perf_counter()
+        for k in range(batches):
+            a = n_bulk + (mi * batches + k) * batch_size
+            b = a + batch_size
+            batch = list(zip(u[a:b].tolist(), i[a:b].tolist(), ts[a:b].tolist(), r[a:b].tolist()))
+            release = t_start + k * period
+            if period > 0.0:
+                while time.perf_counter() < release:      # the batch has not arrived yet
+                    time.sleep(min(0.001, max(0.0, release - time.perf_counter())))
+            t0 = time.perf_counter()
+            model.fit(batch, progress_bar=False)
+            torch.cuda.synchronize()
+            fit_ms.append((time.perf_counter() - t0) * 1e3)
+            lag_ms.append((time.perf_counter() - release) * 1e3)          # completion behind release (queueing + service)
+            touched.append(len(set(i[a:b].tolist())))
+            users = rng.integers(0, U, score_users).tolist()
+            t0 = time.perf_counter()
+            model.recommend_batch(users, top_k=10)
+            rec_ms.append((time.perf_counter() - t0) * 1e3)
+        skip = 2 if batches > 4 else 0                                    # the first two include allocation / layout warm-up
+        fit_a, rec_a = np.array(fit_ms[skip:]), np.array(rec_ms[skip:])
+        res = {"fit_mode": mode, "items_touched_per_batch": float(np.mean(touched)),
+               "partial_fit_ms": {"p50": float(np.median(fit_a)), "p95": float(np.quantile(fit_a, 0.95)), "max": float(fit_a.max())},
+               "partial_fit_interactions_per_sec": float(batch_size / (np.mean(fit_a) * 1e-3)),
+               "recommend_after_update_ms": {"users": score_users, "p50": float(np.median(rec_a)), "p95": float(np.quantile(rec_a, 0.95)),
+                                             "note": "first recommend_batch after the refit: includes the device-side rebuild "
+                                                     "of the score layouts from the resident W"},
+               "turnaround_ms_p50": float(np.median(fit_a + rec_a)),
+               "w_host_copies": int(model.model._item_similarity is not None)}
+        if period > 0.0:
+            lag = np.array(lag_ms[skip:])
+            res["fixed_qps"] = {"interactions_per_sec": qps, "batch_period_ms": period * 1e3,
+                                "completion_lag_ms": {"p50": float(np.median(lag)), "p95": float(np.quantile(lag, 0.95)),
+                                                      "max": float(lag.max())},
+                                "keeps_up": bool(lag[-1] <= lag[0] + period * 1e3)}
+        out["modes"][mode] = res
+        log(f"[stream] {mode}: partial_fit p50 {res['partial_fit_ms']['p50']:.1f} ms ({res['partial_fit_interactions_per_sec']:,.0f} "
+            f"interactions/s), recommend({score_users}) after update p50 {res['recommend_after_update_ms']['p50']:.2f} ms")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2", choices=sorted(SHAPES))
@@ -30,75 +109,12 @@ def main():
     ap.add_argument("--qps", type=float, default=0.0,
                     help="fixed arrival rate in interactions/s (0 = back to back): mini-batch k is released at "
                          "k * batch_size / qps; reports how far completion lags behind release")
-    ap.add_argument("--fit-mode", default="exact", choices=["exact", "gram", "shuffle"],
-                    help="SLIMElastic fit_mode: exact (bit-identical to scikit-learn) or a tolerance mode (DESIGN.md 3.4)")
+    ap.add_argument("--fit-mode", default="exact",
+                    help="comma-separated SLIMElastic fit modes to stream with: exact (bit-identical to scikit-learn), gram, shuffle")
     ap.add_argument("--bulk-chunk", type=int, default=4_000_000, help="rows per vectorised bulk-ingest call")
     args = ap.parse_args()
-    import torch
-    from rtrec_amd import SLIM
-    from rtrec_amd.synth import zipf_pairs
-
-    U, I, draws = SHAPES[args.workload]
-    rng = np.random.default_rng(5)
-    u, i = zipf_pairs(U, I, draws, seed=20251003)
-    n = len(u)
-    order = rng.permutation(n)
-    u, i = u[order], i[order]
-    r = (rng.integers(1, 6, n) * np.exp(-rng.random(n) * 0.7)).astype(np.float64)
-    ts = 1.7e9 + np.arange(n, dtype=np.float64)
-    n_stream = args.batches * args.batch_size
-    n_bulk = n - n_stream
-
-    model = SLIM(min_value=0, max_value=15, nn_feature_selection=50, fit_mode=args.fit_mode)
-    t0 = time.time()
-    for a in range(0, n_bulk, args.bulk_chunk):    # vectorised bulk ingest
-        b = min(a + args.bulk_chunk, n_bulk)
-        model.interactions.add_interactions_batch(model.user_ids.identify_many(u[a:b].astype(np.int64)),
-                                                  model.item_ids.identify_many(i[a:b].astype(np.int64)), ts[a:b], r[a:b])
-    t_ingest = time.time() - t0
-    t0 = time.time()
-    model.bulk_fit(parallel=True, progress_bar=False)
-    torch.cuda.synchronize()
-    t_fit = time.time() - t0
-    model.recommend_batch(list(range(args.score_users)), top_k=10)          # warm the scoring path
-    print(f"bulk: {n_bulk} interactions ingested in {t_ingest:.2f}s, fitted in {t_fit:.2f}s, "
-          f"W nnz={model.model._w_dev.nnz if model.model._w_dev is not None else model.model.item_similarity.nnz}", file=sys.stderr)
-
-    fit_ms, rec_ms, touched, lag_ms = [], [], [], []
-    period = args.batch_size / args.qps if args.qps > 0 else 0.0
-    t_start = time.perf_counter()
-    for k in range(args.batches):
-        a = n_bulk + k * args.batch_size
-        b = a + args.batch_size
-        batch = list(zip(u[a:b].tolist(), i[a:b].tolist(), ts[a:b].tolist(), r[a:b].tolist()))
-        release = t_start + k * period
-        if period > 0.0:
-            while time.perf_counter() < release:      # the batch has not arrived yet
-                time.sleep(min(0.001, max(0.0, release - time.perf_counter())))
-        t0 = time.perf_counter()
-        model.fit(batch, progress_bar=False)
-        torch.cuda.synchronize()
-        fit_ms.append((time.perf_counter() - t0) * 1e3)
-        lag_ms.append((time.perf_counter() - release) * 1e3)          # completion behind release (queueing + service)
-        touched.append(len(set(i[a:b].tolist())))
-        users = rng.integers(0, U, args.score_users).tolist()
-        t0 = time.perf_counter()
-        model.recommend_batch(users, top_k=10)
-        rec_ms.append((time.perf_counter() - t0) * 1e3)
-    fit_ms, rec_ms = np.array(fit_ms[2:]), np.array(rec_ms[2:])      # first two include allocation / layout warm-up
-    out = {"workload": args.workload, "fit_mode": args.fit_mode, "w_host_copies": int(model.model._item_similarity is not None), "n_users": U, "n_items": I, "bulk_interactions": int(n_bulk),
-           "batch_size": args.batch_size, "batches": args.batches, "items_touched_per_batch": float(np.mean(touched)),
-           "partial_fit_ms": {"p50": float(np.median(fit_ms)), "p95": float(np.quantile(fit_ms, 0.95)), "max": float(fit_ms.max())},
-           "partial_fit_interactions_per_sec": float(args.batch_size / (np.mean(fit_ms) * 1e-3)),
-           "recommend_ms_per_call": {"users": args.score_users, "p50": float(np.median(rec_ms)), "p95": float(np.quantile(rec_ms, 0.95))},
-           "bulk_ingest_interactions_per_sec": float(n_bulk / t_ingest), "bulk_fit_seconds": t_fit}
-    if period > 0.0:
-        lag = np.array(lag_ms[2:])
-        out["fixed_qps"] = {"interactions_per_sec": args.qps, "batch_period_ms": period * 1e3,
-                            "completion_lag_ms": {"p50": float(np.median(lag)), "p95": float(np.quantile(lag, 0.95)),
-                                                  "max": float(lag.max())},
-                            "keeps_up": bool(lag[-1] <= lag[0] + period * 1e3)}
-    print(json.dumps(out))
+    print(json.dumps(run_stream(args.workload, args.batches, args.batch_size, args.score_users, args.qps,
+                                tuple(args.fit_mode.split(",")), args.bulk_chunk)))
 
 
 if __name__ == "__main__":
