@@ -239,6 +239,7 @@ def main() -> None:
     if prof_fn is not None:          # diagnostic build (-DSCORE_PROFILE): per-phase clocks of the sparse kernel
         prof_fn(None, 1)
     eng.score_timer = eng.be.timer_create()
+    eng.rescored = torch.zeros(1, dtype=torch.int32, device=f"cuda:{local_rank}")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -251,6 +252,8 @@ def main() -> None:
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kern_total_ms, kern_launches = eng.be.timer_read(eng.score_timer)
+    n_rescored = int(eng.rescored.item())
+    eng.rescored = None
     tot_ms, n_launch = C.c_double(kern_total_ms), C.c_int64(kern_launches)
     eng.be.timer_destroy(eng.score_timer)
     eng.score_timer = 0
@@ -396,7 +399,7 @@ def main() -> None:
                    "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
                                    else f"user-row shard x{world}, W replicated")},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend,
-        "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc,
+        "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc, "rows_rescored_by_exact_tie_pass": n_rescored,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()), "mode": "exact", "tolerance_modes": fit_fast,
                 "to_score": {"write_back_ms": merge_s * 1e3, "layouts_ms": layout_s * 1e3,

@@ -255,6 +255,8 @@ typedef struct {
     void          *timer;         /* rtrec_timer object or NULL */
     int32_t        diagnostics;   /* ablation switches of tools/score_ablate.sh; honoured by diagnostic builds
                                      (-DRTREC_DIAGNOSTICS) only, ignored by the release library */
+    int32_t       *d_rescored;    /* optional int32[1] on the device: receives the number of rows the exact-tie pass
+                                     re-scored (SPARSE mode; rows whose fast-pass list held an exact tie or overflowed) */
 } rtrec_score_opts;
 
 size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols);

@@ -739,11 +739,13 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
     for (;;) {
         if (w_next >= w_end) {
             int w0 = 0;
-            if (lane == 0) w0 = atomicAdd(a.queue, kQueueChunk);
+            // (the exact-tie pass has a handful of rows: one job per claim spreads them over the chip)
+            constexpr int chunk = FT ? 1 : kQueueChunk;
+            if (lane == 0) w0 = atomicAdd(a.queue, chunk);
             w_next = readfirst_i(w0);
             PF_MARK(PF_QUEUE)
             if (w_next >= total) break;
-            w_end = min(w_next + kQueueChunk, total);
+            w_end = min(w_next + chunk, total);
         }
         const int w = w_next++;
         const int tile = w / n_rows;             // tile-major: concurrent waves share a W tile in L2
@@ -988,8 +990,10 @@ __host__ __device__ constexpr size_t fr_wave_scratch_words(int n_tiles, int regs
 }
 constexpr int kFrCandCap = 64;               // candidates a wave buffers per merge round (one per lane)
 __host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
+constexpr int kFrStep = 2;                   // rows of W per sweep step
+constexpr int kFrZeroRowBytes = 1024;        // one slice row of +0.0 (the widest tile: 256 columns)
 __host__ __device__ constexpr size_t fr_lds_bytes(int buf_bytes) {
-    return 2 * static_cast<size_t>(buf_bytes) + kFrWaves * fr_wave_extra_bytes() + 16;
+    return 2 * static_cast<size_t>(buf_bytes) + kFrWaves * fr_wave_extra_bytes() + kFrZeroRowBytes + 16;
 }
 
 typedef __attribute__((address_space(3))) void fr_lds_void;
@@ -1091,6 +1095,8 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
     float *cv = reinterpret_cast<float *>(extra);                     // [kFrCandCap] candidate scores of one user
     int *cp = reinterpret_cast<int *>(cv + kFrCandCap);               // [kFrCandCap] their layout columns
     int *s_job = reinterpret_cast<int *>(smem + fr_lds_bytes(a.buf_bytes) - 16);
+    const unsigned char *zrow = smem + 2 * static_cast<size_t>(a.buf_bytes) + kFrWaves * fr_wave_extra_bytes();
+    for (int o = tid * 4; o < kFrZeroRowBytes; o += kFrWaves * 64 * 4) *reinterpret_cast<float *>(smem + (zrow - smem) + o) = 0.0f;
     const int n_jobs = (a.n_rows + UW * kFrWaves - 1) / (UW * kFrWaves);
     const float ninf = -__builtin_huge_valf();
     const int mwords = a.n_tiles * REGS;
@@ -1186,12 +1192,21 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         __syncthreads();
         PF_MARK(PF_GROUP)
 
+        // rows of W that at least one of the wave's users rates: the sweep below visits only those
+        unsigned long long own_or[XR];
+        fr_static_for<XR>([&](auto H) {
+            constexpr int h = decltype(H)::value;
+            unsigned long long m = 0ull;
+            fr_static_for<UW>([&](auto Uc) { m |= __ballot(xr[decltype(Uc)::value][h] != 0.0f); });
+            own_or[h] = m;
+        });
+
         for (int sidx = 0; sidx < a.n_super; ++sidx) {
             const unsigned char *wb = (sidx & 1) ? buf1 : buf0;
             if (sidx + 1 < a.n_super) load_super(sidx + 1, (sidx & 1) ? buf0 : buf1);
             const int t_lo = a.st_tile[sidx], t_hi = a.st_tile[sidx + 1];
             // the tiles' row masks and slice offsets, lane tt = tile t_lo + tt: one load per super-tile, read back
-            // with v_readlane below (no memory latency inside the user loops)
+            // with v_readlane below (no memory latency inside the tile loop)
             unsigned long long nzv[2] = {0ull, 0ull};
             int toffv = 0;
             if (lane < t_hi - t_lo) {
@@ -1199,16 +1214,104 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                 nzv[1] = a.tile_rows[(t_lo + lane) * 2 + 1];
                 toffv = a.tile_off[t_lo + lane];
             }
+            const unsigned char *wlane = wb + lane16;             // this lane's columns in a slice row
+            const unsigned char *wzero = zrow + lane16;           // a row of +0.0: what a step reads past the last row
 
-            fr_static_for<UW>([&](auto Uc) {
-                constexpr int u = decltype(Uc)::value;
-                constexpr int g = u >> 2, lb = (u & 3) * 16;
-                fr_const_u64 *mc = (fr_const_u64 *)(ms_wave + static_cast<size_t>(u) * mwords);
-                float thr = readlane_f(ls4[g], lb + kk - 1);      // the user's current kk-th best score
-                int nc = 0;
+            for (int t = t_lo; t < t_hi; ++t) {
+                // ---- tile-major sweep: every row of W that holds a weight in this tile (and that one of the wave's
+                //      users rates) is read from LDS ONCE and applied to all eight users: acc_u += x_u * w, one
+                //      rounded product and one rounded add per column (two v_pk_mul_f32 + two v_pk_add_f32 per user
+                //      and 256 columns), rows ascending = scipy's order.  A user that does not rate the row has
+                //      x_u = 0: x * w = +-0 changes no sum (a sum that starts at +0 never becomes -0), and the same
+                //      holds for rows and blocks that are skipped altogether. ----
+                vec acc[UW];
+                fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });
+                const int toff = readlane_i(toffv, t - t_lo);
+                int below = 0;                                   // rows of this tile's slice before half h
+                fr_static_for<XR>([&](auto H) {
+                    constexpr int h = decltype(H)::value;
+                    const unsigned long long nz =
+                        (static_cast<unsigned long long>(readlane_u(static_cast<uint32_t>(nzv[h] >> 32), t - t_lo)) << 32) |
+                        readlane_u(static_cast<uint32_t>(nzv[h]), t - t_lo);
+                    unsigned long long rows = nz & own_or[h];
+                    while (rows) {
+                        // two rows per step: their LDS reads go out together; eight users' applies (80 vector
+                        // instructions) cover the latency of the next pair
+                        int f[kFrStep];
+                        vec w[kFrStep];
+#pragma unroll
+                        for (int q = 0; q < kFrStep; ++q) {
+                            const bool live = rows != 0ull;
+                            f[q] = live ? __builtin_ctzll(rows) : 0;
+                            rows &= rows - 1;          // 0 stays 0
+                            // slice position of row f: the rows of the tile below it (scalar arithmetic)
+                            const int pos = below + static_cast<int>(__builtin_popcountll(nz & ((1ull << f[q]) - 1ull)));
+                            const unsigned char *src = live ? wlane + toff + pos * ROWB : wzero;
+                            w[q] = *reinterpret_cast<const vec *>(src);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < kFrStep; ++q) {
+                            fr_static_for<UW>([&](auto Uc) {
+                                constexpr int u = decltype(Uc)::value;
+                                acc[u] = acc[u] + w[q] * readlane_f(xr[u][h], f[q]);
+                            });
+                        }
+                        PF_ADD(PF_N_DENSE, kFrStep)
+                    }
+                    below += static_cast<int>(__builtin_popcountll(nz));
+                });
 
-                // merge the user's buffered candidates into its list (lane lb + j = rank j)
-                auto merge = [&]() {
+                // ---- candidates, user after user: columns that beat the user's kk-th score and are not interacted ----
+                fr_static_for<UW>([&](auto Uc) {
+                    constexpr int u = decltype(Uc)::value;
+                    constexpr int g = u >> 2, lb = (u & 3) * 16;
+                    float best = acc[u][0];
+                    fr_static_for<REGS>([&](auto Rc) { best = acc[u][Rc()] > best ? acc[u][Rc()] : best; });
+                    float thr = readlane_f(ls4[g], lb + kk - 1);      // the user's current kk-th best score
+                    float tcut = thr;
+                    fr_const_u64 *mc = (fr_const_u64 *)(ms_wave + static_cast<size_t>(u) * mwords);
+                    if (thr >= 0.0f) {
+                        if (!__ballot(best > thr)) return;        // the common case after the first tiles: nothing enters
+                    } else if (thr == ninf) {
+                        // The list is not full yet (first tile, or a user with few scored columns): everything
+                        // non-zero would pass.  Take the tile's own kk-th best admissible score (a bound from the
+                        // lane maxima) as the cut instead.
+                        PF_ADD(PF_N_OVERFLOW, 1)
+                        float bm = ninf;
+                        fr_static_for<REGS>([&](auto Rc) {
+                            constexpr int r = decltype(Rc)::value;
+                            const unsigned long long ex = a.filter ? mc[t * REGS + r] : 0ull;
+                            const float v = acc[u][r];
+                            const float vm = (v != 0.0f && !((ex >> lane) & 1ull)) ? v : ninf;
+                            bm = vm > bm ? vm : bm;
+                        });
+                        // kk-th largest of the 64 lane maxima (the 16 quad maxima would do as a bound, but a loose one:
+                        // half the tile can lie above it); -inf: fewer than kk lanes hold a score, and everything
+                        // they hold (< kk * REGS <= kFrCandCap) fits the buffer
+                        const float t0 = fr_kth_lane_best(bm, 64 + kk);
+                        if (t0 != ninf) tcut = float_prev(t0);      // candidates are the values >= t0
+                    }
+                    int nc = 0;
+                    fr_static_for<REGS>([&](auto Rc) {
+                        constexpr int r = decltype(Rc)::value;
+                        const float v = acc[u][r];
+                        // only non-zero sums compete (scipy keeps `!= 0`)
+                        unsigned long long m = __ballot(v > tcut && v != 0.0f);
+                        if (!m) return;
+                        if (a.filter) m &= ~mc[t * REGS + r];
+                        if (!m) return;
+                        const int cnt = static_cast<int>(__builtin_popcountll(m));
+                        if (nc + cnt > kFrCandCap) { spilled |= 1u << u; return; }
+                        if ((m >> lane) & 1ull) {
+                            const int pos = nc + lane_prefix(m);
+                            cv[pos] = v;
+                            cp[pos] = t * TC + lane * REGS + r;
+                        }
+                        nc += cnt;
+                    });
+                    if (nc == 0) return;
+                    // merge the tile's candidates into the user's list (lane lb + j = rank j)
                     const float myv = lane < nc ? cv[lane] : ninf;
                     const int mycol = lane < nc ? cp[lane] : 0;
                     const int rel = lane - lb;
@@ -1229,98 +1332,8 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                         ls4[g] = !in || rel < pos ? s : (rel == pos ? v : s_up);
                         lc4[g] = !in || rel < pos ? c : (rel == pos ? col : c_up);
                     }
-                    nc = 0;
-                    thr = readlane_f(ls4[g], lb + kk - 1);
-                };
-
-                for (int t = t_lo; t < t_hi; ++t) {
-                    // ---- the user's rows of W that hold a weight in this tile, ascending: acc += x * w, one rounded
-                    //      product and one rounded add per column (two v_pk_mul_f32 + two v_pk_add_f32 per 256
-                    //      columns), four rows per step: their LDS reads go out together, the applies follow; a
-                    //      step that runs past the last row repeats one with x = 0 (x * w = +-0 changes no sum).
-                    //      Blocks of W without a weight are skipped: they would only add +-0 as well. ----
-                    vec acc = vec(0.0f);
-                    const int toff = readlane_i(toffv, t - t_lo);
-                    int below = 0;                               // rows of this tile's slice before half h
-                    fr_static_for<XR>([&](auto H) {
-                        constexpr int h = decltype(H)::value;
-                        const unsigned long long nz =
-                            (static_cast<unsigned long long>(readlane_u(static_cast<uint32_t>(nzv[h] >> 32), t - t_lo)) << 32) |
-                            readlane_u(static_cast<uint32_t>(nzv[h]), t - t_lo);
-                        unsigned long long own = __ballot(xr[u][h] != 0.0f) & nz;
-                        // lane f: byte offset of row 64 h + f in the buffer (rows without a weight are not stored)
-                        const int offv = toff + (below + lane_prefix(nz)) * ROWB;
-                        below += static_cast<int>(__builtin_popcountll(nz));
-                        while (own) {
-                            int f[4];
-                            bool live[4];
-                            vec w[4];
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                live[q] = own != 0ull;
-                                f[q] = live[q] ? __builtin_ctzll(own) : f[0];
-                                own &= own - 1;        // 0 stays 0
-                                w[q] = *reinterpret_cast<const vec *>(wb + readlane_i(offv, f[q]) + lane16);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const float x = readlane_f(xr[u][h], f[q]);
-                                const float xs = live[q] ? x : 0.0f;
-                                acc = acc + w[q] * xs;
-                            }
-                            PF_ADD(PF_N_DENSE, 4)
-                        }
-                    });
-
-                    // ---- candidates: columns that beat the user's kk-th score and are not interacted ----
-                    float best = acc[0];
-                    fr_static_for<REGS>([&](auto Rc) { best = acc[Rc()] > best ? acc[Rc()] : best; });
-                    float tcut = thr;
-                    if (thr >= 0.0f) {
-                        if (!__ballot(best > thr)) continue;      // the common case after the first tiles: nothing enters
-                    } else if (thr == ninf) {
-                        // The list is not full yet (first tile, or a user with few scored columns): everything
-                        // non-zero would pass.  Take the tile's own kk-th best admissible score (a bound from the
-                        // lane maxima) as the cut instead.
-                        PF_ADD(PF_N_OVERFLOW, 1)
-                        float bm = ninf;
-                        fr_static_for<REGS>([&](auto Rc) {
-                            constexpr int r = decltype(Rc)::value;
-                            const unsigned long long ex = a.filter ? mc[t * REGS + r] : 0ull;
-                            const float v = acc[r];
-                            const float vm = (v != 0.0f && !((ex >> lane) & 1ull)) ? v : ninf;
-                            bm = vm > bm ? vm : bm;
-                        });
-                        // kk-th largest of the 64 lane maxima (the 16 quad maxima would do as a bound, but a loose one:
-                        // half the tile can lie above it); -inf: fewer than kk lanes hold a score, and everything
-                        // they hold (< kk * REGS <= kFrCandCap) fits the buffer
-                        const float t0 = fr_kth_lane_best(bm, 64 + kk);
-                        if (t0 != ninf) tcut = float_prev(t0);      // candidates are the values >= t0
-                    }
-                    fr_static_for<REGS>([&](auto Rc) {
-                        constexpr int r = decltype(Rc)::value;
-                        const float v = acc[r];
-                        // only non-zero sums compete (scipy keeps `!= 0`)
-                        unsigned long long m = __ballot(v > tcut && v != 0.0f);
-                        if (!m) return;
-                        if (a.filter) m &= ~mc[t * REGS + r];
-                        if (!m) return;
-                        const int cnt = static_cast<int>(__builtin_popcountll(m));
-                        if (nc + cnt > kFrCandCap) { spilled |= 1u << u; return; }
-                        if ((m >> lane) & 1ull) {
-                            const int pos = nc + lane_prefix(m);
-                            cv[pos] = v;
-                            cp[pos] = t * TC + lane * REGS + r;
-                        }
-                        nc += cnt;
-                    });
-                    // while the list is filling up merge after every tile (the cut of the next tile needs it),
-                    // later only when the buffer runs full or the user's tiles of this super-tile are done
-                    if (nc > 0 && (thr == ninf || nc > kFrCandCap / 2)) merge();
-                }
-                if (nc > 0) merge();
-            });
+                });
+            }
             PF_MARK(PF_DENSE)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // super-tile s+1 has landed ...
             __syncthreads();                                    // ... and every wave has left super-tile s
@@ -1464,7 +1477,8 @@ bool fr_usable(const FrLayout &F, int kk) {
 template <typename ACC>
 int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_ids, float *d_out_scores,
                double *d_out_scores64, uint32_t *d_out_aux, int32_t *d_out_count,
-               unsigned char *ws, const ScoreWs &L, hipStream_t st, KernelTimer *tmr, const FrLayout &FR, int n_x_rows) {
+               unsigned char *ws, const ScoreWs &L, hipStream_t st, KernelTimer *tmr, const FrLayout &FR, int n_x_rows,
+               int32_t *d_rescored) {
     ScoreArgs a = base;
     const bool sparse = (a.mode == RTREC_TOPK_SPARSE);
     const bool single = (a.n_tiles == 1);
@@ -1565,6 +1579,9 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
             hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows < 2048 ? a.n_rows : 2048), dim3(64), 0, st, mf);
             debug_stage(st, "merge_topk_kernel (exact ties)");
         }
+        if (d_rescored && hipMemcpyAsync(d_rescored, flag_len, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    } else if (d_rescored && hipMemsetAsync(d_rescored, 0, 4, st) != hipSuccess) {
+        return RTREC_ERR_LAUNCH;
     }
     return rtrec::launch_status();
 }
@@ -1678,9 +1695,9 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
     unsigned char *ws = static_cast<unsigned char *>(d_workspace);
     if (acc_f64)
         return score_impl<double>(a, top_k, 8, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
-                                  tmr, FR, a.n_x_rows);
+                                  tmr, FR, a.n_x_rows, opts ? opts->d_rescored : nullptr);
     return score_impl<float>(a, top_k, 4, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
-                             tmr, FR, a.n_x_rows);
+                             tmr, FR, a.n_x_rows, opts ? opts->d_rescored : nullptr);
 }
 
 extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,

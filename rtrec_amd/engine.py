@@ -178,6 +178,10 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     # ... descending, so that the columns with the most / rarest rows -- the high scorers -- come FIRST: the
     # kernel's running top-k then settles within the first tiles (ascending, nearly every column displaces one)
     order = np.lexsort(tuple(pattern[r] for r in by_rarity[::-1]))[::-1]     # layout position -> compacted column
+    # ... and the TILES this order forms are visited heaviest first (sum of |w|): the columns that end up in a user's
+    # top-k are overwhelmingly in the heavy tiles, so the running k-th best score is near its final value after the
+    # first tiles and almost nothing enters the lists later (ML-20M shape: 113 -> 14 list candidates per user).
+    order = _heavy_tiles_first(order, np.bincount(c_of, weights=np.abs(vals).astype(np.float64), minlength=n_cols), tc)
     fr_col_ids = np.asarray(col_ids, dtype=np.int32)[order]
     fr_col_map = np.full(n_items, -1, dtype=np.int32)
     fr_col_map[fr_col_ids] = np.arange(n_cols, dtype=np.int32)
@@ -205,10 +209,21 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
 
 
 
+def _heavy_tiles_first(order: np.ndarray, col_mass: np.ndarray, tc: int) -> np.ndarray:
+    """Permute the full tiles of a column order by descending weight mass (float32-rounded, ties: earlier tile first);
+    a partial last tile stays last."""
+    n_full = len(order) // tc
+    if n_full < 2:
+        return order
+    head = order[:n_full * tc].reshape(n_full, tc)
+    tmass = col_mass[head].sum(axis=1).astype(np.float32)
+    return np.concatenate([head[np.argsort(-tmass, kind="stable")].ravel(), order[n_full * tc:]])
+
+
 def _pack_super_tiles(n_rows_t: np.ndarray, tc: int):
     """Greedy packing of consecutive tiles into LDS-sized super-tiles (shared by the host and device builders of the
     feature-row layout).  None when one tile alone does not fit."""
-    buf_cap = (160 * 1024 - 16 * 512 - 16) // 2 // 1024 * 1024
+    buf_cap = (160 * 1024 - 16 * 512 - 1024 - 16) // 2 // 1024 * 1024      # fr_lds_bytes of csrc/score.hip
     row_bytes = tc * 4
     n_tiles = len(n_rows_t)
     if int(n_rows_t.max()) * row_bytes > buf_cap:
@@ -269,6 +284,12 @@ def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int
         word = torch.zeros(n_cols, dtype=i64, device=dev)
         word.index_add_(0, c_of[inw], torch.ones_like(sig[inw]) << (sig[inw] % 60))
         order = order[torch.argsort(word[order], descending=True, stable=True)]
+    n_full = n_cols // tc                                        # tiles heaviest first (see build_feature_rows)
+    if n_full > 1:
+        col_mass = torch.zeros(n_cols, dtype=torch.float64, device=dev).index_add_(0, c_of, v.abs().double())
+        head = order[:n_full * tc].view(n_full, tc)
+        tmass = col_mass[head].sum(dim=1).float()
+        order = torch.cat([head[torch.argsort(tmass, descending=True, stable=True)].reshape(-1), order[n_full * tc:]])
     fr_col_ids = col_ids_sorted[order].to(torch.int32)
     fr_col_map = torch.full((n_items,), -1, dtype=torch.int32, device=dev)
     fr_col_map[fr_col_ids.to(i64)] = torch.arange(n_cols, dtype=torch.int32, device=dev)
@@ -501,7 +522,7 @@ class HipBackend:
     supports_feature_rows = True
 
     def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
-                   acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None):
+                   acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None, rescored=None):
         fr = lay if (use_fr and lay.get("fr_w") is not None) else {}
         self.ops.score_topk(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo,
                             lay["col_ids"], lay["col_map"], lay["tile_cols"], lay["n_tiles"],
@@ -513,7 +534,7 @@ class HipBackend:
                             int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)), int(fr.get("fr_n_tiles", 0)),
                             int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
                             fr.get("fr_scratch"),
-                            row_order if fr else None, int(timer), int(diagnostics))
+                            row_order if fr else None, int(timer), int(diagnostics), rescored)
 
     def decay_f32(self, raw, ts, rate: float, now: float):
         """float32(raw * rate ** ((now - ts) / 86400)) for resident arrays: rtrec_store_decay_device, plus the host's libm
@@ -798,6 +819,8 @@ class SlimEngine:
             lo_, hi_ = d["lo"], d["hi"]
             if device_out:
                 kept.append(d)
+                if trace:
+                    trace_out[lo_:hi_] = d["trace"].cpu().numpy()
                 return
             items_out[lo_:hi_] = d["items"].cpu().numpy()
             coef_out[lo_:hi_] = d["coef"].cpu().numpy()
@@ -829,6 +852,7 @@ class SlimEngine:
                 niter_out[over] = full[3]
                 items_out, coef_out = items_w, coef_w
         self.last_fit_stats = {"n_targets": n, "slots": slots, "cap": cap, "trace": trace_out, "n_heavy": n_heavy}
+        self.last_fit_targets = targets
         if device_out:
             kept.sort(key=lambda d: d["lo"])
             cat = (lambda k, shape, dt: torch.cat([d[k] for d in kept]) if kept else be.empty(shape, dt))
@@ -975,17 +999,24 @@ class SlimEngine:
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = be.empty((need,), torch.uint8)
         if isinstance(be, HipBackend):
-            use_fr = self.use_feature_rows and mode == _native.TOPK_SPARSE and lay.get("fr_w") is not None
+            use_fr = (self.use_feature_rows and mode == _native.TOPK_SPARSE and lay.get("fr_w") is not None
+                      and n_rows >= self.FR_MIN_ROWS)
             order = self._row_order(d_row_ids, n_rows, xb) if use_fr else None
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws, timer=self.score_timer,
-                          diagnostics=self.diagnostics, use_fr=use_fr, row_order=order)
+                          diagnostics=self.diagnostics, use_fr=use_fr, row_order=order, rescored=self.rescored)
         else:
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws)
         return ids, sc, sc64, aux, cnt
 
     ROW_ORDER_MIN = 2048        # batches below this are one or two waves of jobs: nothing to level
+    # The feature-row kernel is a throughput design (a workgroup takes 128 users through ALL of W, 8 users per wave):
+    # a small batch leaves most of the chip idle and waits for one wave's pass over every tile.  Below this many rows
+    # the tiled-CSR kernel scores the batch -- one job per (user, tile), so even one user spreads over several
+    # workgroups (tools/score_batch_sweep.py: DESIGN.md section 3.1).
+    FR_MIN_ROWS = 24576
+    rescored = None             # optional int32[1] device tensor: rows the exact-tie pass re-scored in the last call
 
     def _row_order(self, d_row_ids, n_rows: int, xb):
         """Work order for the feature-row kernel: the batch's rows by descending length (rtrec_score_opts.d_row_order).

@@ -78,7 +78,7 @@ def fit_columns(cptr: Tensor, crow: Tensor, cval: Tensor, rptr: Tensor, rcol: Te
         cap, _p(ws), ws.numel(), n_slots, _p(queue), _stream(out_items), C.byref(opts)), "rtrec_slim_fit_columns_opt")
 
 
-@custom_op("rtrec_amd::score_topk", mutates_args=("ids", "scores", "scores64", "aux", "count", "ws", "fr_scratch"),
+@custom_op("rtrec_amd::score_topk", mutates_args=("ids", "scores", "scores64", "aux", "count", "ws", "fr_scratch", "rescored"),
            device_types="cuda")
 def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val: Tensor, n_rows: int,
                n_items: int, n_cols: int, col_offset: int, col_ids: Optional[Tensor], col_map: Optional[Tensor],
@@ -90,14 +90,14 @@ def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val
                fr_tile_rows: Optional[Tensor], fr_tile_off: Optional[Tensor], fr_super_kb: Optional[Tensor],
                fr_super_tile: Optional[Tensor], fr_rows: int, fr_tile_cols: int, fr_n_tiles: int, fr_n_super: int,
                fr_buf_bytes: int, fr_scratch: Optional[Tensor], row_order: Optional[Tensor], timer: int,
-               diagnostics: int) -> None:
+               diagnostics: int, rescored: Optional[Tensor]) -> None:
     """rtrec_slim_score_topk_opt.  n_x_rows is taken from xb_ptr; fr_* is the optional feature-row form of the
     shard; `timer` is an rtrec_timer handle (0 = none)."""
     lib = _native.load()
     opts = _native.ScoreOpts(int(xb_ptr.shape[0]) - 1, _p(fr_map), _p(fr_col_ids), _p(fr_col_map), _p(fr_w),
                              _p(fr_tile_rows), _p(fr_tile_off), _p(fr_super_kb), _p(fr_super_tile), fr_rows, fr_tile_cols,
                              fr_n_tiles, fr_n_super, fr_buf_bytes, _p(fr_scratch), fr_scratch.numel() if fr_scratch is not None else 0,
-                             _p(row_order), C.c_void_p(timer or None), diagnostics)
+                             _p(row_order), C.c_void_p(timer or None), diagnostics, _p(rescored))
     _native.check(lib.rtrec_slim_score_topk_opt(
         n_rows, _p(row_ids), _p(xb_ptr), _p(xb_col), _p(xb_val), n_items, n_cols, col_offset, _p(col_ids), _p(col_map),
         tile_cols, n_tiles, _p(tile_ptr), _p(w_col), _p(w_val), _p(dense_idx), _p(dense_val), _p(row_hdr), _p(col_rank),

@@ -21,7 +21,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD" \
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_READ_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O -o pmc${i}_$WL --output-format csv -- python3 bench.py --workload $WL --steps 3 --no-cpu-baseline > /dev/null 2> $O/rocprof_pmc$i.log
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O -o pmc${i}_$WL --output-format csv -- python3 bench.py --workload $WL --steps 3 --no-cpu-baseline --no-fast-fit --stream-batches 0 > /dev/null 2> $O/rocprof_pmc$i.log
   echo "pmc pass $i rc=$?"
 done
 python3 tools/pmc_round_summary.py $O $TAG $WL

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--batches", type=int, default=6)
     ap.add_argument("--batch-size", type=int, default=1000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--fit-mode", default="exact")
     args = ap.parse_args()
     import torch
     from rtrec_amd import SLIM
@@ -61,7 +62,7 @@ def main():
     ts = 1.7e9 + np.arange(n, dtype=np.float64)
     n_bulk = n - args.batches * args.batch_size
 
-    model = SLIM(min_value=0, max_value=15, nn_feature_selection=50)
+    model = SLIM(min_value=0, max_value=15, nn_feature_selection=50, fit_mode=args.fit_mode)
     for a in range(0, n_bulk, 4_000_000):
         b = min(a + 4_000_000, n_bulk)
         model.interactions.add_interactions_batch(model.user_ids.identify_many(u[a:b].astype(np.int64)),
@@ -105,9 +106,13 @@ def main():
         prep = (tr[:, 1] - tr[:, 0]) * tick
         span = (tr[:, 2].max() - tr[:, 0].min()) * tick
         top = np.argsort(-dur)[:5]
+        X = eng._X
+        ny = X["col_nnz"][eng.last_fit_targets] if hasattr(eng, "last_fit_targets") else None
         rep = {"batch": k, "total_ms": total * 1e3, **{f"{kk}_ms": v * 1e3 for kk, v in ck.t.items()},
                "targets": int(len(dur)), "kernel_span_ms": span * 1e3, "sum_target_s": float(dur.sum()),
-               "top": [dict(dur_ms=float(dur[j] * 1e3), prep_ms=float(prep[j] * 1e3), folded=float(tr[j, 3]), fold_ms=float(tr[j, 4] * 1e-5), upd_ms=float(tr[j, 5] * 1e-5), gap_ms=float(tr[j, 6] * 1e-5), fold_cycles_per_entry=float(tr[j, 7] / max(tr[j, 3], 1))) for j in top[:3]]}
+               "dur_ms_quantiles": [float(np.quantile(dur, q) * 1e3) for q in (0.5, 0.9, 0.99, 1.0)],
+               "prep_ms_quantiles": [float(np.quantile(prep, q) * 1e3) for q in (0.5, 0.9, 0.99, 1.0)], "sum_prep_s": float(prep.sum()),
+               "top": [dict(ny=(int(ny[j]) if ny is not None else None), dur_ms=float(dur[j] * 1e3), prep_ms=float(prep[j] * 1e3), folded=float(tr[j, 3]), fold_ms=float(tr[j, 4] * 1e-5), upd_ms=float(tr[j, 5] * 1e-5), gap_ms=float(tr[j, 6] * 1e-5), fold_cycles_per_entry=float(tr[j, 7] / max(tr[j, 3], 1))) for j in top[:3]]}
         reports.append(rep)
         print(json.dumps(rep), flush=True)
     if args.out:
