@@ -158,7 +158,18 @@ typedef struct {
     int32_t        colwalk_min_rows;
     int32_t        screen_min;
     int32_t        lane_max;
+    /* Optional scratch for calls of <= 2048 targets with feature selection (online partial_fit): with it the call
+     * computes X^T y of ALL its targets in one pass over X (xty_batch_kernel: a wave per item column, the sums of every
+     * target in LDS, products folded in the reference's ascending-user order) instead of one walk per target; results
+     * are unchanged.  rtrec_slim_xty_workspace_bytes(n_users, n_items, nnz, n_targets) bytes, nnz = stored entries of X. */
+    void          *d_xty_ws;
+    size_t         xty_ws_bytes;
+    int64_t        nnz;
+    const int32_t *d_col_order;   /* optional int32[n_items]: item ids by descending column length (the one-pass X^T y
+                                     starts its longest columns first); any permutation gives the same results */
 } rtrec_fit_opts;
+
+size_t rtrec_slim_xty_workspace_bytes(int32_t n_users, int32_t n_items, int64_t nnz, int32_t n_targets);
 
 /* rtrec_slim_fit_columns with options; opts == NULL behaves exactly like rtrec_slim_fit_columns. */
 int rtrec_slim_fit_columns_opt(int32_t n_users, int32_t n_items,

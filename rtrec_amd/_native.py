@@ -22,7 +22,7 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
 EXPORTS = [
     "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_timer_create", "rtrec_timer_read", "rtrec_timer_destroy",
     "rtrec_slim_score_fr_scratch_bytes", "rtrec_slim_score_topk_opt", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
-    "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_gram_workspace_bytes", "rtrec_slim_gram_matrix", "rtrec_slim_score_workspace_bytes",
+    "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_gram_workspace_bytes", "rtrec_slim_xty_workspace_bytes", "rtrec_slim_gram_matrix", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
     "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round", "rtrec_store_decay",
     "rtrec_store_decay_device",
@@ -37,7 +37,8 @@ class FitCfg(C.Structure):
 class FitOpts(C.Structure):
     _fields_ = [("d_trace", C.c_void_p), ("d_gram", C.c_void_p), ("d_gram_index", C.c_void_p),
                 ("gram_n", C.c_int32), ("gram_rel_err", C.c_double), ("fast", C.c_int32), ("kernel", C.c_int32),
-                ("colwalk_min_rows", C.c_int32), ("screen_min", C.c_int32), ("lane_max", C.c_int32)]
+                ("colwalk_min_rows", C.c_int32), ("screen_min", C.c_int32), ("lane_max", C.c_int32),
+                ("d_xty_ws", C.c_void_p), ("xty_ws_bytes", C.c_size_t), ("nnz", C.c_int64), ("d_col_order", C.c_void_p)]
 
 
 class ScoreOpts(C.Structure):
@@ -101,6 +102,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_fit_columns_opt.argtypes = L.rtrec_slim_fit_columns.argtypes + [C.POINTER(FitOpts)]
     L.rtrec_slim_gram_workspace_bytes.restype = u64
     L.rtrec_slim_gram_workspace_bytes.argtypes = [i32, i32]
+    L.rtrec_slim_xty_workspace_bytes.restype = u64
+    L.rtrec_slim_xty_workspace_bytes.argtypes = [i32, i32, C.c_int64, i32]
     L.rtrec_slim_gram_matrix.restype = C.c_int
     L.rtrec_slim_gram_matrix.argtypes = [i32, i32, vp, vp, vp, vp, i32, vp, u64, vp, vp]
     L.rtrec_slim_score_workspace_bytes.restype = u64

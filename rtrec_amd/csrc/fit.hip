@@ -62,6 +62,9 @@ struct FitArgs {
     int gram_n;
     double gram_rel_err;      // |gram - exact| <= gram_rel_err * exact
     int fast;                 // tolerance mode (rtrec_fit_opts.fast): 1 tree-reduced dots, 2 also Gram-form CD (fit_gram_cd)
+    // optional, latency mode: the non-zero entries of X^T y of every target of the call, computed beforehand by
+    // xty_batch_kernel (one pass over X for the whole call); target t owns [t * I, t * I + pre_cnt[t])
+    const int *pre_cnt; const int *pre_i; const float *pre_s;
 };
 
 __device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, float nrm, int positive) {
@@ -496,7 +499,7 @@ struct Prep {
 // the top-K feature selection written to the LDS feature arrays.
 template <bool ALLF>
 __device__ __forceinline__ Prep prep_target(const FitArgs &a, int j, int K, float *s, int *touched, float *cand_s,
-                                            int *cand_i, const FeatLds &F, int tc_in = -1) {
+                                            int *cand_i, const FeatLds &F, int tc_in = -1, int t_pre = -1) {
     const int lane = lane_id();
     const int I = a.I;
     int *f_id = F.f_id, *f_b = F.f_b, *f_e = F.f_e, *f_ever = F.f_ever;
@@ -515,6 +518,17 @@ __device__ __forceinline__ Prep prep_target(const FitArgs &a, int j, int K, floa
 
     // ---- 1. s = X^T y (target column masked), touched list ----
     int tc = tc_in >= 0 ? tc_in : 0;
+    if (t_pre >= 0) {    // the call's batched X^T y pass has the non-zero sums: scatter them, nothing to walk
+        const int n0 = a.pre_cnt[t_pre];
+        const size_t o0 = static_cast<size_t>(t_pre) * I;
+        for (int tt = lane; tt < n0; tt += 64) {
+            const int i = a.pre_i[o0 + tt];
+            s[i] = a.pre_s[o0 + tt];
+            touched[tt] = i;
+        }
+        tc = n0;
+        tc_in = n0;
+    }
     for (int ob = yb; ob < ye && tc_in < 0; ob += 64) {
         const int n = min(64, ye - ob);
         int rb_l = 0, re_l = 0;
@@ -1724,6 +1738,143 @@ __device__ Screen mw_screen(const int *__restrict__ crow, const float *__restric
     return screen_interval(ps, pa, e - b);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched X^T y for a call of few targets (online partial_fit): ONE pass over X serves every target.
+//   s_t[i] = sum over users u (ascending) of X[u, i] * X[u, t]        (csr_matvec order, the target's own item masked)
+// Per target this is a walk over the users of t and their rows (prep_target) or over all of X (column walk): for a
+// mini-batch of ~850 popular items that is 850 passes over a 170 MB matrix.  Here a wave owns an item column i, keeps
+// s_.[i] for ALL targets of the call in LDS (n_t floats) and streams the column once: for entry (u, x) it adds x * y to
+// the sums of the targets user u has rated -- read from a compacted copy of the rows restricted to the call's targets
+// (xty_compact_kernel).  Users ascend along a column, and a user's targets are distinct, so every (i, t) sum sees its
+// products in exactly the reference order.  Non-zero sums are appended to the target's candidate list (cand_i, cand_s).
+// ---------------------------------------------------------------------------------------------
+constexpr int kXtyWaves = 8;
+constexpr int kXtyMaxTargets = 2048;     // = kMwMaxTargets: 8 KiB of LDS per wave
+constexpr int kXtyBatch = 16;            // users whose target lists are fetched together (memory-level parallelism of a wave)
+
+struct XtyArgs {
+    int U, I, n_t;
+    const int *cptr; const int *crow; const float *cval;
+    const int *rptr; const int *rcol; const float *rval;
+    const int *col_order;
+    const int *targets;
+    int *tmap;              // [I]  item -> index in `targets` or -1
+    int *ypos; int *ylen;   // [U]  the user's compacted target list in yt / yv
+    int *yt; float *yv;     // [<= nnz]
+    int *cursor;            // [2]  compaction cursor, column queue
+    int *cand_cnt; int *cand_i; float *cand_s;
+};
+
+// S[t] += p as one LDS float atomic without return (ds_add_f32): the LDS applies a wave's atomics in issue order
+// with one IEEE round-to-nearest add each, so the sum is the same left-to-right fold a read-add-write would give,
+// without the wave waiting a round trip per user.
+__device__ __forceinline__ void lds_add_f32(float *p, float v) {
+    (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+__global__ __launch_bounds__(256) void xty_tmap_kernel(XtyArgs a) {
+    const int g = static_cast<int>(blockIdx.x * blockDim.x + threadIdx.x);
+    if (g < a.n_t) { a.tmap[a.targets[g]] = g; a.cand_cnt[g] = 0; }
+    if (g == 0) { a.cursor[0] = 0; a.cursor[1] = 0; }
+}
+
+// one wave per user row: keep the entries whose item is a target of the call
+__global__ __launch_bounds__(256) void xty_compact_kernel(XtyArgs a) {
+    const int lane = lane_id();
+    const int u = static_cast<int>(blockIdx.x) * 4 + static_cast<int>(threadIdx.x >> 6);
+    if (u >= a.U) return;
+    const int rb = a.rptr[u], re = a.rptr[u + 1];
+    int cnt = 0;
+    for (int o = rb; o < re; o += 64) cnt += __builtin_popcountll(__ballot(o + lane < re && a.tmap[a.rcol[o + lane]] >= 0));
+    int pos = 0;
+    if (lane == 0 && cnt > 0) pos = atomicAdd(&a.cursor[0], cnt);
+    pos = readfirst_i(pos);
+    if (lane == 0) { a.ypos[u] = pos; a.ylen[u] = cnt; }
+    for (int o = rb; o < re && cnt > 0; o += 64) {
+        int t = -1;
+        float y = 0.0f;
+        if (o + lane < re) { t = a.tmap[a.rcol[o + lane]]; y = a.rval[o + lane]; }
+        const unsigned long long m = __ballot(t >= 0);
+        if (t >= 0) { const int q = pos + lane_prefix(m); a.yt[q] = t; a.yv[q] = y; }
+        pos += __builtin_popcountll(m);
+    }
+}
+
+__global__ __launch_bounds__(kXtyWaves * 64) void xty_batch_kernel(XtyArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id(), wave = static_cast<int>(threadIdx.x >> 6);
+    float *S = reinterpret_cast<float *>(smem) + static_cast<size_t>(wave) * a.n_t;
+    for (int t = lane; t < a.n_t; t += 64) S[t] = 0.0f;
+    for (;;) {
+        int pos = 0;
+        if (lane == 0) pos = atomicAdd(&a.cursor[1], 1);
+        pos = readfirst_i(pos);
+        if (pos >= a.I) break;
+        const int i = a.col_order ? a.col_order[pos] : pos;
+        const int b = a.cptr[i], e = a.cptr[i + 1];
+        if (b == e) continue;
+        const int t_self = a.tmap[i];                      // fitting item i masks its own column
+        bool any = false;
+        for (int ob = b; ob < e; ob += 64) {
+            const int n = min(64, e - ob);
+            int yp_l = 0, yl_l = 0;
+            float x_l = 0.0f;
+            if (lane < n) {
+                const int u = a.crow[ob + lane];
+                x_l = a.cval[ob + lane];
+                yp_l = a.ypos[u];
+                yl_l = a.ylen[u];
+            }
+            unsigned long long live = __ballot(yl_l > 0);       // users that rated one of the targets
+            while (live) {
+                // the target lists of the next kXtyBatch users are fetched together, then applied user after user
+                int q[kXtyBatch], len[kXtyBatch], tt[kXtyBatch];
+                float yy[kXtyBatch], xx[kXtyBatch];
+#pragma unroll
+                for (int k = 0; k < kXtyBatch; ++k) {
+                    q[k] = live ? __builtin_ctzll(live) : -1;
+                    live &= live - 1;
+                    len[k] = 0; tt[k] = -1; yy[k] = 0.0f; xx[k] = 0.0f;
+                    if (q[k] >= 0) {
+                        const int p0 = readlane_i(yp_l, q[k]);
+                        len[k] = readlane_i(yl_l, q[k]);
+                        xx[k] = readlane_f(x_l, q[k]);
+                        if (lane < len[k]) { tt[k] = a.yt[p0 + lane]; yy[k] = a.yv[p0 + lane]; }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < kXtyBatch; ++k) {
+                    if (q[k] < 0) break;
+                    any = true;
+                    if (tt[k] >= 0 && tt[k] != t_self) lds_add_f32(&S[tt[k]], __fmul_rn(xx[k], yy[k]));
+                    if (len[k] > 64) {                          // a user with more than 64 of the call's targets
+                        const int p0 = readlane_i(yp_l, q[k]);
+                        for (int c = 64; c < len[k]; c += 64) {
+                            if (c + lane < len[k]) {
+                                const int t2 = a.yt[p0 + c + lane];
+                                if (t2 != t_self) lds_add_f32(&S[t2], __fmul_rn(xx[k], a.yv[p0 + c + lane]));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!any) continue;
+        // non-zero sums -> the targets' candidate lists; the accumulators return to +0
+        for (int tb = 0; tb < a.n_t; tb += 64) {
+            const int t = tb + lane;
+            float v = 0.0f;
+            if (t < a.n_t) v = S[t];
+            if (v != 0.0f) {
+                const int slot = atomicAdd(&a.cand_cnt[t], 1);
+                a.cand_i[static_cast<size_t>(t) * a.I + slot] = i;
+                a.cand_s[static_cast<size_t>(t) * a.I + slot] = v;
+                S[t] = 0.0f;
+            }
+        }
+    }
+}
+
 // X^T y by COLUMN walk, all waves of the workgroup (latency mode, popular targets).
 // The row walk of prep_target visits the rows of U_j one after the other (two dependent memory
 // round trips each: 70k rows -> 0.3 s for the most popular item).  Here y is first scattered into
@@ -1805,11 +1956,12 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     if (tid == 0) *M.done = 0;
     int seq = 0;
     // popular targets: column walk by all waves (R = y is materialised as a by-product)
-    const bool col_walk = ny >= a.colwalk_min_rows;
+    const bool pre = a.pre_cnt != nullptr;
+    const bool col_walk = !pre && ny >= a.colwalk_min_rows;
     int tc_cw = -1;
     if (col_walk) tc_cw = xty_colwalk_mw(a, j, R, s, touched, &M.bc_i[4], wave, lane, kMwWaves);
     if (wave == 0) {
-        const Prep P = prep_target<false>(a, j, K, s, touched, cand_s, cand_i, F, tc_cw);
+        const Prep P = prep_target<false>(a, j, K, s, touched, cand_s, cand_i, F, tc_cw, pre ? t : -1);
         if (lane == 0) { M.bc_f[0] = P.yy; M.bc_f[1] = P.tol_s; M.bc_i[0] = P.tc; M.bc_i[1] = P.Kc; }
     }
     __syncthreads();
@@ -2208,6 +2360,29 @@ extern "C" int rtrec_slim_fit_workspace_init(void *d_workspace, size_t workspace
     return rtrec::launch_status();
 }
 
+struct XtyWs { size_t tmap, ypos, ylen, cursor, cand_cnt, yt, yv, cand_i, cand_s, total; };
+static XtyWs xty_ws_layout(int n_users, int n_items, long long nnz, int n_targets) {
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    XtyWs w;
+    size_t o = 0;
+    w.tmap = o;     o = up(o + static_cast<size_t>(n_items) * 4);
+    w.ypos = o;     o = up(o + static_cast<size_t>(n_users) * 4);
+    w.ylen = o;     o = up(o + static_cast<size_t>(n_users) * 4);
+    w.cursor = o;   o = up(o + 256);
+    w.cand_cnt = o; o = up(o + static_cast<size_t>(n_targets) * 4);
+    w.yt = o;       o = up(o + static_cast<size_t>(nnz) * 4);
+    w.yv = o;       o = up(o + static_cast<size_t>(nnz) * 4);
+    w.cand_i = o;   o = up(o + static_cast<size_t>(n_targets) * n_items * 4);
+    w.cand_s = o;   o = up(o + static_cast<size_t>(n_targets) * n_items * 4);
+    w.total = o;
+    return w;
+}
+
+extern "C" size_t rtrec_slim_xty_workspace_bytes(int32_t n_users, int32_t n_items, int64_t nnz, int32_t n_targets) {
+    if (n_users <= 0 || n_items <= 0 || nnz <= 0 || n_targets <= 0 || n_targets > kXtyMaxTargets) return 0;
+    return xty_ws_layout(n_users, n_items, nnz, n_targets).total;
+}
+
 static int fit_columns_impl(int32_t n_users, int32_t n_items,
                             const int32_t *d_csc_ptr, const int32_t *d_csc_row, const float *d_csc_val,
                             const int32_t *d_csr_ptr, const int32_t *d_csr_col, const float *d_csr_val,
@@ -2271,6 +2446,29 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
         const int force = opts ? opts->kernel : 0;
         // tolerance mode: the multi-wave kernel serves Gram-form CD only (fast = 2); tree-reduced dots are single-wave
         const bool latency_mode = a.fast != 1 && (force == 2 || (force == 0 && n_targets <= kMwMaxTargets));
+        if (latency_mode && opts && opts->d_xty_ws && opts->nnz > 0 && n_targets <= kXtyMaxTargets) {
+            // X^T y of every target of the call in one pass over X (xty_batch_kernel); the fit kernel then only selects
+            const XtyWs X = xty_ws_layout(n_users, n_items, opts->nnz, n_targets);
+            if (opts->xty_ws_bytes < X.total) return RTREC_ERR_WORKSPACE;
+            unsigned char *xw = static_cast<unsigned char *>(opts->d_xty_ws);
+            XtyArgs x{};
+            x.U = n_users; x.I = n_items; x.n_t = n_targets;
+            x.cptr = d_csc_ptr; x.crow = d_csc_row; x.cval = d_csc_val;
+            x.rptr = d_csr_ptr; x.rcol = d_csr_col; x.rval = d_csr_val;
+            x.col_order = opts->d_col_order; x.targets = d_targets;
+            x.tmap = reinterpret_cast<int *>(xw + X.tmap); x.ypos = reinterpret_cast<int *>(xw + X.ypos);
+            x.ylen = reinterpret_cast<int *>(xw + X.ylen); x.cursor = reinterpret_cast<int *>(xw + X.cursor);
+            x.cand_cnt = reinterpret_cast<int *>(xw + X.cand_cnt);
+            x.yt = reinterpret_cast<int *>(xw + X.yt); x.yv = reinterpret_cast<float *>(xw + X.yv);
+            x.cand_i = reinterpret_cast<int *>(xw + X.cand_i); x.cand_s = reinterpret_cast<float *>(xw + X.cand_s);
+            if (hipMemsetAsync(x.tmap, 0xff, static_cast<size_t>(n_items) * 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+            hipLaunchKernelGGL(xty_tmap_kernel, dim3((n_targets + 255) / 256), dim3(256), 0, st, x);
+            hipLaunchKernelGGL(xty_compact_kernel, dim3((n_users + 3) / 4), dim3(256), 0, st, x);
+            const size_t xl = static_cast<size_t>(kXtyWaves) * n_targets * 4;
+            const int per_cu = xl * 2 <= 160u * 1024u ? 2 : 1;
+            hipLaunchKernelGGL(xty_batch_kernel, dim3(256 * per_cu), dim3(kXtyWaves * 64), xl, st, x);
+            a.pre_cnt = x.cand_cnt; a.pre_i = x.cand_i; a.pre_s = x.cand_s;
+        }
         if (latency_mode) {
             size_t mw_lds = mw_lds_bytes(K);
             if (a.fast >= 2 && a.gram && K <= 64) mw_lds = ((mw_lds + 15) / 16) * 16 + static_cast<size_t>(K) * 64 * 4;

@@ -33,6 +33,7 @@ ALLF_OUTPUT_CAP = 2048      # coefficients per target the K=None output block ho
 GRAM_ITEMS = 512            # most popular items whose pairwise dot products the fit kernel may look up
 FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
 FIT_MW_MAX_TARGETS = 2048   # kMwMaxTargets of csrc/fit.hip: calls up to this size run the multi-wave kernel
+XTY_SCRATCH_MAX_BYTES = 32 << 30   # such calls get the one-pass X^T y (rtrec_fit_opts.d_xty_ws) while its scratch stays below this
 FIT_HEAVY_TARGETS = 256     # head of a bulk call sent to the multi-wave kernel (one workgroup per CU)
 FIT_HEAVY_SLOTS = 256
 FIT_HEAVY_MIN_ROWS = 2048   # ... as long as the target has at least this many users
@@ -431,6 +432,7 @@ class HipBackend:
         self.lib = _native.load()
         from . import ops as _ops  # noqa: F401  (registers torch.ops.rtrec_amd.*)
         self.ops = torch.ops.rtrec_amd
+        self._xty_ws = None              # scratch of the one-pass X^T y of small fit calls (grown on demand)
         # one-time costs of a process (custom-op dispatcher set-up, loading the gfx950 code objects)
         # belong here, next to the HIP context creation, not inside the first fit or recommend call
         w = torch.ones(1, dtype=torch.float32, device=self.device)
@@ -489,12 +491,25 @@ class HipBackend:
                     ws, queue, slots, trace=None, gram=None, fast=False):
         g = gram or {}
         k = self.fit_knobs()
+        # small calls with feature selection (online partial_fit): scratch for the one-pass X^T y of all targets
+        xty = None
+        n_t, nnz = int(targets.shape[0]), int(X["rcol"].shape[0])
+        if (0 < n_t <= FIT_MW_MAX_TARGETS and int(cfg.top_features) > 0 and int(fast) != 1 and k["kernel"] != 1 and nnz > 0
+                and os.environ.get("RTREC_AMD_XTY_BATCH", "1") != "0"):
+            need = int(self.lib.rtrec_slim_xty_workspace_bytes(n_users, n_items, nnz, n_t))
+            if 0 < need <= XTY_SCRATCH_MAX_BYTES:
+                if self._xty_ws is None or self._xty_ws.numel() < need:
+                    self._xty_ws = None
+                    self._xty_ws = self.empty((int(need * 1.25),), self.torch.uint8)
+                xty = self._xty_ws
+                if "col_order" not in X:          # longest columns first (lengths from the resident CSC pointer array)
+                    X["col_order"] = self.torch.argsort(X["cptr"][1:] - X["cptr"][:-1], descending=True, stable=True).to(self.torch.int32)
         self.ops.fit_columns(X["cptr"], X["crow"], X["cval"], X["rptr"], X["rcol"], X["rval"], X["sqn"], targets,
                              n_users, n_items, float(cfg.l1_reg), float(cfg.l2_reg), float(cfg.tol), int(cfg.max_iter),
                              int(cfg.seed), bool(cfg.positive), int(cfg.top_features),
                              out_items, out_coef, out_count, out_niter, cap, ws, slots, queue, trace,
                              g.get("G"), g.get("index"), int(g.get("n", 0)), float(g.get("rel_err", 0.0)),
-                             int(fast), k["kernel"], k["colwalk_min_rows"], k["screen_min"], k["lane_max"])
+                             int(fast), k["kernel"], k["colwalk_min_rows"], k["screen_min"], k["lane_max"], xty, X.get("col_order") if xty is not None else None)
 
     def gram_matrix(self, X, n_users, n_items, n_top):
         """Gram matrix X_P^T X_P of the n_top most popular items in float64 for the fit kernel's Gram

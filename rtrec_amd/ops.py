@@ -60,18 +60,20 @@ def gram_matrix(cptr: Tensor, crow: Tensor, cval: Tensor, top_items: Tensor, ws:
 
 
 @custom_op("rtrec_amd::fit_columns",
-           mutates_args=("out_items", "out_coef", "out_count", "out_n_iter", "ws", "queue", "trace"), device_types="cuda")
+           mutates_args=("out_items", "out_coef", "out_count", "out_n_iter", "ws", "queue", "trace", "xty_ws"), device_types="cuda")
 def fit_columns(cptr: Tensor, crow: Tensor, cval: Tensor, rptr: Tensor, rcol: Tensor, rval: Tensor, sqn: Tensor,
                 targets: Tensor, n_users: int, n_items: int,
                 l1_reg: float, l2_reg: float, tol: float, max_iter: int, seed: int, positive: bool, top_features: int,
                 out_items: Tensor, out_coef: Tensor, out_count: Tensor, out_n_iter: Tensor, cap: int,
                 ws: Tensor, n_slots: int, queue: Tensor, trace: Optional[Tensor],
                 gram: Optional[Tensor], gram_index: Optional[Tensor], gram_n: int, gram_rel_err: float,
-                fast: int, kernel: int, colwalk_min_rows: int, screen_min: int, lane_max: int) -> None:
+                fast: int, kernel: int, colwalk_min_rows: int, screen_min: int, lane_max: int,
+                xty_ws: Optional[Tensor], col_order: Optional[Tensor]) -> None:
     lib = _native.load()
     cfg = _native.FitCfg(l1_reg, l2_reg, tol, max_iter, seed, int(positive), top_features)
     opts = _native.FitOpts(_p(trace), _p(gram), _p(gram_index), gram_n if gram is not None else 0, gram_rel_err,
-                           int(fast), kernel, colwalk_min_rows, screen_min, lane_max)
+                           int(fast), kernel, colwalk_min_rows, screen_min, lane_max,
+                           _p(xty_ws), xty_ws.numel() if xty_ws is not None else 0, int(rcol.shape[0]), _p(col_order))
     _native.check(lib.rtrec_slim_fit_columns_opt(
         n_users, n_items, _p(cptr), _p(crow), _p(cval), _p(rptr), _p(rcol), _p(rval), _p(sqn),
         _p(targets), int(targets.shape[0]), C.byref(cfg), _p(out_items), _p(out_coef), _p(out_count), _p(out_n_iter),
