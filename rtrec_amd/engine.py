@@ -33,6 +33,7 @@ ALLF_OUTPUT_CAP = 2048      # coefficients per target the K=None output block ho
 GRAM_ITEMS = 512            # most popular items whose pairwise dot products the fit kernel may look up
 FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
 FIT_MW_MAX_TARGETS = 2048   # kMwMaxTargets of csrc/fit.hip: calls up to this size run the multi-wave kernel
+XTY_MIN_WALK_ENTRIES = 1e9         # ... and the per-target column walks it replaces would visit at least this many entries
 XTY_SCRATCH_MAX_BYTES = 32 << 30   # such calls get the one-pass X^T y (rtrec_fit_opts.d_xty_ws) while its scratch stays below this
 FIT_HEAVY_TARGETS = 256     # head of a bulk call sent to the multi-wave kernel (one workgroup per CU)
 FIT_HEAVY_SLOTS = 256
@@ -488,13 +489,13 @@ class HipBackend:
                     lane_max=0 if lane_max is None else (-1 if int(lane_max) == 0 else int(lane_max)))
 
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
-                    ws, queue, slots, trace=None, gram=None, fast=False):
+                    ws, queue, slots, trace=None, gram=None, fast=False, one_pass_xty=True):
         g = gram or {}
         k = self.fit_knobs()
         # small calls with feature selection (online partial_fit): scratch for the one-pass X^T y of all targets
         xty = None
         n_t, nnz = int(targets.shape[0]), int(X["rcol"].shape[0])
-        if (0 < n_t <= FIT_MW_MAX_TARGETS and int(cfg.top_features) > 0 and int(fast) != 1 and k["kernel"] != 1 and nnz > 0
+        if (one_pass_xty and 0 < n_t <= FIT_MW_MAX_TARGETS and int(cfg.top_features) > 0 and int(fast) != 1 and k["kernel"] != 1 and nnz > 0
                 and os.environ.get("RTREC_AMD_XTY_BATCH", "1") != "0"):
             need = int(self.lib.rtrec_slim_xty_workspace_bytes(n_users, n_items, nnz, n_t))
             if 0 < need <= XTY_SCRATCH_MAX_BYTES:
@@ -824,7 +825,10 @@ class SlimEngine:
                      ws=(ws, queue))   # keeps the scratch alive while the kernel runs
             if isinstance(be, HipBackend):
                 be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
-                               ws_slots, d["trace"], gram, fast=fast)
+                               ws_slots, d["trace"], gram, fast=fast,
+                               # the heavy head of a bulk call starts its long ordered folds at once: its targets' own
+                               # multi-wave walks overlap them, a one-pass X^T y up front would only delay the chain
+                               one_pass_xty=(role != "heavy" and self._one_pass_xty_pays(tg)))
             else:
                 be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
                                ws_slots, d["trace"], gram)
@@ -875,6 +879,18 @@ class SlimEngine:
             return (cat("t", (0,), torch.int32), cat("items", (0, cap), torch.int32), cat("coef", (0, cap), torch.float32),
                     cat("count", (0,), torch.int32), d_niter.cpu().numpy())
         return targets, items_out, coef_out, count_out, niter_out
+
+    def _one_pass_xty_pays(self, targets: np.ndarray) -> bool:
+        """The one-pass X^T y of a small call (csrc/fit.hip, xty_batch_kernel) replaces one walk per target by one pass
+        over X plus fixed costs (row compaction, per-column scans of the target sums, the latency chain of the longest
+        column).  Targets with >= 1024 users walk all of X each (kColWalkMinRows), so it pays when that traffic is
+        large (targets x entries of the matrix being fitted): measured between C2 (175 such targets x 1.1 M entries: 16 -> 23 ms with
+        it) and C3 (450 x 5.0 M: 58 -> 44 ms)."""
+        col_nnz = self._X["col_nnz"]
+        big = int(np.count_nonzero(col_nnz[targets] >= 1024))
+        if os.environ.get("RTREC_AMD_DEBUG_XTY"):
+            print(f"[xty] targets={len(targets)} big={big} nnz={int(col_nnz.sum())} product={big * float(col_nnz.sum()):.3g}", flush=True)
+        return big * float(col_nnz.sum()) >= XTY_MIN_WALK_ENTRIES
 
     def _fit_overflow(self, targets: np.ndarray, cfg, U: int, I: int, slots: int):
         """K = None targets whose solution did not fit the output block: fit them again with cap = I."""
