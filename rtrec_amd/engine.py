@@ -886,6 +886,8 @@ class SlimEngine:
         column).  Targets with >= 1024 users walk all of X each (kColWalkMinRows), so it pays when that traffic is
         large (targets x entries of the matrix being fitted): measured between C2 (175 such targets x 1.1 M entries: 16 -> 23 ms with
         it) and C3 (450 x 5.0 M: 58 -> 44 ms)."""
+        if os.environ.get("RTREC_AMD_XTY_BATCH") == "force":      # parity tests: small matrices through this path
+            return True
         col_nnz = self._X["col_nnz"]
         big = int(np.count_nonzero(col_nnz[targets] >= 1024))
         if os.environ.get("RTREC_AMD_DEBUG_XTY"):

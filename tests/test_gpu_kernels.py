@@ -33,8 +33,9 @@ def bits(a):
     (3000, 800, 90000, 50, True, False),     # integer ratings: ties everywhere, same tie rule both sides
     (400, 30, 3000, 50, True, True),         # K > I
 ])
-# single-wave (throughput) kernel, multi-wave (latency) kernel, and the latter with the column-walk X^T y forced
-@pytest.mark.parametrize("fit_mode", ["sw", "mw", "mw-colwalk"])
+# single-wave (throughput) kernel, multi-wave (latency) kernel, the latter with the column-walk X^T y forced, and with the
+# one-pass X^T y of all the call's targets (xty_batch_kernel: LDS float atomics in the reference's fold order) forced
+@pytest.mark.parametrize("fit_mode", ["sw", "mw", "mw-colwalk", "mw-xty"])
 # screening (order-free pass + error bound before an ordered fold) from its default length, and forced on
 # every column so that these small matrices exercise it
 @pytest.mark.parametrize("screen_min", [None, "1"])
@@ -45,6 +46,7 @@ def test_fit_columns_bit_exact(engine, oracle, U, I, draws, K, positive, float_r
         monkeypatch.setenv("RTREC_AMD_SCREEN_MIN", screen_min)
     if fit_mode == "mw-colwalk":
         monkeypatch.setenv("RTREC_AMD_COLWALK_MIN", "1")
+    monkeypatch.setenv("RTREC_AMD_XTY_BATCH", "force" if fit_mode == "mw-xty" else "0")
     X = interaction_matrix(U, I, draws, seed=11, float_ratings=float_ratings)
     Xc = X.tocsc()
     Xc.sort_indices()
@@ -339,6 +341,7 @@ def test_fit_with_negative_ratings_bit_exact(engine, oracle, fit_mode, positive,
     monkeypatch.setenv("RTREC_AMD_FIT_MODE", fit_mode)
     monkeypatch.setenv("RTREC_AMD_SCREEN_MIN", "1")
     monkeypatch.setenv("RTREC_AMD_GRAM", "force")
+    monkeypatch.setenv("RTREC_AMD_XTY_BATCH", "force")      # latency kernel: one-pass X^T y with products of either sign
     X = interaction_matrix(1500, 300, 40000, seed=77)
     rng = np.random.default_rng(5)
     X.data = (X.data * np.where(rng.random(X.nnz) < 0.25, -1.0, 1.0)).astype(np.float32)
