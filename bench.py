@@ -465,12 +465,13 @@ def main() -> None:
                 ok = ok and np.array_equal(o_ids, ids_gpu[rows_s])
                 done += len(rows_s)
                 n = min(n * 2, 8192 * threads)
-            return {"value": done / spent, "unit": "users/s", "cores": threads, "kind": "port",
+            return {"value": done / max(spent, 1e-9), "unit": "users/s", "cores": threads, "kind": "port",
                     "sample": f"{done} random users of the same workload scored with the C oracle in {spent:.1f}s "
                               f"(top-k ids identical to the GPU: {ok})"}, done
 
         leg1, used = score_leg(1, args.cpu_seconds / 2, 0)
-        legn, _ = score_leg(n_cores, args.cpu_seconds / 2, used)
+        # (a small workload can be finished by the first leg: the second then re-scores the sample from its start)
+        legn, _ = score_leg(n_cores, args.cpu_seconds / 2, used if used + 64 * n_cores <= U else 0)
         line["cpu_baseline"] = dict(leg1, all_cores=legn)
 
         # fit: a STRATIFIED sample of target columns (by column length: the top 1 %, the next 19 %, the tail), each
