@@ -966,8 +966,9 @@ struct FrArgs {
     const unsigned long long *tile_rows;   // [n_tiles][2]: bit f of word h set <=> row 64 h + f holds a weight in the tile
     const int *tile_off;    // [n_tiles]: byte offset of the tile's slice inside its super-tile
     const int *st_kb;       // [n_super + 1]: KiB offset of super-tile s in wd (one LDS-DMA wave-instruction moves 1 KiB)
-    const int *st_tile;     // [n_super + 1]: first tile of super-tile s (at most 32 tiles each)
+    const int *st_tile;     // [n_super + 1]: first tile of super-tile s (at most 32 tiles each; resident: 64)
     int n_super;
+    int resident;           // one super-tile that stays in LDS for the life of the workgroup
     int buf_bytes;          // bytes of one LDS buffer (>= the largest super-tile, >= the setup scratch)
     unsigned long long *mscratch;   // [gridDim.x][waves][users][n_tiles * REGS] interacted-column lane masks
     int kk, top_k, filter;
@@ -992,8 +993,13 @@ constexpr int kFrCandCap = 64;               // candidates a wave buffers per me
 __host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
 constexpr int kFrStep = 2;                   // rows of W per sweep step
 constexpr int kFrZeroRowBytes = 1024;        // one slice row of +0.0 (the widest tile: 256 columns)
-__host__ __device__ constexpr size_t fr_lds_bytes(int buf_bytes) {
-    return 2 * static_cast<size_t>(buf_bytes) + kFrWaves * fr_wave_extra_bytes() + kFrZeroRowBytes + 16;
+// per-wave LDS setup scratch actually needed: the interacted-column mask words, a pad, 128 ratings
+__host__ __device__ constexpr int fr_setup_scratch(int mask_words) { return ((mask_words * 8 + 256 + 512) + 255) / 256 * 256; }
+// Streaming layout: two slice buffers (the second doubles as setup scratch).  RESIDENT layout (all of W's slices in ONE
+// super-tile that fits next to the setup scratch): one buffer, loaded once per workgroup and kept across its jobs.
+__host__ __device__ constexpr size_t fr_lds_bytes(int buf_bytes, bool resident = false, int mask_words = kFrMaskWords) {
+    return (resident ? static_cast<size_t>(buf_bytes) + kFrWaves * fr_setup_scratch(mask_words) : 2 * static_cast<size_t>(buf_bytes)) +
+           kFrWaves * fr_wave_extra_bytes() + kFrZeroRowBytes + 16;
 }
 
 typedef __attribute__((address_space(3))) void fr_lds_void;
@@ -1090,12 +1096,16 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
     const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
     const int kk = a.kk;                                    // <= 16
     unsigned char *buf0 = smem;
-    unsigned char *buf1 = smem + a.buf_bytes;               // >= kFrWaves * kFrWaveScratch: doubles as setup scratch
-    unsigned char *extra = smem + 2 * static_cast<size_t>(a.buf_bytes) + static_cast<size_t>(wave) * fr_wave_extra_bytes();
+    unsigned char *buf1 = smem + a.buf_bytes;               // second slice buffer; also (or, resident: only) setup scratch
+    const bool resident = a.resident != 0;                  // W's slices stay in buf0 for the life of the workgroup
+    const int wscratch = resident ? fr_setup_scratch(a.n_tiles * REGS) : kFrWaveScratch;
+    const size_t lds_front = resident ? static_cast<size_t>(a.buf_bytes) + kFrWaves * static_cast<size_t>(wscratch)
+                                      : 2 * static_cast<size_t>(a.buf_bytes);
+    unsigned char *extra = smem + lds_front + static_cast<size_t>(wave) * fr_wave_extra_bytes();
     float *cv = reinterpret_cast<float *>(extra);                     // [kFrCandCap] candidate scores of one user
     int *cp = reinterpret_cast<int *>(cv + kFrCandCap);               // [kFrCandCap] their layout columns
-    int *s_job = reinterpret_cast<int *>(smem + fr_lds_bytes(a.buf_bytes) - 16);
-    const unsigned char *zrow = smem + 2 * static_cast<size_t>(a.buf_bytes) + kFrWaves * fr_wave_extra_bytes();
+    const unsigned char *zrow = smem + lds_front + kFrWaves * fr_wave_extra_bytes();
+    int *s_job = reinterpret_cast<int *>(smem + lds_front + kFrWaves * fr_wave_extra_bytes() + kFrZeroRowBytes);
     for (int o = tid * 4; o < kFrZeroRowBytes; o += kFrWaves * 64 * 4) *reinterpret_cast<float *>(smem + (zrow - smem) + o) = 0.0f;
     const int n_jobs = (a.n_rows + UW * kFrWaves - 1) / (UW * kFrWaves);
     const float ninf = -__builtin_huge_valf();
@@ -1120,14 +1130,18 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
 #ifdef SCORE_PROFILE
     const unsigned long long pf_start_ = pf_t_;
 #endif
+    if (resident) {                                         // all of W's slices: once per workgroup
+        load_super(0, buf0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     for (;;) {
-        __syncthreads();                                    // the previous job has left both buffers
+        __syncthreads();                                    // the previous job has left both buffers (resident: W has landed)
         PF_MARK(PF_QUEUE)
         if (tid == 0) *s_job = atomicAdd(a.queue, 1);
         __syncthreads();
         const int job = *s_job;
         if (job >= n_jobs) break;
-        load_super(0, buf0);
+        if (!resident) load_super(0, buf0);
         // Row positions of this wave: position p of the job's 128 goes to wave p % 16, so that with rows handed
         // over longest-first (a.order) every wave of the workgroup gets the same mix of long and short rows and
         // the barriers find the waves level.
@@ -1136,32 +1150,58 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         // ---- setup: per user its ratings of the R feature items (dense, lane = row of W) and the interacted-column
         //      masks, built in LDS (the second buffer is free until super-tile 0 starts) and parked in the wave's
         //      global scratch; the ratings come back into registers below ----
-        unsigned long long *Ml = reinterpret_cast<unsigned long long *>(buf1 + wave * kFrWaveScratch);
-        float *xl = reinterpret_cast<float *>(Ml + kFrMaskWords) + 64;                     // [128] floats
-        for (int u = 0; u < UW; ++u) {
-            const int p = base + u * kFrWaves;
-            int a0 = 0, n_a = 0;
+        unsigned long long *Ml = reinterpret_cast<unsigned long long *>(buf1 + wave * wscratch);
+        float *xl = reinterpret_cast<float *>(Ml + (resident ? mwords : kFrMaskWords)) + 64;   // [128] floats
+        // the eight users' row extents: lane u follows user u's chain of dependent loads (work order -> row id -> row
+        // pointers), all eight chains in parallel; then the first 64 entries of every row and what they map to
+        // (feature row, layout column), again all eight users' loads in flight together -- three memory round trips
+        // per job instead of four per user
+        int a0_l = 0, na_l = 0;
+        if (lane < UW) {
+            const int p = base + lane * kFrWaves;
             if (p < a.n_rows) {
                 const int r = a.order ? a.order[p] : p;
                 const int xrow = a.row_ids ? a.row_ids[r] : r;
-                if (xrow >= 0 && xrow < a.n_x_rows) { a0 = a.xb_ptr[xrow]; n_a = a.xb_ptr[xrow + 1] - a0; }
+                if (xrow >= 0 && xrow < a.n_x_rows) { a0_l = a.xb_ptr[xrow]; na_l = a.xb_ptr[xrow + 1] - a0_l; }
             }
-            a0 = readfirst_i(a0); n_a = readfirst_i(n_a);
+        }
+        int it0[UW], fm0[UW], cm0[UW];
+        float xv0[UW];
+        fr_static_for<UW>([&](auto Uc) {
+            constexpr int u = decltype(Uc)::value;
+            const int a0 = readlane_i(a0_l, u), n_a = readlane_i(na_l, u);
+            it0[u] = -1; xv0[u] = 0.0f;
+            if (lane < n_a) { it0[u] = a.xb_col[a0 + lane]; xv0[u] = a.xb_val[a0 + lane]; }
+        });
+        fr_static_for<UW>([&](auto Uc) {
+            constexpr int u = decltype(Uc)::value;
+            fm0[u] = -1; cm0[u] = -1;
+            if (it0[u] >= 0 && it0[u] < a.n_items) {
+                fm0[u] = a.fmap[it0[u]];
+                if (a.filter) cm0[u] = a.col_map[it0[u]];
+            }
+        });
+        auto mark = [&](int c) {      // interacted layout column c -> its bit in the user's mask words
+            const int cl = c & (TC - 1);
+            atomicOr(&Ml[(c / TC) * REGS + (cl & (REGS - 1))], 1ull << (cl / REGS));
+        };
+        fr_static_for<UW>([&](auto Uc) {
+            constexpr int u = decltype(Uc)::value;
+            const int a0 = readlane_i(a0_l, u), n_a = readlane_i(na_l, u);
             for (int w = lane; w < mwords; w += 64) Ml[w] = 0ull;
             fr_static_for<2>([&](auto H) { xl[H() * 64 + lane] = 0.0f; });
-            for (int b = 0; b < n_a; b += 64) {
+            if (fm0[u] >= 0) xl[fm0[u]] = xv0[u];                           // the items of one row are distinct
+            if (cm0[u] >= 0) mark(cm0[u]);
+            for (int b = 64; b < n_a; b += 64) {                            // rows beyond 64 entries
                 const int q = b + lane;
                 if (q < n_a) {
                     const int item = a.xb_col[a0 + q];
                     if (item < a.n_items) {
                         const int f = a.fmap[item];
-                        if (f >= 0) xl[f] = a.xb_val[a0 + q];             // the items of one row are distinct
+                        if (f >= 0) xl[f] = a.xb_val[a0 + q];
                         if (a.filter) {
                             const int c = a.col_map[item];
-                            if (c >= 0) {
-                                const int cl = c & (TC - 1);
-                                atomicOr(&Ml[(c / TC) * REGS + (cl & (REGS - 1))], 1ull << (cl / REGS));
-                            }
+                            if (c >= 0) mark(c);
                         }
                     }
                 }
@@ -1169,7 +1209,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             uint32_t *xu = xs_wave + u * kFrUserWords;
             fr_static_for<2>([&](auto H) { xu[H() * 64 + lane] = __float_as_uint(xl[H() * 64 + lane]); });
             for (int w = lane; w < mwords; w += 64) ms_wave[static_cast<size_t>(u) * mwords + w] = Ml[w];
-        }
+        });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_dcache_inv();                   // the masks are read back through the scalar cache
         float xr[UW][XR];          // lane f: the user's rating of the item of row 64 * h + f of W (0: not owned)
@@ -1188,8 +1228,10 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         uint32_t spilled = 0u;     // bit u: user u's candidates overflowed the buffer -> its row goes to the exact-tie pass
 
         PF_MARK(PF_HDR) PF_ADD(PF_JOBS, 1)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // super-tile 0 has landed
-        __syncthreads();
+        if (!resident) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // super-tile 0 has landed
+            __syncthreads();
+        }
         PF_MARK(PF_GROUP)
 
         // rows of W that at least one of the wave's users rates: the sweep below visits only those
@@ -1335,8 +1377,10 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                 });
             }
             PF_MARK(PF_DENSE)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // super-tile s+1 has landed ...
-            __syncthreads();                                    // ... and every wave has left super-tile s
+            if (!resident) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // super-tile s+1 has landed ...
+                __syncthreads();                                    // ... and every wave has left super-tile s
+            }
             PF_MARK(PF_GROUP)
         }
 
@@ -1469,7 +1513,10 @@ bool fr_usable(const FrLayout &F, int kk) {
     const int regs = F.tile_cols / 64;
     if (F.rows <= 0 || F.rows > kFrMaxRows || F.n_tiles <= 0 || F.n_tiles * regs > kFrMaskWords) return false;
     if (F.n_super <= 0 || F.n_super > F.n_tiles) return false;
-    if (F.buf_bytes < kFrWaves * kFrWaveScratch || (F.buf_bytes & 1023) || fr_lds_bytes(F.buf_bytes) > 160u * 1024u) return false;
+    if (F.buf_bytes <= 0 || (F.buf_bytes & 1023)) return false;
+    const int regs_ = F.tile_cols / 64;
+    const bool resident = F.n_super == 1 && F.n_tiles <= 64 && fr_lds_bytes(F.buf_bytes, true, F.n_tiles * regs_) <= 160u * 1024u;
+    if (!resident && (F.buf_bytes < kFrWaves * kFrWaveScratch || fr_lds_bytes(F.buf_bytes) > 160u * 1024u)) return false;
     if (F.scratch_bytes < fr_scratch_bytes(F.n_tiles, F.tile_cols)) return false;
     return kk >= 1 && kk <= kFrMaxKk;
 }
@@ -1520,7 +1567,10 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.flag_list = flag_list; f.flag_len = flag_len; f.queue = queue;
         const int n_jobs = (a.n_rows + kFrUsers * kFrWaves - 1) / (kFrUsers * kFrWaves);
         const unsigned grid = static_cast<unsigned>(n_jobs < 256 ? n_jobs : 256);
-        const size_t lds = fr_lds_bytes(FR.buf_bytes);
+        // all slices in one super-tile that fits next to the setup scratch: W stays in LDS for the life of a workgroup
+        f.resident = (FR.n_super == 1 && FR.n_tiles <= 64 &&
+                      fr_lds_bytes(FR.buf_bytes, true, FR.n_tiles * (FR.tile_cols / 64)) <= 160u * 1024u) ? 1 : 0;
+        const size_t lds = f.resident ? fr_lds_bytes(FR.buf_bytes, true, FR.n_tiles * (FR.tile_cols / 64)) : fr_lds_bytes(FR.buf_bytes);
         const bool two = FR.rows > 64;
         if (FR.tile_cols == 256) {
             if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 2>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);

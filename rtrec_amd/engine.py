@@ -228,6 +228,14 @@ def _pack_super_tiles(n_rows_t: np.ndarray, tc: int):
     buf_cap = (160 * 1024 - 16 * 512 - 1024 - 16) // 2 // 1024 * 1024      # fr_lds_bytes of csrc/score.hip
     row_bytes = tc * 4
     n_tiles = len(n_rows_t)
+    # RESIDENT form: all slices in one super-tile that fits LDS next to the per-wave setup scratch -- the kernel then
+    # loads W once per workgroup and keeps it across its jobs (no staging, no super-tile barriers)
+    total = -(-(int(n_rows_t.sum()) * row_bytes) // 1024) * 1024
+    setup = 16 * (-(-(n_tiles * (tc // 64) * 8 + 768) // 256) * 256)
+    if n_tiles <= 64 and total + setup + 16 * 512 + 1024 + 16 <= 160 * 1024:
+        first = np.cumsum(n_rows_t) - n_rows_t
+        return (np.asarray([0, n_tiles], dtype=np.int64), np.zeros(n_tiles, dtype=np.int64), np.asarray([0, total // 1024], dtype=np.int64),
+                first, max(total, 1024))
     if int(n_rows_t.max()) * row_bytes > buf_cap:
         return None
     st_tile, used = [0], 0
