@@ -1031,6 +1031,10 @@ __device__ __forceinline__ float fr_shift_down(float v, float fill) {    // lane
 }
 
 
+template <int CTRL> __device__ __forceinline__ float fr_dpp_f(float v, float fill) {   // lanes without a source keep `fill`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 // kk-th largest of the 64 per-lane values `best` (-inf = no value), or -inf when fewer than kk lanes hold
 // one: a LOWER BOUND of the kk-th largest element of any set whose per-lane maxima these are.  Uniform.
 __device__ __forceinline__ float fr_kth_lane_best(float best, int kk) {
@@ -1038,14 +1042,24 @@ __device__ __forceinline__ float fr_kth_lane_best(float best, int kk) {
     const int lane = lane_id();
     float tau = ninf;
     if (kk > 64) {           // kk - 64: over the 64 lane values themselves
+        // kk - 64 <= 16 rounds of "take the maximum out": a DPP max-reduction (row_shr 1/2/4/8, row_bcast 15/31: six
+        // v_max_f32_dpp, result in lane 63) and one select that retires the first lane holding it -- ~10 vector
+        // instructions per round where ranking all 64 values costs ~350
         kk -= 64;
-        int rank = 0;
-        for (int t = 0; t < 64; ++t) {
-            const float o = readlane_f(best, t);
-            rank += (o > best || (o == best && t < lane)) ? 1 : 0;
+        float v = best;
+        for (int r = 0; r < kk; ++r) {
+            float t = v;
+            t = fmaxf(t, fr_dpp_f<0x111>(t, ninf));
+            t = fmaxf(t, fr_dpp_f<0x112>(t, ninf));
+            t = fmaxf(t, fr_dpp_f<0x114>(t, ninf));
+            t = fmaxf(t, fr_dpp_f<0x118>(t, ninf));
+            t = fmaxf(t, fr_dpp_f<0x142>(t, ninf));      // row_bcast:15
+            t = fmaxf(t, fr_dpp_f<0x143>(t, ninf));      // row_bcast:31
+            tau = readlane_f(t, 63);
+            if (tau == ninf) break;                      // fewer than kk values
+            const unsigned long long at = __ballot(v == tau);
+            v = lane == static_cast<int>(__builtin_ctzll(at)) ? ninf : v;
         }
-        const unsigned long long at = __ballot(rank == kk - 1);
-        if (at) tau = readlane_f(best, __builtin_ctzll(at));
     } else if (kk <= 16) {   // the kk-th largest of the 16 quad maxima is a bound as well, at a quarter of the steps
         float q = best;
         { const float o = shfl_xor_t(q, 1); q = o > q ? o : q; }
