@@ -1148,18 +1148,34 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         load_super(0, buf0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    // Streaming layout: a job = 128 users of the whole workgroup (the waves share the staged slices and meet at its
+    // barriers).  Resident layout: W is read-only in LDS, so every WAVE claims its own 8 users and no barrier is left
+    // inside the loop -- a wave never waits for a slower neighbour.
+    const int n_wave_jobs = (a.n_rows + UW - 1) / UW;
+    if (resident) __syncthreads();                          // W has landed
     for (;;) {
-        __syncthreads();                                    // the previous job has left both buffers (resident: W has landed)
-        PF_MARK(PF_QUEUE)
-        if (tid == 0) *s_job = atomicAdd(a.queue, 1);
-        __syncthreads();
-        const int job = *s_job;
-        if (job >= n_jobs) break;
-        if (!resident) load_super(0, buf0);
-        // Row positions of this wave: position p of the job's 128 goes to wave p % 16, so that with rows handed
-        // over longest-first (a.order) every wave of the workgroup gets the same mix of long and short rows and
-        // the barriers find the waves level.
-        const int base = job * kFrWaves * UW + wave;
+        int base, pstride;
+        if (resident) {
+            PF_MARK(PF_GROUP)
+            int j = 0;
+            if (lane == 0) j = atomicAdd(a.queue, 1);
+            j = readfirst_i(j);
+            PF_MARK(PF_QUEUE)
+            if (j >= n_wave_jobs) break;
+            // positions j, j + n_wave_jobs, ...: with rows handed over longest-first every wave job is the same mix
+            base = j; pstride = n_wave_jobs;
+        } else {
+            __syncthreads();                                // the previous job has left both buffers
+            PF_MARK(PF_QUEUE)
+            if (tid == 0) *s_job = atomicAdd(a.queue, 1);
+            __syncthreads();
+            const int job = *s_job;
+            if (job >= n_jobs) break;
+            load_super(0, buf0);
+            // position p of the job's 128 goes to wave p % 16, so that with rows handed over longest-first (a.order)
+            // every wave of the workgroup gets the same mix of long and short rows and the barriers find the waves level
+            base = job * kFrWaves * UW + wave; pstride = kFrWaves;
+        }
 
         // ---- setup: per user its ratings of the R feature items (dense, lane = row of W) and the interacted-column
         //      masks, built in LDS (the second buffer is free until super-tile 0 starts) and parked in the wave's
@@ -1172,7 +1188,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         // per job instead of four per user
         int a0_l = 0, na_l = 0;
         if (lane < UW) {
-            const int p = base + lane * kFrWaves;
+            const int p = base + lane * pstride;
             if (p < a.n_rows) {
                 const int r = a.order ? a.order[p] : p;
                 const int xrow = a.row_ids ? a.row_ids[r] : r;
@@ -1402,7 +1418,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         int gid[NL], orow = 0;
         fr_static_for<NL>([&](auto G4) { gid[G4()] = lc4[G4()] >= 0 ? a.col_ids[lc4[G4()]] : -1; });    // all gathers in flight together
         if (lane < UW) {
-            const int p = base + lane * kFrWaves;
+            const int p = base + lane * pstride;
             orow = p < a.n_rows ? (a.order ? a.order[p] : p) : -1;
         }
         fr_static_for<UW>([&](auto Uc) {
