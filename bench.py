@@ -313,7 +313,7 @@ def main() -> None:
     if fr is not None and eng.use_feature_rows:
         tc, R = fr["fr_tile_cols"], fr["fr_rows"]
         kernel_name = f"score_frows_kernel<{tc // 64},{2 if R > 64 else 1}>"
-        tr = fr["fr_tile_rows"].view(np.uint64).reshape(-1, 2)
+        tr = fr["fr_rows_of_tile"].view(np.uint64).reshape(-1, 2)
         feat_items = np.flatnonzero(fr["fr_map"] >= 0)
         tiles_of_row = np.array([sum(((int(tr[t, f // 64]) >> (f % 64)) & 1) for t in range(tr.shape[0])) for f in range(R)],
                                 dtype=np.float64)
@@ -323,17 +323,22 @@ def main() -> None:
         # rates (one LDS read per row, applied to all 8): the union over the wave's users, in the order the engine hands
         # the rows over (position p of a 128-user job -> wave p % 16)
         Xsc = (X if n_scored == U else Xs)[:, feat_items].tocsr()
-        own = np.zeros((n_scored + (-n_scored) % 128 + 1, R), dtype=bool)
+        own = np.zeros((n_scored + 1, R), dtype=bool)                          # last row: padding (no ratings)
         own[np.repeat(np.arange(n_scored), np.diff(Xsc.indptr)), Xsc.indices] = Xsc.data != 0
         order = eng._X.get("_order") if n_scored == U else None
         order = order.cpu().numpy().astype(np.int64) if order is not None else np.arange(n_scored, dtype=np.int64)
-        pos = np.concatenate([order, np.full((-n_scored) % 128, own.shape[0] - 1, dtype=np.int64)])
-        own_or = own[pos.reshape(-1, 8, 16)].any(axis=1)                        # [jobs, 16 waves, R]
+        if fr.get("fr_resident"):          # every wave claims 8 users: positions j, j + n_wj, ... (score_frows_kernel)
+            n_wj = -(-n_scored // 8)
+            pos = np.concatenate([order, np.full(8 * n_wj - n_scored, n_scored, dtype=np.int64)])
+            own_or = own[pos.reshape(8, n_wj)].any(axis=0)                      # [wave jobs, R]
+        else:                              # jobs of 64 users, position p -> wave p % 8
+            pos = np.concatenate([order, np.full((-n_scored) % 64, n_scored, dtype=np.int64)])
+            own_or = own[pos.reshape(-1, 8, 8)].any(axis=1)                     # [jobs, 8 waves, R]
         nz_rt = np.array([[(int(tr[t, f // 64]) >> (f % 64)) & 1 for f in range(R)] for t in range(tr.shape[0])], dtype=np.int32)
         swept_rows = float((own_or.reshape(-1, R).astype(np.int32) @ nz_rt.T).sum())      # (wave, tile, row) reads of 1 slice row
         lds_bytes = swept_rows * tc * 4.0
         executed_flops = 2.0 * swept_rows * 8.0 * tc
-        n_jobs = -(-n_scored // 128)
+        n_jobs = 256 if fr.get("fr_resident") else -(-n_scored // 64)     # resident: W is loaded once per workgroup
         l2_bytes = float(n_jobs) * float(fr["fr_super_kb"][-1]) * 1024.0 + 8.0 * (nnz if n_scored == U else int(Xs.nnz))
         bounds = {"valu": {"achieved": flops / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": flops / kern_s / 1e12 / VALU_PEAK_TFLOPS, "flops_per_launch": flops,
@@ -347,7 +352,7 @@ def main() -> None:
                           "note": "slice rows read from LDS: one ds_read_b128 per lane and swept (wave, tile, row), shared by the wave's 8 users"},
                   "l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
                          "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes,
-                         "note": "W slices staged into LDS once per 128-user job + the user rows"}}
+                         "note": "W slices staged into LDS once per 64-user job (once per workgroup when resident) + the user rows"}}
         bound = max(bounds, key=lambda k: bounds[k]["frac"])
     else:
         l2_bytes = 6.0 * gathered_entries + 24.0 * (nnz if n_scored == U else int(Xs.nnz)) * max(lay["n_tiles"], 1)

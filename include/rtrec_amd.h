@@ -237,14 +237,20 @@ typedef struct {
      *     d_fr_col_ids[n_cols]  layout column -> item id,   d_fr_col_map[n_items]  item id -> layout column or -1
      * (n_cols as in the compacted tiled layout), cut into fr_n_tiles = ceil(n_cols / fr_tile_cols) tiles of
      * fr_tile_cols (256 or 128) columns.  d_fr_map[n_items] = row f of an item or -1.  Only the rows that hold a
-     * weight in a tile are stored: d_fr_tile_rows[t * 2 + h] bit f = 1 iff row 64 h + f does, and the tile's slice is
-     * those rows in ascending order, fr_tile_cols floats each (0 where W[row, column] is not stored).  Blocks without
-     * a weight are never visited, so an order of the columns that clusters the rows' weights saves work without
-     * changing a sum.  Consecutive tiles are grouped into fr_n_super super-tiles (tiles d_fr_super_tile[s] ..
-     * d_fr_super_tile[s + 1] - 1, at most 32 each), each staged in LDS as one piece: d_fr_w holds the super-tiles
-     * back to back, each a whole number of KiB starting at KiB d_fr_super_kb[s] (fr_n_super + 1 entries both),
-     * d_fr_tile_off[t] is the byte offset of tile t's slice inside its super-tile, and fr_buf_bytes (a multiple of 1024, >= 64 KiB, >= the
-     * largest super-tile, 2 * fr_buf_bytes + 8208 <= 160 KiB) is the size of one LDS staging buffer.
+     * weight in a tile are stored: the tile's SLICE is those rows in ascending order, fr_tile_cols floats each (0 where
+     * W[row, column] is not stored).  Blocks without a weight are never visited, so an order of the columns that
+     * clusters the rows' weights saves work without changing a sum.  For staging in LDS a slice is cut into
+     * FRAGMENTS (consecutive rows of it; fr_n_frags in all, in tile order): d_fr_frag_tile[g] = tile | first << 24 |
+     * last << 25, d_fr_tile_rows[g * 2 + h] bit f = 1 iff the fragment holds row 64 h + f, d_fr_tile_off[g] = its byte
+     * offset inside its super-tile.  Consecutive fragments (at most 64) form fr_n_super super-tiles, fragments
+     * d_fr_super_tile[s] .. d_fr_super_tile[s + 1] - 1, each staged as one piece: d_fr_w holds the super-tiles back
+     * to back, each a whole number of KiB starting at KiB d_fr_super_kb[s] (fr_n_super + 1 entries both).
+     * fr_buf_bytes (a multiple of 1024, >= the largest super-tile) is the size of one LDS staging buffer.  Two forms:
+     *   streaming  fr_buf_bytes >= 32 KiB and 2 * (2 * fr_buf_bytes + 5136) <= 160 KiB: two 8-wave workgroups per CU,
+     *              two buffers each (a tile may continue in the next super-tile: its sums stay in registers);
+     *   resident   fr_n_super == 1, fr_n_tiles <= 64 and everything fits next to the per-wave setup scratch
+     *              (fr_buf_bytes + 16 * ceil256(fr_n_tiles * fr_tile_cols / 8 + 768) + 9232 <= 160 KiB): one 16-wave
+     *              workgroup per CU loads W once and keeps it.
      * d_fr_scratch: rtrec_slim_score_fr_scratch_bytes() bytes of device scratch.  Scores and ids are identical to
      * the tiled-CSR path; accumulators live in registers and the matrix is streamed through LDS
      * (csrc/score.hip, score_frows_kernel). */
@@ -256,7 +262,8 @@ typedef struct {
     const int32_t *d_fr_tile_off;
     const int32_t *d_fr_super_kb;
     const int32_t *d_fr_super_tile;
-    int32_t        fr_rows, fr_tile_cols, fr_n_tiles, fr_n_super, fr_buf_bytes;
+    const int32_t *d_fr_frag_tile;
+    int32_t        fr_rows, fr_tile_cols, fr_n_tiles, fr_n_frags, fr_n_super, fr_buf_bytes;
     void          *d_fr_scratch;
     size_t         fr_scratch_bytes;
     /* Optional work order for the feature-row kernel: a permutation of 0 .. n_rows-1; job position p scores row

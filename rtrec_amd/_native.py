@@ -45,7 +45,8 @@ class ScoreOpts(C.Structure):
     _fields_ = [("n_x_rows", C.c_int32), ("d_fr_map", C.c_void_p), ("d_fr_col_ids", C.c_void_p),
                 ("d_fr_col_map", C.c_void_p), ("d_fr_w", C.c_void_p), ("d_fr_tile_rows", C.c_void_p),
                 ("d_fr_tile_off", C.c_void_p), ("d_fr_super_kb", C.c_void_p), ("d_fr_super_tile", C.c_void_p),
-                ("fr_rows", C.c_int32), ("fr_tile_cols", C.c_int32), ("fr_n_tiles", C.c_int32),
+                ("d_fr_frag_tile", C.c_void_p),
+                ("fr_rows", C.c_int32), ("fr_tile_cols", C.c_int32), ("fr_n_tiles", C.c_int32), ("fr_n_frags", C.c_int32),
                 ("fr_n_super", C.c_int32), ("fr_buf_bytes", C.c_int32), ("d_fr_scratch", C.c_void_p), ("fr_scratch_bytes", C.c_size_t),
                 ("d_row_order", C.c_void_p), ("timer", C.c_void_p), ("diagnostics", C.c_int32), ("d_rescored", C.c_void_p)]
 

@@ -963,10 +963,11 @@ struct FrArgs {
     const int *col_ids;     // [n_cols]  layout column -> item id (ascending)
     int n_cols, R, n_tiles;
     const float *wd;        // the tiles' slices, super-tile after super-tile: per tile its rows that hold a weight, ascending
-    const unsigned long long *tile_rows;   // [n_tiles][2]: bit f of word h set <=> row 64 h + f holds a weight in the tile
-    const int *tile_off;    // [n_tiles]: byte offset of the tile's slice inside its super-tile
+    const unsigned long long *tile_rows;   // [n_frags][2]: bit f of word h set <=> the fragment holds row 64 h + f of its tile's slice
+    const int *tile_off;    // [n_frags]: byte offset of the fragment inside its super-tile
+    const int *frag_tile;   // [n_frags]: tile | first << 24 | last << 25 (a slice may be cut into consecutive fragments)
     const int *st_kb;       // [n_super + 1]: KiB offset of super-tile s in wd (one LDS-DMA wave-instruction moves 1 KiB)
-    const int *st_tile;     // [n_super + 1]: first tile of super-tile s (at most 32 tiles each; resident: 64)
+    const int *st_tile;     // [n_super + 1]: first FRAGMENT of super-tile s (at most 64 fragments each)
     int n_super;
     int resident;           // one super-tile that stays in LDS for the life of the workgroup
     int buf_bytes;          // bytes of one LDS buffer (>= the largest super-tile, >= the setup scratch)
@@ -997,9 +998,11 @@ constexpr int kFrZeroRowBytes = 1024;        // one slice row of +0.0 (the wides
 __host__ __device__ constexpr int fr_setup_scratch(int mask_words) { return ((mask_words * 8 + 256 + 512) + 255) / 256 * 256; }
 // Streaming layout: two slice buffers (the second doubles as setup scratch).  RESIDENT layout (all of W's slices in ONE
 // super-tile that fits next to the setup scratch): one buffer, loaded once per workgroup and kept across its jobs.
+constexpr int kFrWavesStream = 8;            // streaming layout: two 8-wave workgroups per CU
 __host__ __device__ constexpr size_t fr_lds_bytes(int buf_bytes, bool resident = false, int mask_words = kFrMaskWords) {
-    return (resident ? static_cast<size_t>(buf_bytes) + kFrWaves * fr_setup_scratch(mask_words) : 2 * static_cast<size_t>(buf_bytes)) +
-           kFrWaves * fr_wave_extra_bytes() + kFrZeroRowBytes + 16;
+    return resident ? static_cast<size_t>(buf_bytes) + kFrWaves * fr_setup_scratch(mask_words) + kFrWaves * fr_wave_extra_bytes() +
+                          kFrZeroRowBytes + 16
+                    : 2 * static_cast<size_t>(buf_bytes) + kFrWavesStream * fr_wave_extra_bytes() + kFrZeroRowBytes + 16;
 }
 
 typedef __attribute__((address_space(3))) void fr_lds_void;
@@ -1108,25 +1111,26 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
     constexpr int UW = kFrUsers;
     constexpr int NL = UW / 4;                              // list registers: four users per 64 lanes, 16 lanes each
     const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
+    const int NW = static_cast<int>(blockDim.x) >> 6;       // waves of this workgroup: 16 (resident layout) or 8 (streaming)
     const int kk = a.kk;                                    // <= 16
     unsigned char *buf0 = smem;
     unsigned char *buf1 = smem + a.buf_bytes;               // second slice buffer; also (or, resident: only) setup scratch
     const bool resident = a.resident != 0;                  // W's slices stay in buf0 for the life of the workgroup
     const int wscratch = resident ? fr_setup_scratch(a.n_tiles * REGS) : kFrWaveScratch;
-    const size_t lds_front = resident ? static_cast<size_t>(a.buf_bytes) + kFrWaves * static_cast<size_t>(wscratch)
+    const size_t lds_front = resident ? static_cast<size_t>(a.buf_bytes) + NW * static_cast<size_t>(wscratch)
                                       : 2 * static_cast<size_t>(a.buf_bytes);
     unsigned char *extra = smem + lds_front + static_cast<size_t>(wave) * fr_wave_extra_bytes();
     float *cv = reinterpret_cast<float *>(extra);                     // [kFrCandCap] candidate scores of one user
     int *cp = reinterpret_cast<int *>(cv + kFrCandCap);               // [kFrCandCap] their layout columns
-    const unsigned char *zrow = smem + lds_front + kFrWaves * fr_wave_extra_bytes();
-    int *s_job = reinterpret_cast<int *>(smem + lds_front + kFrWaves * fr_wave_extra_bytes() + kFrZeroRowBytes);
-    for (int o = tid * 4; o < kFrZeroRowBytes; o += kFrWaves * 64 * 4) *reinterpret_cast<float *>(smem + (zrow - smem) + o) = 0.0f;
-    const int n_jobs = (a.n_rows + UW * kFrWaves - 1) / (UW * kFrWaves);
+    const unsigned char *zrow = smem + lds_front + NW * fr_wave_extra_bytes();
+    int *s_job = reinterpret_cast<int *>(smem + lds_front + NW * fr_wave_extra_bytes() + kFrZeroRowBytes);
+    for (int o = tid * 4; o < kFrZeroRowBytes; o += NW * 64 * 4) *reinterpret_cast<float *>(smem + (zrow - smem) + o) = 0.0f;
+    const int n_jobs = (a.n_rows + UW * NW - 1) / (UW * NW);
     const float ninf = -__builtin_huge_valf();
     const int mwords = a.n_tiles * REGS;
     // per-wave global scratch: per user 192 words (its ratings by row of W: 128; pad), then the users' mask words
     const size_t wave_words = fr_wave_scratch_words(a.n_tiles, REGS);
-    unsigned long long *sc_wave = a.mscratch + (static_cast<size_t>(blockIdx.x) * kFrWaves + wave) * wave_words;
+    unsigned long long *sc_wave = a.mscratch + (static_cast<size_t>(blockIdx.x) * NW + wave) * wave_words;
     uint32_t *xs_wave = reinterpret_cast<uint32_t *>(sc_wave);
     unsigned long long *ms_wave = sc_wave + kFrUsers * kFrUserWords / 2;
     const uint32_t lane16 = static_cast<uint32_t>(lane) * (REGS * 4);         // byte offset of this lane in a row
@@ -1135,7 +1139,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
     auto load_super = [&](int sidx, unsigned char *dst) {
         const int kb0 = a.st_kb[sidx], kb1 = a.st_kb[sidx + 1];
         const unsigned char *src = reinterpret_cast<const unsigned char *>(a.wd) + (static_cast<size_t>(kb0) << 10);
-        for (int c = wave; c < kb1 - kb0; c += kFrWaves)
+        for (int c = wave; c < kb1 - kb0; c += NW)
             __builtin_amdgcn_global_load_lds((fr_glb_void *)(src + (static_cast<size_t>(c) << 10) + lane * 16),
                                              (fr_lds_void *)(dst + (c << 10)), 16, 0, 0);
     };
@@ -1172,9 +1176,9 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             const int job = *s_job;
             if (job >= n_jobs) break;
             load_super(0, buf0);
-            // position p of the job's 128 goes to wave p % 16, so that with rows handed over longest-first (a.order)
+            // position p of the job's users goes to wave p % NW, so that with rows handed over longest-first (a.order)
             // every wave of the workgroup gets the same mix of long and short rows and the barriers find the waves level
-            base = job * kFrWaves * UW + wave; pstride = kFrWaves;
+            base = job * NW * UW + wave; pstride = NW;
         }
 
         // ---- setup: per user its ratings of the R feature items (dense, lane = row of W) and the interacted-column
@@ -1273,38 +1277,43 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             own_or[h] = m;
         });
 
+        // the eight users' sums over the current tile: they outlive a super-tile when the tile's slice continues in the next
+        vec acc[UW];
+        fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });
         for (int sidx = 0; sidx < a.n_super; ++sidx) {
             const unsigned char *wb = (sidx & 1) ? buf1 : buf0;
             if (sidx + 1 < a.n_super) load_super(sidx + 1, (sidx & 1) ? buf0 : buf1);
-            const int t_lo = a.st_tile[sidx], t_hi = a.st_tile[sidx + 1];
-            // the tiles' row masks and slice offsets, lane tt = tile t_lo + tt: one load per super-tile, read back
-            // with v_readlane below (no memory latency inside the tile loop)
+            const int t_lo = a.st_tile[sidx], t_hi = a.st_tile[sidx + 1];      // fragments of this super-tile
+            // the fragments' row masks, offsets and tiles, lane g = fragment t_lo + g: one load per super-tile, read
+            // back with v_readlane below (no memory latency inside the loop)
             unsigned long long nzv[2] = {0ull, 0ull};
-            int toffv = 0;
+            int toffv = 0, ftilev = 0;
             if (lane < t_hi - t_lo) {
                 nzv[0] = a.tile_rows[(t_lo + lane) * 2];
                 nzv[1] = a.tile_rows[(t_lo + lane) * 2 + 1];
                 toffv = a.tile_off[t_lo + lane];
+                ftilev = a.frag_tile[t_lo + lane];
             }
             const unsigned char *wlane = wb + lane16;             // this lane's columns in a slice row
             const unsigned char *wzero = zrow + lane16;           // a row of +0.0: what a step reads past the last row
 
-            for (int t = t_lo; t < t_hi; ++t) {
+            for (int g = t_lo; g < t_hi; ++g) {
+                const int ft = readlane_i(ftilev, g - t_lo);
+                const int t = ft & 0xffffff;                     // the tile this fragment belongs to
                 // ---- tile-major sweep: every row of W that holds a weight in this tile (and that one of the wave's
                 //      users rates) is read from LDS ONCE and applied to all eight users: acc_u += x_u * w, one
                 //      rounded product and one rounded add per column (two v_pk_mul_f32 + two v_pk_add_f32 per user
                 //      and 256 columns), rows ascending = scipy's order.  A user that does not rate the row has
                 //      x_u = 0: x * w = +-0 changes no sum (a sum that starts at +0 never becomes -0), and the same
                 //      holds for rows and blocks that are skipped altogether. ----
-                vec acc[UW];
-                fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });
-                const int toff = readlane_i(toffv, t - t_lo);
+                if (ft & (1 << 24)) fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });   // first fragment
+                const int toff = readlane_i(toffv, g - t_lo);
                 int below = 0;                                   // rows of this tile's slice before half h
                 fr_static_for<XR>([&](auto H) {
                     constexpr int h = decltype(H)::value;
                     const unsigned long long nz =
-                        (static_cast<unsigned long long>(readlane_u(static_cast<uint32_t>(nzv[h] >> 32), t - t_lo)) << 32) |
-                        readlane_u(static_cast<uint32_t>(nzv[h]), t - t_lo);
+                        (static_cast<unsigned long long>(readlane_u(static_cast<uint32_t>(nzv[h] >> 32), g - t_lo)) << 32) |
+                        readlane_u(static_cast<uint32_t>(nzv[h]), g - t_lo);
                     unsigned long long rows = nz & own_or[h];
                     while (rows) {
                         // two rows per step: their LDS reads go out together; eight users' applies (80 vector
@@ -1334,6 +1343,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                     below += static_cast<int>(__builtin_popcountll(nz));
                 });
 
+                if (!(ft & (1 << 25))) continue;                 // the tile's slice continues in the next super-tile
                 // ---- candidates, user after user: columns that beat the user's kk-th score and are not interacted ----
                 fr_static_for<UW>([&](auto Uc) {
                     constexpr int u = decltype(Uc)::value;
@@ -1529,8 +1539,8 @@ unsigned persistent_grid(size_t lds_bytes, long long jobs) {
 struct FrLayout {
     const int *fmap = nullptr; const float *wd = nullptr; const int *order = nullptr;
     const int *col_ids = nullptr; const int *col_map = nullptr; const unsigned long long *tile_rows = nullptr;
-    int rows = 0, tile_cols = 0, n_tiles = 0, n_super = 0, buf_bytes = 0;
-    const int *tile_off = nullptr; const int *st_kb = nullptr; const int *st_tile = nullptr;
+    int rows = 0, tile_cols = 0, n_tiles = 0, n_frags = 0, n_super = 0, buf_bytes = 0;
+    const int *tile_off = nullptr; const int *st_kb = nullptr; const int *st_tile = nullptr; const int *frag_tile = nullptr;
     unsigned long long *scratch = nullptr; size_t scratch_bytes = 0;
 };
 size_t fr_scratch_bytes(int n_tiles, int tile_cols) {
@@ -1538,15 +1548,17 @@ size_t fr_scratch_bytes(int n_tiles, int tile_cols) {
     return static_cast<size_t>(256) * kFrWaves * fr_wave_scratch_words(n_tiles, regs) * sizeof(unsigned long long);
 }
 bool fr_usable(const FrLayout &F, int kk) {
-    if (!F.fmap || !F.wd || !F.scratch || !F.col_ids || !F.col_map || !F.tile_rows || !F.tile_off || !F.st_kb || !F.st_tile) return false;
+    if (!F.fmap || !F.wd || !F.scratch || !F.col_ids || !F.col_map || !F.tile_rows || !F.tile_off || !F.st_kb || !F.st_tile ||
+        !F.frag_tile) return false;
     if (F.tile_cols != 256 && F.tile_cols != 128) return false;
     const int regs = F.tile_cols / 64;
     if (F.rows <= 0 || F.rows > kFrMaxRows || F.n_tiles <= 0 || F.n_tiles * regs > kFrMaskWords) return false;
-    if (F.n_super <= 0 || F.n_super > F.n_tiles) return false;
+    if (F.n_frags < F.n_tiles || F.n_super <= 0 || F.n_super > F.n_frags) return false;
     if (F.buf_bytes <= 0 || (F.buf_bytes & 1023)) return false;
     const int regs_ = F.tile_cols / 64;
     const bool resident = F.n_super == 1 && F.n_tiles <= 64 && fr_lds_bytes(F.buf_bytes, true, F.n_tiles * regs_) <= 160u * 1024u;
-    if (!resident && (F.buf_bytes < kFrWaves * kFrWaveScratch || fr_lds_bytes(F.buf_bytes) > 160u * 1024u)) return false;
+    // streaming: two 8-wave workgroups per CU, each with two slice buffers (the second doubles as 4 KiB of setup scratch per wave)
+    if (!resident && (F.buf_bytes < kFrWavesStream * kFrWaveScratch || 2 * fr_lds_bytes(F.buf_bytes) > 160u * 1024u)) return false;
     if (F.scratch_bytes < fr_scratch_bytes(F.n_tiles, F.tile_cols)) return false;
     return kk >= 1 && kk <= kFrMaxKk;
 }
@@ -1591,23 +1603,28 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.fmap = FR.fmap; f.col_map = FR.col_map; f.col_ids = FR.col_ids; f.tile_rows = FR.tile_rows;
         f.n_cols = a.n_cols; f.R = FR.rows; f.n_tiles = FR.n_tiles; f.wd = FR.wd;
         f.tile_off = FR.tile_off; f.st_kb = FR.st_kb; f.st_tile = FR.st_tile; f.n_super = FR.n_super; f.buf_bytes = FR.buf_bytes;
+        f.frag_tile = FR.frag_tile;
         f.mscratch = FR.scratch;
         f.kk = a.kk; f.top_k = top_k; f.filter = a.filter;
         f.out_id = d_out_ids; f.out_score = d_out_scores; f.out_aux = d_out_aux; f.out_cnt = d_out_count;
         f.flag_list = flag_list; f.flag_len = flag_len; f.queue = queue;
-        const int n_jobs = (a.n_rows + kFrUsers * kFrWaves - 1) / (kFrUsers * kFrWaves);
-        const unsigned grid = static_cast<unsigned>(n_jobs < 256 ? n_jobs : 256);
-        // all slices in one super-tile that fits next to the setup scratch: W stays in LDS for the life of a workgroup
+        // all slices in one super-tile that fits next to the setup scratch: W stays in LDS for the life of a 16-wave
+        // workgroup; otherwise two 8-wave workgroups per CU stream the super-tiles (one computes while the other sets a
+        // job up or waits at a super-tile barrier)
         f.resident = (FR.n_super == 1 && FR.n_tiles <= 64 &&
                       fr_lds_bytes(FR.buf_bytes, true, FR.n_tiles * (FR.tile_cols / 64)) <= 160u * 1024u) ? 1 : 0;
+        const int nw = f.resident ? kFrWaves : kFrWavesStream;
+        const int n_jobs = (a.n_rows + kFrUsers * nw - 1) / (kFrUsers * nw);
+        const int max_grid = f.resident ? 256 : 512;
+        const unsigned grid = static_cast<unsigned>(n_jobs < max_grid ? n_jobs : max_grid);
         const size_t lds = f.resident ? fr_lds_bytes(FR.buf_bytes, true, FR.n_tiles * (FR.tile_cols / 64)) : fr_lds_bytes(FR.buf_bytes);
         const bool two = FR.rows > 64;
         if (FR.tile_cols == 256) {
-            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 2>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 1>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
+            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 2>), dim3(grid), dim3(nw * 64), lds, st, f);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 1>), dim3(grid), dim3(nw * 64), lds, st, f);
         } else {
-            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 2>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 1>), dim3(grid), dim3(kFrWaves * 64), lds, st, f);
+            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 2>), dim3(grid), dim3(nw * 64), lds, st, f);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 1>), dim3(grid), dim3(nw * 64), lds, st, f);
         }
         fr_done = true;
     } else if (sparse) {
@@ -1762,9 +1779,9 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
     FrLayout FR;
     if (opts && opts->d_fr_map && opts->d_fr_w) {
         FR.fmap = opts->d_fr_map; FR.wd = opts->d_fr_w; FR.rows = opts->fr_rows; FR.tile_cols = opts->fr_tile_cols;
-        FR.n_tiles = opts->fr_n_tiles; FR.n_super = opts->fr_n_super;
+        FR.n_tiles = opts->fr_n_tiles; FR.n_frags = opts->fr_n_frags; FR.n_super = opts->fr_n_super;
         FR.buf_bytes = opts->fr_buf_bytes; FR.tile_off = opts->d_fr_tile_off; FR.st_kb = opts->d_fr_super_kb;
-        FR.st_tile = opts->d_fr_super_tile;
+        FR.st_tile = opts->d_fr_super_tile; FR.frag_tile = opts->d_fr_frag_tile;
         FR.scratch = static_cast<unsigned long long *>(opts->d_fr_scratch); FR.scratch_bytes = opts->fr_scratch_bytes;
         FR.order = opts->d_row_order;
         FR.col_ids = opts->d_fr_col_ids; FR.col_map = opts->d_fr_col_map;

@@ -193,21 +193,21 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     present[t_of, f_of] = True
     n_rows_t = present.sum(axis=1)
     local = np.cumsum(present, axis=1) - 1                  # row -> index inside the tile's compact slice
-    packed = _pack_super_tiles(n_rows_t.astype(np.int64), tc)     # consecutive tiles staged in LDS as one piece
-    if packed is None:
-        return None
-    st_tile, super_of, super_kb, first, buf_bytes = packed
-    n_super = len(st_tile) - 1
-    row_bytes = tc * 4
-    tile_off = (first * row_bytes).astype(np.int32)
-    wd = np.zeros(max(int(super_kb[-1]) * 256, 256), dtype=np.float32)
-    base = super_kb[super_of[t_of]] * 256 + first[t_of] * tc
-    wd[base + local[t_of, f_of] * tc + lc % tc] = vals
+    P = _pack_fragments(n_rows_t.astype(np.int64), tc)           # slices -> fragments -> super-tiles staged in LDS
+    k_of = local[t_of, f_of]                                     # rank of the weight's row among its tile's stored rows
+    g_of = P["frag_of"][t_of, k_of]                              # ... and the fragment that holds it
+    wd = np.zeros(max(int(P["super_kb"][-1]) * 256, 256), dtype=np.float32)
+    base = P["super_kb"][P["frag_super"][g_of]] * 256 + P["frag_off"][g_of] // 4
+    wd[base + (k_of - P["frag_k0"][g_of]) * tc + lc % tc] = vals
+    frag_rows = np.zeros((P["n_frags"], 2), dtype=np.uint64)
+    np.bitwise_or.at(frag_rows, (g_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
     tile_rows = np.zeros((n_tiles, 2), dtype=np.uint64)
     np.bitwise_or.at(tile_rows, (t_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
-    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=tile_rows.view(np.int64),
-                fr_tile_off=tile_off, fr_super_kb=super_kb.astype(np.int32), fr_super_tile=st_tile.astype(np.int32), fr_rows=R,
-                fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_super=n_super, fr_buf_bytes=buf_bytes)
+    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=frag_rows.view(np.int64),
+                fr_tile_off=P["frag_off"].astype(np.int32), fr_frag_tile=P["frag_flags"].astype(np.int32),
+                fr_super_kb=P["super_kb"].astype(np.int32), fr_super_tile=P["super_frag"].astype(np.int32), fr_rows=R,
+                fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_frags=P["n_frags"], fr_n_super=P["n_super"], fr_buf_bytes=P["buf_bytes"],
+                fr_rows_of_tile=tile_rows.view(np.int64))
 
 
 
@@ -222,40 +222,57 @@ def _heavy_tiles_first(order: np.ndarray, col_mass: np.ndarray, tc: int) -> np.n
     return np.concatenate([head[np.argsort(-tmass, kind="stable")].ravel(), order[n_full * tc:]])
 
 
-def _pack_super_tiles(n_rows_t: np.ndarray, tc: int):
-    """Greedy packing of consecutive tiles into LDS-sized super-tiles (shared by the host and device builders of the
-    feature-row layout).  None when one tile alone does not fit."""
-    buf_cap = (160 * 1024 - 16 * 512 - 1024 - 16) // 2 // 1024 * 1024      # fr_lds_bytes of csrc/score.hip
+FR_STREAM_BUF_BYTES = 36 * 1024     # slice buffer of the streaming layout: two 8-wave workgroups (2 buffers each) share a CU's LDS
+
+
+def _pack_fragments(n_rows_t: np.ndarray, tc: int) -> Dict[str, Any]:
+    """Lay the tiles' slices (n_rows_t[t] rows of tc floats each, rows ascending) out for LDS staging -- shared by the
+    host and device builders of the feature-row layout.
+
+    RESIDENT form: everything fits one CU's LDS next to the per-wave setup scratch -> one super-tile, one fragment
+    per tile; the kernel loads it once per workgroup.  STREAMING form: super-tiles of at most FR_STREAM_BUF_BYTES, filled
+    greedily with FRAGMENTS -- a tile's slice may continue in the next super-tile (its accumulators stay in registers
+    across the hand-over), so the buffer size is independent of the tallest tile.
+    Returns per fragment: tile, k0, k1 (ranks of the tile's stored rows it holds), first / last flags, byte offset inside
+    its super-tile; per super-tile: first fragment, KiB offset in the weight array; buf_bytes; resident."""
     row_bytes = tc * 4
     n_tiles = len(n_rows_t)
-    # RESIDENT form: all slices in one super-tile that fits LDS next to the per-wave setup scratch -- the kernel then
-    # loads W once per workgroup and keeps it across its jobs (no staging, no super-tile barriers)
     total = -(-(int(n_rows_t.sum()) * row_bytes) // 1024) * 1024
     setup = 16 * (-(-(n_tiles * (tc // 64) * 8 + 768) // 256) * 256)
-    if n_tiles <= 64 and total + setup + 16 * 512 + 1024 + 16 <= 160 * 1024:
-        first = np.cumsum(n_rows_t) - n_rows_t
-        return (np.asarray([0, n_tiles], dtype=np.int64), np.zeros(n_tiles, dtype=np.int64), np.asarray([0, total // 1024], dtype=np.int64),
-                first, max(total, 1024))
-    if int(n_rows_t.max()) * row_bytes > buf_cap:
-        return None
-    st_tile, used = [0], 0
+    resident = n_tiles <= 64 and total + setup + 16 * 512 + 1024 + 16 <= 160 * 1024
+    cap = max(total, 1024) if resident else FR_STREAM_BUF_BYTES
+    f_tile, f_k0, f_k1, f_off, f_super, st_frag, used = [], [], [], [], [], [0], 0
     for t in range(n_tiles):
-        need = int(n_rows_t[t]) * row_bytes
-        if t > st_tile[-1] and (used + need > buf_cap or t - st_tile[-1] >= 32):
-            st_tile.append(t)
-            used = 0
-        used += need
-    st_tile.append(n_tiles)
-    st_tile = np.asarray(st_tile, dtype=np.int64)
-    n_super = len(st_tile) - 1
-    super_of = np.repeat(np.arange(n_super), np.diff(st_tile))
-    super_rows = np.add.reduceat(n_rows_t, st_tile[:-1])
+        k, n = 0, int(n_rows_t[t])
+        while k < n:
+            room = (cap - used) // row_bytes
+            # close the super-tile when it is full, holds 64 fragments (a lane per fragment), or the rest of it would
+            # take less than 8 rows of a slice that needs more
+            if used > 0 and (room < min(n - k, 8) or len(f_tile) - st_frag[-1] >= 64):
+                st_frag.append(len(f_tile))
+                used = 0
+                continue
+            take = min(n - k, room)
+            f_tile.append(t); f_k0.append(k); f_k1.append(k + take); f_off.append(used); f_super.append(len(st_frag) - 1)
+            used += take * row_bytes
+            k += take
+    st_frag.append(len(f_tile))
+    f_tile, f_k0, f_k1 = (np.asarray(a, dtype=np.int64) for a in (f_tile, f_k0, f_k1))
+    f_super, st_frag = np.asarray(f_super, dtype=np.int64), np.asarray(st_frag, dtype=np.int64)
+    n_super = len(st_frag) - 1
+    bytes_s = np.zeros(n_super, dtype=np.int64)
+    np.add.at(bytes_s, f_super, (f_k1 - f_k0) * row_bytes)
     super_kb = np.zeros(n_super + 1, dtype=np.int64)
-    super_kb[1:] = np.cumsum(-(-(super_rows * row_bytes) // 1024))
-    first = np.cumsum(n_rows_t) - n_rows_t
-    first = first - first[st_tile[:-1]][super_of]
-    buf_bytes = max(64 * 1024, int(-(-(int(super_rows.max()) * row_bytes) // 1024) * 1024))
-    return st_tile, super_of, super_kb, first, buf_bytes
+    super_kb[1:] = np.cumsum(-(-bytes_s // 1024))
+    flags = f_tile | ((f_k0 == 0).astype(np.int64) << 24) | ((f_k1 == n_rows_t[f_tile]).astype(np.int64) << 25)
+    # (tile, rank of a stored row) -> fragment
+    frag_of = np.zeros((n_tiles, max(int(n_rows_t.max()), 1)), dtype=np.int64)
+    for i in range(len(f_tile)):
+        frag_of[f_tile[i], f_k0[i]:f_k1[i]] = i
+    buf_bytes = int(cap) if resident else FR_STREAM_BUF_BYTES
+    return dict(frag_tile=f_tile, frag_k0=f_k0, frag_flags=flags, frag_off=np.asarray(f_off, dtype=np.int64), frag_super=f_super,
+                super_frag=st_frag, super_kb=super_kb, frag_of=frag_of, buf_bytes=buf_bytes, resident=bool(resident),
+                n_frags=len(f_tile), n_super=n_super)
 
 
 def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int) -> Optional[Dict[str, Any]]:
@@ -308,30 +325,30 @@ def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int
     present = torch.zeros((n_tiles, R), dtype=torch.bool, device=dev)
     present[t_of, f_of] = True
     n_rows_t = present.sum(dim=1).cpu().numpy().astype(np.int64)
-    packed = _pack_super_tiles(n_rows_t, tc)
-    if packed is None:
-        return None
-    st_tile, super_of, super_kb, first, buf_bytes = packed
+    P = _pack_fragments(n_rows_t, tc)
     local = torch.cumsum(present.to(i64), dim=1) - 1
-    d_super_kb = torch.from_numpy(super_kb).to(dev)
-    d_super_of = torch.from_numpy(super_of).to(dev)
-    d_first = torch.from_numpy(first).to(dev)
-    wd = torch.zeros(max(int(super_kb[-1]) * 256, 256), dtype=torch.float32, device=dev)
-    base = d_super_kb[d_super_of[t_of]] * 256 + d_first[t_of] * tc
-    wd[base + local[t_of, f_of] * tc + lc % tc] = v
-    # one bit per (row, tile) block that holds a weight
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    k_of = local[t_of, f_of]
+    g_of = dv(P["frag_of"])[t_of, k_of]
+    wd = torch.zeros(max(int(P["super_kb"][-1]) * 256, 256), dtype=torch.float32, device=dev)
+    base = dv(P["super_kb"])[dv(P["frag_super"])[g_of]] * 256 + dv(P["frag_off"])[g_of] // 4
+    wd[base + (k_of - dv(P["frag_k0"])[g_of]) * tc + lc % tc] = v
+    # one bit per (row, fragment) / (row, tile) block that holds a weight
+    blk_key = torch.unique(g_of * 128 + f_of)
+    bg, bf = blk_key // 128, blk_key % 128
+    frag_rows = torch.zeros((P["n_frags"], 2), dtype=i64, device=dev)
+    frag_rows.view(-1).index_add_(0, bg * 2 + bf // 64, torch.ones_like(bf) << (bf % 64))
     blk = torch.zeros((n_tiles, 2), dtype=i64, device=dev)
     pt, pf = torch.nonzero(present, as_tuple=True)
     blk.view(-1).index_add_(0, pt * 2 + pf // 64, torch.ones_like(pf) << (pf % 64))
     fmap_host = fmap.cpu().numpy()
-    host = dict(fr_map=fmap_host, fr_tile_rows=blk.cpu().numpy(), fr_super_kb=super_kb.astype(np.int32), fr_rows=R,
-                fr_tile_cols=tc)
-    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=blk,
-                fr_tile_off=torch.from_numpy((first * tc * 4).astype(np.int32)).to(dev),
-                fr_super_kb=torch.from_numpy(super_kb.astype(np.int32)).to(dev),
-                fr_super_tile=torch.from_numpy(st_tile.astype(np.int32)).to(dev), fr_rows=R, fr_tile_cols=tc,
-                fr_n_tiles=n_tiles, fr_n_super=len(st_tile) - 1, fr_buf_bytes=buf_bytes, fr_host=host,
-                col_ids_sorted=col_ids_sorted)
+    host = dict(fr_map=fmap_host, fr_rows_of_tile=blk.cpu().numpy(), fr_super_kb=P["super_kb"].astype(np.int32), fr_rows=R,
+                fr_tile_cols=tc, fr_resident=P["resident"])
+    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=frag_rows,
+                fr_tile_off=dv(P["frag_off"].astype(np.int32)), fr_frag_tile=dv(P["frag_flags"].astype(np.int32)),
+                fr_super_kb=dv(P["super_kb"].astype(np.int32)), fr_super_tile=dv(P["super_frag"].astype(np.int32)),
+                fr_rows=R, fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_frags=P["n_frags"], fr_n_super=P["n_super"],
+                fr_buf_bytes=P["buf_bytes"], fr_host=host, col_ids_sorted=col_ids_sorted)
 
 
 def build_tiled_w_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int, tile_cols: int,
@@ -555,8 +572,9 @@ class HipBackend:
                             ids, sc, sc64, aux, cnt, ws,
                             fr.get("fr_map"), fr.get("fr_col_ids"), fr.get("fr_col_map"), fr.get("fr_w"),
                             fr.get("fr_tile_rows"), fr.get("fr_tile_off"), fr.get("fr_super_kb"), fr.get("fr_super_tile"),
+                            fr.get("fr_frag_tile"),
                             int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)), int(fr.get("fr_n_tiles", 0)),
-                            int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
+                            int(fr.get("fr_n_frags", 0)), int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
                             fr.get("fr_scratch"),
                             row_order if fr else None, int(timer), int(diagnostics), rescored)
 

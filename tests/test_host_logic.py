@@ -234,9 +234,10 @@ def test_device_layout_builders_equal_the_host_builders(shard):
                 F = build_feature_rows_device(torch, r, c, v, I, lo, hi)
                 assert (H is None) == (F is None)
                 if H is not None:
-                    for k in ("fr_map", "fr_col_ids", "fr_col_map", "fr_w", "fr_tile_rows", "fr_tile_off", "fr_super_kb", "fr_super_tile"):
+                    for k in ("fr_map", "fr_col_ids", "fr_col_map", "fr_w", "fr_tile_rows", "fr_tile_off", "fr_super_kb", "fr_super_tile",
+                              "fr_frag_tile"):
                         assert np.array_equal(F[k].numpy().ravel(), np.asarray(H[k]).ravel()), k
-                    for k in ("fr_rows", "fr_tile_cols", "fr_n_tiles", "fr_n_super", "fr_buf_bytes"):
+                    for k in ("fr_rows", "fr_tile_cols", "fr_n_tiles", "fr_n_frags", "fr_n_super", "fr_buf_bytes"):
                         assert F[k] == H[k], k
     assert build_feature_rows_device(*_device_coo(_feature_row_w()), 700, 0, 700) is not None     # the dense form was exercised
 
