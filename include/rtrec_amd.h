@@ -275,6 +275,8 @@ typedef struct {
                                      (-DRTREC_DIAGNOSTICS) only, ignored by the release library */
     int32_t       *d_rescored;    /* optional int32[1] on the device: receives the number of rows the exact-tie pass
                                      re-scored (SPARSE mode; rows whose fast-pass list held an exact tie or overflowed) */
+    int32_t        row_order_grouped;  /* d_row_order is sorted by similarity (rows that rate the same rows of W are
+                                     neighbours): a wave then takes eight CONSECUTIVE positions instead of a strided deal */
 } rtrec_score_opts;
 
 size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols);

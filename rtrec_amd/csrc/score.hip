@@ -970,6 +970,7 @@ struct FrArgs {
     const int *st_tile;     // [n_super + 1]: first FRAGMENT of super-tile s (at most 64 fragments each)
     int n_super;
     int resident;           // one super-tile that stays in LDS for the life of the workgroup
+    int consecutive;        // a wave takes 8 consecutive positions of the work order (pattern-sorted) instead of a strided deal
     int buf_bytes;          // bytes of one LDS buffer (>= the largest super-tile, >= the setup scratch)
     unsigned long long *mscratch;   // [gridDim.x][waves][users][n_tiles * REGS] interacted-column lane masks
     int kk, top_k, filter;
@@ -1167,7 +1168,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             PF_MARK(PF_QUEUE)
             if (j >= n_wave_jobs) break;
             // positions j, j + n_wave_jobs, ...: with rows handed over longest-first every wave job is the same mix
-            base = j; pstride = n_wave_jobs;
+            base = a.consecutive ? j * UW : j; pstride = a.consecutive ? 1 : n_wave_jobs;
         } else {
             __syncthreads();                                // the previous job has left both buffers
             PF_MARK(PF_QUEUE)
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             load_super(0, buf0);
             // position p of the job's users goes to wave p % NW, so that with rows handed over longest-first (a.order)
             // every wave of the workgroup gets the same mix of long and short rows and the barriers find the waves level
-            base = job * NW * UW + wave; pstride = NW;
+            base = job * NW * UW + (a.consecutive ? wave * UW : wave); pstride = a.consecutive ? 1 : NW;
         }
 
         // ---- setup: per user its ratings of the R feature items (dense, lane = row of W) and the interacted-column
@@ -1542,6 +1543,7 @@ struct FrLayout {
     int rows = 0, tile_cols = 0, n_tiles = 0, n_frags = 0, n_super = 0, buf_bytes = 0;
     const int *tile_off = nullptr; const int *st_kb = nullptr; const int *st_tile = nullptr; const int *frag_tile = nullptr;
     unsigned long long *scratch = nullptr; size_t scratch_bytes = 0;
+    int consecutive = 0;
 };
 size_t fr_scratch_bytes(int n_tiles, int tile_cols) {
     const int regs = tile_cols / 64;
@@ -1604,6 +1606,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.n_cols = a.n_cols; f.R = FR.rows; f.n_tiles = FR.n_tiles; f.wd = FR.wd;
         f.tile_off = FR.tile_off; f.st_kb = FR.st_kb; f.st_tile = FR.st_tile; f.n_super = FR.n_super; f.buf_bytes = FR.buf_bytes;
         f.frag_tile = FR.frag_tile;
+        f.consecutive = FR.consecutive;
         f.mscratch = FR.scratch;
         f.kk = a.kk; f.top_k = top_k; f.filter = a.filter;
         f.out_id = d_out_ids; f.out_score = d_out_scores; f.out_aux = d_out_aux; f.out_cnt = d_out_count;
@@ -1783,7 +1786,7 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
         FR.buf_bytes = opts->fr_buf_bytes; FR.tile_off = opts->d_fr_tile_off; FR.st_kb = opts->d_fr_super_kb;
         FR.st_tile = opts->d_fr_super_tile; FR.frag_tile = opts->d_fr_frag_tile;
         FR.scratch = static_cast<unsigned long long *>(opts->d_fr_scratch); FR.scratch_bytes = opts->fr_scratch_bytes;
-        FR.order = opts->d_row_order;
+        FR.order = opts->d_row_order; FR.consecutive = (opts->d_row_order && opts->row_order_grouped) ? 1 : 0;
         FR.col_ids = opts->d_fr_col_ids; FR.col_map = opts->d_fr_col_map;
         FR.tile_rows = reinterpret_cast<const unsigned long long *>(opts->d_fr_tile_rows);
         if (FR.n_tiles != (n_cols + FR.tile_cols - 1) / (FR.tile_cols > 0 ? FR.tile_cols : 1)) return RTREC_ERR_INVALID_ARG;
