@@ -25,4 +25,6 @@ for C in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
   echo "pmc pass $i rc=$?"
 done
 python3 tools/pmc_round_summary.py $O $TAG $WL
+# the raw traces are large (gpurun copies back at most 64 MiB): the summaries above are what is kept
+rm -f $O/*_kernel_trace.csv $O/*_counter_collection.csv $O/*_agent_info.csv
 ls $O | head -40
