@@ -16,7 +16,8 @@
  *    boundary.  The library keeps no mutable state of its own and reads no environment variables:
  *    everything a call depends on is in its arguments (optional ones in the rtrec_*_opts structs, a
  *    timing bracket in a caller-owned rtrec_timer object), so calls on different streams / threads
- *    are independent as long as they do not share buffers.
+ *    are independent as long as they do not share buffers.  (The one thing it remembers is errno-style and
+ *    thread-local: the HIP error code behind the calling thread's last RTREC_ERR_LAUNCH, for rtrec_amd_last_error.)
  *  - Index arrays are int32, values float32 (rtrec/utils/interactions.py:276,303 builds
  *    float32 matrices whose scipy index dtype is int32).
  */
