@@ -994,6 +994,7 @@ __host__ __device__ constexpr size_t fr_wave_scratch_words(int n_tiles, int regs
 constexpr int kFrCandCap = 64;               // candidates a wave buffers per merge round (one per lane)
 __host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
 constexpr int kFrStep = 2;                   // rows of W per sweep step
+constexpr int kFrTileHeaderBytes = 512;      // per tile, in front of its first fragment: max |w| of each row (FR_TILE_HEADER_BYTES)
 constexpr int kFrZeroRowBytes = 1024;        // one slice row of +0.0 (the widest tile: 256 columns)
 // per-wave LDS setup scratch actually needed: the interacted-column mask words, a pad, 128 ratings
 __host__ __device__ constexpr int fr_setup_scratch(int mask_words) { return ((mask_words * 8 + 256 + 512) + 255) / 256 * 256; }
@@ -1281,6 +1282,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         // the eight users' sums over the current tile: they outlive a super-tile when the tile's slice continues in the next
         vec acc[UW];
         fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });
+        bool tile_skip = false;    // the current tile cannot place a column in any of the wave's lists (decided at its first fragment)
         for (int sidx = 0; sidx < a.n_super; ++sidx) {
             const unsigned char *wb = (sidx & 1) ? buf1 : buf0;
             if (sidx + 1 < a.n_super) load_super(sidx + 1, (sidx & 1) ? buf0 : buf1);
@@ -1307,8 +1309,37 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                 //      and 256 columns), rows ascending = scipy's order.  A user that does not rate the row has
                 //      x_u = 0: x * w = +-0 changes no sum (a sum that starts at +0 never becomes -0), and the same
                 //      holds for rows and blocks that are skipped altogether. ----
-                if (ft & (1 << 24)) fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });   // first fragment
                 const int toff = readlane_i(toffv, g - t_lo);
+                if (ft & (1 << 24)) {                            // first fragment of a tile
+                    // ---- can this tile matter at all?  Its header holds max |w| of every row of W over the tile's
+                    //      columns (lane f = row 64 h + f), so  B_u = sum_f |x_uf| max|w_f|  bounds every score user u
+                    //      can have in it, rounding of the float32 sums included in the 1e-4 margin.  A column enters a
+                    //      list only by BEATING the user's (k+1)-th best: when B_u <= that for all eight users the
+                    //      sweep, the selection and the tile's further fragments are skipped -- after the heavy first
+                    //      tiles that is the fate of nine tiles in ten (ML-20M shape). ----
+                    float wm[XR];
+                    fr_static_for<XR>([&](auto H) {
+                        wm[H()] = *reinterpret_cast<const float *>(wb + toff - kFrTileHeaderBytes + (H() * 64 + lane) * 4);
+                    });
+                    bool all_skip = true;
+                    fr_static_for<UW>([&](auto Uc) {
+                        constexpr int u = decltype(Uc)::value;
+                        float b = __fmul_rn(fabsf(xr[u][0]), wm[0]);
+                        if constexpr (XR == 2) b = __fadd_rn(b, __fmul_rn(fabsf(xr[u][1]), wm[1]));
+                        b = __fadd_rn(b, fr_dpp_f<0x111>(b, 0.0f));
+                        b = __fadd_rn(b, fr_dpp_f<0x112>(b, 0.0f));
+                        b = __fadd_rn(b, fr_dpp_f<0x114>(b, 0.0f));
+                        b = __fadd_rn(b, fr_dpp_f<0x118>(b, 0.0f));
+                        b = __fadd_rn(b, fr_dpp_f<0x142>(b, 0.0f));      // row_bcast:15
+                        b = __fadd_rn(b, fr_dpp_f<0x143>(b, 0.0f));      // row_bcast:31: lane 63 holds the wave's sum
+                        const float bound = __fmul_rn(readlane_f(b, 63), 1.0001f);
+                        const float thr_u = readlane_f(ls4[u >> 2], (u & 3) * 16 + kk - 1);
+                        if (!(thr_u >= 0.0f && bound <= thr_u)) all_skip = false;
+                    });
+                    tile_skip = all_skip;
+                    if (!tile_skip) fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });
+                }
+                if (tile_skip) continue;
                 int below = 0;                                   // rows of this tile's slice before half h
                 fr_static_for<XR>([&](auto H) {
                     constexpr int h = decltype(H)::value;

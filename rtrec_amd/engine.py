@@ -199,6 +199,10 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     wd = np.zeros(max(int(P["super_kb"][-1]) * 256, 256), dtype=np.float32)
     base = P["super_kb"][P["frag_super"][g_of]] * 256 + P["frag_off"][g_of] // 4
     wd[base + (k_of - P["frag_k0"][g_of]) * tc + lc % tc] = vals
+    # tile headers: max |w| per row -- the kernel skips a tile for a wave when sum_f |x_f| max|w_f| cannot beat any of
+    # its users' current (k+1)-th best scores
+    hbase = P["super_kb"][P["frag_super"][P["first_frag"]]] * 256 + (P["frag_off"][P["first_frag"]] - FR_TILE_HEADER_BYTES) // 4
+    np.maximum.at(wd, hbase[t_of] + f_of, np.abs(vals))
     frag_rows = np.zeros((P["n_frags"], 2), dtype=np.uint64)
     np.bitwise_or.at(frag_rows, (g_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
     tile_rows = np.zeros((n_tiles, 2), dtype=np.uint64)
@@ -222,6 +226,7 @@ def _heavy_tiles_first(order: np.ndarray, col_mass: np.ndarray, tc: int) -> np.n
     return np.concatenate([head[np.argsort(-tmass, kind="stable")].ravel(), order[n_full * tc:]])
 
 
+FR_TILE_HEADER_BYTES = 512          # per tile, in front of its first fragment: max |w| of each of the (<= 128) rows in the tile
 FR_STREAM_BUF_BYTES = 36 * 1024     # slice buffer of the streaming layout: two 8-wave workgroups (2 buffers each) share a CU's LDS
 
 
@@ -237,7 +242,7 @@ def _pack_fragments(n_rows_t: np.ndarray, tc: int) -> Dict[str, Any]:
     its super-tile; per super-tile: first fragment, KiB offset in the weight array; buf_bytes; resident."""
     row_bytes = tc * 4
     n_tiles = len(n_rows_t)
-    total = -(-(int(n_rows_t.sum()) * row_bytes) // 1024) * 1024
+    total = -(-(int(n_rows_t.sum()) * row_bytes + n_tiles * FR_TILE_HEADER_BYTES) // 1024) * 1024
     setup = 16 * (-(-(n_tiles * (tc // 64) * 8 + 768) // 256) * 256)
     resident = n_tiles <= 64 and total + setup + 16 * 512 + 1024 + 16 <= 160 * 1024
     cap = max(total, 1024) if resident else FR_STREAM_BUF_BYTES
@@ -245,7 +250,8 @@ def _pack_fragments(n_rows_t: np.ndarray, tc: int) -> Dict[str, Any]:
     for t in range(n_tiles):
         k, n = 0, int(n_rows_t[t])
         while k < n:
-            room = (cap - used) // row_bytes
+            hdr = FR_TILE_HEADER_BYTES if k == 0 else 0      # the tile's header sits in front of its first fragment
+            room = (cap - used - hdr) // row_bytes
             # close the super-tile when it is full, holds 64 fragments (a lane per fragment), or the rest of it would
             # take less than 8 rows of a slice that needs more
             if used > 0 and (room < min(n - k, 8) or len(f_tile) - st_frag[-1] >= 64):
@@ -253,15 +259,15 @@ def _pack_fragments(n_rows_t: np.ndarray, tc: int) -> Dict[str, Any]:
                 used = 0
                 continue
             take = min(n - k, room)
-            f_tile.append(t); f_k0.append(k); f_k1.append(k + take); f_off.append(used); f_super.append(len(st_frag) - 1)
-            used += take * row_bytes
+            f_tile.append(t); f_k0.append(k); f_k1.append(k + take); f_off.append(used + hdr); f_super.append(len(st_frag) - 1)
+            used += hdr + take * row_bytes
             k += take
     st_frag.append(len(f_tile))
     f_tile, f_k0, f_k1 = (np.asarray(a, dtype=np.int64) for a in (f_tile, f_k0, f_k1))
     f_super, st_frag = np.asarray(f_super, dtype=np.int64), np.asarray(st_frag, dtype=np.int64)
     n_super = len(st_frag) - 1
     bytes_s = np.zeros(n_super, dtype=np.int64)
-    np.add.at(bytes_s, f_super, (f_k1 - f_k0) * row_bytes)
+    np.add.at(bytes_s, f_super, (f_k1 - f_k0) * row_bytes + np.where(f_k0 == 0, FR_TILE_HEADER_BYTES, 0))
     super_kb = np.zeros(n_super + 1, dtype=np.int64)
     super_kb[1:] = np.cumsum(-(-bytes_s // 1024))
     flags = f_tile | ((f_k0 == 0).astype(np.int64) << 24) | ((f_k1 == n_rows_t[f_tile]).astype(np.int64) << 25)
@@ -270,7 +276,9 @@ def _pack_fragments(n_rows_t: np.ndarray, tc: int) -> Dict[str, Any]:
     for i in range(len(f_tile)):
         frag_of[f_tile[i], f_k0[i]:f_k1[i]] = i
     buf_bytes = int(cap) if resident else FR_STREAM_BUF_BYTES
-    return dict(frag_tile=f_tile, frag_k0=f_k0, frag_flags=flags, frag_off=np.asarray(f_off, dtype=np.int64), frag_super=f_super,
+    first_frag = np.zeros(n_tiles, dtype=np.int64)
+    first_frag[f_tile[f_k0 == 0]] = np.flatnonzero(f_k0 == 0)
+    return dict(first_frag=first_frag, frag_tile=f_tile, frag_k0=f_k0, frag_flags=flags, frag_off=np.asarray(f_off, dtype=np.int64), frag_super=f_super,
                 super_frag=st_frag, super_kb=super_kb, frag_of=frag_of, buf_bytes=buf_bytes, resident=bool(resident),
                 n_frags=len(f_tile), n_super=n_super)
 
@@ -333,6 +341,8 @@ def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int
     wd = torch.zeros(max(int(P["super_kb"][-1]) * 256, 256), dtype=torch.float32, device=dev)
     base = dv(P["super_kb"])[dv(P["frag_super"])[g_of]] * 256 + dv(P["frag_off"])[g_of] // 4
     wd[base + (k_of - dv(P["frag_k0"])[g_of]) * tc + lc % tc] = v
+    hbase = dv(P["super_kb"][P["frag_super"][P["first_frag"]]] * 256 + (P["frag_off"][P["first_frag"]] - FR_TILE_HEADER_BYTES) // 4)
+    wd.scatter_reduce_(0, hbase[t_of] + f_of, v.abs(), reduce="amax")             # tile headers: max |w| per row
     # one bit per (row, fragment) / (row, tile) block that holds a weight
     blk_key = torch.unique(g_of * 128 + f_of)
     bg, bf = blk_key // 128, blk_key % 128
