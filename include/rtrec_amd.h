@@ -238,8 +238,10 @@ typedef struct {
      *     d_fr_col_ids[n_cols]  layout column -> item id,   d_fr_col_map[n_items]  item id -> layout column or -1
      * (n_cols as in the compacted tiled layout), cut into fr_n_tiles = ceil(n_cols / fr_tile_cols) tiles of
      * fr_tile_cols (256 or 128) columns.  d_fr_map[n_items] = row f of an item or -1.  Only the rows that hold a
-     * weight in a tile are stored: the tile's SLICE is those rows in ascending order, fr_tile_cols floats each (0 where
-     * W[row, column] is not stored).  Blocks without a weight are never visited, so an order of the columns that
+     * weight in a tile are stored: the tile's SLICE is a 512-byte header (max |w| of each row over the tile's columns,
+     * one float per row: sum_f |x_f| max|w_f| bounds every score a user can have in the tile, and a tile that cannot
+     * beat the user's current (k+1)-th best is skipped) and those rows in ascending order, fr_tile_cols floats each
+     * (0 where W[row, column] is not stored).  Blocks without a weight are never visited, so an order of the columns that
      * clusters the rows' weights saves work without changing a sum.  For staging in LDS a slice is cut into
      * FRAGMENTS (consecutive rows of it; fr_n_frags in all, in tile order): d_fr_frag_tile[g] = tile | first << 24 |
      * last << 25, d_fr_tile_rows[g * 2 + h] bit f = 1 iff the fragment holds row 64 h + f, d_fr_tile_off[g] = its byte
