@@ -728,7 +728,7 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
     const int n_rows = FT ? *a.row_list_len : a.n_rows;
     const int total = n_rows * a.n_tiles;
     if (total == 0) return;              // the exact-tie pass usually has nothing to do: leave before touching LDS
-    for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
+    bool lds_ready = false;              // ... and a workgroup that never gets a job never initialises its tile either
 
     PF_DECL
 #ifdef SCORE_PROFILE
@@ -746,6 +746,10 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
             PF_MARK(PF_QUEUE)
             if (w_next >= total) break;
             w_end = min(w_next + chunk, total);
+        }
+        if (!lds_ready) {
+            for (int c = lane; c < S; c += 64) { L.acc[c] = unt; if (FT) L.ft[c] = 0xffffffffu; }
+            lds_ready = true;
         }
         const int w = w_next++;
         const int tile = w / n_rows;             // tile-major: concurrent waves share a W tile in L2
@@ -1261,7 +1265,6 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
         float ls4[NL];
         int lc4[NL];
         fr_static_for<NL>([&](auto G4) { ls4[G4()] = ninf; lc4[G4()] = -1; });
-        uint32_t spilled = 0u;     // bit u: user u's candidates overflowed the buffer -> its row goes to the exact-tie pass
 
         PF_MARK(PF_HDR) PF_ADD(PF_JOBS, 1)
         if (!resident) {
@@ -1407,6 +1410,30 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                         if (t0 != ninf) tcut = float_prev(t0);      // candidates are the values >= t0
                     }
                     int nc = 0;
+                    const int rel = lane - lb;
+                    const bool in = rel >= 0 && rel < kk;
+                    // merge the buffered candidates into the user's list (lane lb + j = rank j)
+                    auto merge = [&]() {
+                        const float myv = lane < nc ? cv[lane] : ninf;
+                        const int mycol = lane < nc ? cp[lane] : 0;
+                        for (int i = 0; i < nc; ++i) {
+                            const float v = readlane_f(myv, i);
+                            const int col = readlane_i(mycol, i);
+                            const float s = ls4[g];
+                            const int c = lc4[g];
+                            PF_ADD(PF_N_SPARSE_CHUNKS, 1)
+                            if (!(v > readlane_f(s, lb + kk - 1))) continue;            // the threshold has risen meanwhile
+                            // ties inside the fast pass order by higher column; exact ties are re-scored anyway
+                            const bool better = in && ((s > v) || (s == v && c > col));
+                            const int pos = static_cast<int>(__builtin_popcountll(__ballot(better)));
+                            PF_ADD(PF_N_SPARSE_ROWS, 1)
+                            const float s_up = fr_row_shift_up(s, ninf);
+                            const int c_up = fr_row_shift_up(c, -1);
+                            ls4[g] = !in || rel < pos ? s : (rel == pos ? v : s_up);
+                            lc4[g] = !in || rel < pos ? c : (rel == pos ? col : c_up);
+                        }
+                        nc = 0;
+                    };
                     fr_static_for<REGS>([&](auto Rc) {
                         constexpr int r = decltype(Rc)::value;
                         const float v = acc[u][r];
@@ -1416,7 +1443,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                         if (a.filter) m &= ~mc[t * REGS + r];
                         if (!m) return;
                         const int cnt = static_cast<int>(__builtin_popcountll(m));
-                        if (nc + cnt > kFrCandCap) { spilled |= 1u << u; return; }
+                        if (nc + cnt > kFrCandCap) merge();      // the buffer holds one ballot's worth (64): make room first
                         if ((m >> lane) & 1ull) {
                             const int pos = nc + lane_prefix(m);
                             cv[pos] = v;
@@ -1424,28 +1451,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                         }
                         nc += cnt;
                     });
-                    if (nc == 0) return;
-                    // merge the tile's candidates into the user's list (lane lb + j = rank j)
-                    const float myv = lane < nc ? cv[lane] : ninf;
-                    const int mycol = lane < nc ? cp[lane] : 0;
-                    const int rel = lane - lb;
-                    const bool in = rel >= 0 && rel < kk;
-                    for (int i = 0; i < nc; ++i) {
-                        const float v = readlane_f(myv, i);
-                        const int col = readlane_i(mycol, i);
-                        const float s = ls4[g];
-                        const int c = lc4[g];
-                        PF_ADD(PF_N_SPARSE_CHUNKS, 1)
-                        if (!(v > readlane_f(s, lb + kk - 1))) continue;            // the threshold has risen meanwhile
-                        // ties inside the fast pass order by higher column; exact ties are re-scored anyway
-                        const bool better = in && ((s > v) || (s == v && c > col));
-                        const int pos = static_cast<int>(__builtin_popcountll(__ballot(better)));
-                        PF_ADD(PF_N_SPARSE_ROWS, 1)
-                        const float s_up = fr_row_shift_up(s, ninf);
-                        const int c_up = fr_row_shift_up(c, -1);
-                        ls4[g] = !in || rel < pos ? s : (rel == pos ? v : s_up);
-                        lc4[g] = !in || rel < pos ? c : (rel == pos ? col : c_up);
-                    }
+                    if (nc > 0) merge();
                 });
             }
             PF_MARK(PF_DENSE)
@@ -1485,7 +1491,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             const unsigned long long tie = __ballot(rel >= 0 && rel + 1 < n_valid && s == nxt);
             if (lane == lb) {
                 a.out_cnt[r] = n_fin;
-                if (tie || ((spilled >> u) & 1u)) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+                if (tie) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
             }
         });
         PF_MARK(PF_EMIT)
