@@ -336,16 +336,18 @@ def main() -> None:
             own_or = own[pos.reshape(-1, 8, 8)].any(axis=2 if eng._grouped_order(lay) else 1)      # [jobs, 8 waves, R]
         nz_rt = np.array([[(int(tr[t, f // 64]) >> (f % 64)) & 1 for f in range(R)] for t in range(tr.shape[0])], dtype=np.int32)
         swept_rows = float((own_or.reshape(-1, R).astype(np.int32) @ nz_rt.T).sum())      # (wave, tile, row) reads of 1 slice row
-        lds_bytes = swept_rows * tc * 4.0
+        lds_bytes = swept_rows * tc * 4.0                 # upper bound: tiles pruned by the score bound are not read
         executed_flops = 2.0 * swept_rows * 8.0 * tc
         n_jobs = 256 if fr.get("fr_resident") else -(-n_scored // 64)     # resident: W is loaded once per workgroup
         l2_bytes = float(n_jobs) * float(fr["fr_super_kb"][-1]) * 1024.0 + 8.0 * (nnz if n_scored == U else int(Xs.nnz))
         bounds = {"valu": {"achieved": flops / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": flops / kern_s / 1e12 / VALU_PEAK_TFLOPS, "flops_per_launch": flops,
-                           "useful_flops_per_launch": 2.0 * gathered_entries, "executed_flops_per_launch": executed_flops,
+                           "useful_flops_per_launch": 2.0 * gathered_entries, "unpruned_lockstep_flops_per_launch": executed_flops,
                            "note": "algorithmic work of the feature-row formulation: unfused float32 multiply + add over every "
                                    "(user, rated row of W, tile) block that holds a weight (zeros inside a block included); "
-                                   "`executed` adds the lock-step waste (a wave applies each swept row to all 8 of its users); "
+                                   "`unpruned_lockstep` is what the sweep would execute without pruning (a wave applies each swept "
+                                   "row to all 8 of its users); the kernel skips every tile whose score bound sum|x|max|w| cannot "
+                                   "beat its users' current (k+1)-th best, so it executes far less than either figure; "
                                    "peak = vector f32 lane-ops/s without FMA"},
                   "lds": {"achieved": lds_bytes / kern_s / 1e9, "peak": LDS_READ_PEAK_GBS, "unit": "GB/s",
                           "frac": lds_bytes / kern_s / 1e9 / LDS_READ_PEAK_GBS, "bytes_per_launch": lds_bytes,
