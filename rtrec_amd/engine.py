@@ -1091,7 +1091,7 @@ class SlimEngine:
     # a small batch leaves most of the chip idle and waits for one wave's pass over every tile.  Below this many rows
     # the tiled-CSR kernel scores the batch -- one job per (user, tile), so even one user spreads over several
     # workgroups (tools/score_batch_sweep.py: DESIGN.md section 3.1).
-    FR_MIN_ROWS = 8192
+    FR_MIN_ROWS = 32
     pattern_order = os.environ.get("RTREC_AMD_PATTERN_ORDER", "1") != "0"
     rescored = None             # optional int32[1] device tensor: rows the exact-tie pass re-scored in the last call
 
