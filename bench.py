@@ -310,60 +310,75 @@ def main() -> None:
     bounds, kernel_name, bound = {}, "score_sparse_kernel<float,false>", "l2"
     compulsory_hbm = 8.0 * (nnz if n_scored == U else int(Xs.nnz)) + 4.0 * (n_scored + 1) + (8.0 * top_k + 4.0) * n_scored
     fr = lay.get("fr_host")
+
+    def tiled_model():
+            l2_bytes = 6.0 * gathered_entries + 24.0 * (nnz if n_scored == U else int(Xs.nnz)) * max(lay["n_tiles"], 1)
+            lds_bytes = 8.0 * gathered_entries
+            bounds = {"l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                             "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes},
+                      "lds": {"achieved": lds_bytes / kern_s / 1e9, "peak": 44_000.0, "unit": "GB/s",
+                              "frac": lds_bytes / kern_s / 1e9 / 44_000.0, "bytes_per_launch": lds_bytes,
+                              "note": "read-modify-write of the LDS accumulators, priced at the LDS write rate"}}
+            return bounds, "score_sparse_kernel<float,false>"
+
+    def feature_row_model():
+            tc, R = fr["fr_tile_cols"], fr["fr_rows"]
+            kernel_name = f"score_frows_kernel<{tc // 64},{2 if R > 64 else 1}>"
+            tr = fr["fr_rows_of_tile"].view(np.uint64).reshape(-1, 2)
+            feat_items = np.flatnonzero(fr["fr_map"] >= 0)
+            tiles_of_row = np.array([sum(((int(tr[t, f // 64]) >> (f % 64)) & 1) for t in range(tr.shape[0])) for f in range(R)],
+                                    dtype=np.float64)
+            blocks = float((users_per_item[feat_items] * tiles_of_row).sum())      # (user, row, tile) blocks that hold a weight
+            flops = 2.0 * blocks * tc                                               # one rounded multiply + one rounded add per column
+            # what the kernel executes: a wave sweeps, per tile, the rows that hold a weight there and that ANY of its 8 users
+            # rates (one LDS read per row, applied to all 8): the union over the wave's users, in the order the engine hands
+            # the rows over (position p of a 128-user job -> wave p % 16)
+            Xsc = (X if n_scored == U else Xs)[:, feat_items].tocsr()
+            own = np.zeros((n_scored + 1, R), dtype=bool)                          # last row: padding (no ratings)
+            own[np.repeat(np.arange(n_scored), np.diff(Xsc.indptr)), Xsc.indices] = Xsc.data != 0
+            order = eng._X.get("_order") if n_scored == U else None
+            order = order.cpu().numpy().astype(np.int64) if order is not None else np.arange(n_scored, dtype=np.int64)
+            if len(order) != n_scored:         # the sharded path scores in row chunks: the cached order is one chunk's
+                order = np.arange(n_scored, dtype=np.int64)
+            if fr.get("fr_resident"):          # every wave claims 8 users: positions j, j + n_wj, ... (score_frows_kernel)
+                n_wj = -(-n_scored // 8)
+                pos = np.concatenate([order, np.full(8 * n_wj - n_scored, n_scored, dtype=np.int64)])
+                own_or = own[pos.reshape(8, n_wj)].any(axis=0)                      # [wave jobs, R]
+            else:                              # jobs of 64 users: a wave takes 8 consecutive positions of the pattern-sorted
+                pos = np.concatenate([order, np.full((-n_scored) % 64, n_scored, dtype=np.int64)])      # order, else p % 8
+                own_or = own[pos.reshape(-1, 8, 8)].any(axis=2 if eng._grouped_order(lay) else 1)      # [jobs, 8 waves, R]
+            nz_rt = np.array([[(int(tr[t, f // 64]) >> (f % 64)) & 1 for f in range(R)] for t in range(tr.shape[0])], dtype=np.int32)
+            swept_rows = float((own_or.reshape(-1, R).astype(np.int32) @ nz_rt.T).sum())      # (wave, tile, row) reads of 1 slice row
+            lds_bytes = swept_rows * tc * 4.0                 # upper bound: tiles pruned by the score bound are not read
+            executed_flops = 2.0 * swept_rows * 8.0 * tc
+            n_jobs = 256 if fr.get("fr_resident") else -(-n_scored // 64)     # resident: W is loaded once per workgroup
+            l2_bytes = float(n_jobs) * float(fr["fr_super_kb"][-1]) * 1024.0 + 8.0 * (nnz if n_scored == U else int(Xs.nnz))
+            bounds = {"valu": {"achieved": flops / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": flops / kern_s / 1e12 / VALU_PEAK_TFLOPS, "flops_per_launch": flops,
+                               "useful_flops_per_launch": 2.0 * gathered_entries, "unpruned_lockstep_flops_per_launch": executed_flops,
+                               "note": "algorithmic work of the feature-row formulation: unfused float32 multiply + add over every "
+                                       "(user, rated row of W, tile) block that holds a weight (zeros inside a block included); "
+                                       "`unpruned_lockstep` is what the sweep would execute without pruning (a wave applies each swept "
+                                       "row to all 8 of its users); the kernel skips every tile whose score bound sum|x|max|w| cannot "
+                                       "beat its users' current (k+1)-th best, so it executes far less than either figure; "
+                                       "peak = vector f32 lane-ops/s without FMA"},
+                      "lds": {"achieved": lds_bytes / kern_s / 1e9, "peak": LDS_READ_PEAK_GBS, "unit": "GB/s",
+                              "frac": lds_bytes / kern_s / 1e9 / LDS_READ_PEAK_GBS, "bytes_per_launch": lds_bytes,
+                              "note": "slice rows read from LDS: one ds_read_b128 per lane and swept (wave, tile, row), shared by the wave's 8 users"},
+                      "l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                             "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes,
+                             "note": "W slices staged into LDS once per 64-user job (once per workgroup when resident) + the user rows"}}
+            return bounds, kernel_name
+
     if fr is not None and eng.use_feature_rows:
-        tc, R = fr["fr_tile_cols"], fr["fr_rows"]
-        kernel_name = f"score_frows_kernel<{tc // 64},{2 if R > 64 else 1}>"
-        tr = fr["fr_rows_of_tile"].view(np.uint64).reshape(-1, 2)
-        feat_items = np.flatnonzero(fr["fr_map"] >= 0)
-        tiles_of_row = np.array([sum(((int(tr[t, f // 64]) >> (f % 64)) & 1) for t in range(tr.shape[0])) for f in range(R)],
-                                dtype=np.float64)
-        blocks = float((users_per_item[feat_items] * tiles_of_row).sum())      # (user, row, tile) blocks that hold a weight
-        flops = 2.0 * blocks * tc                                               # one rounded multiply + one rounded add per column
-        # what the kernel executes: a wave sweeps, per tile, the rows that hold a weight there and that ANY of its 8 users
-        # rates (one LDS read per row, applied to all 8): the union over the wave's users, in the order the engine hands
-        # the rows over (position p of a 128-user job -> wave p % 16)
-        Xsc = (X if n_scored == U else Xs)[:, feat_items].tocsr()
-        own = np.zeros((n_scored + 1, R), dtype=bool)                          # last row: padding (no ratings)
-        own[np.repeat(np.arange(n_scored), np.diff(Xsc.indptr)), Xsc.indices] = Xsc.data != 0
-        order = eng._X.get("_order") if n_scored == U else None
-        order = order.cpu().numpy().astype(np.int64) if order is not None else np.arange(n_scored, dtype=np.int64)
-        if fr.get("fr_resident"):          # every wave claims 8 users: positions j, j + n_wj, ... (score_frows_kernel)
-            n_wj = -(-n_scored // 8)
-            pos = np.concatenate([order, np.full(8 * n_wj - n_scored, n_scored, dtype=np.int64)])
-            own_or = own[pos.reshape(8, n_wj)].any(axis=0)                      # [wave jobs, R]
-        else:                              # jobs of 64 users: a wave takes 8 consecutive positions of the pattern-sorted
-            pos = np.concatenate([order, np.full((-n_scored) % 64, n_scored, dtype=np.int64)])      # order, else p % 8
-            own_or = own[pos.reshape(-1, 8, 8)].any(axis=2 if eng._grouped_order(lay) else 1)      # [jobs, 8 waves, R]
-        nz_rt = np.array([[(int(tr[t, f // 64]) >> (f % 64)) & 1 for f in range(R)] for t in range(tr.shape[0])], dtype=np.int32)
-        swept_rows = float((own_or.reshape(-1, R).astype(np.int32) @ nz_rt.T).sum())      # (wave, tile, row) reads of 1 slice row
-        lds_bytes = swept_rows * tc * 4.0                 # upper bound: tiles pruned by the score bound are not read
-        executed_flops = 2.0 * swept_rows * 8.0 * tc
-        n_jobs = 256 if fr.get("fr_resident") else -(-n_scored // 64)     # resident: W is loaded once per workgroup
-        l2_bytes = float(n_jobs) * float(fr["fr_super_kb"][-1]) * 1024.0 + 8.0 * (nnz if n_scored == U else int(Xs.nnz))
-        bounds = {"valu": {"achieved": flops / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": flops / kern_s / 1e12 / VALU_PEAK_TFLOPS, "flops_per_launch": flops,
-                           "useful_flops_per_launch": 2.0 * gathered_entries, "unpruned_lockstep_flops_per_launch": executed_flops,
-                           "note": "algorithmic work of the feature-row formulation: unfused float32 multiply + add over every "
-                                   "(user, rated row of W, tile) block that holds a weight (zeros inside a block included); "
-                                   "`unpruned_lockstep` is what the sweep would execute without pruning (a wave applies each swept "
-                                   "row to all 8 of its users); the kernel skips every tile whose score bound sum|x|max|w| cannot "
-                                   "beat its users' current (k+1)-th best, so it executes far less than either figure; "
-                                   "peak = vector f32 lane-ops/s without FMA"},
-                  "lds": {"achieved": lds_bytes / kern_s / 1e9, "peak": LDS_READ_PEAK_GBS, "unit": "GB/s",
-                          "frac": lds_bytes / kern_s / 1e9 / LDS_READ_PEAK_GBS, "bytes_per_launch": lds_bytes,
-                          "note": "slice rows read from LDS: one ds_read_b128 per lane and swept (wave, tile, row), shared by the wave's 8 users"},
-                  "l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                         "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes,
-                         "note": "W slices staged into LDS once per 64-user job (once per workgroup when resident) + the user rows"}}
-        bound = max(bounds, key=lambda k: bounds[k]["frac"])
+        try:
+            bounds, kernel_name = feature_row_model()
+        except Exception as exc:      # the model is bookkeeping: it must never cost the measurement
+            log(f"[bench] feature-row bounds model failed ({exc!r}); falling back to the tiled-CSR model")
+            bounds, kernel_name = tiled_model()
+            kernel_name = "score_frows_kernel"
     else:
-        l2_bytes = 6.0 * gathered_entries + 24.0 * (nnz if n_scored == U else int(Xs.nnz)) * max(lay["n_tiles"], 1)
-        lds_bytes = 8.0 * gathered_entries
-        bounds = {"l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
-                         "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes},
-                  "lds": {"achieved": lds_bytes / kern_s / 1e9, "peak": 44_000.0, "unit": "GB/s",
-                          "frac": lds_bytes / kern_s / 1e9 / 44_000.0, "bytes_per_launch": lds_bytes,
-                          "note": "read-modify-write of the LDS accumulators, priced at the LDS write rate"}}
+        bounds, kernel_name = tiled_model()
     bounds["hbm"] = {"achieved": compulsory_hbm / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": compulsory_hbm / kern_s / 1e9 / HBM_PEAK_GBS, "compulsory_bytes_per_launch": compulsory_hbm,
                      "note": "user rows + outputs: the only bytes that must come from / go to HBM"}
