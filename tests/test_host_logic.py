@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from rtrec_amd.engine import (DENSE_ROW_FILL, DeviceWeights, SlimEngine, build_feature_rows, build_feature_rows_device, build_tiled_w,
+from rtrec_amd.engine import (DENSE_ROW_FILL, DeviceWeights, FR_STREAM_BUF_BYTES, FR_TILE_HEADER_BYTES, SlimEngine, _pack_fragments, build_feature_rows, build_feature_rows_device, build_tiled_w,
                               build_tiled_w_device, coefficients_to_updates, merge_coefficients, row_header_table, shard_bounds,
                               sklearn_seed)
 from rtrec_amd.utils.identifiers import Identifier, IdentifierError
@@ -240,6 +240,48 @@ def test_device_layout_builders_equal_the_host_builders(shard):
                     for k in ("fr_rows", "fr_tile_cols", "fr_n_tiles", "fr_n_frags", "fr_n_super", "fr_buf_bytes"):
                         assert F[k] == H[k], k
     assert build_feature_rows_device(*_device_coo(_feature_row_w()), 700, 0, 700) is not None     # the dense form was exercised
+
+
+@pytest.mark.parametrize("tc", [256, 128])
+def test_fragment_packing_invariants(tc):
+    """engine._pack_fragments: every stored row of every tile sits in exactly one fragment, fragments of a tile are
+    consecutive and ascending, a tile's header fits in front of its first fragment, nothing overlaps or leaves its
+    super-tile's buffer, at most 64 fragments per super-tile; small layouts come out resident (one super-tile)."""
+    rng = np.random.default_rng(tc)
+    row_bytes = tc * 4
+    cases = [rng.integers(1, 128 if tc == 128 else 67, size=n) for n in (1, 5, 59, 200, 400)] + [np.full(300, 1), np.array([66] * 12)]
+    for n_rows_t in cases:
+        n_rows_t = np.asarray(n_rows_t, dtype=np.int64)
+        P = _pack_fragments(n_rows_t, tc)
+        F = P["n_frags"]
+        assert P["super_frag"][0] == 0 and P["super_frag"][-1] == F and np.all(np.diff(P["super_frag"]) >= 1)
+        assert np.all(np.diff(P["super_frag"]) <= 64)
+        tile = P["frag_flags"] & 0xffffff
+        first, last = (P["frag_flags"] >> 24) & 1, (P["frag_flags"] >> 25) & 1
+        assert np.array_equal(tile, P["frag_tile"]) and np.all(np.diff(tile) >= 0)
+        k1 = np.zeros(F, dtype=np.int64)
+        for t in range(len(n_rows_t)):
+            fr = np.flatnonzero(tile == t)
+            assert len(fr) >= 1 and np.all(np.diff(fr) == 1) and first[fr[0]] == 1 and last[fr[-1]] == 1
+            assert first[fr].sum() == 1 and last[fr].sum() == 1
+            ends = list(P["frag_k0"][fr[1:]]) + [n_rows_t[t]]
+            assert P["frag_k0"][fr[0]] == 0 and np.all(np.asarray(ends) > P["frag_k0"][fr])
+            k1[fr] = ends
+            for i, g in enumerate(fr):                      # the lookup table agrees
+                assert np.all(P["frag_of"][t, P["frag_k0"][g]:k1[g]] == g)
+        for s_ in range(P["n_super"]):
+            lo, hi = P["super_frag"][s_], P["super_frag"][s_ + 1]
+            cur = 0
+            for g in range(lo, hi):
+                start = P["frag_off"][g] - (FR_TILE_HEADER_BYTES if first[g] else 0)
+                assert start == cur                            # packed back to back, header in front of a first fragment
+                cur = P["frag_off"][g] + (k1[g] - P["frag_k0"][g]) * row_bytes
+            assert cur <= P["buf_bytes"] and cur <= (P["super_kb"][s_ + 1] - P["super_kb"][s_]) * 1024
+        total = int(n_rows_t.sum()) * row_bytes + len(n_rows_t) * FR_TILE_HEADER_BYTES
+        if P["resident"]:
+            assert P["n_super"] == 1 and len(n_rows_t) <= 64 and P["buf_bytes"] >= total
+        else:
+            assert P["buf_bytes"] == FR_STREAM_BUF_BYTES and 2 * (2 * P["buf_bytes"] + 8 * 512 + 1024 + 16) <= 160 * 1024
 
 
 def test_device_merge_equals_the_host_write_back():
