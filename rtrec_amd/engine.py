@@ -146,8 +146,8 @@ FR_MAX_ROWS = 128           # kFrMaxRows of csrc/score.hip
 FR_MIN_FILL = 1.0 / 64.0    # the dense R x n_cols form pays when at least this share of it is stored weights
 
 
-def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: np.ndarray, col_map: np.ndarray
-                       ) -> Optional[Dict[str, Any]]:
+def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: np.ndarray, col_map: np.ndarray,
+                       tile_cols: int = 256) -> Optional[Dict[str, Any]]:
     """"Feature-row" form of columns [col_lo, col_hi) of W for score_frows_kernel (include/rtrec_amd.h,
     rtrec_score_opts): only items that some column selected with a non-zero weight have a row in W; when
     those rows are few the shard is the small dense matrix of those rows over the compacted columns, cut
@@ -163,7 +163,8 @@ def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: 
     R, n_cols = int(len(F)), int(len(col_ids))
     if R == 0 or R > FR_MAX_ROWS or n_cols == 0 or len(vals) < FR_MIN_FILL * R * n_cols:
         return None
-    tc = 256 if R <= 66 else 128
+    tc = 128 if int(tile_cols) == 128 else 256      # 256: four sums per lane and instruction; slices are cut into fragments, so
+                                                    # the tallest tile (R rows) no longer has to fit one LDS buffer
     n_tiles = -(-n_cols // tc)
     if n_tiles * (tc // 64) > 416:
         return None
@@ -283,7 +284,8 @@ def _pack_fragments(n_rows_t: np.ndarray, tc: int) -> Dict[str, Any]:
                 n_frags=len(f_tile), n_super=n_super)
 
 
-def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int) -> Optional[Dict[str, Any]]:
+def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int,
+                              tile_cols: int = 256) -> Optional[Dict[str, Any]]:
     """build_feature_rows for a W that is resident on the device as COO triples (int64 rows / cols sorted by (col, row),
     float32 vals): the same layout, built with tensor ops -- only the per-tile row counts (a few dozen integers) visit
     the host for the super-tile packing.  Returns device tensors (plus the scalars and, for bench.py, small host copies)."""
@@ -296,7 +298,8 @@ def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int
     R, n_cols = int(F.numel()), int(col_ids_sorted.numel())
     if R > FR_MAX_ROWS or r.numel() < FR_MIN_FILL * R * n_cols:
         return None
-    tc = 256 if R <= 66 else 128
+    tc = 128 if int(tile_cols) == 128 else 256      # 256: four sums per lane and instruction; slices are cut into fragments, so
+                                                    # the tallest tile (R rows) no longer has to fit one LDS buffer
     n_tiles = -(-n_cols // tc)
     if n_tiles * (tc // 64) > 416:
         return None
@@ -1045,7 +1048,8 @@ class SlimEngine:
                 if lay is not None and compact:
                     W["n_active"] = lay["n_cols"]
                     if not W["acc_f64"] and getattr(be, "supports_feature_rows", False):
-                        fr = build_feature_rows_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"])
+                        fr = build_feature_rows_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"],
+                                                       tile_cols=self.FR_TILE_COLS)
                         if fr is not None:
                             nb = int(be.lib.rtrec_slim_score_fr_scratch_bytes(fr["fr_n_tiles"], fr["fr_tile_cols"]))
                             fr.pop("col_ids_sorted")
@@ -1092,6 +1096,7 @@ class SlimEngine:
     # the tiled-CSR kernel scores the batch -- one job per (user, tile), so even one user spreads over several
     # workgroups (tools/score_batch_sweep.py: DESIGN.md section 3.1).
     FR_MIN_ROWS = 32
+    FR_TILE_COLS = 256          # columns per tile of the feature-row layout (128: the narrow kernels, kept for A/B and tests)
     pattern_order = os.environ.get("RTREC_AMD_PATTERN_ORDER", "1") != "0"
     rescored = None             # optional int32[1] device tensor: rows the exact-tie pass re-scored in the last call
 

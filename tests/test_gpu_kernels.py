@@ -403,10 +403,11 @@ def test_fit_every_item_output_overflow_is_refitted(engine, oracle, monkeypatch)
         assert np.array_equal(bits(coef[t, :c]), bits(val[ptr[t]:ptr[t + 1]]))
 
 
-@pytest.mark.parametrize("R,n_cols,per_col", [(5, 40, 3), (64, 700, 12), (66, 3000, 20), (100, 900, 25), (128, 2600, 30),
-                                               (30, 9000, 6)])
+@pytest.mark.parametrize("R,n_cols,per_col,tile_cols", [(5, 40, 3, 256), (64, 700, 12, 256), (66, 3000, 20, 256), (100, 900, 25, 256),
+                                                         (128, 2600, 30, 256), (30, 9000, 6, 256), (128, 2600, 30, 128),
+                                                         (40, 3000, 10, 128)])
 @pytest.mark.parametrize("integer_ratings", [False, True])
-def test_feature_row_kernel_shapes(oracle, R, n_cols, per_col, integer_ratings):
+def test_feature_row_kernel_shapes(oracle, R, n_cols, per_col, tile_cols, integer_ratings):
     """score_frows_kernel over the shapes it specialises on: <= 64 / 65-66 / <= 128 rows of W (one or two
     rating registers, 256- or 128-column tiles), one tile to dozens (several super-tiles), negative ratings,
     integer ratings (exact score ties -> the exact-tie pass), users without any feature item, empty users,
@@ -438,10 +439,11 @@ def test_feature_row_kernel_shapes(oracle, R, n_cols, per_col, integer_ratings):
     X = sp.csr_matrix((xv, (ur, ui)), shape=(U, I), dtype=np.float32)
     X.sum_duplicates(); X.eliminate_zeros(); X.sort_indices()
     eng = SlimEngine(device="cuda:0")
+    eng.FR_TILE_COLS = tile_cols                                 # 128: the narrow-tile kernels
     eng.set_interactions(None, X, need_csc=False)
     eng.set_weights(W)
     lay = eng._layout(True)
-    assert lay.get("fr_w") is not None and lay["fr_rows"] == len(np.unique(W.tocoo().row))
+    assert lay.get("fr_w") is not None and lay["fr_rows"] == len(np.unique(W.tocoo().row)) and lay["fr_tile_cols"] == tile_cols
     Wr = W.tocsr()
     for rows in (np.arange(U), rng.permutation(U)[:333]):
         for top_k, filt in ((10, True), (1, True), (15, False), (7, False)):

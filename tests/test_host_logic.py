@@ -230,8 +230,8 @@ def test_device_layout_builders_equal_the_host_builders(shard):
                 assert np.array_equal(D["dense_idx"].numpy(), T.dense_idx) and np.array_equal(D["dense_val"].numpy(), T.dense_val)
             if compact:
                 assert np.array_equal(D["col_ids"].numpy(), T.col_ids) and np.array_equal(D["col_map"].numpy(), T.col_map)
-                H = build_feature_rows(W, lo, hi, T.col_ids, T.col_map)
-                F = build_feature_rows_device(torch, r, c, v, I, lo, hi)
+                H = build_feature_rows(W, lo, hi, T.col_ids, T.col_map, tile_cols=128 if tile == 256 else 256)
+                F = build_feature_rows_device(torch, r, c, v, I, lo, hi, tile_cols=128 if tile == 256 else 256)
                 assert (H is None) == (F is None)
                 if H is not None:
                     for k in ("fr_map", "fr_col_ids", "fr_col_map", "fr_w", "fr_tile_rows", "fr_tile_off", "fr_super_kb", "fr_super_tile",
