@@ -515,3 +515,12 @@ def test_fit_tolerance_modes_track_the_exact_solution(engine, oracle, U, I, draw
     # ... and nearly everywhere in practice
     full = o_cnt >= 10
     assert (ids[full] == o_ids[full, :10]).all(axis=1).mean() > 0.97
+
+
+def test_score_path_randomised_parity():
+    """tools/fuzz_score.py: random numbers of rows of W / columns / densities / users / top_k, filter on and off, integer,
+    float and negative values, both tile widths, with and without the small-batch threshold -- ids, score bits and counts
+    against the oracle (1,000 configurations were run clean when the feature-row kernel got its tile test; 25 run here)."""
+    from tools.fuzz_score import run
+    messages = []
+    assert run(25, seed=4, log=messages.append) == 0, messages

@@ -27,6 +27,7 @@ def main() -> None:
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--out", default=None)
     ap.add_argument("--shards", type=int, default=1, help="fit only shard 0 of this many column shards")
+    ap.add_argument("--mode", default="exact", choices=["exact", "gram", "shuffle"])
     args = ap.parse_args()
     import torch
     from rtrec_amd.engine import SlimEngine, shard_bounds
@@ -40,10 +41,10 @@ def main() -> None:
     eng = SlimEngine(device="cuda:0")
     eng.set_interactions(Xc, X)
     lo, hi = shard_bounds(I, args.shards, 0)
-    eng.fit_columns(np.arange(lo, min(hi, lo + 64)), nn_feature_selection=K)   # warm-up (allocations, sqnorms)
+    eng.fit_columns(np.arange(lo, hi), nn_feature_selection=K, mode=args.mode)   # warm-up (allocations, sqnorms, Gram matrix)
     torch.cuda.synchronize()
     t0 = time.time()
-    tg, items, coef, count, n_iter = eng.fit_columns(np.arange(lo, hi), nn_feature_selection=K, trace=True)
+    tg, items, coef, count, n_iter = eng.fit_columns(np.arange(lo, hi), nn_feature_selection=K, trace=True, mode=args.mode)
     torch.cuda.synchronize()
     wall = time.time() - t0
     tr = eng.last_fit_stats["trace"].astype(np.float64)

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Randomised parity run of the SPARSE-mode score path (feature-row kernel: resident and streaming layouts, fragments,
+tile test, exact-tie pass) against the C oracle: random numbers of rows of W, columns, densities, users, top_k, filter,
+integer / float / negative values, 256- and 128-column tiles.   python tools/fuzz_score.py --iters 60 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def run(iters: int, seed: int, log=print) -> int:
+    """Number of (configuration, call) pairs whose ids, score bits or counts differ from the oracle's."""
+    from oracle import slim_oracle as so
+    from rtrec_amd.engine import SlimEngine
+    rng = np.random.default_rng(seed)
+    bad = 0
+    t0 = time.time()
+    for it in range(iters):
+        R = int(rng.choice([1, 3, 17, 40, 64, 65, 66, 90, 128]))
+        n_cols = int(rng.choice([8, 100, 700, 3000, 9000, 20000]))
+        I = max(n_cols + int(rng.integers(50, 3000)), R + 10)
+        U = int(rng.choice([97, 700, 3000, 9000]))
+        per_col = int(rng.integers(1, max(2, min(R, 40)) + 1))
+        integer = bool(rng.integers(0, 2))
+        feat = np.sort(rng.choice(I, R, replace=False))
+        cols = np.sort(rng.choice(I, n_cols, replace=False))
+        pop = 1.0 / np.arange(1, R + 1) ** float(rng.uniform(0.3, 1.5))
+        rr, cc = [], []
+        for c in cols:
+            k = min(R, max(1, int(rng.integers(1, per_col + 1))))
+            rr.append(rng.choice(feat, k, replace=False, p=pop / pop.sum()))
+            cc.append(np.full(k, c))
+        rr, cc = np.concatenate(rr), np.concatenate(cc)
+        vals = (rng.random(len(rr)).astype(np.float32) + 0.05) * np.where(rng.random(len(rr)) < rng.choice([0.0, 0.1, 0.5]), -1, 1).astype(np.float32)
+        if integer:
+            vals = np.round(vals * 4).astype(np.float32)
+            vals[vals == 0] = 1.0
+        W = sp.csc_matrix((vals, (rr, cc)), shape=(I, I), dtype=np.float32)
+        W.sum_duplicates(); W.eliminate_zeros(); W.sort_indices()
+        n_it = rng.integers(0, int(rng.choice([5, 60, 400])), U)
+        ur = np.repeat(np.arange(U), n_it)
+        ui = np.where(rng.random(len(ur)) < rng.uniform(0.1, 0.9), rng.choice(feat, len(ur)), rng.integers(0, I, len(ur)))
+        xv = rng.integers(1, 6, len(ur)).astype(np.float32) if integer else (rng.random(len(ur)).astype(np.float32) * 5 - rng.choice([0.0, 0.5]))
+        X = sp.csr_matrix((xv, (ur, ui)), shape=(U, I), dtype=np.float32)
+        X.sum_duplicates(); X.eliminate_zeros(); X.sort_indices()
+        eng = SlimEngine(device="cuda:0")
+        eng.FR_TILE_COLS = int(rng.choice([256, 256, 128]))
+        eng.FR_MIN_ROWS = int(rng.choice([0, 32]))
+        eng.set_interactions(None, X, need_csc=False)
+        eng.set_weights(W)
+        lay = eng._layout(True)
+        Wr = W.tocsr()
+        for _ in range(2):
+            top_k = int(rng.integers(1, 16))
+            filt = bool(rng.integers(0, 2))
+            rows = np.arange(U) if rng.integers(0, 2) else rng.permutation(U)[:int(rng.integers(1, U + 1))]
+            ids, sc, cnt = eng.recommend_rows(rows, top_k=top_k, filter_interacted=filt)
+            o_ids, o_sc, o_cnt = so.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt)
+            ok = np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(sc.view(np.uint32), o_sc.view(np.uint32))
+            if not ok:
+                bad += 1
+                wrong = np.flatnonzero((ids != o_ids).any(axis=1) | (cnt != o_cnt))
+                log(f"MISMATCH it={it} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} integer={integer} tc={eng.FR_TILE_COLS} "
+                    f"fr={lay.get('fr_w') is not None} rows_wrong={len(wrong)} first={wrong[:5].tolist()}")
+        if it % 50 == 49:
+            log(f"[fuzz] {it + 1} configurations, {bad} mismatches, {time.time() - t0:.0f}s")
+    return bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    bad = run(args.iters, args.seed, log=lambda m: print(m, flush=True))
+    print(f"fuzz done: {args.iters} configurations x 2 calls, mismatches: {bad}")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
