@@ -524,3 +524,12 @@ def test_score_path_randomised_parity():
     from tools.fuzz_score import run
     messages = []
     assert run(25, seed=4, log=messages.append) == 0, messages
+
+
+def test_fit_path_randomised_parity():
+    """tools/fuzz_fit.py: random matrix shapes, densities, K (incl. every item), sign constraint, negative ratings, screening
+    thresholds, through the throughput kernel, the latency kernel and the latency kernel with the one-pass X^T y --
+    coefficient bits, feature sets and sweep counts against the oracle (3,000 configurations were run clean; 40 run here)."""
+    from tools.fuzz_fit import run
+    messages = []
+    assert run(40, seed=5, log=messages.append) == 0, messages
