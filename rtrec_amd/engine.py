@@ -1122,8 +1122,9 @@ class SlimEngine:
         fr_host = (lay or {}).get("fr_host")
         key = (n_rows, None if d_row_ids is None else (d_row_ids.data_ptr(), d_row_ids._version),
                None if fr_host is None else id(fr_host))
-        if resident and self._X.get("_order_key") == key:
-            return self._X["_order"]
+        cache = self._X.setdefault("_orders", {}) if resident else None      # one entry per (row set, layout): the sharded
+        if cache is not None and key in cache:                                # path scores the same chunks step after step
+            return cache[key]
         ptr, col = xb[0], xb[1]
         if d_row_ids is None:
             rows = None
@@ -1161,8 +1162,11 @@ class SlimEngine:
             for w in range(n_words):                                  # least significant word first, stable sorts
                 order = order[torch.argsort(words[order, w], descending=True, stable=True)]
             order = order.to(torch.int32)
-        if resident:
-            self._X["_order_key"], self._X["_order"] = key, order
+        if cache is not None:
+            if len(cache) >= 32:
+                cache.clear()
+            cache[key] = order
+            self._X["_order"] = order          # the most recent one (bench.py's bounds model reads it)
         return order
 
     def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
@@ -1270,7 +1274,14 @@ class SlimEngine:
         torch = be.torch
         G = self.world_size
         q = -(-n_rows // G)
-        mine = d_rows[self.rank::G].contiguous()
+        # this rank's slice of the batch, kept while the same row tensor is scored again (its work order is cached by it)
+        skey = (d_rows.data_ptr(), d_rows._version, n_rows, self.rank, G)
+        slices = self._X.setdefault("_row_slices", {})
+        if skey not in slices:
+            if len(slices) >= 8:
+                slices.clear()
+            slices[skey] = d_rows[self.rank::G].contiguous()
+        mine = slices[skey]
         m = int(mine.shape[0])
         fwidth = 2 * k + 1
         fwidth += fwidth & 1
