@@ -454,6 +454,16 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
     // Once a user is known to touch most of the tile (a long W row, or the list is full) the
     // touched list is pointless: stop maintaining it and let the caller scan / reset the whole tile.
     bool track = TOUCH;
+    // One rounded product.  Where the accumulators start from the -0.0 "untouched" marker (TOUCH / FT) a product
+    // of -0.0 -- a stored -0.0 rating (a decayed negative rating that underflowed), or a negative denormal rating
+    // times a small coefficient -- would leave the marker in place: (-0) + (-0) = -0, the column would look
+    // untouched to its next contribution and enter the touched list twice.  p + (+0) turns -0 into +0 and changes
+    // nothing else, which is also what scipy computes (its sums start at +0, and (+0) + (-0) = +0).
+    auto prod = [](ACC x, float v) {
+        ACC p = x * static_cast<ACC>(v);
+        if constexpr (TOUCH || FT) p = p + ACC(0);
+        return p;
+    };
     auto push = [&](bool first, int c) {
         if (!track) return;
         const unsigned long long m = __ballot(first);
@@ -575,10 +585,10 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                             if (w4.z != 0.0f && is_untouched(o2)) L.ft[c + 2] = ps[j];
                             if (w4.w != 0.0f && is_untouched(o3)) L.ft[c + 3] = ps[j];
                             // a padded zero must not make the column look touched
-                            if (w4.x != 0.0f) acc[c] = o0 + xj * static_cast<ACC>(w4.x);
-                            if (w4.y != 0.0f) acc[c + 1] = o1 + xj * static_cast<ACC>(w4.y);
-                            if (w4.z != 0.0f) acc[c + 2] = o2 + xj * static_cast<ACC>(w4.z);
-                            if (w4.w != 0.0f) acc[c + 3] = o3 + xj * static_cast<ACC>(w4.w);
+                            if (w4.x != 0.0f) acc[c] = o0 + prod(xj, w4.x);
+                            if (w4.y != 0.0f) acc[c + 1] = o1 + prod(xj, w4.y);
+                            if (w4.z != 0.0f) acc[c + 2] = o2 + prod(xj, w4.z);
+                            if (w4.w != 0.0f) acc[c + 3] = o3 + prod(xj, w4.w);
                         } else {
                             acc[c] = o0 + xj * static_cast<ACC>(w4.x);
                             acc[c + 1] = o1 + xj * static_cast<ACC>(w4.y);
@@ -593,7 +603,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                 if (cc[j] >= 0) {
                     const ACC old = acc[cc[j]];
                     first = is_untouched(old);
-                    acc[cc[j]] = old + xx[j] * static_cast<ACC>(vv[j]);
+                    acc[cc[j]] = old + prod(xx[j], vv[j]);
                     if (FT && first) L.ft[cc[j]] = ps[j];
                 }
                 if (TOUCH) push(first, cc[j]);
@@ -616,7 +626,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                     for (int u = 0; u < kStreamDepth; ++u) old[u] = acc[c[u]];
 #pragma unroll
                     for (int u = 0; u < kStreamDepth; ++u) {
-                        acc[c[u]] = old[u] + xj * static_cast<ACC>(v[u]);
+                        acc[c[u]] = old[u] + prod(xj, v[u]);
                         if (FT && is_untouched(old[u])) L.ft[c[u]] = pos;
                     }
                     if (TOUCH && track) {
@@ -632,7 +642,7 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                         c = a.w_col[o];
                         const ACC old = acc[c];
                         f2 = is_untouched(old);
-                        acc[c] = old + xj * static_cast<ACC>(a.w_val[o]);
+                        acc[c] = old + prod(xj, a.w_val[o]);
                         if (FT && f2) L.ft[c] = pos;
                     }
                     if (TOUCH) push(f2, c);

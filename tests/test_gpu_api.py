@@ -382,3 +382,13 @@ def test_evaluate_matches_the_reference_end_to_end_on_gpu():
     from rtrec_amd import SLIM
     from tests.test_pipeline_cpu import _evaluate_against_golden
     _evaluate_against_golden(SLIM)
+
+
+def test_api_randomised_parity():
+    """tools/fuzz_api.py: random interaction streams (bulk fit, mini-batches with repeats and upserts, time decay, negative
+    ratings, int or str ids, K or every item) through rtrec_amd.SLIM on the GPU and on the oracle backend -- W bits,
+    recommend_batch and similar_items after every step (1,500 scenarios run clean after the -0.0 product fix it led to;
+    40 run here)."""
+    from tools.fuzz_api import run
+    messages = []
+    assert run(40, seed=3, log=messages.append) == 0, messages

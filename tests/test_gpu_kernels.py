@@ -140,6 +140,50 @@ def test_score_exact_ties_follow_reference_order(oracle):
             assert np.array_equal(bits(sc), bits(o_sc))
 
 
+@pytest.mark.parametrize("f64", [False, True])
+def test_score_signed_zero_and_denormal_ratings(oracle, f64):
+    """Time decay turns old ratings into float32 denormals and negative ones into -0.0 (rtrec stores both).  A product
+    of -0.0 -- a stored -0.0, or a negative denormal times a small coefficient -- must still count as the column's first
+    contribution: the tiled kernel's accumulators start from a -0.0 marker, and (-0) + (-0) = -0 used to leave the column
+    "untouched", so that its next contribution listed it a second time (duplicate / uninitialised ids in the answer;
+    found by tools/fuzz_api.py)."""
+    rng = np.random.default_rng(12)
+    U, I = 120, 90
+    rows_, cols_, vals_ = [], [], []
+    specials = np.array([-0.0, 0.0, -1.4e-40, 1.4e-40, -3e-39, 2.5, -1.5, 1e-38, -1e-38], np.float32)
+    for u in range(U):
+        its = np.sort(rng.choice(I, size=int(rng.integers(1, 9)), replace=False))
+        rows_ += [u] * len(its)
+        cols_ += its.tolist()
+        vals_ += rng.choice(specials, size=len(its)).tolist()
+    X = sp.csr_matrix((np.array(vals_, np.float32), (rows_, cols_)), shape=(U, I))
+    X.sort_indices()
+    assert (X.data == 0).any() and np.signbit(X.data[X.data == 0]).any()      # the explicit zeros are still stored
+    Wd = sp.random(I, I, density=0.12, random_state=3, format="csc", dtype=np.float32)
+    Wd.data = (Wd.data * rng.choice(np.array([1.0, -1.0, 1e-6, -1e-6, 1e-3], np.float32), size=Wd.nnz)).astype(np.float32)
+    Wd.setdiag(0)
+    Wd.eliminate_zeros()
+    Wd.sort_indices()
+    Wn = Wd.copy()                                   # a second W with few non-empty rows: the feature-row kernel's shape
+    keep = np.isin(Wn.indices, np.arange(0, I, 9))
+    Wn.data[~keep] = 0
+    Wn.eliminate_zeros()
+    for W in (Wd, Wn):
+        for feature_rows, rows in ((False, np.arange(U)), (False, np.arange(0, U, 7)), (True, np.arange(U))):
+            if f64 and feature_rows:
+                continue
+            eng = SlimEngine(device="cuda:0", tile_cols=256)
+            eng.use_feature_rows = feature_rows
+            eng.set_interactions(None, X, need_csc=False)
+            eng.set_weights(W.astype(np.float64) if f64 else W, acc_f64=f64)
+            for filt in (False, True):
+                ids, sc, cnt = eng.recommend_rows(rows, top_k=6, filter_interacted=filt, mode=_native.TOPK_SPARSE)
+                o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], W.tocsr(), top_k=6, filter_interacted=filt, use_f64=f64)
+                assert np.array_equal(cnt, o_cnt)
+                assert np.array_equal(ids, o_ids)
+                assert np.array_equal(bits(sc), bits(o_sc))
+
+
 def test_candidate_mode(oracle):
     X, W = make_model(oracle, U=400, I=300, draws=8000, K=10)
     eng = SlimEngine(device="cuda:0", tile_cols=256)
