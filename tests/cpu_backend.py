@@ -99,6 +99,27 @@ class OracleBackend:
         ptr, col, val = (t.numpy() for t in xb)
         Xall = sp.csr_matrix((val, col, ptr), shape=(len(ptr) - 1, n_items))
         rsel = row_ids.numpy() if row_ids is not None else np.arange(n_rows)
+        if mode == 2:
+            # candidate mode (slim_elastic.py:723-735): dense scores of the candidate columns, argsort()[-k:][::-1] with the
+            # stable-argsort tie rule (DESIGN D1: later candidate first), zeros included, filter_interacted ignored
+            cr = col_rank.numpy()
+            cols = lay["col_ids"].numpy()[:lay["n_cols"]] if lay["col_ids"] is not None else np.arange(col_lo, col_lo + lay["n_cols"])
+            cand = cols[cr[cols] >= 0]
+            cand = cand[np.argsort(cr[cand], kind="stable")]
+            dt = np.float64 if acc_f64 else np.float32
+            S = (Xall[rsel].astype(dt) @ Wr.astype(dt).tocsc()[:, cand]).toarray()
+            o_ids = np.full((n_rows, top_k), -1, np.int32)
+            o_sc = np.full((n_rows, top_k), -np.inf, dt)
+            o_aux = np.zeros((n_rows, top_k), np.int32)
+            for r in range(n_rows):
+                idx = np.argsort(S[r], kind="stable")[-top_k:][::-1] if len(cand) else np.empty(0, np.int64)
+                o_ids[r, :len(idx)] = cand[idx]; o_sc[r, :len(idx)] = S[r, idx]; o_aux[r, :len(idx)] = cr[cand[idx]]
+            ids.copy_(torch.from_numpy(o_ids)); sc.copy_(torch.from_numpy(o_sc.astype(np.float32)))
+            cnt.fill_(min(top_k, len(cand)))
+            aux.copy_(torch.from_numpy(o_aux))
+            if sc64 is not None:
+                sc64.copy_(torch.from_numpy(o_sc.astype(np.float64)))
+            return
         o_ids, o_sc, o_cnt = so.recommend_batch(Xall[rsel], Wr, top_k=top_k, filter_interacted=filter_interacted,
                                                 dense=(mode == 1), use_f64=bool(acc_f64))
         ids.copy_(torch.from_numpy(o_ids)); sc.copy_(torch.from_numpy(o_sc)); cnt.copy_(torch.from_numpy(o_cnt))

@@ -439,3 +439,23 @@ def _evaluate_against_golden(make_model):
 
 def test_evaluate_matches_the_reference_end_to_end():
     _evaluate_against_golden(cpu_slim)
+
+
+def test_candidate_lists_follow_the_reference_ranking_on_the_oracle_backend():
+    """Candidate mode of the CPU backend that tools/fuzz_api.py compares the GPU with (slim_elastic.py:723-735: dense scores
+    of the candidate columns, argsort()[-k:][::-1]; ties by the stable-argsort rule of DESIGN D1, zeros included,
+    filter_interacted ignored) -- against a direct numpy statement of those lines."""
+    rng = np.random.default_rng(0)
+    m = SLIM(min_value=0, max_value=15, nn_feature_selection=5)
+    m.model._engine = SlimEngine(backend=OracleBackend())
+    n, U, I = 300, 60, 25
+    m.fit([(int(a), int(b), 1.7e9 + t, float(r)) for t, (a, b, r) in
+           enumerate(zip(rng.zipf(1.6, n) % U, rng.zipf(1.4, n) % I, rng.integers(1, 6, n)))], progress_bar=False)
+    cands = [13, 11, 0, 19, 3, 22, 1, 14, 5]
+    X, W = m.interactions.to_csr(), m.model.item_similarity.tocsc()
+    users = [u for u in range(U) if m.user_ids.get_id(u) is not None]
+    for filt in (True, False):
+        got = m.recommend_batch(users, candidate_items=cands, top_k=5, filter_interacted=filt)
+        for u, g in zip(users, got):
+            s = (X[m.user_ids.get_id(u)] @ W[:, cands]).toarray().ravel()
+            assert g == [cands[i] for i in np.argsort(s, kind="stable")[-5:][::-1]]

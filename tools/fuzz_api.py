@@ -31,7 +31,7 @@ def run(iters: int, seed: int, log=print) -> int:
     bad = 0
     t0 = time.time()
     for it in range(iters):
-        U, I = int(rng.choice([40, 150, 400])), int(rng.choice([25, 80, 250]))
+        U, I = int(rng.choice([40, 150, 400])), int(rng.choice([25, 80, 250, 1200]))
         kw = dict(min_value=0, max_value=15)
         K = [None, 5, 20][int(rng.integers(0, 3))]
         if K is not None:
@@ -63,14 +63,24 @@ def run(iters: int, seed: int, log=print) -> int:
                 for m in (g, c):
                     m.fit(batch, update_interaction=upsert, progress_bar=False)
             users = [uid(x) for x in rng.integers(0, U + 5, 25)]
-            k = int(rng.integers(1, 13))
+            k = int(rng.integers(1, 13)) if rng.random() < 0.85 else int(rng.choice([40, 64, 90]))
             filt = bool(rng.integers(0, 2))
-            rg, rc = g.recommend_batch(users, top_k=k, filter_interacted=filt), c.recommend_batch(users, top_k=k, filter_interacted=filt)
+            cands = None
+            if rng.random() < 0.25:          # a candidate list (known and unknown items, random order)
+                cands = [iid(x) for x in rng.permutation(I + 3)[:int(rng.integers(1, min(I, 40) + 1))]]
+            if rng.random() < 0.3:           # a large batch: the feature-row kernel where W has few non-empty rows
+                users = [uid(x) for x in rng.integers(0, U + 5, 300)]
+            rg = g.recommend_batch(users, candidate_items=cands, top_k=k, filter_interacted=filt)
+            rc = c.recommend_batch(users, candidate_items=cands, top_k=k, filter_interacted=filt)
+            one = users[0]
+            og = g.recommend(one, candidate_items=cands, top_k=k, filter_interacted=filt)
+            oc = c.recommend(one, candidate_items=cands, top_k=k, filter_interacted=filt)
             q = iid(int(rng.integers(0, I)))
             sg, sc_ = g.similar_items(q, top_k=5), c.similar_items(q, top_k=5)
-            if rg != rc or sg != sc_ or not same_w(g.model.item_similarity, c.model.item_similarity):
+            if rg != rc or og != oc or sg != sc_ or not same_w(g.model.item_similarity, c.model.item_similarity):
                 ok = False
-                log(f"MISMATCH it={it} step={step} kw={kw} strings={strings} upsert={upsert} rec_equal={rg == rc} sim_equal={sg == sc_}")
+                log(f"MISMATCH it={it} step={step} kw={kw} strings={strings} upsert={upsert} cands={cands is not None} k={k} "
+                    f"rec_equal={rg == rc} one_equal={og == oc} sim_equal={sg == sc_}")
                 break
         bad += 0 if ok else 1
         if it % 10 == 9:
