@@ -109,6 +109,7 @@ constexpr int kQueueChunk = 8;   // jobs claimed per work-queue atomic
 constexpr int kRowGroup = 8;     // W rows whose first loads are issued together
 constexpr int kStreamDepth = 8;  // 64-entry chunks of a long W row requested per round trip
 constexpr int kDenseUnroll = 4;  // 256-column steps of a dense W block per pipeline stage
+constexpr int kDenseBatch = 8;   // ... per round trip in the generic (exact-tie / float64) form of that loop
 typedef float vf4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int res_cap(int kk) { return kk <= kResCap ? kResCap : (kk + 63) / 64 * 64; }
@@ -576,24 +577,37 @@ __device__ __forceinline__ int accumulate_tile(const ScoreArgs &a, const TileLds
                         PF_MARK(PF_DENSE) PF_ADD(PF_N_DENSE, 1)
                         continue;
                     }
-                    for (int c = lane * 4; c < a.tile_cols; c += 256) {
-                        const float4 w4 = *reinterpret_cast<const float4 *>(dv + c);
-                        ACC o0 = acc[c], o1 = acc[c + 1], o2 = acc[c + 2], o3 = acc[c + 3];
-                        if (FT) {
-                            if (w4.x != 0.0f && is_untouched(o0)) L.ft[c] = ps[j];
-                            if (w4.y != 0.0f && is_untouched(o1)) L.ft[c + 1] = ps[j];
-                            if (w4.z != 0.0f && is_untouched(o2)) L.ft[c + 2] = ps[j];
-                            if (w4.w != 0.0f && is_untouched(o3)) L.ft[c + 3] = ps[j];
-                            // a padded zero must not make the column look touched
-                            if (w4.x != 0.0f) acc[c] = o0 + prod(xj, w4.x);
-                            if (w4.y != 0.0f) acc[c + 1] = o1 + prod(xj, w4.y);
-                            if (w4.z != 0.0f) acc[c + 2] = o2 + prod(xj, w4.z);
-                            if (w4.w != 0.0f) acc[c + 3] = o3 + prod(xj, w4.w);
-                        } else {
-                            acc[c] = o0 + xj * static_cast<ACC>(w4.x);
-                            acc[c + 1] = o1 + xj * static_cast<ACC>(w4.y);
-                            acc[c + 2] = o2 + xj * static_cast<ACC>(w4.z);
-                            acc[c + 3] = o3 + xj * static_cast<ACC>(w4.w);
+                    // the W block is fetched kDenseBatch steps at a time: one memory round trip per batch instead of one
+                    // per step (the exact-tie pass of a single row is a chain of these: 16 steps per row of a 4096-column tile)
+                    for (int c0 = lane * 4; c0 < a.tile_cols; c0 += 256 * kDenseBatch) {
+                        float4 wb[kDenseBatch];
+#pragma unroll
+                        for (int u = 0; u < kDenseBatch; ++u) {
+                            const int c = c0 + 256 * u;
+                            wb[u] = c < a.tile_cols ? *reinterpret_cast<const float4 *>(dv + c) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        }
+#pragma unroll
+                        for (int u = 0; u < kDenseBatch; ++u) {
+                            const int c = c0 + 256 * u;
+                            if (c >= a.tile_cols) break;
+                            const float4 w4 = wb[u];
+                            ACC o0 = acc[c], o1 = acc[c + 1], o2 = acc[c + 2], o3 = acc[c + 3];
+                            if (FT) {
+                                if (w4.x != 0.0f && is_untouched(o0)) L.ft[c] = ps[j];
+                                if (w4.y != 0.0f && is_untouched(o1)) L.ft[c + 1] = ps[j];
+                                if (w4.z != 0.0f && is_untouched(o2)) L.ft[c + 2] = ps[j];
+                                if (w4.w != 0.0f && is_untouched(o3)) L.ft[c + 3] = ps[j];
+                                // a padded zero must not make the column look touched
+                                if (w4.x != 0.0f) acc[c] = o0 + prod(xj, w4.x);
+                                if (w4.y != 0.0f) acc[c + 1] = o1 + prod(xj, w4.y);
+                                if (w4.z != 0.0f) acc[c + 2] = o2 + prod(xj, w4.z);
+                                if (w4.w != 0.0f) acc[c + 3] = o3 + prod(xj, w4.w);
+                            } else {
+                                acc[c] = o0 + xj * static_cast<ACC>(w4.x);
+                                acc[c + 1] = o1 + xj * static_cast<ACC>(w4.y);
+                                acc[c + 2] = o2 + xj * static_cast<ACC>(w4.z);
+                                acc[c + 3] = o3 + xj * static_cast<ACC>(w4.w);
+                            }
                         }
                     }
                     continue;
@@ -989,7 +1003,8 @@ struct FrArgs {
     unsigned long long *mscratch;   // [gridDim.x][waves][users][n_tiles * REGS] interacted-column lane masks
     int kk, top_k, filter;
     int *out_id; float *out_score; uint32_t *out_aux; int *out_cnt;
-    int *flag_list; int *flag_len;
+    int *flag_list; int *flag_len;   // rows for the exact-tie pass
+    int *tie_list; int *tie_len;     // rows whose ties fr_ties_kernel orders
     int *queue;
 };
 
@@ -1117,6 +1132,37 @@ __device__ __forceinline__ void fr_static_for(F &&f) {
 }
 
 typedef const __attribute__((address_space(4))) unsigned long long fr_const_u64;
+
+// First-touch row of layout column c for a user who rates the rows own0 / own1 (bit f: row f / 64 + f of W): the lowest
+// such row with a weight in that column -- scipy's csr_matmat meets the user's items in ascending order, and rows of W
+// ascend with the item id.  Walks the fragments of the column's tile in global memory (rows ascending across and inside
+// fragments; a row's index inside a fragment = the number of lower rows the fragment holds).  Rare path (exact ties).
+template <int TC>
+__device__ int fr_first_touch(const FrArgs &a, int c, unsigned long long own0, unsigned long long own1) {
+    const int t = c / TC, cl = c % TC;
+    const int n_frags = a.st_tile[a.n_super];
+    int sup = 0;
+    for (int g = 0; g < n_frags; ++g) {
+        while (g >= a.st_tile[sup + 1]) ++sup;
+        const int ft = a.frag_tile[g];
+        if ((ft & 0xffffff) != t) continue;
+        const unsigned long long m0 = a.tile_rows[2 * g], m1 = a.tile_rows[2 * g + 1];
+        const float *base = a.wd + (static_cast<size_t>(a.st_kb[sup]) << 8) + (a.tile_off[g] >> 2) + cl;
+        for (unsigned long long w = m0 & own0; w; w &= w - 1) {
+            const int f = __builtin_ctzll(w);
+            const int k = __builtin_popcountll(m0 & ((1ull << f) - 1ull));
+            if (base[static_cast<size_t>(k) * TC] != 0.0f) return f;
+        }
+        const int k1 = __builtin_popcountll(m0);
+        for (unsigned long long w = m1 & own1; w; w &= w - 1) {
+            const int f = __builtin_ctzll(w);
+            const int k = k1 + __builtin_popcountll(m1 & ((1ull << f) - 1ull));
+            if (base[static_cast<size_t>(k) * TC] != 0.0f) return 64 + f;
+        }
+        if (ft & (1 << 25)) break;          // the tile's last fragment
+    }
+    return -1;
+}
 
 template <int REGS, int XR>
 __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a) {
@@ -1520,6 +1566,8 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             const int c = lc4[u >> 2];
             const int n_valid = static_cast<int>(__builtin_popcountll(__ballot(in && c >= 0)));
             const int n_fin = min(n_valid, a.top_k);
+            const float nxt = fr_shift_down(s, ninf);
+            const unsigned long long tie = __ballot(rel >= 0 && rel + 1 < n_valid && s == nxt);
             if (rel >= 0 && rel < a.top_k) {
                 const long long o = static_cast<long long>(r) * a.top_k + rel;
                 const bool ok = rel < n_fin;
@@ -1527,11 +1575,16 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                 a.out_score[o] = ok ? s : ninf;
                 if (a.out_aux) a.out_aux[o] = 0u;
             }
-            const float nxt = fr_shift_down(s, ninf);
-            const unsigned long long tie = __ballot(rel >= 0 && rel + 1 < n_valid && s == nxt);
             if (lane == lb) {
                 a.out_cnt[r] = n_fin;
-                if (tie) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+                if (tie) {
+                    // A tie that reaches the (k+1)-th entry may have lost equal columns at the list's threshold: the row is
+                    // re-scored by the exact-tie pass.  Otherwise the answer's SET is right and only the order of the tied
+                    // entries is open: fr_ties_kernel settles it from W.
+                    const bool boundary = n_valid == kk && ((tie >> (lb + kk - 2)) & 1ull);
+                    if (boundary) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+                    else a.tie_list[atomicAdd(a.tie_len, 1)] = r;
+                }
             }
         });
         PF_MARK(PF_EMIT)
@@ -1586,8 +1639,81 @@ void timer_collect(KernelTimer &t) {
     t.pending = false;
 }
 
+// Exact ties inside the leading k of a row scored by score_frows_kernel (a.tie_list): the answer's set is right, the order
+// of the tied entries is open.  The reference orders equal scores by reverse first touch, then by higher item id.  One wave
+// per row: read the row's list back, take each entry's first-touch row from W (fr_first_touch), turn it into the position
+// of that item in the user's row (what the exact-tie pass reports as aux), rank the list by (score, position, item id)
+// and rewrite the row.  A user with a stored zero rating on a row of W touches columns the feature-row kernel does not
+// see (the rating is indistinguishable from "not rated" there): such a row is handed to the exact-tie pass instead.
+template <int TC>
+__global__ __launch_bounds__(64) void fr_ties_kernel(FrArgs a) {
+    const int lane = lane_id();
+    const int n = *a.tie_len;
+    const float ninf = -__builtin_huge_valf();
+    for (int w = blockIdx.x; w < n; w += gridDim.x) {
+        const int r = a.tie_list[w];
+        const int n_fin = a.out_cnt[r];
+        float s = ninf;
+        int g = -1, c = -1;
+        if (lane < n_fin) {
+            const long long o = static_cast<long long>(r) * a.top_k + lane;
+            g = a.out_id[o];
+            s = a.out_score[o];
+            c = a.col_map[g];
+        }
+        const int xrow = a.row_ids ? a.row_ids[r] : r;
+        const int a0 = a.xb_ptr[xrow], n_a = a.xb_ptr[xrow + 1] - a0;
+        unsigned long long own0 = 0ull, own1 = 0ull;
+        bool zero_stored = false;
+        for (int b = 0; b < n_a; b += 64) {
+            int fm = -1;
+            float x = 0.0f;
+            if (b + lane < n_a) {
+                const int item = a.xb_col[a0 + b + lane];
+                x = a.xb_val[a0 + b + lane];
+                if (item < a.n_items) fm = a.fmap[item];
+            }
+            if (__ballot(fm >= 0 && x == 0.0f)) zero_stored = true;
+            for (unsigned long long m = __ballot(fm >= 0); m; m &= m - 1) {
+                const int f = readlane_i(fm, __builtin_ctzll(m));
+                if (f < 64) own0 |= 1ull << f; else own1 |= 1ull << (f - 64);
+            }
+        }
+        if (zero_stored) {
+            if (lane == 0) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+            continue;
+        }
+        int ftv = -1;
+        if (lane < n_fin) ftv = fr_first_touch<TC>(a, c, own0, own1);
+        int pv = 0;
+        for (int b = 0; b < n_a; b += 64) {
+            int fm = -1;
+            if (b + lane < n_a) {
+                const int item = a.xb_col[a0 + b + lane];
+                if (item < a.n_items) fm = a.fmap[item];
+            }
+            for (int j = 0; j < n_fin; ++j) {
+                const unsigned long long m = __ballot(fm >= 0 && fm == readlane_i(ftv, j));
+                if (m && lane == j) pv = b + static_cast<int>(__builtin_ctzll(m));
+            }
+        }
+        int rank = 0;
+        for (int j = 0; j < n_fin; ++j) {
+            const float sj = readlane_f(s, j);
+            const int pj = readlane_i(pv, j), gj = readlane_i(g, j);
+            rank += (sj > s || (sj == s && (pj > pv || (pj == pv && gj > g)))) ? 1 : 0;
+        }
+        if (lane < n_fin) {
+            const long long o = static_cast<long long>(r) * a.top_k + rank;
+            a.out_id[o] = g;
+            a.out_score[o] = s;
+            if (a.out_aux) a.out_aux[o] = static_cast<uint32_t>(pv);
+        }
+    }
+}
+
 struct ScoreWs {
-    size_t cand_score, cand_id, cand_aux, cand_cnt, flag_list, flag_len, queue, total;
+    size_t cand_score, cand_id, cand_aux, cand_cnt, flag_list, tie_list, flag_len, queue, total;
 };
 ScoreWs score_ws_layout(int n_rows, int n_tiles, int top_k) {
     ScoreWs w;
@@ -1599,8 +1725,10 @@ ScoreWs score_ws_layout(int n_rows, int n_tiles, int top_k) {
     w.cand_aux = o;   o = align_up(o + n * sizeof(uint32_t), 256);
     w.cand_cnt = o;   o = align_up(o + (n_tiles > 1 ? static_cast<size_t>(n_rows) * n_tiles * sizeof(int) : 0), 256);
     w.flag_list = o;  o = align_up(o + static_cast<size_t>(n_rows) * sizeof(int), 256);
-    w.flag_len = o;   o = align_up(o + 256, 256);
-    w.queue = o;      o = align_up(o + 256, 256);
+    w.tie_list = o;   o = align_up(o + static_cast<size_t>(n_rows) * sizeof(int), 256);
+    // the per-call counters share one block (one memset): [0] rows for the exact-tie pass, [1] rows for fr_ties_kernel,
+    // [2], [3] the job queues of the fast pass and the exact-tie pass
+    w.flag_len = o;   w.queue = o + 8;  o = align_up(o + 256, 256);
     w.total = o;
     return w;
 }
@@ -1667,13 +1795,13 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     a.row_list = flag_list; a.row_list_len = flag_len;
     a.queue = queue;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
-    if (hipMemsetAsync(flag_len, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
-    if (hipMemsetAsync(queue, 0, 8, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    if (hipMemsetAsync(flag_len, 0, 16, st) != hipSuccess) return RTREC_ERR_LAUNCH;      // both list lengths and both queues
 
     const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
     debug_stage(st, "score: begin");
     if (tmr) { timer_collect(*tmr); (void)hipEventRecord(tmr->start, st); }
     bool fr_done = false;
+    FrArgs f_fr{};
     if (sparse && sizeof(ACC) == 4 && fr_usable(FR, a.kk)) {
         // few, long rows in W: accumulators in registers, the dense R x n_cols matrix streamed through LDS
         FrArgs f{};
@@ -1688,6 +1816,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.kk = a.kk; f.top_k = top_k; f.filter = a.filter;
         f.out_id = d_out_ids; f.out_score = d_out_scores; f.out_aux = d_out_aux; f.out_cnt = d_out_count;
         f.flag_list = flag_list; f.flag_len = flag_len; f.queue = queue;
+        f.tie_list = reinterpret_cast<int *>(ws + L.tie_list); f.tie_len = flag_len + 1;
         // all slices in one super-tile that fits next to the setup scratch: W stays in LDS for the life of a 16-wave
         // workgroup; otherwise two 8-wave workgroups per CU stream the super-tiles (one computes while the other sets a
         // job up or waits at a super-tile barrier)
@@ -1706,6 +1835,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
             if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 2>), dim3(grid), dim3(nw * 64), lds, st, f);
             else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 1>), dim3(grid), dim3(nw * 64), lds, st, f);
         }
+        f_fr = f;
         fr_done = true;
     } else if (sparse) {
         const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true, a.kk);
@@ -1719,6 +1849,11 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     }
     if (tmr) { (void)hipEventRecord(tmr->stop, st); tmr->pending = true; }
     debug_stage(st, "score tiles");
+    if (fr_done) {      // ties inside the leading k: ordered from W, row by row (usually none)
+        if (FR.tile_cols == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(fr_ties_kernel<256>), dim3(64), dim3(64), 0, st, f_fr);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(fr_ties_kernel<128>), dim3(64), dim3(64), 0, st, f_fr);
+        debug_stage(st, "fr_ties_kernel");
+    }
 
     MergeArgs m{};
     m.n_rows = a.n_rows; m.n_lists = a.n_tiles; m.kk = a.kk; m.top_k = top_k;

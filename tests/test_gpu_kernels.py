@@ -168,7 +168,9 @@ def test_score_signed_zero_and_denormal_ratings(oracle, f64):
     keep = np.isin(Wn.indices, np.arange(0, I, 9))
     Wn.data[~keep] = 0
     Wn.eliminate_zeros()
-    for W in (Wd, Wn):
+    Wt = sp.csc_matrix(Wn[:, rng.integers(0, 12, size=I)])      # every column a copy of one of 12: exact ties everywhere, which
+    Wt.sort_indices()                                            # the feature-row kernel orders itself unless a stored zero rating
+    for W in (Wd, Wn, Wt):                                       # of the user may have touched a column first
         for feature_rows, rows in ((False, np.arange(U)), (False, np.arange(0, U, 7)), (True, np.arange(U))):
             if f64 and feature_rows:
                 continue
