@@ -69,6 +69,7 @@ struct ScoreArgs {
     const int *row_list;
     const int *row_list_len;
     int *queue;
+    int *rescored;        // exact-tie pass, optional: receives the number of rows it re-scores
     int ablate;           // diagnostics: bit0 skip accumulate, bit1 skip select, bit2 skip reset, bit3 skip filter
 };
 
@@ -751,6 +752,7 @@ __global__ __launch_bounds__(64) void score_sparse_kernel(ScoreArgs a) {
     const ACC unt = untouched_value(ACC(0));
     const int n_rows = FT ? *a.row_list_len : a.n_rows;
     const int total = n_rows * a.n_tiles;
+    if (FT && a.rescored && blockIdx.x == 0 && lane == 0) *a.rescored = n_rows;
     if (total == 0) return;              // the exact-tie pass usually has nothing to do: leave before touching LDS
     bool lds_ready = false;              // ... and a workgroup that never gets a job never initialises its tile either
 
@@ -845,7 +847,9 @@ struct MergeArgs {
 };
 
 // One wave per row: the row's n_lists * kk candidates -> top_k by (score, aux, id).
-template <typename ACC>
+// NS: candidate slots per lane (n_lists * kk <= 64 * NS) -- every round scans a lane's slots, so the common small merges
+// (a few tiles or shards of ~10 entries each: one slot) cost a sixteenth of the general case's slot work.
+template <typename ACC, int NS>
 __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs m) {
     const int lane = lane_id();
     const ACC *sc = reinterpret_cast<const ACC *>(m.in_score);
@@ -854,7 +858,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs m) {
     const int n_work = m.row_list ? *m.row_list_len : m.n_rows;
     for (int work = blockIdx.x; work < n_work; work += gridDim.x) {
     const int row = m.row_list ? m.row_list[work] : work;
-    constexpr int kMaxPerLane = 16;   // n_lists * kk <= 1024
+    constexpr int kMaxPerLane = NS;   // n_lists * kk <= 1024 = 64 * 16
     Cand<ACC> mine[kMaxPerLane];
     const int total = m.n_lists * m.kk;
 #pragma unroll
@@ -873,6 +877,43 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(MergeArgs m) {
         }
     }
     const int want = m.detect_ties ? m.top_k + 1 : m.top_k;
+    if constexpr (NS == 1) {
+        // one candidate per lane: its rank is the number of better candidates -- `total` steps of readlane + compare
+        // instead of top_k rounds of a wave-wide arg-max -- and the leading top_k lanes write their own slot
+        const Cand<ACC> me = mine[0];
+        int rank = 0;
+        bool eq = false;
+        for (int t = 0; t < total; ++t) {
+            const Cand<ACC> o = cand_readlane<ACC>(me, t);
+            rank += cand_better(o, me) ? 1 : 0;
+            eq = eq || (t != lane && o.id >= 0 && o.score == me.score);
+        }
+        const bool valid = me.id >= 0;
+        const int n_valid = static_cast<int>(__builtin_popcountll(__ballot(valid)));
+        const int n_fin = min(n_valid, m.top_k);
+        if (valid && rank < m.top_k) {
+            const long long o = static_cast<long long>(row) * m.top_k + rank;
+            m.out_id[o] = me.id;
+            m.out_score[o] = static_cast<float>(me.score);
+            if (m.out_score64) m.out_score64[o] = static_cast<double>(me.score);
+            if (m.out_aux) m.out_aux[o] = me.aux;
+        }
+        if (lane >= n_fin && lane < m.top_k) {
+            const long long o = static_cast<long long>(row) * m.top_k + lane;
+            m.out_id[o] = -1;
+            m.out_score[o] = -__builtin_huge_valf();
+            if (m.out_score64) m.out_score64[o] = -__builtin_huge_val();
+            if (m.out_aux) m.out_aux[o] = 0u;
+        }
+        // equal scores take consecutive ranks: two of them lie inside the leading `want` iff the first of a group does so
+        // with room for a second, i.e. some member of a group has a rank below want - 1
+        const unsigned long long tied = __ballot(valid && eq && rank < want - 1);
+        if (lane == 0) {
+            m.out_cnt[row] = n_fin;
+            if (m.detect_ties && tied) m.flag_list[atomicAdd(m.flag_len, 1)] = row;
+        }
+        continue;
+    }
     int n_out = 0;
     bool tie = false;
     ACC prev = ninf;
@@ -1712,6 +1753,15 @@ __global__ __launch_bounds__(64) void fr_ties_kernel(FrArgs a) {
     }
 }
 
+template <typename ACC>
+void launch_merge_topk(unsigned grid, hipStream_t st, const MergeArgs &m) {
+    const int total = m.n_lists * m.kk;
+    if (total <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC, 1>), dim3(grid), dim3(64), 0, st, m);
+    else if (total <= 128) hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC, 2>), dim3(grid), dim3(64), 0, st, m);
+    else if (total <= 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC, 4>), dim3(grid), dim3(64), 0, st, m);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC, 16>), dim3(grid), dim3(64), 0, st, m);
+}
+
 struct ScoreWs {
     size_t cand_score, cand_id, cand_aux, cand_cnt, flag_list, tie_list, flag_len, queue, total;
 };
@@ -1867,7 +1917,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     m.flag_list = flag_list; m.flag_len = flag_len;
     m.row_list = nullptr; m.row_list_len = nullptr;
     if (!single && !fr_done) {      // the feature-row kernel writes final lists itself
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows), dim3(64), 0, st, m);
+        launch_merge_topk<ACC>(static_cast<unsigned>(a.n_rows), st, m);
         debug_stage(st, "merge_topk_kernel");
     }
 
@@ -1877,6 +1927,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.kk = top_k;
         f.detect_ties = 0;
         f.queue = queue + 1;
+        f.rescored = d_rescored;
         const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, true, true, f.kk);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, true>), dim3(persistent_grid(lds, total)), dim3(64),
                            lds, st, f);
@@ -1888,10 +1939,9 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
             mf.s_list_stride = mf.list_stride; mf.s_row_stride = mf.row_stride;
             mf.detect_ties = 0;
             mf.row_list = flag_list; mf.row_list_len = flag_len;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<ACC>), dim3(a.n_rows < 2048 ? a.n_rows : 2048), dim3(64), 0, st, mf);
+            launch_merge_topk<ACC>(static_cast<unsigned>(a.n_rows < 256 ? a.n_rows : 256), st, mf);
             debug_stage(st, "merge_topk_kernel (exact ties)");
         }
-        if (d_rescored && hipMemcpyAsync(d_rescored, flag_len, 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     } else if (d_rescored && hipMemsetAsync(d_rescored, 0, 4, st) != hipSuccess) {
         return RTREC_ERR_LAUNCH;
     }
@@ -2087,11 +2137,11 @@ extern "C" int rtrec_slim_merge_topk_strided(int32_t n_rows, int32_t n_lists, in
     if (d_in_scores64) {
         m.in_score = d_in_scores64;
         m.s_list_stride = score64_list_stride; m.s_row_stride = score64_row_stride;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<double>), dim3(n_rows), dim3(64), 0, st, m);
+        launch_merge_topk<double>(static_cast<unsigned>(n_rows), st, m);
     } else {
         m.in_score = d_in_scores;
         m.s_list_stride = list_stride; m.s_row_stride = row_stride;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(merge_topk_kernel<float>), dim3(n_rows), dim3(64), 0, st, m);
+        launch_merge_topk<float>(static_cast<unsigned>(n_rows), st, m);
     }
     return rtrec::launch_status();
 }

@@ -27,7 +27,8 @@ from . import _native
 DEFAULT_TILE_COLS = 4096   # 16 KB of float accumulators: 8 persistent waves per CU (2 per SIMD) hide each other's latency
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
 MAX_SLOTS = 4096   # 4 single-wave workgroups per SIMD; with Gram tracking the sweet spot moved down from 5120 (C3: 2.16 s vs 2.3 s)
-GATHER_CHUNK_ROWS = 32768   # rows per all-gather chunk of a sharded scoring call
+GATHER_CHUNK_ROWS = 131072  # rows per exchange chunk of a column-sharded scoring call: a launch of the score kernel needs this
+                            # many users to fill the chip a few times over (32k-row chunks: 6.4 ms per ML-20M pass against 2.6)
 MAX_GATHER_CHUNKS = 8
 ALLF_OUTPUT_CAP = 2048      # coefficients per target the K=None output block holds before a refit with cap = I
 GRAM_ITEMS = 512            # most popular items whose pairwise dot products the fit kernel may look up
@@ -1202,10 +1203,10 @@ class SlimEngine:
             d_rows = torch.arange(n_rows, dtype=torch.int32, device=xb[0].device)
         if self.score_shard == "rows":
             return self._score_row_sharded(d_rows, n_rows, xb, k, filter_interacted, mode, d_rank)
-        # a chunk's local kernel shrinks with the shard (1/G of W), its launch + exchange overhead does not:
-        # chunks grow with G so that one still amortises the other
-        per = max(1, int(self.gather_chunk_rows) * max(1, G // 2))
-        n_chunks = max(1, min(MAX_GATHER_CHUNKS, -(-n_rows // per)))
+        # chunks exist so that one chunk's exchange overlaps the next chunk's kernel; a chunk must still be large enough to
+        # fill the chip (GATHER_CHUNK_ROWS), so passes of up to ~200k rows are one chunk
+        per = max(1, int(self.gather_chunk_rows))
+        n_chunks = max(1, min(MAX_GATHER_CHUNKS, (n_rows + per // 2) // per))
         per = -(-n_rows // n_chunks)
         # exchanged record (int32 words): [2k float64 scores]? | k scores | k ids | k aux | count | pad to even
         o_sc = 2 * k if f64 else 0
