@@ -6,9 +6,13 @@ Contract (one JSON line on rank 0):
           (interactions/sec) is reported in the `fit` object of the same line.
   step    one pass of the fused SpMV + interacted filter + top-k path over ALL users of the
           workload, inputs (X in CSR, W tiles) already resident in HBM.
-  N > 1   W is sharded by item column over the ranks (each rank also fits only its own columns);
-          every rank scores all users against its shard, the per-shard top-k lists are
-          all-gathered over RCCL and merged -> total work is fixed: "scaling": "strong".
+  N > 1   the fit is sharded by item column (each rank fits its own columns, the coefficients are all-gathered
+          on the device, every rank holds W).  Scoring is divided over the ranks either by USER ROWS (default:
+          W is ~1 MB and replicated, a rank scores every N-th user, only the final lists are all-gathered)
+          or by ITEM COLUMNS as BASELINE.json words it (--score-shard columns: every rank scores all users
+          against its shard, the per-shard lists go through an all-to-all, a merge and an all-gather);
+          the division not chosen is timed right after the pass of record and reported as `alt_sharding`.
+          Total work is fixed either way: "scaling": "strong".
   roofline  the dominant score kernel against the limits that can bind it -- vector-ALU issue (the sums
           are unfused float32 multiply + add), LDS reads, L2 -> LDS staging -- and its compulsory HBM
           bytes; mean launch time from HIP events on the launch stream (a caller-owned rtrec_timer).
@@ -25,6 +29,7 @@ import json
 import os
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -65,11 +70,15 @@ def main() -> None:
     ap.add_argument("--stream-batches", type=int, default=8,
                     help="streaming leg (N = 1 only): this many 1,000-interaction SLIM.fit mini-batches per fit mode, each "
                          "followed by a 100-user recommend_batch, on a model bulk-fitted at the same workload shape (0 = skip)")
-    ap.add_argument("--score-shard", default="columns", choices=["columns", "rows"],
+    ap.add_argument("--score-shard", default="auto", choices=["auto", "columns", "rows"],
                     help="multi-GPU scoring: item-column shards of W + list exchange (BASELINE.json's configuration), or "
-                         "user-row shards with W replicated (for catalogues whose W is tiny, e.g. c4)")
+                         "user-row shards with W replicated.  auto = rows: W is ~1 MB on every BASELINE shape and a pass costs "
+                         "per user, not per column, so dividing the users is what divides the work (DESIGN.md section 6); the "
+                         "other division is timed right after and reported as `alt_sharding`")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget per cpu_baseline leg (4 legs)")
     args = ap.parse_args()
+    if args.score_shard == "auto":
+        args.score_shard = "rows"
 
     # `python3 bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
     # driver's own torch.distributed.run command line) as a CHILD, before this process has touched the GPU,
@@ -272,6 +281,36 @@ def main() -> None:
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = U * args.steps / dt
+    crc_main = zlib.crc32(out[0].cpu().numpy().tobytes())
+
+    # the other way of dividing the scoring pass over the ranks, timed the same way (K steps, barrier + synchronize on both
+    # sides, max over ranks) right after the pass of record; the answers must agree
+    alt_sharding = None
+    if world > 1:
+        other = "columns" if args.score_shard == "rows" else "rows"
+        dw = eng.weights
+        eng.score_shard = other
+        eng.set_weights(dw)                    # this rank's layouts for the other division (built on the device)
+        for _ in range(max(args.warmup, 1)):
+            out_alt = step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out_alt = step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t = torch.tensor([time.perf_counter() - t1], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_alt = float(t.item())
+        alt_sharding = {"score_shard": other, "ms_per_step": dt_alt / args.steps * 1e3, "users_per_sec": U * args.steps / dt_alt,
+                        "same_topk_ids": bool(zlib.crc32(out_alt[0].cpu().numpy().tobytes()) == crc_main)}
+        eng.score_shard = args.score_shard
+        eng.set_weights(dw)
+        step()                                 # the layouts of the division of record again (the models below read them)
+        torch.cuda.synchronize()
 
     # host-buffer boundary (SLIMElastic.recommend_batch hands over a scipy CSR): upload the user
     # rows over PCIe, score, download ids + scores.  Reported beside `value`, never as `value`.
@@ -387,7 +426,6 @@ def main() -> None:
                    "note": "SURVEY 8d figure (8 B per gathered W entry); it prices W entries that never reach DRAM, so it "
                            "is NOT a fraction of any hardware limit and is kept for continuity with round 1 only"}
 
-    import zlib
     # same value for every --gpus N: the sharded path returns the unsharded answer
     topk_crc = zlib.crc32(out[0].cpu().numpy().tobytes()) if rank == 0 else 0
     if rank != 0:
@@ -437,7 +475,7 @@ def main() -> None:
                    "active_columns": lay["n_cols"], "w_rows": (fr["fr_rows"] if fr is not None else None),
                    "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
                                    else f"user-row shard x{world}, W replicated")},
-        "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend,
+        "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend, "alt_sharding": alt_sharding,
         "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc, "rows_rescored_by_exact_tie_pass": n_rescored,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()), "mode": "exact", "tolerance_modes": fit_fast,
