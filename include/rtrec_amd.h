@@ -274,8 +274,10 @@ typedef struct {
      * kernel's waves and shortens its tail; results do not depend on it. */
     const int32_t *d_row_order;
     void          *timer;         /* rtrec_timer object or NULL */
-    int32_t        diagnostics;   /* ablation switches of tools/score_ablate.sh; honoured by diagnostic builds
-                                     (-DRTREC_DIAGNOSTICS) only, ignored by the release library */
+    int32_t        diagnostics;   /* bits 0-7: ablation switches of tools/score_ablate.sh; honoured by diagnostic builds
+                                     (-DRTREC_DIAGNOSTICS) only, ignored by the release library.  bits 8-11: users per wave
+                                     of the feature-row kernel (8, 4 or 2; 0 = chosen from the batch size) -- test / tuning
+                                     knob, results do not depend on it */
     int32_t       *d_rescored;    /* optional int32[1] on the device: receives the number of rows the exact-tie pass
                                      re-scored (SPARSE mode; rows whose fast-pass list held an exact tie or overflowed) */
     int32_t        row_order_grouped;  /* d_row_order is sorted by similarity (rows that rate the same rows of W are

@@ -1205,14 +1205,17 @@ __device__ int fr_first_touch(const FrArgs &a, int c, unsigned long long own0, u
     return -1;
 }
 
-template <int REGS, int XR>
+// UW: users per wave.  8 is the throughput form (every LDS read of a row of W is shared by 8 users).  A launch cannot be
+// shorter than its longest job, though, and a job's length is its waves' serial work for UW users each: passes too small
+// to give every workgroup slot several 8-user jobs (a rank's share of a row-sharded pass, mid-sized request batches)
+// run the same code with 4 or 2 users per wave -- more, shorter jobs.
+template <int REGS, int XR, int UW = kFrUsers>
 __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef typename FrVec<REGS>::type vec;
     constexpr int TC = 64 * REGS;
     constexpr int ROWB = TC * 4;                            // bytes of one row of a tile
-    constexpr int UW = kFrUsers;
-    constexpr int NL = UW / 4;                              // list registers: four users per 64 lanes, 16 lanes each
+    constexpr int NL = (UW + 3) / 4;                        // list registers: four users per 64 lanes, 16 lanes each
     const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
     const int NW = static_cast<int>(blockDim.x) >> 6;       // waves of this workgroup: 16 (resident layout) or 8 (streaming)
     const int kk = a.kk;                                    // <= 16
@@ -1799,6 +1802,7 @@ struct FrLayout {
     const int *tile_off = nullptr; const int *st_kb = nullptr; const int *st_tile = nullptr; const int *frag_tile = nullptr;
     unsigned long long *scratch = nullptr; size_t scratch_bytes = 0;
     int consecutive = 0;
+    int users_per_wave = 0;      // 8 / 4 / 2 forces the kernel form; 0: by batch size
 };
 size_t fr_scratch_bytes(int n_tiles, int tile_cols) {
     const int regs = tile_cols / 64;
@@ -1873,18 +1877,27 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.resident = (FR.n_super == 1 && FR.n_tiles <= 64 &&
                       fr_lds_bytes(FR.buf_bytes, true, FR.n_tiles * (FR.tile_cols / 64)) <= 160u * 1024u) ? 1 : 0;
         const int nw = f.resident ? kFrWaves : kFrWavesStream;
-        const int n_jobs = (a.n_rows + kFrUsers * nw - 1) / (kFrUsers * nw);
         const int max_grid = f.resident ? 256 : 512;
+        // users per wave: 8 when that still gives every workgroup slot a few jobs, else 4, else 2 (FR.users_per_wave forces one)
+        const long long slots_rows = static_cast<long long>(max_grid) * nw;            // rows per round at one user per wave
+        int uw = a.n_rows >= 24 * slots_rows ? 8 : (a.n_rows >= 6 * slots_rows ? 4 : 2);
+        if (FR.users_per_wave == 8 || FR.users_per_wave == 4 || FR.users_per_wave == 2) uw = FR.users_per_wave;
+        const int n_jobs = (a.n_rows + uw * nw - 1) / (uw * nw);
         const unsigned grid = static_cast<unsigned>(n_jobs < max_grid ? n_jobs : max_grid);
         const size_t lds = f.resident ? fr_lds_bytes(FR.buf_bytes, true, FR.n_tiles * (FR.tile_cols / 64)) : fr_lds_bytes(FR.buf_bytes);
         const bool two = FR.rows > 64;
+#define RTREC_FR_LAUNCH(REGS_, XR_)                                                                                            \
+        do {                                                                                                                   \
+            if (uw == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<REGS_, XR_, 8>), dim3(grid), dim3(nw * 64), lds, st, f);      \
+            else if (uw == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<REGS_, XR_, 4>), dim3(grid), dim3(nw * 64), lds, st, f); \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<REGS_, XR_, 2>), dim3(grid), dim3(nw * 64), lds, st, f);              \
+        } while (0)
         if (FR.tile_cols == 256) {
-            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 2>), dim3(grid), dim3(nw * 64), lds, st, f);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<4, 1>), dim3(grid), dim3(nw * 64), lds, st, f);
+            if (two) RTREC_FR_LAUNCH(4, 2); else RTREC_FR_LAUNCH(4, 1);
         } else {
-            if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 2>), dim3(grid), dim3(nw * 64), lds, st, f);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_frows_kernel<2, 1>), dim3(grid), dim3(nw * 64), lds, st, f);
+            if (two) RTREC_FR_LAUNCH(2, 2); else RTREC_FR_LAUNCH(2, 1);
         }
+#undef RTREC_FR_LAUNCH
         f_fr = f;
         fr_done = true;
     } else if (sparse) {
@@ -2036,7 +2049,7 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
     a.filter = filter_interacted; a.mode = mode;
     a.n_x_rows = (opts && opts->n_x_rows > 0) ? opts->n_x_rows : 0x7fffffff;
 #ifdef RTREC_DIAGNOSTICS
-    a.ablate = opts ? opts->diagnostics : 0;       // tools/score_ablate.sh, diagnostic build only
+    a.ablate = opts ? (opts->diagnostics & 0xff) : 0;       // tools/score_ablate.sh, diagnostic build only
 #else
     a.ablate = 0;
 #endif
@@ -2049,6 +2062,7 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
         FR.st_tile = opts->d_fr_super_tile; FR.frag_tile = opts->d_fr_frag_tile;
         FR.scratch = static_cast<unsigned long long *>(opts->d_fr_scratch); FR.scratch_bytes = opts->fr_scratch_bytes;
         FR.order = opts->d_row_order; FR.consecutive = (opts->d_row_order && opts->row_order_grouped) ? 1 : 0;
+        FR.users_per_wave = (opts->diagnostics >> 8) & 0xf;
         FR.col_ids = opts->d_fr_col_ids; FR.col_map = opts->d_fr_col_map;
         FR.tile_rows = reinterpret_cast<const unsigned long long *>(opts->d_fr_tile_rows);
         if (FR.n_tiles != (n_cols + FR.tile_cols - 1) / (FR.tile_cols > 0 ? FR.tile_cols : 1)) return RTREC_ERR_INVALID_ARG;

@@ -674,7 +674,8 @@ class SlimEngine:
         self.score_timer = 0          # rtrec_timer handle (HipBackend.timer_create) bracketing the dominant score kernel
         self.use_feature_rows = os.environ.get("RTREC_AMD_FEATURE_ROWS", "1") != "0"     # A/B switch of the score kernel
         # ablation switches of tools/score_ablate.sh: only a diagnostic build of the library looks at them
-        self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0"))
+        self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0")) & 0xff
+        self.fr_users_per_wave = int(os.environ.get("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
 
     # ------------------------------------------------------------------------------ X
     def set_interactions(self, X_csc: sp.csc_matrix, X_csr: Optional[sp.csr_matrix] = None,
@@ -1084,7 +1085,8 @@ class SlimEngine:
             order = self._row_order(d_row_ids, n_rows, xb, lay) if use_fr else None
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws, timer=self.score_timer,
-                          diagnostics=self.diagnostics, use_fr=use_fr, row_order=order, rescored=self.rescored,
+                          diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8), use_fr=use_fr, row_order=order,
+                          rescored=self.rescored,
                           row_order_grouped=(order is not None and self._grouped_order(lay)))
         else:
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
@@ -1092,11 +1094,10 @@ class SlimEngine:
         return ids, sc, sc64, aux, cnt
 
     ROW_ORDER_MIN = 2048        # batches below this are one or two waves of jobs: nothing to level
-    # The feature-row kernel is a throughput design (a workgroup takes 128 users through ALL of W, 8 users per wave):
-    # a small batch leaves most of the chip idle and waits for one wave's pass over every tile.  Below this many rows
-    # the tiled-CSR kernel scores the batch -- one job per (user, tile), so even one user spreads over several
-    # workgroups (tools/score_batch_sweep.py: DESIGN.md section 3.1).
-    FR_MIN_ROWS = 32
+    # Batches below this many rows go to the tiled-CSR kernel.  Since the feature-row kernel has its 4- and 2-users-per-wave
+    # forms (chosen from the batch size inside rtrec_slim_score_topk) it is ahead at every batch size, one user included
+    # (tools/score_batch_sweep.py: DESIGN.md section 3.1); the threshold is kept for A/B runs and the tests.
+    FR_MIN_ROWS = 1
     FR_TILE_COLS = 256          # columns per tile of the feature-row layout (128: the narrow kernels, kept for A/B and tests)
     pattern_order = os.environ.get("RTREC_AMD_PATTERN_ORDER", "1") != "0"
     rescored = None             # optional int32[1] device tensor: rows the exact-tie pass re-scored in the last call

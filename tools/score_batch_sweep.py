@@ -34,7 +34,7 @@ def main():
     eng.set_weights(eng.merge_fit(None, I, False, *out[:4]))
     rng = np.random.default_rng(1)
     res = []
-    for n in (1, 8, 64, 256, 1024, 4096, 16384, 65536, U):
+    for n in (1, 2, 4, 8, 16, 32, 64, 256, 1024, 4096, 16384, 65536, U):
         rows = np.sort(rng.choice(U, n, replace=False)).astype(np.int32)
         d_rows = eng.be.to_dev(rows)
         rec = {"rows": n}
