@@ -1065,10 +1065,15 @@ class SlimEngine:
                     d_col_rank):
         be, W = self.be, self._W
         torch = be.torch
-        ids = be.empty((n_rows, top_k), torch.int32)
-        sc = be.empty((n_rows, top_k), torch.float32)
+        # ids | scores | counts are views of ONE buffer: a caller that wants them on the host downloads it in one copy
+        # (_download: a single-user recommend is three device-to-host round trips otherwise)
+        nk = n_rows * top_k
+        pack = be.empty((2 * nk + n_rows,), torch.int32)
+        ids = pack[:nk].view(n_rows, top_k)
+        sc = pack[nk:2 * nk].view(torch.float32).view(n_rows, top_k)
+        cnt = pack[2 * nk:]
+        ids._rtrec_pack = pack
         aux = be.empty((n_rows, top_k), torch.int32)
-        cnt = be.empty((n_rows,), torch.int32)
         sc64 = be.empty((n_rows, top_k), torch.float64) if W["acc_f64"] else None
         lay = self._layout(compact=(mode == _native.TOPK_SPARSE), top_k=top_k)
         if lay is None:
@@ -1346,8 +1351,17 @@ class SlimEngine:
             return (np.empty((0, top_k), np.int32), np.empty((0, top_k), np.float32), np.empty((0,), np.int32))
         self._check_rows(row_ids)
         row_ids = row_ids.astype(np.int32)
-        ids, sc, cnt = self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank)
-        return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        return self._download(*self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank))
+
+    @staticmethod
+    def _download(ids, sc, cnt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(ids, scores, counts) device tensors -> numpy; one copy when they are the views _local_topk hands out."""
+        pack = getattr(ids, "_rtrec_pack", None)
+        if pack is None:
+            return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        n, k = ids.shape
+        h = pack.cpu().numpy()
+        return h[:n * k].reshape(n, k), h[n * k:2 * n * k].view(np.float32).reshape(n, k), h[2 * n * k:]
 
     def recommend_csr(self, Xb: sp.csr_matrix, top_k: int = 10, filter_interacted: bool = True,
                       mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None
@@ -1361,8 +1375,7 @@ class SlimEngine:
             Xb = Xb.sorted_indices()
         xb = (be.to_dev(np.asarray(Xb.indptr, dtype=np.int32)), be.to_dev(np.asarray(Xb.indices, dtype=np.int32)),
               be.to_dev(np.asarray(Xb.data, dtype=np.float32)))
-        ids, sc, cnt = self.score_topk_device(None, B, top_k, filter_interacted, mode, col_rank, xb=xb)
-        return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
+        return self._download(*self.score_topk_device(None, B, top_k, filter_interacted, mode, col_rank, xb=xb))
 
     # ------------------------------------------------------------------------------ score vectors
     def predict_csr(self, Xb: sp.csr_matrix) -> np.ndarray:
