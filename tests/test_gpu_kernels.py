@@ -186,6 +186,31 @@ def test_score_signed_zero_and_denormal_ratings(oracle, f64):
                 assert np.array_equal(bits(sc), bits(o_sc))
 
 
+@pytest.mark.parametrize("users_per_wave", [2, 4, 8])
+def test_feature_row_kernel_users_per_wave_forms(oracle, users_per_wave):
+    """score_frows_kernel<REGS, XR, UW>: the library picks 8, 4 or 2 users per wave from the batch size (small passes get
+    more, shorter jobs); every form must give the same answer at any size -- forced here through rtrec_score_opts.diagnostics
+    bits 8-11, on a float W, on a W of duplicated columns (ties inside the list and at its threshold) and for batches that
+    leave waves partly or wholly without users."""
+    X, W = make_model(oracle, U=900, I=500, draws=30000, K=12, seed=5)
+    keep = np.isin(W.indices, np.arange(0, 500, 11))                  # few non-empty rows: the feature-row kernel's shape
+    Wn = W.copy(); Wn.data[~keep] = 0; Wn.eliminate_zeros()
+    rng = np.random.default_rng(2)
+    Wt = sp.csc_matrix(Wn[:, rng.integers(0, 30, size=500)]); Wt.sort_indices()
+    for Wx in (Wn, Wt):
+        eng = SlimEngine(device="cuda:0", tile_cols=256)
+        eng.fr_users_per_wave = users_per_wave
+        eng.set_interactions(None, X, need_csc=False)
+        eng.set_weights(Wx)
+        for rows in (np.arange(X.shape[0]), np.arange(0, X.shape[0], 7), np.array([3]), np.arange(5, 22)):
+            for filt in (True, False):
+                ids, sc, cnt = eng.recommend_rows(rows, top_k=10, filter_interacted=filt, mode=_native.TOPK_SPARSE)
+                o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], Wx.tocsr(), top_k=10, filter_interacted=filt)
+                assert np.array_equal(cnt, o_cnt)
+                assert np.array_equal(ids, o_ids)
+                assert np.array_equal(bits(sc), bits(o_sc))
+
+
 def test_candidate_mode(oracle):
     X, W = make_model(oracle, U=400, I=300, draws=8000, K=10)
     eng = SlimEngine(device="cuda:0", tile_cols=256)
