@@ -362,7 +362,9 @@ def main() -> None:
 
     def feature_row_model():
             tc, R = fr["fr_tile_cols"], fr["fr_rows"]
-            kernel_name = f"score_frows_kernel<{tc // 64},{2 if R > 64 else 1}>"
+            # users per wave: the library's choice for this launch (csrc/score.hip: 8 from ~98k rows, 4 from ~25k, else 2)
+            uw = 8 if n_scored >= 24 * 4096 else (4 if n_scored >= 6 * 4096 else 2)
+            kernel_name = f"score_frows_kernel<{tc // 64},{2 if R > 64 else 1},{uw}>"
             tr = fr["fr_rows_of_tile"].view(np.uint64).reshape(-1, 2)
             feat_items = np.flatnonzero(fr["fr_map"] >= 0)
             tiles_of_row = np.array([sum(((int(tr[t, f // 64]) >> (f % 64)) & 1) for t in range(tr.shape[0])) for f in range(R)],
