@@ -1062,17 +1062,20 @@ class SlimEngine:
 
     # ------------------------------------------------------------------------------ score
     def _local_topk(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
-                    d_col_rank):
+                    d_col_rank, pad_rows: int = 0):
         be, W = self.be, self._W
         torch = be.torch
         # ids | scores | counts are views of ONE buffer: a caller that wants them on the host downloads it in one copy
-        # (_download: a single-user recommend is three device-to-host round trips otherwise)
-        nk = n_rows * top_k
-        pack = be.empty((2 * nk + n_rows,), torch.int32)
-        ids = pack[:nk].view(n_rows, top_k)
-        sc = pack[nk:2 * nk].view(torch.float32).view(n_rows, top_k)
-        cnt = pack[2 * nk:]
-        ids._rtrec_pack = pack
+        # (_download: a single-user recommend is three device-to-host round trips otherwise), and the row-sharded path
+        # all-gathers it as it is (pad_rows: the buffer is laid out for that many rows, so that every rank's has one size)
+        cap = max(n_rows, int(pad_rows))
+        nk = cap * top_k
+        pack = be.empty((2 * nk + cap,), torch.int32)
+        ids = pack[:nk].view(cap, top_k)[:n_rows]
+        sc = pack[nk:2 * nk].view(torch.float32).view(cap, top_k)[:n_rows]
+        cnt = pack[2 * nk:2 * nk + n_rows]
+        if cap == n_rows:
+            ids._rtrec_pack = pack
         aux = be.empty((n_rows, top_k), torch.int32)
         sc64 = be.empty((n_rows, top_k), torch.float64) if W["acc_f64"] else None
         lay = self._layout(compact=(mode == _native.TOPK_SPARSE), top_k=top_k)
@@ -1290,18 +1293,23 @@ class SlimEngine:
             slices[skey] = d_rows[self.rank::G].contiguous()
         mine = slices[skey]
         m = int(mine.shape[0])
-        fwidth = 2 * k + 1
-        fwidth += fwidth & 1
-        fin = torch.zeros((q, fwidth), dtype=torch.int32, device=d_rows.device)      # short / empty slices: count 0
+        # every rank's (ids | scores | counts) buffer, laid out for q rows, is gathered as it is; rows a short slice does
+        # not have (global row index >= n_rows) are cut off below, so their slots may hold anything
+        width = (2 * k + 1) * q
         if m > 0:
-            ids, sc, sc64, aux, cnt = self._local_topk(mine, m, xb, k, filter_interacted, mode, d_rank)
-            fin[:m, :k] = sc.view(torch.int32)
-            fin[:m, k:2 * k] = ids
-            fin[:m, 2 * k] = cnt
-        out = be.empty((G * q, fwidth), torch.int32)
+            ids, sc, sc64, aux, cnt = self._local_topk(mine, m, xb, k, filter_interacted, mode, d_rank, pad_rows=q)
+            fin = ids._base if ids._base is not None else ids          # the flat buffer the three are views of
+            fin = fin.reshape(-1)
+        else:
+            fin = be.empty((width,), torch.int32)
+        out = be.empty((G * width,), torch.int32)
         dist.all_gather_into_tensor(out, fin, group=self.group)
-        out = out.view(G, q, fwidth).transpose(0, 1).reshape(G * q, fwidth)[:n_rows]    # row i*G + p <- rank p, slot i
-        return out[:, k:2 * k].contiguous(), out[:, :k].contiguous().view(torch.float32), out[:, 2 * k].contiguous()
+        out = out.view(G, width)
+        # row i*G + p of the batch <- rank p, slot i
+        o_ids = out[:, :q * k].view(G, q, k).transpose(0, 1).reshape(G * q, k)[:n_rows]
+        o_sc = out[:, q * k:2 * q * k].view(G, q, k).transpose(0, 1).reshape(G * q, k)[:n_rows].view(torch.float32)
+        o_cnt = out[:, 2 * q * k:].t().reshape(G * q)[:n_rows]
+        return o_ids, o_sc, o_cnt
 
     MAX_TOP_K = 1023            # kMaxTopK of csrc/score.hip
     MAX_MERGE_CANDIDATES = 1024  # per-tile lists of one row the merge kernel takes: n_tiles * (top_k + 1)
