@@ -1019,8 +1019,9 @@ __global__ __launch_bounds__(64) void similar_topk_kernel(int n_queries, const i
 //     a column enters only if it beats the current (k+1)-th score, so after the first tiles a
 //     (user, tile) pair costs four compares.  The list is the row's final answer: no per-tile
 //     candidate lists, no merge kernel.
-// Exact score ties inside the leading k+1 are flagged and re-scored by score_sparse_kernel<ACC, true>
-// like before.  No LDS accumulators, no touched lists, no per-user reset.
+// Exact score ties: a tie inside the leading k is ordered from W by fr_ties_kernel (first-touch row of each tied
+// column); a tie that reaches the (k+1)-th entry is re-scored by score_sparse_kernel<ACC, true> like before.
+// No LDS accumulators, no touched lists, no per-user reset.
 // =============================================================================================
 struct FrArgs {
     int n_rows; const int *row_ids; int n_x_rows;
