@@ -1065,6 +1065,7 @@ __host__ __device__ constexpr size_t fr_wave_scratch_words(int n_tiles, int regs
 constexpr int kFrCandCap = 64;               // candidates a wave buffers per merge round (one per lane)
 __host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
 constexpr int kFrStep = 2;                   // rows of W per sweep step
+constexpr int kFrSetupChunks = 4;            // 64-entry chunks of a long user row whose loads are issued together
 constexpr int kFrTileHeaderBytes = 512;      // per tile, in front of its first fragment: max |w| of each row (FR_TILE_HEADER_BYTES)
 constexpr int kFrZeroRowBytes = 1024;        // one slice row of +0.0 (the widest tile: 256 columns)
 // per-wave LDS setup scratch actually needed: the interacted-column mask words, a pad, 128 ratings
@@ -1333,18 +1334,27 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             fr_static_for<2>([&](auto H) { xl[H() * 64 + lane] = 0.0f; });
             if (fm0[u] >= 0) xl[fm0[u]] = xv0[u];                           // the items of one row are distinct
             if (cm0[u] >= 0) mark(cm0[u]);
-            for (int b = 64; b < n_a; b += 64) {                            // rows beyond 64 entries
-                const int q = b + lane;
-                if (q < n_a) {
-                    const int item = a.xb_col[a0 + q];
-                    if (item < a.n_items) {
-                        const int f = a.fmap[item];
-                        if (f >= 0) xl[f] = a.xb_val[a0 + q];
-                        if (a.filter) {
-                            const int c = a.col_map[item];
-                            if (c >= 0) mark(c);
-                        }
+            for (int b = 64; b < n_a; b += 64 * kFrSetupChunks) {           // rows beyond 64 entries, four chunks per round:
+                int item[kFrSetupChunks], f[kFrSetupChunks], c[kFrSetupChunks];   // their entries, then what they map to, are
+                float xv[kFrSetupChunks];                                   // requested together (two round trips per round)
+#pragma unroll
+                for (int j = 0; j < kFrSetupChunks; ++j) {
+                    const int q = b + 64 * j + lane;
+                    item[j] = -1; xv[j] = 0.0f;
+                    if (q < n_a) { item[j] = a.xb_col[a0 + q]; xv[j] = a.xb_val[a0 + q]; }
+                }
+#pragma unroll
+                for (int j = 0; j < kFrSetupChunks; ++j) {
+                    f[j] = -1; c[j] = -1;
+                    if (item[j] >= 0 && item[j] < a.n_items) {
+                        f[j] = a.fmap[item[j]];
+                        if (a.filter) c[j] = a.col_map[item[j]];
                     }
+                }
+#pragma unroll
+                for (int j = 0; j < kFrSetupChunks; ++j) {
+                    if (f[j] >= 0) xl[f[j]] = xv[j];
+                    if (c[j] >= 0) mark(c[j]);
                 }
             }
             uint32_t *xu = xs_wave + u * kFrUserWords;
