@@ -1307,20 +1307,26 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                 if (xrow >= 0 && xrow < a.n_x_rows) { a0_l = a.xb_ptr[xrow]; na_l = a.xb_ptr[xrow + 1] - a0_l; }
             }
         }
-        int it0[UW], fm0[UW], cm0[UW];
-        float xv0[UW];
+        // (entries 0..63 and 64..127 of every row: a typical row is done after these two)
+        int it0[UW], fm0[UW], cm0[UW], it1[UW], fm1[UW], cm1[UW];
+        float xv0[UW], xv1[UW];
         fr_static_for<UW>([&](auto Uc) {
             constexpr int u = decltype(Uc)::value;
             const int a0 = readlane_i(a0_l, u), n_a = readlane_i(na_l, u);
-            it0[u] = -1; xv0[u] = 0.0f;
+            it0[u] = -1; xv0[u] = 0.0f; it1[u] = -1; xv1[u] = 0.0f;
             if (lane < n_a) { it0[u] = a.xb_col[a0 + lane]; xv0[u] = a.xb_val[a0 + lane]; }
+            if (64 + lane < n_a) { it1[u] = a.xb_col[a0 + 64 + lane]; xv1[u] = a.xb_val[a0 + 64 + lane]; }
         });
         fr_static_for<UW>([&](auto Uc) {
             constexpr int u = decltype(Uc)::value;
-            fm0[u] = -1; cm0[u] = -1;
+            fm0[u] = -1; cm0[u] = -1; fm1[u] = -1; cm1[u] = -1;
             if (it0[u] >= 0 && it0[u] < a.n_items) {
                 fm0[u] = a.fmap[it0[u]];
                 if (a.filter) cm0[u] = a.col_map[it0[u]];
+            }
+            if (it1[u] >= 0 && it1[u] < a.n_items) {
+                fm1[u] = a.fmap[it1[u]];
+                if (a.filter) cm1[u] = a.col_map[it1[u]];
             }
         });
         auto mark = [&](int c) {      // interacted layout column c -> its bit in the user's mask words
@@ -1334,7 +1340,9 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             fr_static_for<2>([&](auto H) { xl[H() * 64 + lane] = 0.0f; });
             if (fm0[u] >= 0) xl[fm0[u]] = xv0[u];                           // the items of one row are distinct
             if (cm0[u] >= 0) mark(cm0[u]);
-            for (int b = 64; b < n_a; b += 64 * kFrSetupChunks) {           // rows beyond 64 entries, four chunks per round:
+            if (fm1[u] >= 0) xl[fm1[u]] = xv1[u];
+            if (cm1[u] >= 0) mark(cm1[u]);
+            for (int b = 128; b < n_a; b += 64 * kFrSetupChunks) {          // rows beyond 128 entries, four chunks per round:
                 int item[kFrSetupChunks], f[kFrSetupChunks], c[kFrSetupChunks];   // their entries, then what they map to, are
                 float xv[kFrSetupChunks];                                   // requested together (two round trips per round)
 #pragma unroll
