@@ -279,7 +279,8 @@ typedef struct {
                                      of the feature-row kernel (8, 4 or 2; 0 = chosen from the batch size) -- test / tuning
                                      knob, results do not depend on it */
     int32_t       *d_rescored;    /* optional int32[1] on the device: receives the number of rows the exact-tie pass
-                                     re-scored (SPARSE mode; rows whose fast-pass list held an exact tie or overflowed) */
+                                     re-scored (SPARSE mode; rows whose fast-pass list held an exact tie reaching its
+                                     (k+1)-th entry -- ties inside the leading k are ordered in place and not counted) */
     int32_t        row_order_grouped;  /* d_row_order is sorted by similarity (rows that rate the same rows of W are
                                      neighbours): a wave then takes eight CONSECUTIVE positions instead of a strided deal */
 } rtrec_score_opts;
