@@ -49,6 +49,13 @@ WORKLOADS = {
     "c4": dict(U=1_000_000, I=500_000, draws=100_000_000, K=50,
                desc="synthetic 1M users x 500k items, 100M interaction draws, K=50 (bulk fit + score; 8-GPU shard config)"),
     "small": dict(U=20_000, I=5_000, draws=500_000, K=50, desc="small plumbing workload 20k x 5k, 500k draws, K=50"),
+    # the C3 shape with item-item structure: 80 item clusters, 85 % of a user's draws inside its home
+    # cluster, same Zipf marginals -> W has thousands of non-empty rows (the general-W scoring path)
+    "c3s": dict(U=138_493, I=26_744, draws=46_000_000, K=50, gen="clustered", clusters=80, p_in=0.85,
+                desc="MovieLens-20M-shaped STRUCTURED synthetic 138,493 users x 26,744 items, ~20M interactions in 80 item "
+                     "clusters (85 % of a user's draws inside its home cluster, Zipf marginals kept), K=50"),
+    "smalls": dict(U=20_000, I=5_000, draws=900_000, K=50, gen="clustered", clusters=25, p_in=0.85,
+                   desc="small structured plumbing workload 20k x 5k in 25 item clusters, K=50"),
 }
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -132,12 +139,12 @@ def main() -> None:
 
     from rtrec_amd import _native
     from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients, shard_bounds
-    from rtrec_amd.synth import interaction_matrix
+    from rtrec_amd.synth import workload_matrix
 
     wl = WORKLOADS[args.workload]
     U, I, K, top_k = wl["U"], wl["I"], wl["K"], args.top_k
     t0 = time.time()
-    X = interaction_matrix(U, I, wl["draws"], seed=20251003, float_ratings=True)
+    X = workload_matrix(wl, seed=20251003, float_ratings=True)
     Xc = X.tocsc()
     Xc.sort_indices()
     nnz = int(X.nnz)

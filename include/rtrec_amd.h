@@ -283,6 +283,31 @@ typedef struct {
                                      (k+1)-th entry -- ties inside the leading k are ordered in place and not counted) */
     int32_t        row_order_grouped;  /* d_row_order is sorted by similarity (rows that rate the same rows of W are
                                      neighbours): a wave then takes eight CONSECUTIVE positions instead of a strided deal */
+    /* "Segment" form of the shard (optional; the fast path for a GENERAL W -- any number of non-empty rows -- in SPARSE
+     * mode with float32 accumulation and top_k <= 63; used when the feature-row form above is absent or does not apply).
+     * The same compacted columns as the tiled layout (sg_n_cols == n_cols) in an order of the caller's choice --
+     * rtrec_amd/seg_layout.py orders them by cluster (label propagation over W's graph) so that the columns a row of W
+     * weights sit together -- cut into sg_n_tiles = ceil(n_cols / sg_tile_cols) <= 128 tiles of sg_tile_cols columns
+     * (a power of two, 256 .. 4096):
+     *     d_sg_col_ids[n_cols]      layout column -> item id
+     *     d_sg_info[n_items][2]     item -> { its row r in the tables below or -1 (no weight in its row of W),
+     *                               its layout column or -1 }     (8-byte aligned)
+     *     d_sg_ptr[sg_rows][sg_n_tiles + 1]   the entries of row r that fall into tile t are d_sg_ptr[r][t] ..
+     *                               d_sg_ptr[r][t + 1] - 1 of d_sg_col (column INSIDE the tile, ascending) / d_sg_val
+     *     d_sg_bound[sg_rows][64]   word l = bfloat16(max |w| of row r in tile 2 l) | bfloat16(... tile 2 l + 1) << 16,
+     *                               each ROUNDED UP (0 for an empty segment / a tile beyond sg_n_tiles)
+     * sum_i |x_ui| bound[i][t] bounds every score user u can have in tile t: the kernel opens a user's tiles in
+     * descending bound order and stops when the best remaining bound cannot beat the user's current (k+1)-th best
+     * score.  Opened tiles are accumulated in scipy's csr_matmat order (ascending item, one rounded product and one
+     * rounded add per entry), so ids, scores and counts are identical to the tiled-CSR path
+     * (csrc/score_seg.hip.h, score_seg_kernel).  d_row_order applies to this kernel as well. */
+    const int32_t *d_sg_info;
+    const int32_t *d_sg_ptr;
+    const uint16_t *d_sg_col;
+    const float   *d_sg_val;
+    const uint32_t *d_sg_bound;
+    const int32_t *d_sg_col_ids;
+    int32_t        sg_tile_cols, sg_n_tiles, sg_rows, sg_n_cols;
 } rtrec_score_opts;
 
 size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols);

@@ -1775,6 +1775,8 @@ __global__ __launch_bounds__(64) void fr_ties_kernel(FrArgs a) {
     }
 }
 
+#include "score_seg.hip.h"
+
 template <typename ACC>
 void launch_merge_topk(unsigned grid, hipStream_t st, const MergeArgs &m) {
     const int total = m.n_lists * m.kk;
@@ -1843,11 +1845,24 @@ bool fr_usable(const FrLayout &F, int kk) {
     return kk >= 1 && kk <= kFrMaxKk;
 }
 
+// Segment form of the shard (rtrec_score_opts.d_sg_*): SPARSE mode, float32 accumulation, top_k <= 63.
+struct SgLayout {
+    const int2 *info = nullptr; const int *seg_ptr = nullptr; const uint16_t *w_col = nullptr; const float *w_val = nullptr;
+    const uint32_t *bound = nullptr; const int *col_ids = nullptr; const int *order = nullptr;
+    int T = 0, n_tiles = 0, rows = 0, n_cols = 0;
+};
+bool sg_usable(const SgLayout &S, int kk) {
+    if (!S.info || !S.seg_ptr || !S.w_col || !S.w_val || !S.bound || !S.col_ids) return false;
+    if (S.T < 256 || S.T > 4096 || (S.T & (S.T - 1))) return false;
+    if (S.n_cols <= 0 || S.rows <= 0 || S.n_tiles != (S.n_cols + S.T - 1) / S.T || S.n_tiles > 128) return false;
+    return kk >= 1 && kk <= kSgMaxKk;
+}
+
 template <typename ACC>
 int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_ids, float *d_out_scores,
                double *d_out_scores64, uint32_t *d_out_aux, int32_t *d_out_count,
-               unsigned char *ws, const ScoreWs &L, hipStream_t st, KernelTimer *tmr, const FrLayout &FR, int n_x_rows,
-               int32_t *d_rescored) {
+               unsigned char *ws, const ScoreWs &L, hipStream_t st, KernelTimer *tmr, const FrLayout &FR, const SgLayout &SG,
+               int n_x_rows, int32_t *d_rescored) {
     ScoreArgs a = base;
     const bool sparse = (a.mode == RTREC_TOPK_SPARSE);
     const bool single = (a.n_tiles == 1);
@@ -1873,7 +1888,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
     debug_stage(st, "score: begin");
     if (tmr) { timer_collect(*tmr); (void)hipEventRecord(tmr->start, st); }
-    bool fr_done = false;
+    bool fr_done = false, sg_done = false;
     FrArgs f_fr{};
     if (sparse && sizeof(ACC) == 4 && fr_usable(FR, a.kk)) {
         // few, long rows in W: accumulators in registers, the dense R x n_cols matrix streamed through LDS
@@ -1919,6 +1934,26 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
 #undef RTREC_FR_LAUNCH
         f_fr = f;
         fr_done = true;
+    } else if (sparse && sizeof(ACC) == 4 && sg_usable(SG, a.kk)) {
+        // many rows in W: one wave per user, tiles opened in descending score-bound order (score_seg.hip.h)
+        SegArgs g{};
+        g.n_rows = a.n_rows; g.row_ids = a.row_ids; g.order = SG.order; g.n_x_rows = n_x_rows;
+        g.xb_ptr = a.xb_ptr; g.xb_col = a.xb_col; g.xb_val = a.xb_val; g.n_items = a.n_items;
+        g.info = SG.info; g.seg_ptr = SG.seg_ptr; g.w_col = SG.w_col; g.w_val = SG.w_val; g.bound = SG.bound;
+        g.col_ids = SG.col_ids; g.n_cols = SG.n_cols; g.T = SG.T; g.n_tiles = SG.n_tiles; g.R = SG.rows;
+        g.kk = a.kk; g.top_k = top_k; g.filter = a.filter;
+        g.out_id = d_out_ids; g.out_score = d_out_scores; g.out_aux = d_out_aux; g.out_cnt = d_out_count;
+        g.flag_list = flag_list; g.flag_len = flag_len; g.queue = queue;
+        const size_t wave_lds = sg_wave_lds(SG.T);
+        int waves_cu = static_cast<int>((160u * 1024u) / wave_lds);
+        waves_cu = waves_cu > 32 ? 32 : waves_cu;
+        int wg_cu = waves_cu / kSgWaves;
+        wg_cu = wg_cu < 1 ? 1 : wg_cu;
+        const long long want = (static_cast<long long>(a.n_rows) + kSgWaves * kSgQueueChunk - 1) / (kSgWaves * kSgQueueChunk);
+        const long long cap = 256ll * wg_cu;
+        const unsigned grid = static_cast<unsigned>(want < cap ? (want > 0 ? want : 1) : cap);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<4>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
+        sg_done = true;
     } else if (sparse) {
         const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true, a.kk);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, false>), dim3(persistent_grid(lds, total)), dim3(64),
@@ -1948,7 +1983,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     m.detect_ties = sparse ? 1 : 0;
     m.flag_list = flag_list; m.flag_len = flag_len;
     m.row_list = nullptr; m.row_list_len = nullptr;
-    if (!single && !fr_done) {      // the feature-row kernel writes final lists itself
+    if (!single && !fr_done && !sg_done) {      // the feature-row and segment kernels write final lists themselves
         launch_merge_topk<ACC>(static_cast<unsigned>(a.n_rows), st, m);
         debug_stage(st, "merge_topk_kernel");
     }
@@ -2086,13 +2121,22 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
         FR.tile_rows = reinterpret_cast<const unsigned long long *>(opts->d_fr_tile_rows);
         if (FR.n_tiles != (n_cols + FR.tile_cols - 1) / (FR.tile_cols > 0 ? FR.tile_cols : 1)) return RTREC_ERR_INVALID_ARG;
     }
+    SgLayout SG;
+    if (opts && opts->d_sg_info && opts->d_sg_val) {
+        if (reinterpret_cast<uintptr_t>(opts->d_sg_info) & 7u) return RTREC_ERR_INVALID_ARG;
+        SG.info = reinterpret_cast<const int2 *>(opts->d_sg_info); SG.seg_ptr = opts->d_sg_ptr; SG.w_col = opts->d_sg_col;
+        SG.w_val = opts->d_sg_val; SG.bound = opts->d_sg_bound; SG.col_ids = opts->d_sg_col_ids;
+        SG.T = opts->sg_tile_cols; SG.n_tiles = opts->sg_n_tiles; SG.rows = opts->sg_rows; SG.n_cols = opts->sg_n_cols;
+        SG.order = opts->d_row_order;
+        if (SG.n_cols != n_cols) return RTREC_ERR_INVALID_ARG;
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned char *ws = static_cast<unsigned char *>(d_workspace);
     if (acc_f64)
         return score_impl<double>(a, top_k, 8, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
-                                  tmr, FR, a.n_x_rows, opts ? opts->d_rescored : nullptr);
+                                  tmr, FR, SG, a.n_x_rows, opts ? opts->d_rescored : nullptr);
     return score_impl<float>(a, top_k, 4, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
-                             tmr, FR, a.n_x_rows, opts ? opts->d_rescored : nullptr);
+                             tmr, FR, SG, a.n_x_rows, opts ? opts->d_rescored : nullptr);
 }
 
 extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,

@@ -575,10 +575,13 @@ class HipBackend:
         return int(self.lib.rtrec_slim_score_workspace_bytes(n_rows, n_tiles, top_k))
 
     supports_feature_rows = True
+    supports_seg_layout = True
 
     def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
-                   acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None, rescored=None, row_order_grouped=False):
+                   acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None, rescored=None, row_order_grouped=False,
+                   use_sg=True):
         fr = lay if (use_fr and lay.get("fr_w") is not None) else {}
+        sg = lay.get("sg") or {} if (use_sg and not fr) else {}
         self.ops.score_topk(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo,
                             lay["col_ids"], lay["col_map"], lay["tile_cols"], lay["n_tiles"],
                             lay["tile_ptr"], lay["w_col"], lay["w_val"], lay.get("dense_idx"), lay.get("dense_val"),
@@ -590,7 +593,10 @@ class HipBackend:
                             int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)), int(fr.get("fr_n_tiles", 0)),
                             int(fr.get("fr_n_frags", 0)), int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
                             fr.get("fr_scratch"),
-                            row_order if fr else None, int(timer), int(diagnostics), rescored, int(bool(row_order_grouped)))
+                            row_order if (fr or sg) else None, int(timer), int(diagnostics), rescored, int(bool(row_order_grouped)),
+                            sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_col"), sg.get("sg_val"), sg.get("sg_bound"),
+                            sg.get("sg_col_ids"), int(sg.get("sg_T", 0)), int(sg.get("sg_n_tiles", 0)), int(sg.get("sg_rows", 0)),
+                            int(sg.get("sg_n_cols", 0)))
 
     def decay_f32(self, raw, ts, rate: float, now: float):
         """float32(raw * rate ** ((now - ts) / 86400)) for resident arrays: rtrec_store_decay_device, plus the host's libm
@@ -676,6 +682,10 @@ class SlimEngine:
         # ablation switches of tools/score_ablate.sh: only a diagnostic build of the library looks at them
         self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0")) & 0xff
         self.fr_users_per_wave = int(os.environ.get("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
+        self.use_seg_layout = os.environ.get("RTREC_AMD_SEG_LAYOUT", "1") != "0"        # A/B switch of the general-W score kernel
+        self.seg_cluster = os.environ.get("RTREC_AMD_SEG_CLUSTER", "1") != "0"          # ... and of its column clustering
+        self.last_score_path = ""     # which kernel family served the last _local_topk call (tests, bench.py)
+        self._sg_labels = None        # (cluster labels of the last segment layout, n_items, nnz of W when they were computed)
 
     # ------------------------------------------------------------------------------ X
     def set_interactions(self, X_csc: sp.csc_matrix, X_csr: Optional[sp.csr_matrix] = None,
@@ -981,6 +991,7 @@ class SlimEngine:
         n_items = dw.n_items
         lo, hi = (0, n_items) if self.score_shard == "rows" else shard_bounds(n_items, self.world_size, self.rank)
         self._W = {"n_items": n_items, "col_lo": lo, "col_hi": hi, "acc_f64": dw.f64, "dw": dw, "layouts": {}}
+        self._X.pop("_orders", None)           # work orders are per layout
 
     @property
     def weights(self) -> Optional[DeviceWeights]:
@@ -1057,6 +1068,22 @@ class SlimEngine:
                             fr.pop("col_ids_sorted")
                             lay.update(fr)           # fr_host: small host copies bench.py prices the kernel's work from
                             lay["fr_scratch"] = be.empty((nb,), torch.uint8)
+                    # a W with many rows (item-item structure in the data): the segment layout (seg_layout.py); the cluster
+                    # labels that order its columns are kept while W changes little (a mini-batch refits ~3 % of the columns)
+                    if (not W["acc_f64"] and lay.get("fr_w") is None and self.use_seg_layout
+                            and getattr(be, "supports_seg_layout", False)):
+                        from .seg_layout import build_seg_layout_device
+                        labels = None
+                        kept = self._sg_labels
+                        if kept is not None and kept[1] == W["n_items"] and abs(dw.nnz - kept[2]) <= 0.05 * max(kept[2], 1):
+                            labels = kept[0]
+                        if not self.seg_cluster:
+                            labels = torch.arange(W["n_items"], dtype=torch.int64, device=dw.rows.device)
+                        sg = build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels=labels)
+                        if sg is not None:
+                            if labels is None:
+                                self._sg_labels = (sg["sg_labels"], W["n_items"], dw.nnz)
+                            lay["sg"] = sg
             W["layouts"][key] = lay
         return W["layouts"][key]
 
@@ -1090,12 +1117,15 @@ class SlimEngine:
         if isinstance(be, HipBackend):
             use_fr = (self.use_feature_rows and mode == _native.TOPK_SPARSE and lay.get("fr_w") is not None
                       and n_rows >= self.FR_MIN_ROWS)
-            order = self._row_order(d_row_ids, n_rows, xb, lay) if use_fr else None
+            use_sg = (not use_fr and self.use_seg_layout and mode == _native.TOPK_SPARSE and lay.get("sg") is not None
+                      and top_k <= self.SG_MAX_TOP_K)
+            order = self._row_order(d_row_ids, n_rows, xb, lay) if (use_fr or use_sg) else None
+            self.last_score_path = "feature_rows" if use_fr else ("segments" if use_sg else "tiled")
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws, timer=self.score_timer,
                           diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8), use_fr=use_fr, row_order=order,
                           rescored=self.rescored,
-                          row_order_grouped=(order is not None and self._grouped_order(lay)))
+                          row_order_grouped=(order is not None and use_fr and self._grouped_order(lay)), use_sg=use_sg)
         else:
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws)
@@ -1106,6 +1136,7 @@ class SlimEngine:
     # forms (chosen from the batch size inside rtrec_slim_score_topk) it is ahead at every batch size, one user included
     # (tools/score_batch_sweep.py: DESIGN.md section 3.1); the threshold is kept for A/B runs and the tests.
     FR_MIN_ROWS = 1
+    SG_MAX_TOP_K = 63           # kSgMaxKk - 1 of csrc/score_seg.hip.h: the list of top_k + 1 entries is one register across the lanes
     FR_TILE_COLS = 256          # columns per tile of the feature-row layout (128: the narrow kernels, kept for A/B and tests)
     pattern_order = os.environ.get("RTREC_AMD_PATTERN_ORDER", "1") != "0"
     rescored = None             # optional int32[1] device tensor: rows the exact-tie pass re-scored in the last call
@@ -1130,11 +1161,14 @@ class SlimEngine:
         torch = self.be.torch
         resident = self._X.get("rptr") is xb[0]
         fr_host = (lay or {}).get("fr_host")
-        key = (n_rows, None if d_row_ids is None else (d_row_ids.data_ptr(), d_row_ids._version),
-               None if fr_host is None else id(fr_host))
-        cache = self._X.setdefault("_orders", {}) if resident else None      # one entry per (row set, layout): the sharded
-        if cache is not None and key in cache:                                # path scores the same chunks step after step
-            return cache[key]
+        # One entry per (row-id tensor, layout), matched by IDENTITY: the entry keeps the tensor and the layout alive, so a
+        # recycled address can never stand for another row set; a temporary row tensor simply misses.
+        cache = self._X.setdefault("_orders", []) if resident else None
+        if cache is not None:
+            for ent in cache:
+                if (ent[0] is d_row_ids and ent[1] == (None if d_row_ids is None else d_row_ids._version) and ent[2] == n_rows
+                        and ent[3] is fr_host):
+                    return ent[4]
         ptr, col = xb[0], xb[1]
         if d_row_ids is None:
             rows = None
@@ -1175,7 +1209,7 @@ class SlimEngine:
         if cache is not None:
             if len(cache) >= 32:
                 cache.clear()
-            cache[key] = order
+            cache.append((d_row_ids, None if d_row_ids is None else d_row_ids._version, n_rows, fr_host, order))
             self._X["_order"] = order          # the most recent one (bench.py's bounds model reads it)
         return order
 
@@ -1285,13 +1319,18 @@ class SlimEngine:
         G = self.world_size
         q = -(-n_rows // G)
         # this rank's slice of the batch, kept while the same row tensor is scored again (its work order is cached by it)
-        skey = (d_rows.data_ptr(), d_rows._version, n_rows, self.rank, G)
-        slices = self._X.setdefault("_row_slices", {})
-        if skey not in slices:
+        # (matched by the IDENTITY of the row tensor, which the entry keeps alive: an address recycled by the allocator for
+        # another call's row ids must never hit -- ADVICE round 2; a temporary tensor simply misses and is sliced again)
+        slices = self._X.setdefault("_row_slices", [])
+        mine = None
+        for ent in slices:
+            if ent[0] is d_rows and ent[1] == d_rows._version and ent[2] == (n_rows, self.rank, G):
+                mine = ent[3]
+        if mine is None:
+            mine = d_rows[self.rank::G].contiguous()
             if len(slices) >= 8:
                 slices.clear()
-            slices[skey] = d_rows[self.rank::G].contiguous()
-        mine = slices[skey]
+            slices.append((d_rows, d_rows._version, (n_rows, self.rank, G), mine))
         m = int(mine.shape[0])
         # every rank's (ids | scores | counts) buffer, laid out for q rows, is gathered as it is; rows a short slice does
         # not have (global row index >= n_rows) are cut off below, so their slots may hold anything

@@ -93,14 +93,19 @@ def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val
                fr_super_tile: Optional[Tensor], fr_frag_tile: Optional[Tensor], fr_rows: int, fr_tile_cols: int, fr_n_tiles: int,
                fr_n_frags: int, fr_n_super: int,
                fr_buf_bytes: int, fr_scratch: Optional[Tensor], row_order: Optional[Tensor], timer: int,
-               diagnostics: int, rescored: Optional[Tensor], row_order_grouped: int) -> None:
+               diagnostics: int, rescored: Optional[Tensor], row_order_grouped: int,
+               sg_info: Optional[Tensor], sg_ptr: Optional[Tensor], sg_col: Optional[Tensor], sg_val: Optional[Tensor],
+               sg_bound: Optional[Tensor], sg_col_ids: Optional[Tensor], sg_tile_cols: int, sg_n_tiles: int, sg_rows: int,
+               sg_n_cols: int) -> None:
     """rtrec_slim_score_topk_opt.  n_x_rows is taken from xb_ptr; fr_* is the optional feature-row form of the
-    shard; `timer` is an rtrec_timer handle (0 = none)."""
+    shard, sg_* its optional segment form; `timer` is an rtrec_timer handle (0 = none)."""
     lib = _native.load()
     opts = _native.ScoreOpts(int(xb_ptr.shape[0]) - 1, _p(fr_map), _p(fr_col_ids), _p(fr_col_map), _p(fr_w),
                              _p(fr_tile_rows), _p(fr_tile_off), _p(fr_super_kb), _p(fr_super_tile), _p(fr_frag_tile), fr_rows,
                              fr_tile_cols, fr_n_tiles, fr_n_frags, fr_n_super, fr_buf_bytes, _p(fr_scratch), fr_scratch.numel() if fr_scratch is not None else 0,
-                             _p(row_order), C.c_void_p(timer or None), diagnostics, _p(rescored), row_order_grouped)
+                             _p(row_order), C.c_void_p(timer or None), diagnostics, _p(rescored), row_order_grouped,
+                             _p(sg_info), _p(sg_ptr), _p(sg_col), _p(sg_val), _p(sg_bound), _p(sg_col_ids),
+                             sg_tile_cols, sg_n_tiles, sg_rows, sg_n_cols)
     _native.check(lib.rtrec_slim_score_topk_opt(
         n_rows, _p(row_ids), _p(xb_ptr), _p(xb_col), _p(xb_val), n_items, n_cols, col_offset, _p(col_ids), _p(col_map),
         tile_cols, n_tiles, _p(tile_ptr), _p(w_col), _p(w_val), _p(dense_idx), _p(dense_val), _p(row_hdr), _p(col_rank),

@@ -1,0 +1,194 @@
+"""Segment layout of W for score_seg_kernel (csrc/score_seg.hip.h): the SPARSE-mode scoring path for a GENERAL W.
+
+A W fitted on data with item-item structure has thousands of non-empty rows (every cluster's popular items are the
+features of that cluster's columns) and its weight sits in blocks: the columns that select a row are that row's
+neighbours.  The layout makes those blocks contiguous and prices them:
+
+  * columns: the columns that hold a weight, ORDERED BY CLUSTER -- a few rounds of label propagation over the graph
+    of W (`cluster_labels*`) put columns with common features next to each other; any order gives the same scores
+    (a column's sum runs over the user's items in ascending item order whatever position the column has);
+  * tiles of T columns (T = 256 unless that makes more than 128 tiles; at most 4096) -- a wave accumulates one
+    (user, tile) at a time in T floats of LDS;
+  * rows: only items that hold a weight have one (`info[item] = (row, layout column)`); a row's entries are sorted by
+    layout column, so its SEGMENT in tile t is the range seg_ptr[row][t] .. seg_ptr[row][t + 1] of (w_col, w_val)
+    (w_col = column inside the tile);
+  * bounds: bound[row][t] = max |w| of the segment, rounded UP to bfloat16 -- sum_i |x_ui| bound[i][t] bounds every
+    score user u can have in tile t, so a tile that cannot beat the user's current (k+1)-th best is never opened.
+
+`build_seg_layout` (numpy) is the executable specification; `build_seg_layout_device` builds the same arrays with
+tensor ops from the device-resident W (tests/test_host_logic.py requires identical arrays).
+Reference path served: slim_elastic.py:707-708 (X[users] @ W) + :782-818 (_sparse_topk_indicies).
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+SG_MIN_TILE = 256
+SG_MAX_TILE = 4096
+SG_MAX_TILES = 128           # two tiles per lane of the bound registers
+SG_LPA_ITERS = 8
+_HASH_MUL = 2654435761
+
+
+def seg_tile_cols(n_cols: int) -> Optional[int]:
+    """Tile width for n_cols active columns: the smallest power of two >= 256 that needs <= 128 tiles; None when even
+    4096-column tiles are too many (> 524,288 active columns in one shard: the tiled-CSR kernel serves that)."""
+    T = SG_MIN_TILE
+    while -(-max(n_cols, 1) // T) > SG_MAX_TILES:
+        T *= 2
+    return T if T <= SG_MAX_TILE else None
+
+
+def _edge_weights_int(absw: np.ndarray) -> np.ndarray:
+    """|w| as integers in 1 .. 2**20 + 1 (relative to the largest |w|): label sums are then exact and independent of
+    the order of summation, so the host and the device builder agree bit for bit."""
+    top = float(absw.max()) if absw.size else 1.0
+    top = top if top > 0 else 1.0
+    return (absw.astype(np.float64) / top * float(1 << 20)).astype(np.int64) + 1
+
+
+def cluster_labels(rows: np.ndarray, cols: np.ndarray, vals: np.ndarray, n_items: int, iters: int = SG_LPA_ITERS) -> np.ndarray:
+    """Label propagation over the undirected graph of W (edge i -- j weighted |W[i, j]|): every node repeatedly takes the
+    label that carries the most weight among its neighbours (ties: the larger label); half of the nodes (a hash parity
+    that alternates per round) update per round, which keeps two-cycles from oscillating.  Returns int64 labels[n_items]
+    (isolated nodes keep their own id).  Deterministic; cluster_labels_device computes the same labels."""
+    rows, cols = np.asarray(rows, dtype=np.int64), np.asarray(cols, dtype=np.int64)
+    wq = _edge_weights_int(np.abs(np.asarray(vals)))
+    src, dst, w = np.concatenate([rows, cols]), np.concatenate([cols, rows]), np.concatenate([wq, wq])
+    lab = np.arange(n_items, dtype=np.int64)
+    h = (np.arange(n_items, dtype=np.int64) * _HASH_MUL) >> 15
+    bits = max(1, int(n_items - 1).bit_length())
+    for it in range(iters):
+        key = dst * n_items + lab[src]
+        o = np.argsort(key, kind="stable")
+        k, ww = key[o], w[o]
+        first = np.concatenate([[True], k[1:] != k[:-1]]) if len(k) else np.zeros(0, bool)
+        start = np.flatnonzero(first)
+        sums = np.add.reduceat(ww, start) if len(start) else np.zeros(0, np.int64)
+        gk = k[first]
+        node, l = gk // n_items, gk % n_items
+        best = np.zeros(n_items, dtype=np.int64)
+        np.maximum.at(best, node, (sums << bits) | l)
+        new = np.where(best > 0, best & ((1 << bits) - 1), lab)
+        upd = ((h + it) & 1) == 0
+        lab = np.where(upd, new, lab)
+    return lab
+
+
+def cluster_labels_device(torch, rows, cols, vals, n_items: int, iters: int = SG_LPA_ITERS):
+    """cluster_labels with tensor ops (one sort of the 2 nnz edge keys per round)."""
+    dev, i64 = rows.device, torch.int64
+    absw = vals.abs().double()
+    top = float(absw.max()) if absw.numel() else 1.0
+    top = top if top > 0 else 1.0
+    wq = (absw / top * float(1 << 20)).to(i64) + 1
+    src, dst, w = torch.cat([rows, cols]).to(i64), torch.cat([cols, rows]).to(i64), torch.cat([wq, wq])
+    lab = torch.arange(n_items, dtype=i64, device=dev)
+    h = (torch.arange(n_items, dtype=i64, device=dev) * _HASH_MUL) >> 15
+    bits = max(1, int(n_items - 1).bit_length())
+    for it in range(iters):
+        key = dst * n_items + lab[src]
+        k, o = torch.sort(key, stable=True)
+        ww = w[o]
+        gk, inv = torch.unique_consecutive(k, return_inverse=True)
+        sums = torch.zeros(gk.numel(), dtype=i64, device=dev).index_add_(0, inv, ww)       # integers: exact in any order
+        node, l = gk // n_items, gk % n_items
+        best = torch.zeros(n_items, dtype=i64, device=dev).scatter_reduce_(0, node, (sums << bits) | l, reduce="amax")
+        new = torch.where(best > 0, best & ((1 << bits) - 1), lab)
+        upd = ((h + it) & 1) == 0
+        lab = torch.where(upd, new, lab)
+    return lab
+
+
+def build_seg_layout(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, labels: Optional[np.ndarray] = None,
+                     iters: int = SG_LPA_ITERS) -> Optional[Dict[str, Any]]:
+    """Segment layout of columns [col_lo, col_hi) of W (CSC, I x I, float32 values).  labels: cluster label per item
+    (None: label propagation over the shard's own graph; np.arange(I) keeps the item-id order)."""
+    n_items = W_csc.shape[0]
+    indptr = np.asarray(W_csc.indptr, dtype=np.int64)
+    s, e = int(indptr[col_lo]), int(indptr[col_hi])
+    rows = np.asarray(W_csc.indices[s:e], dtype=np.int64)
+    vals = np.asarray(W_csc.data[s:e], dtype=np.float32)
+    cols = np.repeat(np.arange(col_lo, col_hi, dtype=np.int64), np.diff(indptr[col_lo:col_hi + 1]))
+    if rows.size == 0:
+        return None
+    active = np.unique(cols)
+    n_cols = int(active.size)
+    T = seg_tile_cols(n_cols)
+    if T is None:
+        return None
+    n_tiles = -(-n_cols // T)
+    if labels is None:
+        labels = cluster_labels(rows, cols, vals, n_items, iters)
+    order = active[np.argsort(np.asarray(labels)[active], kind="stable")]       # layout position -> item id
+    pos = np.full(n_items, -1, dtype=np.int64)
+    pos[order] = np.arange(n_cols)
+    F = np.unique(rows)
+    R = int(F.size)
+    rmap = np.full(n_items, -1, dtype=np.int64)
+    rmap[F] = np.arange(R)
+    rr, pc = rmap[rows], pos[cols]
+    key = rr * (n_tiles * T) + pc
+    o = np.argsort(key, kind="stable")
+    key = key[o]
+    if key.size >= 2 ** 31:
+        raise ValueError("W shard has more than 2**31 stored weights")
+    bnd = (np.arange(R, dtype=np.int64)[:, None] * (n_tiles * T) + np.arange(n_tiles + 1, dtype=np.int64)[None, :] * T).ravel()
+    seg_ptr = np.searchsorted(key, bnd).astype(np.int32).reshape(R, n_tiles + 1)
+    mx = np.zeros(R * SG_MAX_TILES, dtype=np.float32)
+    np.maximum.at(mx, rr * SG_MAX_TILES + pc // T, np.abs(vals))
+    up = (mx.view(np.uint32).astype(np.int64) + 0xFFFF) >> 16                    # bfloat16, rounded up
+    up = up.reshape(R, SG_MAX_TILES // 2, 2)
+    bound = (up[:, :, 0] | (up[:, :, 1] << 16)).astype(np.uint32).view(np.int32)
+    info = np.stack([rmap, pos], axis=1).astype(np.int32)
+    return dict(sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=np.ascontiguousarray(info),
+                sg_ptr=np.ascontiguousarray(seg_ptr), sg_col=(pc[o] % T).astype(np.uint16), sg_val=np.ascontiguousarray(vals[o]),
+                sg_bound=np.ascontiguousarray(bound), sg_col_ids=order.astype(np.int32), sg_nnz=int(key.size),
+                sg_segments=int(np.count_nonzero(np.diff(seg_ptr, axis=1))))
+
+
+def build_seg_layout_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int, labels=None,
+                            iters: int = SG_LPA_ITERS) -> Optional[Dict[str, Any]]:
+    """build_seg_layout for a W resident on the device as COO triples (int64 rows / cols sorted by (col, row), float32
+    vals): the same arrays as device tensors.  `labels` (an int64 device tensor, e.g. the previous layout's) skips the
+    label propagation."""
+    sel = (cols >= col_lo) & (cols < col_hi)
+    r, c, v = rows[sel], cols[sel], vals[sel]
+    if r.numel() == 0:
+        return None
+    dev, i64 = r.device, torch.int64
+    active = torch.unique(c)
+    n_cols = int(active.numel())
+    T = seg_tile_cols(n_cols)
+    if T is None:
+        return None
+    n_tiles = -(-n_cols // T)
+    if labels is None:
+        labels = cluster_labels_device(torch, r, c, v, n_items, iters)
+    order = active[torch.argsort(labels[active], stable=True)]
+    pos = torch.full((n_items,), -1, dtype=i64, device=dev)
+    pos[order] = torch.arange(n_cols, dtype=i64, device=dev)
+    F = torch.unique(r)
+    R = int(F.numel())
+    rmap = torch.full((n_items,), -1, dtype=i64, device=dev)
+    rmap[F] = torch.arange(R, dtype=i64, device=dev)
+    rr, pc = rmap[r], pos[c]
+    key = rr * (n_tiles * T) + pc
+    key, o = torch.sort(key, stable=True)
+    if int(key.numel()) >= 2 ** 31:
+        raise ValueError("W shard has more than 2**31 stored weights")
+    bnd = (torch.arange(R, dtype=i64, device=dev)[:, None] * (n_tiles * T)
+           + torch.arange(n_tiles + 1, dtype=i64, device=dev)[None, :] * T).reshape(-1)
+    seg_ptr = torch.searchsorted(key, bnd).to(torch.int32).view(R, n_tiles + 1)
+    mx = torch.zeros(R * SG_MAX_TILES, dtype=torch.float32, device=dev)
+    mx.scatter_reduce_(0, rr * SG_MAX_TILES + pc // T, v.abs(), reduce="amax")
+    up = (mx.view(torch.int32).to(i64) + 0xFFFF) >> 16
+    up = up.view(R, SG_MAX_TILES // 2, 2)
+    bound = (up[:, :, 0] | (up[:, :, 1] << 16)).to(torch.int32).contiguous()        # sign bit clear: |w| is positive
+    info = torch.stack([rmap, pos], dim=1).to(torch.int32).contiguous()
+    return dict(sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info, sg_ptr=seg_ptr.contiguous(),
+                sg_col=(pc[o] % T).to(torch.int16).contiguous(), sg_val=v[o].contiguous(), sg_bound=bound,
+                sg_col_ids=order.to(torch.int32).contiguous(), sg_nnz=int(key.numel()), sg_labels=labels)

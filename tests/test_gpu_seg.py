@@ -1,0 +1,161 @@
+"""GPU parity of the general-W scoring path (csrc/score_seg.hip.h, rtrec_amd/seg_layout.py) against the CPU oracle.
+
+Bar: ids, score bits and counts identical to oracle.recommend_batch (the restatement of slim_elastic.py:674-741 +
+:782-818) for every W -- many rows, negative weights, exact ties, users too long for the kernel's LDS lists, wide
+catalogues (tiles wider than 256), any top_k the kernel serves, with and without the column clustering."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from rtrec_amd import _native
+from rtrec_amd.engine import SlimEngine, merge_coefficients
+from rtrec_amd.synth import interaction_matrix, structured_matrix
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def random_w(I, density, seed, signed=False, n_blocks=0):
+    """A general item-item matrix: uniformly random entries, optionally concentrated in diagonal blocks."""
+    rng = np.random.default_rng(seed)
+    nnz = int(I * I * density)
+    r, c = rng.integers(0, I, nnz), rng.integers(0, I, nnz)
+    if n_blocks:
+        blk = I // n_blocks
+        inside = rng.random(nnz) < 0.8
+        c = np.where(inside, (r // blk) * blk + rng.integers(0, blk, nnz), c) % I
+    v = (rng.random(nnz).astype(np.float32) + 0.01) * (np.where(rng.random(nnz) < 0.3, -1, 1) if signed else 1)
+    W = sp.csc_matrix((v.astype(np.float32), (r, c)), shape=(I, I))
+    W.sum_duplicates()
+    W.setdiag(0)
+    W.eliminate_zeros()
+    W.sort_indices()
+    return W
+
+
+def check(eng, oracle, X, W, rows, top_k, filt, expect_path="segments"):
+    ids, sc, cnt = eng.recommend_rows(rows, top_k=top_k, filter_interacted=filt, mode=_native.TOPK_SPARSE)
+    if expect_path:
+        assert eng.last_score_path == expect_path
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], W.tocsr(), top_k=top_k, filter_interacted=filt)
+    assert np.array_equal(cnt, o_cnt)
+    bad = np.flatnonzero((ids != o_ids).any(axis=1))
+    assert bad.size == 0, f"ids differ for rows {rows[bad][:8]}: {ids[bad[0]]} vs {o_ids[bad[0]]}"
+    assert np.array_equal(bits(sc), bits(o_sc))
+
+
+@pytest.mark.parametrize("signed", [False, True])
+@pytest.mark.parametrize("top_k", [1, 10, 25, 63])
+@pytest.mark.parametrize("filt", [True, False])
+def test_seg_random_w_bit_exact(oracle, signed, top_k, filt):
+    I = 1500
+    W = random_w(I, 0.01, seed=5, signed=signed, n_blocks=12)
+    X = interaction_matrix(2500, I, 90000, seed=17)
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    check(eng, oracle, X, W, np.arange(0, X.shape[0], 2), top_k, filt)
+
+
+@pytest.mark.parametrize("cluster", [True, False])
+def test_seg_fitted_structured_w(oracle, cluster):
+    """W fitted by the oracle on clustered data (thousands of rows), all users, both column orders."""
+    U, I, K = 6000, 1200, 50
+    X = structured_matrix(U, I, 260000, seed=7, n_clusters=12)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    ptr, idx, val, _ = oracle.fit_columns(Xc, np.arange(I), nn_feature_selection=K, n_threads=8)
+    W = merge_coefficients(None, I, idx.astype(np.int64), np.repeat(np.arange(I, dtype=np.int64), np.diff(ptr)), val)
+    assert np.count_nonzero(np.diff(W.tocsr().indptr)) > 128          # beyond the feature-row kernel
+    eng = SlimEngine(device="cuda:0")
+    eng.seg_cluster = cluster
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    check(eng, oracle, X, W, np.arange(U), 10, True)
+    check(eng, oracle, X, W, np.arange(U)[::-1].copy(), 10, False)
+
+
+def test_seg_long_users_and_foreign_rows(oracle):
+    """Users with more items than the kernel's LDS lists hold (512 items / 256 rows of W): the per-tile re-read path;
+    plus rows outside the matrix in the batch (IndexError) and items newer than W."""
+    I = 2000
+    W = random_w(I, 0.006, seed=9, n_blocks=8)
+    X = interaction_matrix(900, I, 60000, seed=23).tolil()
+    rng = np.random.default_rng(3)
+    for u, n in ((5, 1500), (6, 700), (7, 300), (8, 513), (9, 257)):
+        cols = rng.choice(I, n, replace=False)
+        X[u, cols] = (rng.random(n) * 4 + 0.5).astype(np.float32)
+    X = X.tocsr().astype(np.float32)
+    X.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    check(eng, oracle, X, W, np.arange(X.shape[0]), 10, True)
+    check(eng, oracle, X, W, np.array([5, 6, 7, 8, 9, 5]), 20, False)
+    with pytest.raises(IndexError):
+        eng.recommend_rows(np.array([0, 900]), top_k=5)
+    # X has more item columns than W has rows: those items have no row and no column
+    X2 = sp.hstack([X, sp.csr_matrix(np.ones((X.shape[0], 3), dtype=np.float32))]).tocsr()
+    X2.sort_indices()
+    eng2 = SlimEngine(device="cuda:0")
+    eng2.set_interactions(None, X2, need_csc=False)
+    eng2.set_weights(W)
+    ids, sc, cnt = eng2.recommend_rows(np.arange(50), top_k=10)
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[:50], W.tocsr(), top_k=10)
+    assert eng2.last_score_path == "segments"
+    assert np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc)) and np.array_equal(cnt, o_cnt)
+
+
+def test_seg_exact_ties_go_through_the_exact_pass(oracle):
+    """Integer ratings and duplicated columns of W: exact score ties inside and at the edge of the list; the flagged rows
+    are re-scored by the first-touch kernel and come out in the reference's order."""
+    rng = np.random.default_rng(0)
+    I = 900
+    base = sp.random(I, 60, density=0.05, random_state=1, format="csc", dtype=np.float32)
+    W = sp.csc_matrix(base[:, rng.integers(0, 60, size=I)])
+    W.sort_indices()
+    assert np.count_nonzero(np.diff(W.tocsr().indptr)) > 128
+    X = interaction_matrix(700, I, 20000, seed=9, float_ratings=False)
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    for filt in (True, False):
+        check(eng, oracle, X, W, np.arange(X.shape[0]), 10, filt)
+
+
+def test_seg_wide_catalogue_uses_wider_tiles(oracle):
+    """More than 128 x 256 active columns: tiles of 512 columns."""
+    I = 40000
+    rng = np.random.default_rng(4)
+    nnz = 400000
+    r = rng.integers(0, 3000, nnz)                   # 3000 rows hold the weights
+    c = rng.integers(0, I, nnz)
+    W = sp.csc_matrix(((rng.random(nnz) + 0.05).astype(np.float32), (r, c)), shape=(I, I))
+    W.sum_duplicates()
+    W.sort_indices()
+    X = interaction_matrix(1200, I, 150000, seed=31)
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    check(eng, oracle, X, W, np.arange(X.shape[0]), 10, True)
+    lay = eng._layout(True, 10)
+    assert lay["sg"]["sg_T"] == 512 and lay["sg"]["sg_n_tiles"] <= 128
+
+
+def test_seg_small_and_empty_cases(oracle):
+    I = 400
+    W = random_w(I, 0.02, seed=2)
+    X = interaction_matrix(300, I, 5000, seed=3).tolil()
+    X[10, :] = 0                                         # a user without items
+    X = X.tocsr().astype(np.float32)
+    X.eliminate_zeros()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    check(eng, oracle, X, W, np.array([10]), 10, True)              # empty row: count 0
+    check(eng, oracle, X, W, np.array([3]), 10, True)               # one user
+    check(eng, oracle, X, W, np.arange(300), 63, True)              # k larger than most users' candidate sets
+    check(eng, oracle, X, W, np.arange(300), 64, True, expect_path="tiled")     # beyond the kernel's list: the tiled path

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Round-3 probe: fit a structured workload on the GPU, describe the W it yields (rows, row lengths, score support),
+time the scoring paths that exist for it, and save W (npz) under gpurun_out/ for layout studies on the CPU.
+
+    python tools/c3s_probe.py --workload c3s [--save gpurun_out/c3s_W.npz]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main() -> None:
+    from bench import WORKLOADS
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c3s", choices=sorted(WORKLOADS))
+    ap.add_argument("--save", default="")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--mode", default="exact")
+    args = ap.parse_args()
+    import torch
+    from rtrec_amd import _native
+    from rtrec_amd.engine import SlimEngine
+    from rtrec_amd.synth import workload_matrix
+
+    wl = WORKLOADS[args.workload]
+    U, I, K = wl["U"], wl["I"], wl["K"]
+    t0 = time.time()
+    X = workload_matrix(wl)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    print(f"[probe] {args.workload}: {U} x {I}, nnz={X.nnz}, generated in {time.time() - t0:.1f}s", flush=True)
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(Xc, X)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    d_tg, d_items, d_coef, d_count, n_iter = eng.fit_columns(np.arange(I), nn_feature_selection=K, device_out=True, mode=args.mode)
+    torch.cuda.synchronize()
+    fit_s = time.time() - t0
+    print(f"[probe] fit ({args.mode}) {fit_s:.2f}s = {X.nnz / fit_s:,.0f} interactions/s, mean sweeps {n_iter.mean():.1f}, max {n_iter.max()}",
+          flush=True)
+    eng.set_weights(eng.merge_fit(None, I, False, d_tg, d_items, d_coef, d_count))
+    W = eng.weights.to_csc(torch)
+    Wr = W.tocsr()
+    rl = np.diff(Wr.indptr)
+    cl = np.diff(W.indptr)
+    out = {"workload": args.workload, "nnz_X": int(X.nnz), "fit_s": fit_s, "W_nnz": int(W.nnz), "W_rows_nonempty": int((rl > 0).sum()),
+           "W_cols_nonempty": int((cl > 0).sum()),
+           "row_len_pct_50_90_99_100": [float(v) for v in np.percentile(rl, [50, 90, 99, 100])],
+           "gathered_entries_per_pass": float(rl[X.indices].sum())}
+    print("[probe] " + json.dumps(out), flush=True)
+    if args.save:
+        os.makedirs(os.path.dirname(args.save) or ".", exist_ok=True)
+        np.savez_compressed(args.save, indptr=W.indptr, indices=W.indices, data=W.data, n_iter=n_iter)
+    d_rows = eng.be.to_dev(np.arange(U, dtype=np.int32))
+    xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
+    for label, nrows in (("all users", U), ("16k users", 16384)):
+        for _ in range(1):
+            o = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows[:nrows], xb=xb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            o = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows[:nrows], xb=xb)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        lay = eng._layout(True, 10)
+        print(f"[probe] score {label}: {ms:.2f} ms/pass ({nrows / ms * 1e3:,.0f} users/s), layout tiles={lay['n_tiles']} x {lay['tile_cols']}, "
+              f"active cols={lay['n_cols']}, feature rows={'yes' if lay.get('fr_w') is not None else 'no'}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
