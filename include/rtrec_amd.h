@@ -308,9 +308,23 @@ typedef struct {
     const uint32_t *d_sg_bound;
     const int32_t *d_sg_col_ids;
     int32_t        sg_tile_cols, sg_n_tiles, sg_rows, sg_n_cols;
+    /* Heavy pass of the segment kernel (optional; all three or none).  A user with more items than a wave's LDS lists hold
+     * (512 items) is scored by a whole workgroup from the TILE's side:
+     *     d_sg_trow_ptr[sg_n_tiles + 1], d_sg_trow[...][4] = { item, begin, end, 0 }   the non-empty segments of tile t,
+     *                               ascending item (16-byte aligned)
+     *     d_sg_scratch              rtrec_slim_score_sg_scratch_bytes() bytes, ZERO when the call starts; the kernel
+     *                               leaves it zero (a dense ratings vector and column flags per workgroup)
+     * Without them such users are scored by the per-user wave as well, re-reading their items per tile (slow, same answer). */
+    const int32_t *d_sg_trow_ptr;
+    const int32_t *d_sg_trow;
+    void          *d_sg_scratch;
+    size_t         sg_scratch_bytes;
+    int32_t        row_order_longest_first;   /* d_row_order is sorted by row length, longest first: the heavy pass then finds
+                                     the long users at its head instead of walking all rows */
 } rtrec_score_opts;
 
 size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols);
+size_t rtrec_slim_score_sg_scratch_bytes(int32_t n_items, int32_t sg_n_tiles, int32_t sg_tile_cols);
 
 /* Bytes of scratch for rtrec_slim_score_topk. */
 size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k);

@@ -21,7 +21,7 @@ _STATUS = {0: "ok", -1: "invalid argument", -2: "unsupported parameter", -3: "wo
 
 EXPORTS = [
     "rtrec_amd_version", "rtrec_amd_last_error", "rtrec_timer_create", "rtrec_timer_read", "rtrec_timer_destroy",
-    "rtrec_slim_score_fr_scratch_bytes", "rtrec_slim_score_topk_opt", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
+    "rtrec_slim_score_fr_scratch_bytes", "rtrec_slim_score_sg_scratch_bytes", "rtrec_slim_score_topk_opt", "rtrec_slim_column_sqnorms", "rtrec_slim_fit_workspace_bytes",
     "rtrec_slim_fit_workspace_init", "rtrec_slim_fit_columns", "rtrec_slim_fit_columns_opt", "rtrec_slim_gram_workspace_bytes", "rtrec_slim_xty_workspace_bytes", "rtrec_slim_gram_matrix", "rtrec_slim_score_workspace_bytes",
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
     "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round", "rtrec_store_decay",
@@ -51,7 +51,9 @@ class ScoreOpts(C.Structure):
                 ("d_row_order", C.c_void_p), ("timer", C.c_void_p), ("diagnostics", C.c_int32), ("d_rescored", C.c_void_p), ("row_order_grouped", C.c_int32),
                 ("d_sg_info", C.c_void_p), ("d_sg_ptr", C.c_void_p), ("d_sg_col", C.c_void_p), ("d_sg_val", C.c_void_p),
                 ("d_sg_bound", C.c_void_p), ("d_sg_col_ids", C.c_void_p),
-                ("sg_tile_cols", C.c_int32), ("sg_n_tiles", C.c_int32), ("sg_rows", C.c_int32), ("sg_n_cols", C.c_int32)]
+                ("sg_tile_cols", C.c_int32), ("sg_n_tiles", C.c_int32), ("sg_rows", C.c_int32), ("sg_n_cols", C.c_int32),
+                ("d_sg_trow_ptr", C.c_void_p), ("d_sg_trow", C.c_void_p), ("d_sg_scratch", C.c_void_p), ("sg_scratch_bytes", C.c_size_t),
+                ("row_order_longest_first", C.c_int32)]
 
 
 class NativeLibraryError(RuntimeError):
@@ -93,6 +95,8 @@ def load() -> C.CDLL:
     L.rtrec_timer_destroy.argtypes = [vp]
     L.rtrec_slim_score_fr_scratch_bytes.restype = u64
     L.rtrec_slim_score_fr_scratch_bytes.argtypes = [i32, i32]
+    L.rtrec_slim_score_sg_scratch_bytes.restype = u64
+    L.rtrec_slim_score_sg_scratch_bytes.argtypes = [i32, i32, i32]
     L.rtrec_slim_column_sqnorms.restype = C.c_int
     L.rtrec_slim_column_sqnorms.argtypes = [i32, vp, vp, vp, vp]
     L.rtrec_slim_fit_workspace_bytes.restype = u64

@@ -1849,7 +1849,9 @@ bool fr_usable(const FrLayout &F, int kk) {
 struct SgLayout {
     const int2 *info = nullptr; const int *seg_ptr = nullptr; const uint16_t *w_col = nullptr; const float *w_val = nullptr;
     const uint32_t *bound = nullptr; const int *col_ids = nullptr; const int *order = nullptr;
-    int T = 0, n_tiles = 0, rows = 0, n_cols = 0;
+    int T = 0, n_tiles = 0, rows = 0, n_cols = 0, order_longest_first = 0;
+    const int *trow_ptr = nullptr; const int4 *trow = nullptr;      // heavy pass (optional, with the scratch)
+    unsigned char *scratch = nullptr; size_t scratch_bytes = 0;
 };
 bool sg_usable(const SgLayout &S, int kk) {
     if (!S.info || !S.seg_ptr || !S.w_col || !S.w_val || !S.bound || !S.col_ids) return false;
@@ -1944,15 +1946,28 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         g.kk = a.kk; g.top_k = top_k; g.filter = a.filter;
         g.out_id = d_out_ids; g.out_score = d_out_scores; g.out_aux = d_out_aux; g.out_cnt = d_out_count;
         g.flag_list = flag_list; g.flag_len = flag_len; g.queue = queue;
-        const size_t wave_lds = sg_wave_lds(SG.T);
+        const bool wide = SG.n_cols >= 0xffff || SG.rows >= 0xffff;        // the LDS lists hold 16-bit columns / rows otherwise
+        const size_t wave_lds = sg_wave_lds(SG.T, wide ? 4 : 2);
         int waves_cu = static_cast<int>((160u * 1024u) / wave_lds);
-        waves_cu = waves_cu > 32 ? 32 : waves_cu;
+        waves_cu = waves_cu > 28 ? 28 : waves_cu;             // 7 waves per SIMD: the kernel's scalar registers
         int wg_cu = waves_cu / kSgWaves;
         wg_cu = wg_cu < 1 ? 1 : wg_cu;
         const long long want = (static_cast<long long>(a.n_rows) + kSgWaves * kSgQueueChunk - 1) / (kSgWaves * kSgQueueChunk);
         const long long cap = 256ll * wg_cu;
         const unsigned grid = static_cast<unsigned>(want < cap ? (want > 0 ? want : 1) : cap);
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<4>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
+        const bool heavy = SG.trow_ptr && SG.trow && SG.scratch &&
+                           SG.scratch_bytes >= sg_heavy_scratch_bytes(a.n_items, SG.n_tiles, SG.T);
+        if (heavy) {
+            g.trow_ptr = SG.trow_ptr; g.trow = SG.trow;
+            g.xs = reinterpret_cast<float *>(SG.scratch);
+            g.fl = SG.scratch + static_cast<size_t>(kSgHeavySlots) * a.n_items * 4;
+            g.order_longest_first = (SG.order && SG.order_longest_first) ? 1 : 0;
+        }
+        // users too long for a wave's LDS lists first, one workgroup each (a percent of the rows): the launch is over
+        // at once when there are none
+        if (heavy) hipLaunchKernelGGL(score_seg_heavy_kernel, dim3(kSgHeavySlots), dim3(sg_heavy_waves(SG.T) * 64), sg_heavy_lds(SG.T), st, g);
+        if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<8, int>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<8, uint16_t>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
         sg_done = true;
     } else if (sparse) {
         const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true, a.kk);
@@ -2056,6 +2071,11 @@ extern "C" size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t 
     return fr_scratch_bytes(fr_n_tiles, fr_tile_cols);
 }
 
+extern "C" size_t rtrec_slim_score_sg_scratch_bytes(int32_t n_items, int32_t sg_n_tiles, int32_t sg_tile_cols) {
+    if (n_items <= 0 || sg_n_tiles <= 0 || sg_tile_cols <= 0) return 0;
+    return sg_heavy_scratch_bytes(n_items, sg_n_tiles, sg_tile_cols);
+}
+
 extern "C" size_t rtrec_slim_score_workspace_bytes(int32_t n_rows, int32_t n_tiles, int32_t top_k) {
     if (n_rows < 0 || n_tiles <= 0 || top_k <= 0) return 0;
     return score_ws_layout(n_rows, n_tiles, top_k).total;
@@ -2127,8 +2147,11 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
         SG.info = reinterpret_cast<const int2 *>(opts->d_sg_info); SG.seg_ptr = opts->d_sg_ptr; SG.w_col = opts->d_sg_col;
         SG.w_val = opts->d_sg_val; SG.bound = opts->d_sg_bound; SG.col_ids = opts->d_sg_col_ids;
         SG.T = opts->sg_tile_cols; SG.n_tiles = opts->sg_n_tiles; SG.rows = opts->sg_rows; SG.n_cols = opts->sg_n_cols;
-        SG.order = opts->d_row_order;
-        if (SG.n_cols != n_cols) return RTREC_ERR_INVALID_ARG;
+        SG.order = opts->d_row_order; SG.order_longest_first = opts->row_order_longest_first;
+        SG.trow_ptr = opts->d_sg_trow_ptr; SG.trow = reinterpret_cast<const int4 *>(opts->d_sg_trow);
+        SG.scratch = static_cast<unsigned char *>(opts->d_sg_scratch); SG.scratch_bytes = opts->sg_scratch_bytes;
+        if (SG.n_cols != n_cols || (reinterpret_cast<uintptr_t>(opts->d_sg_trow) & 15u) ||
+            (reinterpret_cast<uintptr_t>(opts->d_sg_scratch) & 15u)) return RTREC_ERR_INVALID_ARG;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned char *ws = static_cast<unsigned char *>(d_workspace);

@@ -42,16 +42,31 @@ struct SegArgs {
     int *out_id; float *out_score; uint32_t *out_aux; int *out_cnt;
     int *flag_list; int *flag_len;
     int *queue;
+    // long users (more items than a wave's LDS lists hold) are left to score_seg_heavy_kernel, one workgroup per user
+    int order_longest_first;   // `order` is sorted by row length, longest first: the long users are its head
+    const int *trow_ptr;       // [n_tiles + 1]: the segments of tile t, ascending item ...
+    const int4 *trow;          // ... as {item, begin, end, 0}
+    float *xs;                 // [slots][n_items] zeroed scratch: a heavy user's ratings by item (null: no heavy pass)
+    unsigned char *fl;         // [slots][n_tiles * T] zeroed scratch: 1 = layout column of one of the user's items
 };
 
 constexpr int kSgWaves = 4;          // waves per workgroup; they share nothing (no barrier in the kernel)
-constexpr int kSgCapAll = 512;       // layout columns of the user's items kept in LDS (interacted filter)
-constexpr int kSgCapRow = 256;       // (row, rating) pairs of the user's items that have a row in W kept in LDS
+constexpr int kSgCap = 512;          // items of a user a wave keeps in LDS (layout columns, rows of W, ratings); longer users: heavy pass
 constexpr int kSgQueueChunk = 4;     // users per queue claim
 constexpr int kSgMaxKk = 64;         // top_k + 1 list entries: one per lane
+constexpr int kSgHeavySlots = 512;   // workgroups (= scratch slots) of the heavy pass: two per CU
 
-__host__ __device__ constexpr size_t sg_wave_lds(int T) {
-    return static_cast<size_t>(T) * 4 + kSgCapAll * 4 + kSgCapRow * 8;
+// per wave: T accumulators, then per item a rating (float), a layout column and a row of W (IDX: uint16_t while both
+// counts stay below 65535, else int)
+__host__ __device__ constexpr size_t sg_wave_lds(int T, int idx_bytes) {
+    return static_cast<size_t>(T) * 4 + static_cast<size_t>(kSgCap) * (4 + 2 * idx_bytes);
+}
+__host__ __device__ constexpr int sg_heavy_waves(int T) { return T <= 2048 ? 16 : 8; }
+__host__ __device__ constexpr size_t sg_heavy_lds(int T) {
+    return static_cast<size_t>(sg_heavy_waves(T)) * (static_cast<size_t>(T) * 4 + 128 * 4 + 64 * 8) + 64;
+}
+__host__ __device__ constexpr size_t sg_heavy_scratch_bytes(int n_items, int n_tiles, int T) {
+    return static_cast<size_t>(kSgHeavySlots) * (static_cast<size_t>(n_items) * 4 + static_cast<size_t>(n_tiles) * T);
 }
 
 __device__ __forceinline__ float sg_wave_max(float v) {       // uniform maximum of the 64 lane values
@@ -80,18 +95,185 @@ __device__ __forceinline__ float sg_kth_lane_best(float v, int kk) {
     return tau;
 }
 
+// A user's best columns so far: lane j holds the j-th best (score, layout column); kk entries at most.
+struct SgList {
+    float ls; int lc; int n; float theta;       // theta: score of the kk-th entry once the list is full, else -inf
+};
+__device__ __forceinline__ SgList sg_list_empty() {
+    SgList L; L.ls = -__builtin_huge_valf(); L.lc = -1; L.n = 0; L.theta = -__builtin_huge_valf(); return L;
+}
+__device__ __forceinline__ void sg_list_insert(SgList &L, float sc, int col, int kk, unsigned long long kkmask) {
+    const float ninf = -__builtin_huge_valf();
+    const int lane = lane_id();
+    if (L.n >= kk && !(sc > L.theta)) return;
+    // entries that stay ahead: a higher score, or the same score and a lower layout column
+    const unsigned long long ahead = __ballot(L.ls > sc || (L.ls == sc && L.lc < col)) & kkmask;
+    const int pos = static_cast<int>(__builtin_popcountll(ahead));
+    if (pos >= kk) return;
+    const float us = fr_shift_up(L.ls, ninf);
+    const int uc = fr_shift_up(L.lc, -1);
+    if (lane > pos) { L.ls = us; L.lc = uc; }
+    else if (lane == pos) { L.ls = sc; L.lc = col; }
+    L.n = min(L.n + 1, kk);
+    L.theta = L.n >= kk ? readlane_f(L.ls, kk - 1) : ninf;
+}
+
+// Lane l holds (s, e, x) of one of the user's rows of W (ascending item order across the lanes), e > s where the row has
+// a segment in the tile: add x * w into acc[column] segment by segment, in lane order.  The first 64 entries of the next
+// GROUP segments are requested together; the updates then go out segment by segment (a segment never repeats a column,
+// LDS operations of a wave execute in program order: every column sees its addends in ascending item order).
 template <int GROUP>
+__device__ __forceinline__ void sg_accumulate(float *acc, const uint16_t *w_col, const float *w_val, int s, int e, float x) {
+    const int lane = lane_id();
+    unsigned long long live = __ballot(e > s);
+    while (live) {
+        int ss[GROUP], ee[GROUP], cc[GROUP];
+        float xx[GROUP], vv[GROUP];
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            ss[j] = 0; ee[j] = 0; xx[j] = 0.0f;
+            if (live) {
+                const int q = __builtin_ctzll(live);
+                live &= live - 1;
+                ss[j] = readlane_i(s, q);
+                ee[j] = readlane_i(e, q);
+                xx[j] = readlane_f(x, q);
+            }
+            cc[j] = -1; vv[j] = 0.0f;
+            if (ss[j] + lane < ee[j]) { cc[j] = w_col[ss[j] + lane]; vv[j] = w_val[ss[j] + lane]; }
+        }
+#pragma unroll
+        for (int j = 0; j < GROUP; ++j) {
+            if (ee[j] == ss[j]) break;
+            if (cc[j] >= 0) acc[cc[j]] = acc[cc[j]] + xx[j] * vv[j];
+            for (int ob = ss[j] + 64; ob < ee[j]; ob += 64) {       // rest of a long segment
+                const int o = ob + lane;
+                if (o < ee[j]) { const int c = w_col[o]; acc[c] = acc[c] + xx[j] * w_val[o]; }
+            }
+        }
+    }
+}
+
+// Read the tile back (4 columns per lane and step), zero it, and insert what can still enter the list: non-zero sums
+// above max(L.theta, floor) whose flag byte (optional: the user's own columns) is clear.
+__device__ __forceinline__ void sg_scan_tile(vf4 *acc4, int T, int t0, SgList &L, int kk, unsigned long long kkmask,
+                                             const unsigned char *flags, float floor) {
+    const float ninf = -__builtin_huge_valf();
+    const int lane = lane_id();
+    const vf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int c4 = lane; c4 < (T >> 2); c4 += 64) {
+        const vf4 v = acc4[c4];
+        acc4[c4] = zero4;
+        uint32_t fw = 0u;
+        if (flags) fw = *reinterpret_cast<const uint32_t *>(flags + 4 * c4);
+        bool h[4];
+        if (L.n >= kk) {
+            const float th = fmaxf(L.theta, floor);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) h[j] = v[j] != 0.0f && v[j] > th && !((fw >> (8 * j)) & 0xffu);
+        } else {
+            // list still filling: at least kk of this step's values are >= the kk-th largest lane maximum, so nothing
+            // below it can end up among the best kk
+            float lb = ninf;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lb = (v[j] != 0.0f && v[j] > lb && !((fw >> (8 * j)) & 0xffu)) ? v[j] : lb;
+            const float cut = sg_kth_lane_best(lb, kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                h[j] = v[j] != 0.0f && v[j] > floor && v[j] >= cut && !((fw >> (8 * j)) & 0xffu);       // floor >= -inf: -inf never passes
+        }
+        if (!__ballot(h[0] || h[1] || h[2] || h[3])) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned long long mj = __ballot(h[j]);
+            while (mj) {
+                const int q = __builtin_ctzll(mj);
+                mj &= mj - 1;
+                sg_list_insert(L, readlane_f(v[j], q), t0 + 4 * (c4 - lane + q) + j, kk, kkmask);
+            }
+        }
+    }
+}
+
+// The list is the answer: ids through col_ids, counts, and the row goes to the exact-tie pass when two of its leading
+// entries have equal scores.
+__device__ __forceinline__ void sg_emit(const SegArgs &a, const SgList &L, int row) {
+    const float ninf = -__builtin_huge_valf();
+    const int lane = lane_id();
+    const int n_fin = min(L.n, a.top_k);
+    if (lane < a.top_k) {
+        const long long o = static_cast<long long>(row) * a.top_k + lane;
+        const bool ok = lane < n_fin;
+        a.out_id[o] = ok ? a.col_ids[L.lc] : -1;
+        a.out_score[o] = ok ? L.ls : ninf;
+        if (a.out_aux) a.out_aux[o] = 0u;
+    }
+    const float below = fr_shift_down(L.ls, ninf);
+    const unsigned long long tie = __ballot(lane + 1 < L.n && L.ls == below);
+    if (lane == 0) {
+        a.out_cnt[row] = n_fin;
+        if (tie) a.flag_list[atomicAdd(a.flag_len, 1)] = row;
+    }
+}
+
+// B0 / B1 += |x| * bound[r][2 lane], [2 lane + 1] for every lane of the chunk that holds a row r >= 0 (eight bound rows in flight)
+__device__ __forceinline__ void sg_add_bounds(const uint32_t *bound, int r, float x, float &B0, float &B1) {
+    const int lane = lane_id();
+    unsigned long long m = __ballot(r >= 0);
+    while (m) {
+        constexpr int NB = 8;
+        int rq[NB];
+        float aq[NB];
+        uint32_t bq[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            rq[j] = -1; aq[j] = 0.0f;
+            if (m) {
+                const int q = __builtin_ctzll(m);
+                m &= m - 1;
+                rq[j] = readlane_i(r, q);
+                aq[j] = fabsf(readlane_f(x, q));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bq[j] = rq[j] >= 0 ? bound[static_cast<size_t>(rq[j]) * 64 + lane] : 0u;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            B0 = __builtin_fmaf(aq[j], __uint_as_float(bq[j] << 16), B0);
+            B1 = __builtin_fmaf(aq[j], __uint_as_float(bq[j] & 0xffff0000u), B1);
+        }
+    }
+}
+
+// The tile with the largest remaining bound: returns it (uniform) and retires it from B0 / B1; bmax <= 0: none left.
+__device__ __forceinline__ int sg_next_tile(float &B0, float &B1, float &bmax) {
+    const int lane = lane_id();
+    const float bm = fmaxf(B0, B1);
+    bmax = sg_wave_max(bm);
+    if (!(bmax > 0.0f)) return -1;
+    const int ql = static_cast<int>(__builtin_ctzll(__ballot(bm == bmax)));
+    const int which = readlane_f(B0, ql) == bmax ? 0 : 1;
+    if (lane == ql) { if (which == 0) B0 = 0.0f; else B1 = 0.0f; }
+    return 2 * ql + which;
+}
+
+template <typename IDX> struct SgNone;
+template <> struct SgNone<uint16_t> { static constexpr int value = 0xffff; };
+template <> struct SgNone<int> { static constexpr int value = -1; };
+
+template <int GROUP, typename IDX>
 __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
     const int wave = static_cast<int>(threadIdx.x) >> 6;
     const int T = a.T;
-    unsigned char *wbase = smem + static_cast<size_t>(wave) * sg_wave_lds(T);
+    unsigned char *wbase = smem + static_cast<size_t>(wave) * sg_wave_lds(T, sizeof(IDX));
     float *acc = reinterpret_cast<float *>(wbase);
     vf4 *acc4 = reinterpret_cast<vf4 *>(wbase);
-    int *lcl = reinterpret_cast<int *>(wbase + static_cast<size_t>(T) * 4);
-    int *rr = lcl + kSgCapAll;
-    float *rx = reinterpret_cast<float *>(rr + kSgCapRow);
+    float *rx = reinterpret_cast<float *>(wbase + static_cast<size_t>(T) * 4);      // rating of the j-th item that has a row in W
+    IDX *lcl = reinterpret_cast<IDX *>(rx + kSgCap);                                  // layout column of the user's j-th item
+    IDX *rr = lcl + kSgCap;                                                           // row of W of the j-th item that has one
+    constexpr int none = SgNone<IDX>::value;
     const float ninf = -__builtin_huge_valf();
     const vf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int kk = a.kk;
@@ -113,11 +295,12 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
         const bool xok = xrow >= 0 && xrow < a.n_x_rows;       // anything else scores as an empty row
         const int a0 = readfirst_i(xok ? a.xb_ptr[xrow] : 0);
         const int n_a = readfirst_i(xok ? a.xb_ptr[xrow + 1] - a0 : 0);
+        const bool in_lds = n_a <= kSgCap;
+        if (!in_lds && a.xs) continue;          // a long user: score_seg_heavy_kernel takes it, one workgroup per user
 
         // ---- 1. setup: rows of W the user rates, layout columns of its items, per-tile score bounds
         float B0 = 0.0f, B1 = 0.0f;
         int n_r = 0;
-        const bool fits = n_a <= kSgCapAll;
         for (int base = 0; base < n_a; base += 64) {
             const int idx = base + lane;
             int r = -1, lc = -1;
@@ -127,56 +310,29 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
                 x = a.xb_val[a0 + idx];
                 if (item < a.n_items) { const int2 f = a.info[item]; r = f.x; lc = f.y; }      // items newer than W have neither
             }
-            if (fits && idx < n_a) lcl[idx] = lc;
-            unsigned long long m = __ballot(r >= 0);
-            if (r >= 0) {
+            if (in_lds && idx < n_a) lcl[idx] = static_cast<IDX>(lc < 0 ? none : lc);
+            const unsigned long long m = __ballot(r >= 0);
+            if (in_lds && r >= 0) {
                 const int pos = n_r + lane_prefix(m);
-                if (pos < kSgCapRow) { rr[pos] = r; rx[pos] = x; }
+                rr[pos] = static_cast<IDX>(r);
+                rx[pos] = x;
             }
             n_r += static_cast<int>(__builtin_popcountll(m));
-            while (m) {
-                int rq[4];
-                float aq[4];
-                uint32_t bq[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    rq[j] = -1; aq[j] = 0.0f;
-                    if (m) {
-                        const int q = __builtin_ctzll(m);
-                        m &= m - 1;
-                        rq[j] = readlane_i(r, q);
-                        aq[j] = fabsf(readlane_f(x, q));
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bq[j] = rq[j] >= 0 ? a.bound[static_cast<size_t>(rq[j]) * 64 + lane] : 0u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    B0 = __builtin_fmaf(aq[j], __uint_as_float(bq[j] << 16), B0);
-                    B1 = __builtin_fmaf(aq[j], __uint_as_float(bq[j] & 0xffff0000u), B1);
-                }
-            }
+            sg_add_bounds(a.bound, r, x, B0, B1);
         }
-        const bool in_lds = fits && n_r <= kSgCapRow;        // else: the user's items are re-read from global per tile
+        // without the heavy pass a long user's items are re-read from global per tile (slow, same answer)
         const int n_ch = in_lds ? (n_r + 63) >> 6 : (n_a + 63) >> 6;
         // a computed score is a float32 sum of rounded products, the bound a float32 sum of |x| * (rounded-up max):
         // score <= B * (1 + (2 n + 2) 2^-24) with n <= n_r addends
         const float slack = 1.0f + 1e-5f + static_cast<float>(n_r) * 1.3e-7f;
 
         // ---- 2. tiles by descending bound
-        float ls = ninf;        // lane j: score of the j-th best column so far
-        int lcid = -1;          //         its layout column
-        int n_list = 0;
-        float theta = ninf;     // score of the (k+1)-th best once the list is full
+        SgList L = sg_list_empty();
         for (;;) {
-            const float bm = fmaxf(B0, B1);
-            const float bmax = sg_wave_max(bm);
-            if (!(bmax > 0.0f)) break;
-            if (n_list >= kk && bmax * slack < theta) break;
-            const int ql = static_cast<int>(__builtin_ctzll(__ballot(bm == bmax)));
-            const int which = readlane_f(B0, ql) == bmax ? 0 : 1;
-            const int t = 2 * ql + which;
-            if (lane == ql) { if (which == 0) B0 = 0.0f; else B1 = 0.0f; }
+            float bmax;
+            const int t = sg_next_tile(B0, B1, bmax);
+            if (t < 0) break;
+            if (L.n >= kk && bmax * slack < L.theta) break;
             const int t0 = t * T;
             const int ncol = min(T, a.n_cols - t0);
 
@@ -185,14 +341,13 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
                     const int idx = base + lane;
                     int lc = -1;
                     if (idx < n_a) {
-                        if (fits) lc = lcl[idx];
+                        if (in_lds) { lc = lcl[idx]; lc = lc == none ? -1 : lc; }
                         else { const int item = a.xb_col[a0 + idx]; if (item < a.n_items) lc = a.info[item].y; }
                     }
-                    lc -= t0;
+                    lc = lc < 0 ? -1 : lc - t0;
                     if (lc >= 0 && lc < ncol) acc[lc] = ninf;
                 }
             }
-
             for (int ch = 0; ch < n_ch; ++ch) {
                 const int idx = (ch << 6) + lane;
                 int r = -1;
@@ -208,94 +363,137 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
                     const int *pp = a.seg_ptr + static_cast<size_t>(r) * (a.n_tiles + 1) + t;
                     s = pp[0]; e = pp[1];
                 }
-                unsigned long long live = __ballot(e > s);
-                while (live) {
-                    // the next GROUP segments (ascending item order): their first 64 entries are requested together,
-                    // the accumulator updates then go out segment by segment
-                    int ss[GROUP], ee[GROUP], cc[GROUP];
-                    float xx[GROUP], vv[GROUP];
-#pragma unroll
-                    for (int j = 0; j < GROUP; ++j) {
-                        ss[j] = 0; ee[j] = 0; xx[j] = 0.0f;
-                        if (live) {
-                            const int q = __builtin_ctzll(live);
-                            live &= live - 1;
-                            ss[j] = readlane_i(s, q);
-                            ee[j] = readlane_i(e, q);
-                            xx[j] = readlane_f(x, q);
-                        }
-                        cc[j] = -1; vv[j] = 0.0f;
-                        if (ss[j] + lane < ee[j]) { cc[j] = a.w_col[ss[j] + lane]; vv[j] = a.w_val[ss[j] + lane]; }
-                    }
-#pragma unroll
-                    for (int j = 0; j < GROUP; ++j) {
-                        if (ee[j] == ss[j]) break;
-                        if (cc[j] >= 0) acc[cc[j]] = acc[cc[j]] + xx[j] * vv[j];
-                        for (int ob = ss[j] + 64; ob < ee[j]; ob += 64) {       // rest of a long segment
-                            const int o = ob + lane;
-                            if (o < ee[j]) { const int c = a.w_col[o]; acc[c] = acc[c] + xx[j] * a.w_val[o]; }
-                        }
-                    }
+                sg_accumulate<GROUP>(acc, a.w_col, a.w_val, s, e, x);
+            }
+            sg_scan_tile(acc4, T, t0, L, kk, kkmask, nullptr, ninf);
+        }
+        sg_emit(a, L, row);
+    }
+}
+
+// ---- heavy pass: one workgroup per long user ---------------------------------------------------------------------
+// A user with thousands of items would keep one wave busy for milliseconds (every opened tile costs a pass over its item
+// list).  Here the user's ratings are scattered once into a dense per-workgroup scratch xs[item]; a tile is then walked
+// from the TILE's side -- trow lists the rows of W that have a segment in it (ascending item), xs[item] != 0 says the
+// user rates it -- the tiles are dealt to the workgroup's waves in descending bound order, every wave keeps a list of its
+// own (the best (k+1)-th score any wave has reached is shared through LDS and prunes for all), and wave 0 merges the
+// lists.  The user's own columns are flag bytes fl[layout column], tested when a tile is read back.
+__global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = static_cast<int>(threadIdx.x) >> 6;
+    const int nw = static_cast<int>(blockDim.x) >> 6;
+    const int T = a.T;
+    const float ninf = -__builtin_huge_valf();
+    float *acc = reinterpret_cast<float *>(smem + static_cast<size_t>(wave) * T * 4);
+    vf4 *acc4 = reinterpret_cast<vf4 *>(acc);
+    float *bred = reinterpret_cast<float *>(smem + static_cast<size_t>(nw) * T * 4);      // [nw][128] partial bounds
+    float *lst_s = bred + nw * 128;                                                         // [nw][64] the waves' lists
+    int *lst_c = reinterpret_cast<int *>(lst_s + nw * 64);
+    int *shared = lst_c + nw * 64;                  // [0]: bits of the best full-list theta (> 0) any wave has reached
+    const vf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int kk = a.kk;
+    const unsigned long long kkmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
+    for (int c = lane; c < (T >> 2); c += 64) acc4[c] = zero4;
+    float *xs = a.xs + static_cast<size_t>(blockIdx.x) * a.n_items;
+    unsigned char *fl = a.fl + static_cast<size_t>(blockIdx.x) * a.n_tiles * T;
+    const int stride = static_cast<int>(blockDim.x);
+
+    // the long users are found by their length: with a longest-first work order they are its head and a workgroup
+    // leaves at the first user that is not long; without one every workgroup walks its share of the rows
+    for (int u = blockIdx.x; u < a.n_rows; u += gridDim.x) {
+        const int row = a.order ? a.order[u] : u;
+        const int xrow = a.row_ids ? a.row_ids[row] : row;
+        const bool xok = xrow >= 0 && xrow < a.n_x_rows;
+        const int a0 = readfirst_i(xok ? a.xb_ptr[xrow] : 0);
+        const int n_a = readfirst_i(xok ? a.xb_ptr[xrow + 1] - a0 : 0);
+        if (n_a <= kSgCap) {
+            if (a.order_longest_first) break;
+            continue;
+        }
+        if (threadIdx.x == 0) shared[0] = 0;
+        // ---- 1. scatter the ratings / flags, partial bounds per wave
+        float B0 = 0.0f, B1 = 0.0f;
+        for (int base = wave * 64; base < n_a; base += stride) {
+            const int idx = base + lane;
+            int r = -1;
+            float x = 0.0f;
+            if (idx < n_a) {
+                const int item = a.xb_col[a0 + idx];
+                x = a.xb_val[a0 + idx];
+                if (item < a.n_items) {
+                    const int2 f = a.info[item];
+                    r = f.x;
+                    if (r >= 0) xs[item] = x;
+                    if (a.filter && f.y >= 0) fl[f.y] = 1;
                 }
             }
+            sg_add_bounds(a.bound, r, x, B0, B1);
+        }
+        bred[wave * 128 + 2 * lane] = B0;
+        bred[wave * 128 + 2 * lane + 1] = B1;
+        __syncthreads();            // xs / fl / bred of all waves are visible (one CU, one L1)
+        B0 = 0.0f; B1 = 0.0f;
+        for (int w = 0; w < nw; ++w) { B0 += bred[w * 128 + 2 * lane]; B1 += bred[w * 128 + 2 * lane + 1]; }
+        const float slack = 1.0f + 1e-5f + static_cast<float>(n_a) * 1.3e-7f;
 
-            // read the tile back (4 columns per lane and step), zero it, keep what can enter the list
-            for (int c4 = lane; c4 < (T >> 2); c4 += 64) {
-                const vf4 v = acc4[c4];
-                acc4[c4] = zero4;
-                bool h[4];
-                if (n_list >= kk) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) h[j] = v[j] != 0.0f && v[j] > theta;
-                } else {
-                    // list still filling: at least kk of this step's values are >= the kk-th largest lane maximum,
-                    // so nothing below it can end up among the best kk
-                    float lb = ninf;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) lb = (v[j] != 0.0f && v[j] > lb) ? v[j] : lb;
-                    const float cut = sg_kth_lane_best(lb, kk);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) h[j] = v[j] != 0.0f && v[j] > ninf && v[j] >= cut;
+        // ---- 2. tiles in descending bound order, dealt to the waves
+        SgList L = sg_list_empty();
+        int rank = 0;
+        for (;;) {
+            float bmax;
+            const int t = sg_next_tile(B0, B1, bmax);
+            if (t < 0) break;
+            const int sb = *reinterpret_cast<volatile int *>(shared);
+            const float floor = sb ? __int_as_float(sb) : ninf;
+            const float th = fmaxf(L.theta, floor);
+            if (th > ninf && bmax * slack < th) break;
+            if ((rank++ % nw) != wave) continue;
+            const int t0 = t * T;
+            const int i1 = a.trow_ptr[t + 1];
+            for (int i0 = a.trow_ptr[t]; i0 < i1; i0 += 64) {
+                const int i = i0 + lane;
+                int s = 0, e = 0;
+                float x = 0.0f;
+                if (i < i1) {
+                    const int4 rec = a.trow[i];
+                    x = xs[rec.x];
+                    if (x != 0.0f) { s = rec.y; e = rec.z; }
                 }
-                if (!__ballot(h[0] || h[1] || h[2] || h[3])) continue;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned long long mj = __ballot(h[j]);
-                    while (mj) {
-                        const int q = __builtin_ctzll(mj);
-                        mj &= mj - 1;
-                        const float sc = readlane_f(v[j], q);
-                        if (n_list >= kk && !(sc > theta)) continue;
-                        const int col = t0 + 4 * (c4 - lane + q) + j;
-                        // entries that stay ahead: a higher score, or the same score and a lower layout column
-                        const unsigned long long ahead = __ballot(ls > sc || (ls == sc && lcid < col)) & kkmask;
-                        const int pos = static_cast<int>(__builtin_popcountll(ahead));
-                        if (pos >= kk) continue;
-                        const float us = fr_shift_up(ls, ninf);
-                        const int uc = fr_shift_up(lcid, -1);
-                        if (lane > pos) { ls = us; lcid = uc; }
-                        else if (lane == pos) { ls = sc; lcid = col; }
-                        n_list = min(n_list + 1, kk);
-                        theta = n_list >= kk ? readlane_f(ls, kk - 1) : ninf;
-                    }
+                sg_accumulate<4>(acc, a.w_col, a.w_val, s, e, x);
+            }
+            sg_scan_tile(acc4, T, t0, L, kk, kkmask, a.filter ? fl + t0 : nullptr, floor);
+            if (L.n >= kk && L.theta > 0.0f && lane == 0) atomicMax(shared, __float_as_int(L.theta));
+        }
+        // ---- 3. merge the waves' lists in wave 0, emit
+        lst_s[wave * 64 + lane] = (lane < L.n) ? L.ls : ninf;
+        lst_c[wave * 64 + lane] = L.lc;
+        __syncthreads();
+        if (wave == 0) {
+            for (int w = 1; w < nw; ++w) {
+                const float os = lst_s[w * 64 + lane];
+                const int oc = lst_c[w * 64 + lane];
+                unsigned long long mm = __ballot(os > ninf) & kkmask;
+                while (mm) {
+                    const int q = __builtin_ctzll(mm);
+                    mm &= mm - 1;
+                    sg_list_insert(L, readlane_f(os, q), readlane_i(oc, q), kk, kkmask);
+                }
+            }
+            sg_emit(a, L, row);
+        }
+        // ---- 4. restore the scratch invariants (all zero)
+        for (int base = wave * 64; base < n_a; base += stride) {
+            const int idx = base + lane;
+            if (idx < n_a) {
+                const int item = a.xb_col[a0 + idx];
+                if (item < a.n_items) {
+                    const int2 f = a.info[item];
+                    if (f.x >= 0) xs[item] = 0.0f;
+                    if (a.filter && f.y >= 0) fl[f.y] = 0;
                 }
             }
         }
-
-        // ---- 3. emit
-        const int n_fin = min(n_list, a.top_k);
-        if (lane < a.top_k) {
-            const long long o = static_cast<long long>(row) * a.top_k + lane;
-            const bool ok = lane < n_fin;
-            a.out_id[o] = ok ? a.col_ids[lcid] : -1;
-            a.out_score[o] = ok ? ls : ninf;
-            if (a.out_aux) a.out_aux[o] = 0u;
-        }
-        const float below = fr_shift_down(ls, ninf);
-        const unsigned long long tie = __ballot(lane + 1 < n_list && ls == below);
-        if (lane == 0) {
-            a.out_cnt[row] = n_fin;
-            if (tie) a.flag_list[atomicAdd(a.flag_len, 1)] = row;
-        }
+        __syncthreads();
     }
 }

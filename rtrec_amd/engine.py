@@ -579,7 +579,7 @@ class HipBackend:
 
     def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
                    acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None, rescored=None, row_order_grouped=False,
-                   use_sg=True):
+                   use_sg=True, use_sg_heavy=True):
         fr = lay if (use_fr and lay.get("fr_w") is not None) else {}
         sg = lay.get("sg") or {} if (use_sg and not fr) else {}
         self.ops.score_topk(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo,
@@ -596,7 +596,8 @@ class HipBackend:
                             row_order if (fr or sg) else None, int(timer), int(diagnostics), rescored, int(bool(row_order_grouped)),
                             sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_col"), sg.get("sg_val"), sg.get("sg_bound"),
                             sg.get("sg_col_ids"), int(sg.get("sg_T", 0)), int(sg.get("sg_n_tiles", 0)), int(sg.get("sg_rows", 0)),
-                            int(sg.get("sg_n_cols", 0)))
+                            int(sg.get("sg_n_cols", 0)), sg.get("sg_trow_ptr"), sg.get("sg_trow"),
+                            sg.get("sg_scratch") if use_sg_heavy else None, int(bool(sg) and row_order is not None))
 
     def decay_f32(self, raw, ts, rate: float, now: float):
         """float32(raw * rate ** ((now - ts) / 86400)) for resident arrays: rtrec_store_decay_device, plus the host's libm
@@ -684,6 +685,7 @@ class SlimEngine:
         self.fr_users_per_wave = int(os.environ.get("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
         self.use_seg_layout = os.environ.get("RTREC_AMD_SEG_LAYOUT", "1") != "0"        # A/B switch of the general-W score kernel
         self.seg_cluster = os.environ.get("RTREC_AMD_SEG_CLUSTER", "1") != "0"          # ... and of its column clustering
+        self.use_seg_heavy = os.environ.get("RTREC_AMD_SEG_HEAVY", "1") != "0"          # ... and of its workgroup-per-long-user pass
         self.last_score_path = ""     # which kernel family served the last _local_topk call (tests, bench.py)
         self._sg_labels = None        # (cluster labels of the last segment layout, n_items, nnz of W when they were computed)
 
@@ -1083,6 +1085,9 @@ class SlimEngine:
                         if sg is not None:
                             if labels is None:
                                 self._sg_labels = (sg["sg_labels"], W["n_items"], dw.nnz)
+                            # zeroed scratch of the heavy pass (long users, one workgroup each); the kernel leaves it zero
+                            nb = int(be.lib.rtrec_slim_score_sg_scratch_bytes(W["n_items"], sg["sg_n_tiles"], sg["sg_T"]))
+                            sg["sg_scratch"] = be.zeros((nb,), torch.uint8)
                             lay["sg"] = sg
             W["layouts"][key] = lay
         return W["layouts"][key]
@@ -1125,7 +1130,8 @@ class SlimEngine:
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws, timer=self.score_timer,
                           diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8), use_fr=use_fr, row_order=order,
                           rescored=self.rescored,
-                          row_order_grouped=(order is not None and use_fr and self._grouped_order(lay)), use_sg=use_sg)
+                          row_order_grouped=(order is not None and use_fr and self._grouped_order(lay)), use_sg=use_sg,
+                          use_sg_heavy=self.use_seg_heavy)
         else:
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws)

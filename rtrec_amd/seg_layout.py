@@ -144,7 +144,13 @@ def build_seg_layout(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, labels: Opt
     up = up.reshape(R, SG_MAX_TILES // 2, 2)
     bound = (up[:, :, 0] | (up[:, :, 1] << 16)).astype(np.uint32).view(np.int32)
     info = np.stack([rmap, pos], axis=1).astype(np.int32)
-    return dict(sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=np.ascontiguousarray(info),
+    # the same segments from the tile's side (heavy pass): per tile its non-empty segments, ascending item
+    sr, st = np.nonzero(np.diff(seg_ptr, axis=1))
+    o2 = np.lexsort((sr, st))
+    sr, st = sr[o2], st[o2]
+    trow = np.stack([F[sr], seg_ptr[sr, st], seg_ptr[sr, st + 1], np.zeros_like(sr)], axis=1).astype(np.int32)
+    trow_ptr = np.searchsorted(st, np.arange(n_tiles + 1)).astype(np.int32)
+    return dict(sg_trow=np.ascontiguousarray(trow).reshape(-1, 4), sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=np.ascontiguousarray(info),
                 sg_ptr=np.ascontiguousarray(seg_ptr), sg_col=(pc[o] % T).astype(np.uint16), sg_val=np.ascontiguousarray(vals[o]),
                 sg_bound=np.ascontiguousarray(bound), sg_col_ids=order.astype(np.int32), sg_nnz=int(key.size),
                 sg_segments=int(np.count_nonzero(np.diff(seg_ptr, axis=1))))
@@ -189,6 +195,12 @@ def build_seg_layout_device(torch, rows, cols, vals, n_items: int, col_lo: int, 
     up = up.view(R, SG_MAX_TILES // 2, 2)
     bound = (up[:, :, 0] | (up[:, :, 1] << 16)).to(torch.int32).contiguous()        # sign bit clear: |w| is positive
     info = torch.stack([rmap, pos], dim=1).to(torch.int32).contiguous()
-    return dict(sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info, sg_ptr=seg_ptr.contiguous(),
+    sr, st = torch.nonzero(seg_ptr[:, 1:] != seg_ptr[:, :-1], as_tuple=True)
+    o2 = torch.argsort(st * R + sr)                          # by tile, then row (= item) ascending
+    sr, st = sr[o2], st[o2]
+    trow = torch.stack([F[sr].to(torch.int32), seg_ptr[sr, st], seg_ptr[sr, st + 1], torch.zeros_like(sr, dtype=torch.int32)],
+                       dim=1).contiguous()
+    trow_ptr = torch.searchsorted(st, torch.arange(n_tiles + 1, dtype=i64, device=dev)).to(torch.int32)
+    return dict(sg_trow=trow.view(-1, 4), sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info, sg_ptr=seg_ptr.contiguous(),
                 sg_col=(pc[o] % T).to(torch.int16).contiguous(), sg_val=v[o].contiguous(), sg_bound=bound,
                 sg_col_ids=order.to(torch.int32).contiguous(), sg_nnz=int(key.numel()), sg_labels=labels)

@@ -78,23 +78,28 @@ def test_seg_fitted_structured_w(oracle, cluster):
     check(eng, oracle, X, W, np.arange(U)[::-1].copy(), 10, False)
 
 
-def test_seg_long_users_and_foreign_rows(oracle):
-    """Users with more items than the kernel's LDS lists hold (512 items / 256 rows of W): the per-tile re-read path;
-    plus rows outside the matrix in the batch (IndexError) and items newer than W."""
+@pytest.mark.parametrize("heavy_pass", [True, False])
+def test_seg_long_users_and_foreign_rows(oracle, heavy_pass):
+    """Users with more items than a wave's LDS lists hold (1024 items / 512 rows of W): the workgroup-per-user heavy pass
+    (or, without its scratch, the per-tile re-read path); plus rows outside the matrix in the batch (IndexError) and
+    items newer than W."""
     I = 2000
     W = random_w(I, 0.006, seed=9, n_blocks=8)
     X = interaction_matrix(900, I, 60000, seed=23).tolil()
     rng = np.random.default_rng(3)
-    for u, n in ((5, 1500), (6, 700), (7, 300), (8, 513), (9, 257)):
+    for u, n in ((5, 1900), (6, 1025), (7, 700), (8, 513), (9, 300), (10, 1024)):
         cols = rng.choice(I, n, replace=False)
         X[u, cols] = (rng.random(n) * 4 + 0.5).astype(np.float32)
     X = X.tocsr().astype(np.float32)
     X.sort_indices()
     eng = SlimEngine(device="cuda:0")
+    eng.use_seg_heavy = heavy_pass
     eng.set_interactions(None, X, need_csc=False)
     eng.set_weights(W)
     check(eng, oracle, X, W, np.arange(X.shape[0]), 10, True)
-    check(eng, oracle, X, W, np.array([5, 6, 7, 8, 9, 5]), 20, False)
+    check(eng, oracle, X, W, np.arange(X.shape[0]), 10, True)          # again: the heavy pass left its scratch zeroed
+    check(eng, oracle, X, W, np.array([5, 6, 7, 8, 9, 10, 5]), 20, False)
+    check(eng, oracle, X, W, np.array([5, 6, 7, 8, 9, 10, 5]), 63, True)
     with pytest.raises(IndexError):
         eng.recommend_rows(np.array([0, 900]), top_k=5)
     # X has more item columns than W has rows: those items have no row and no column

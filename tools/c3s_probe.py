@@ -60,20 +60,28 @@ def main() -> None:
     if args.save:
         os.makedirs(os.path.dirname(args.save) or ".", exist_ok=True)
         np.savez_compressed(args.save, indptr=W.indptr, indices=W.indices, data=W.data, n_iter=n_iter)
-    d_rows = eng.be.to_dev(np.arange(U, dtype=np.int32))
     xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
-    for label, nrows in (("all users", U), ("16k users", 16384)):
-        for _ in range(1):
-            o = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows[:nrows], xb=xb)
+    lens = np.diff(X.indptr)
+    sets = [("all users", np.arange(U, dtype=np.int32)), ("16k users", np.arange(16384, dtype=np.int32))]
+    for cap in (2048, 512, 256):
+        sets.append((f"users with <= {cap} items", np.flatnonzero(lens <= cap).astype(np.int32)))
+    for label, rows in sets:
+        d_rows = eng.be.to_dev(rows)
+        nrows = len(rows)
+        o = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
         torch.cuda.synchronize()
+        eng.score_timer = eng.be.timer_create()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            o = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows[:nrows], xb=xb)
+            o = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
+        kms, kn = eng.be.timer_read(eng.score_timer)
+        eng.be.timer_destroy(eng.score_timer)
+        eng.score_timer = 0
         lay = eng._layout(True, 10)
-        print(f"[probe] score {label}: {ms:.2f} ms/pass ({nrows / ms * 1e3:,.0f} users/s), layout tiles={lay['n_tiles']} x {lay['tile_cols']}, "
-              f"active cols={lay['n_cols']}, feature rows={'yes' if lay.get('fr_w') is not None else 'no'}", flush=True)
+        print(f"[probe] score {label} ({nrows}): {ms:.2f} ms/pass, kernel {kms / max(kn, 1):.3f} ms ({nrows / ms * 1e3:,.0f} users/s), "
+              f"path={eng.last_score_path}, tiled layout {lay['n_tiles']} x {lay['tile_cols']}, active cols={lay['n_cols']}", flush=True)
 
 
 if __name__ == "__main__":
