@@ -292,8 +292,9 @@ typedef struct {
      *     d_sg_col_ids[n_cols]      layout column -> item id
      *     d_sg_info[n_items][2]     item -> { its row r in the tables below or -1 (no weight in its row of W),
      *                               its layout column or -1 }     (8-byte aligned)
-     *     d_sg_ptr[sg_rows][sg_n_tiles + 1]   the entries of row r that fall into tile t are d_sg_ptr[r][t] ..
-     *                               d_sg_ptr[r][t + 1] - 1 of d_sg_col (column INSIDE the tile, ascending) / d_sg_val
+     *     d_sg_ptr[sg_rows][sg_n_tiles + 1]   the entries of row r that fall into tile t are records d_sg_ptr[r][t] ..
+     *                               d_sg_ptr[r][t + 1] - 1 of d_sg_ent[sg_nnz][2] = { column INSIDE the tile (ascending),
+     *                               float32 bits of the weight }   (8-byte aligned, sg_nnz < 2^28)
      *     d_sg_bound[sg_rows][64]   word l = bfloat16(max |w| of row r in tile 2 l) | bfloat16(... tile 2 l + 1) << 16,
      *                               each ROUNDED UP (0 for an empty segment / a tile beyond sg_n_tiles)
      * sum_i |x_ui| bound[i][t] bounds every score user u can have in tile t: the kernel opens a user's tiles in
@@ -303,8 +304,8 @@ typedef struct {
      * (csrc/score_seg.hip.h, score_seg_kernel).  d_row_order applies to this kernel as well. */
     const int32_t *d_sg_info;
     const int32_t *d_sg_ptr;
-    const uint16_t *d_sg_col;
-    const float   *d_sg_val;
+    const uint32_t *d_sg_ent;
+    int64_t        sg_nnz;
     const uint32_t *d_sg_bound;
     const int32_t *d_sg_col_ids;
     int32_t        sg_tile_cols, sg_n_tiles, sg_rows, sg_n_cols;

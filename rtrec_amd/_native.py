@@ -49,7 +49,7 @@ class ScoreOpts(C.Structure):
                 ("fr_rows", C.c_int32), ("fr_tile_cols", C.c_int32), ("fr_n_tiles", C.c_int32), ("fr_n_frags", C.c_int32),
                 ("fr_n_super", C.c_int32), ("fr_buf_bytes", C.c_int32), ("d_fr_scratch", C.c_void_p), ("fr_scratch_bytes", C.c_size_t),
                 ("d_row_order", C.c_void_p), ("timer", C.c_void_p), ("diagnostics", C.c_int32), ("d_rescored", C.c_void_p), ("row_order_grouped", C.c_int32),
-                ("d_sg_info", C.c_void_p), ("d_sg_ptr", C.c_void_p), ("d_sg_col", C.c_void_p), ("d_sg_val", C.c_void_p),
+                ("d_sg_info", C.c_void_p), ("d_sg_ptr", C.c_void_p), ("d_sg_ent", C.c_void_p), ("sg_nnz", C.c_int64),
                 ("d_sg_bound", C.c_void_p), ("d_sg_col_ids", C.c_void_p),
                 ("sg_tile_cols", C.c_int32), ("sg_n_tiles", C.c_int32), ("sg_rows", C.c_int32), ("sg_n_cols", C.c_int32),
                 ("d_sg_trow_ptr", C.c_void_p), ("d_sg_trow", C.c_void_p), ("d_sg_scratch", C.c_void_p), ("sg_scratch_bytes", C.c_size_t),

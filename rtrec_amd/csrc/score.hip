@@ -1775,6 +1775,9 @@ __global__ __launch_bounds__(64) void fr_ties_kernel(FrArgs a) {
     }
 }
 
+#ifndef SG_GROUP
+#define SG_GROUP 8
+#endif
 #include "score_seg.hip.h"
 
 template <typename ACC>
@@ -1847,14 +1850,14 @@ bool fr_usable(const FrLayout &F, int kk) {
 
 // Segment form of the shard (rtrec_score_opts.d_sg_*): SPARSE mode, float32 accumulation, top_k <= 63.
 struct SgLayout {
-    const int2 *info = nullptr; const int *seg_ptr = nullptr; const uint16_t *w_col = nullptr; const float *w_val = nullptr;
+    const int2 *info = nullptr; const int *seg_ptr = nullptr; const uint32_t *w_ent = nullptr; long long nnz = 0;
     const uint32_t *bound = nullptr; const int *col_ids = nullptr; const int *order = nullptr;
     int T = 0, n_tiles = 0, rows = 0, n_cols = 0, order_longest_first = 0;
     const int *trow_ptr = nullptr; const int4 *trow = nullptr;      // heavy pass (optional, with the scratch)
     unsigned char *scratch = nullptr; size_t scratch_bytes = 0;
 };
 bool sg_usable(const SgLayout &S, int kk) {
-    if (!S.info || !S.seg_ptr || !S.w_col || !S.w_val || !S.bound || !S.col_ids) return false;
+    if (!S.info || !S.seg_ptr || !S.w_ent || S.nnz <= 0 || S.nnz >= (1ll << 28) || !S.bound || !S.col_ids) return false;
     if (S.T < 256 || S.T > 4096 || (S.T & (S.T - 1))) return false;
     if (S.n_cols <= 0 || S.rows <= 0 || S.n_tiles != (S.n_cols + S.T - 1) / S.T || S.n_tiles > 128) return false;
     return kk >= 1 && kk <= kSgMaxKk;
@@ -1941,7 +1944,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         SegArgs g{};
         g.n_rows = a.n_rows; g.row_ids = a.row_ids; g.order = SG.order; g.n_x_rows = n_x_rows;
         g.xb_ptr = a.xb_ptr; g.xb_col = a.xb_col; g.xb_val = a.xb_val; g.n_items = a.n_items;
-        g.info = SG.info; g.seg_ptr = SG.seg_ptr; g.w_col = SG.w_col; g.w_val = SG.w_val; g.bound = SG.bound;
+        g.info = SG.info; g.seg_ptr = SG.seg_ptr; g.w_ent = SG.w_ent; g.nnz = SG.nnz; g.bound = SG.bound;
         g.col_ids = SG.col_ids; g.n_cols = SG.n_cols; g.T = SG.T; g.n_tiles = SG.n_tiles; g.R = SG.rows;
         g.kk = a.kk; g.top_k = top_k; g.filter = a.filter;
         g.out_id = d_out_ids; g.out_score = d_out_scores; g.out_aux = d_out_aux; g.out_cnt = d_out_count;
@@ -1966,8 +1969,9 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         // users too long for a wave's LDS lists first, one workgroup each (a percent of the rows): the launch is over
         // at once when there are none
         if (heavy) hipLaunchKernelGGL(score_seg_heavy_kernel, dim3(kSgHeavySlots), dim3(sg_heavy_waves(SG.T) * 64), sg_heavy_lds(SG.T), st, g);
-        if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<8, int>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<8, uint16_t>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
+        if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, int, false>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
+        else if (SG.T == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, uint16_t, true>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, uint16_t, false>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
         sg_done = true;
     } else if (sparse) {
         const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true, a.kk);
@@ -2059,6 +2063,11 @@ extern "C" void rtrec_timer_destroy(void *timer) {
 }
 
 #ifdef SCORE_PROFILE
+extern "C" int rtrec_amd_seg_profile(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_seg_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_seg_prof), z, sizeof(z)) != hipSuccess) return -4; }
+    return 0;
+}
 extern "C" int rtrec_amd_score_profile(unsigned long long *out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(rtrec::g_score_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rtrec::g_score_prof), z, sizeof(z)) != hipSuccess) return -4; }
@@ -2142,10 +2151,10 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
         if (FR.n_tiles != (n_cols + FR.tile_cols - 1) / (FR.tile_cols > 0 ? FR.tile_cols : 1)) return RTREC_ERR_INVALID_ARG;
     }
     SgLayout SG;
-    if (opts && opts->d_sg_info && opts->d_sg_val) {
+    if (opts && opts->d_sg_info && opts->d_sg_ent) {
         if (reinterpret_cast<uintptr_t>(opts->d_sg_info) & 7u) return RTREC_ERR_INVALID_ARG;
-        SG.info = reinterpret_cast<const int2 *>(opts->d_sg_info); SG.seg_ptr = opts->d_sg_ptr; SG.w_col = opts->d_sg_col;
-        SG.w_val = opts->d_sg_val; SG.bound = opts->d_sg_bound; SG.col_ids = opts->d_sg_col_ids;
+        SG.info = reinterpret_cast<const int2 *>(opts->d_sg_info); SG.seg_ptr = opts->d_sg_ptr; SG.w_ent = opts->d_sg_ent;
+        SG.nnz = opts->sg_nnz; SG.bound = opts->d_sg_bound; SG.col_ids = opts->d_sg_col_ids;
         SG.T = opts->sg_tile_cols; SG.n_tiles = opts->sg_n_tiles; SG.rows = opts->sg_rows; SG.n_cols = opts->sg_n_cols;
         SG.order = opts->d_row_order; SG.order_longest_first = opts->row_order_longest_first;
         SG.trow_ptr = opts->d_sg_trow_ptr; SG.trow = reinterpret_cast<const int4 *>(opts->d_sg_trow);

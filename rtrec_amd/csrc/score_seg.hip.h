@@ -8,7 +8,7 @@
 //
 // Layout (rtrec_amd/seg_layout.py, rtrec_score_opts.seg): the columns that hold a weight, ordered by cluster
 // (label propagation over W's graph), in tiles of T columns; per row of W its entries sorted by layout column,
-// seg_ptr[row][t] .. [t + 1] = its SEGMENT in tile t; bound[row][t] = max |w| of that segment (bfloat16, rounded up).
+// seg_ptr[row][t] .. [t + 1] = its SEGMENT in tile t ({column, weight} records); bound[row][t] = max |w| of that segment (bfloat16, rounded up).
 //
 // One wave scores one user at a time (persistent waves, users claimed longest first):
 //   1. setup: the user's items -> (row of W, layout column) by one 8-byte gather each; items that have a row are
@@ -33,8 +33,8 @@ struct SegArgs {
     int n_items;
     const int2 *info;          // [n_items] {row of W or -1, layout column or -1}
     const int *seg_ptr;        // [R][n_tiles + 1]
-    const uint16_t *w_col;     // column inside the tile
-    const float *w_val;
+    const uint32_t *w_ent;     // [nnz][2]: {column inside the tile, float32 bits of the weight}
+    long long nnz;
     const uint32_t *bound;     // [R][64]: lane l -> bfloat16 bounds of tiles 2l (low half) and 2l + 1 (high half)
     const int *col_ids;        // layout column -> item id
     int n_cols, T, n_tiles, R;
@@ -59,11 +59,11 @@ constexpr int kSgHeavySlots = 512;   // workgroups (= scratch slots) of the heav
 // per wave: T accumulators, then per item a rating (float), a layout column and a row of W (IDX: uint16_t while both
 // counts stay below 65535, else int)
 __host__ __device__ constexpr size_t sg_wave_lds(int T, int idx_bytes) {
-    return static_cast<size_t>(T) * 4 + static_cast<size_t>(kSgCap) * (4 + 2 * idx_bytes);
+    return static_cast<size_t>(T + 64) * 4 + static_cast<size_t>(kSgCap) * (4 + 2 * idx_bytes);        // + 64 junk slots
 }
 __host__ __device__ constexpr int sg_heavy_waves(int T) { return T <= 2048 ? 16 : 8; }
 __host__ __device__ constexpr size_t sg_heavy_lds(int T) {
-    return static_cast<size_t>(sg_heavy_waves(T)) * (static_cast<size_t>(T) * 4 + 128 * 4 + 64 * 8) + 64;
+    return static_cast<size_t>(sg_heavy_waves(T)) * (static_cast<size_t>(T + 64) * 4 + 128 * 4 + 64 * 8) + 64;
 }
 __host__ __device__ constexpr size_t sg_heavy_scratch_bytes(int n_items, int n_tiles, int T) {
     return static_cast<size_t>(kSgHeavySlots) * (static_cast<size_t>(n_items) * 4 + static_cast<size_t>(n_tiles) * T);
@@ -118,37 +118,110 @@ __device__ __forceinline__ void sg_list_insert(SgList &L, float sc, int col, int
     L.theta = L.n >= kk ? readlane_f(L.ls, kk - 1) : ninf;
 }
 
+// Raw buffer view of a device array (gfx9 resource word 3; offsets beyond `bytes` read as 0): loads then take a lane
+// offset register and a scalar offset, no 64-bit address arithmetic per lane.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_buffer(const void *p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, static_cast<int>(bytes > 0xfffffffcull ? 0xfffffffcull : bytes),
+                                             0x00020000);
+}
+typedef unsigned int sg_u2 __attribute__((ext_vector_type(2)));
+
+typedef unsigned int sg_u4 __attribute__((ext_vector_type(4)));
+
 // Lane l holds (s, e, x) of one of the user's rows of W (ascending item order across the lanes), e > s where the row has
-// a segment in the tile: add x * w into acc[column] segment by segment, in lane order.  The first 64 entries of the next
-// GROUP segments are requested together; the updates then go out segment by segment (a segment never repeats a column,
-// LDS operations of a wave execute in program order: every column sees its addends in ascending item order).
+// a segment in the tile: add x * w into acc[column] segment by segment, in lane order -- a segment never repeats a column
+// and the LDS operations of a wave execute in program order, so every column sees its addends in ascending item order.
+// GENERIC form (tiles wider than 256 columns): the first 64 records of the next GROUP segments are requested together,
+// the updates then go out segment by segment, a long segment 64 records at a time.
+// (Measured and dropped: a two-group software pipeline -- loads of group g + 1 in flight while group g updates -- was no
+// faster than this: the other waves of the SIMD already fill the waits.)
 template <int GROUP>
-__device__ __forceinline__ void sg_accumulate(float *acc, const uint16_t *w_col, const float *w_val, int s, int e, float x) {
+__device__ __forceinline__ void sg_accumulate(float *acc, __amdgpu_buffer_rsrc_t went, int s, int e, float x) {
     const int lane = lane_id();
+    const int lane8 = lane * 8;
+    s &= 0x7fffffff; e &= 0x7fffffff;
     unsigned long long live = __ballot(e > s);
     while (live) {
-        int ss[GROUP], ee[GROUP], cc[GROUP];
-        float xx[GROUP], vv[GROUP];
+        int ss[GROUP], len[GROUP];
+        float xx[GROUP];
+        sg_u2 ent[GROUP];
 #pragma unroll
         for (int j = 0; j < GROUP; ++j) {
-            ss[j] = 0; ee[j] = 0; xx[j] = 0.0f;
+            ss[j] = 0; len[j] = 0; xx[j] = 0.0f;
+            ent[j] = sg_u2{0u, 0u};
             if (live) {
                 const int q = __builtin_ctzll(live);
                 live &= live - 1;
                 ss[j] = readlane_i(s, q);
-                ee[j] = readlane_i(e, q);
+                len[j] = readlane_i(e, q) - ss[j];
                 xx[j] = readlane_f(x, q);
+                if (lane < len[j]) ent[j] = __builtin_amdgcn_raw_buffer_load_b64(went, lane8, ss[j] * 8, 0);
             }
-            cc[j] = -1; vv[j] = 0.0f;
-            if (ss[j] + lane < ee[j]) { cc[j] = w_col[ss[j] + lane]; vv[j] = w_val[ss[j] + lane]; }
         }
 #pragma unroll
         for (int j = 0; j < GROUP; ++j) {
-            if (ee[j] == ss[j]) break;
-            if (cc[j] >= 0) acc[cc[j]] = acc[cc[j]] + xx[j] * vv[j];
-            for (int ob = ss[j] + 64; ob < ee[j]; ob += 64) {       // rest of a long segment
-                const int o = ob + lane;
-                if (o < ee[j]) { const int c = w_col[o]; acc[c] = acc[c] + xx[j] * w_val[o]; }
+            if (len[j] == 0) break;
+            const float p = xx[j] * __uint_as_float(ent[j].y);
+            if (lane < len[j]) acc[ent[j].x] = acc[ent[j].x] + p;
+            for (int ob = 64; ob < len[j]; ob += 64) {       // rest of a long segment
+                const sg_u2 en = __builtin_amdgcn_raw_buffer_load_b64(went, lane8, (ss[j] + ob) * 8, 0);
+                if (ob + lane < len[j]) acc[en.x] = acc[en.x] + xx[j] * __uint_as_float(en.y);
+            }
+        }
+    }
+}
+
+// 256-COLUMN TILES (up to 32,768 active columns per shard: every BASELINE shape but the 500k-item one).  The loop above
+// spends most of its instructions on scalar bookkeeping (next set bit, mask updates, exec masks, address arithmetic: the
+// counters showed as many scalar as vector instructions, and one scalar unit serves the CU's four SIMDs).  Here
+//   * the lanes that hold a segment are COMPACTED to lanes 0 .. n-1 once per chunk (three ds_permute: byte offset | dense
+//     flag, entries, rating), so that segment k is read with v_readlane at the constant lane k of an unrolled loop;
+//   * a segment is at most one step: sparse (<= 64 records, one 8-byte record per lane) or dense (256 floats, 16 bytes per
+//     lane, bit 31 of its begin pointer) -- see seg_layout.py;
+//   * nothing is exec-masked: lanes beyond a sparse segment's end update a junk slot behind the tile (acc[256 + lane]),
+//     slots beyond the chunk's last segment read past the end of the buffer view (no memory access, zeros).
+// Per segment that leaves ~12 vector / LDS / memory instructions and a scalar branch (dense or sparse).
+__device__ __forceinline__ void sg_accumulate256(float *acc, __amdgpu_buffer_rsrc_t went, int s_raw, int e, float x) {
+    const int lane = lane_id();
+    const int sb = s_raw & 0x7fffffff;
+    const bool has = (e & 0x7fffffff) > sb;
+    const unsigned long long live = __ballot(has);
+    if (!live) return;
+    const int n = static_cast<int>(__builtin_popcountll(live));
+    const int dl = (has ? lane_prefix(live) : n + lane_prefix(~live)) << 2;
+    const int cs = __builtin_amdgcn_ds_permute(dl, has ? ((sb << 3) | (s_raw & static_cast<int>(0x80000000u))) : 0x7ffffff8);
+    const int cl = __builtin_amdgcn_ds_permute(dl, has ? (e & 0x7fffffff) - sb : 0);
+    const float cx = __int_as_float(__builtin_amdgcn_ds_permute(dl, __float_as_int(x)));
+    vf4 *acc4 = reinterpret_cast<vf4 *>(acc);
+    const int lane8 = lane * 8, lane16 = lane * 16;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g * 8 >= n) break;
+        sg_u4 ent[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int so = readlane_i(cs, g * 8 + j);
+            if (so < 0) ent[j] = __builtin_amdgcn_raw_buffer_load_b128(went, lane16, so & 0x7fffffff, 0);
+            else {
+                const sg_u2 t = __builtin_amdgcn_raw_buffer_load_b64(went, lane8, so, 0);
+                ent[j] = sg_u4{t.x, t.y, 0u, 0u};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int so = readlane_i(cs, g * 8 + j);
+            const float xj = readlane_f(cx, g * 8 + j);
+            if (so < 0) {
+                vf4 v = acc4[lane];
+                v.x = v.x + xj * __uint_as_float(ent[j].x);
+                v.y = v.y + xj * __uint_as_float(ent[j].y);
+                v.z = v.z + xj * __uint_as_float(ent[j].z);
+                v.w = v.w + xj * __uint_as_float(ent[j].w);
+                acc4[lane] = v;
+            } else {
+                const int ln = readlane_i(cl, g * 8 + j);
+                const int c = lane < ln ? static_cast<int>(ent[j].x) : 256 + lane;
+                acc[c] = acc[c] + xj * __uint_as_float(ent[j].y);
             }
         }
     }
@@ -217,8 +290,8 @@ __device__ __forceinline__ void sg_emit(const SegArgs &a, const SgList &L, int r
 }
 
 // B0 / B1 += |x| * bound[r][2 lane], [2 lane + 1] for every lane of the chunk that holds a row r >= 0 (eight bound rows in flight)
-__device__ __forceinline__ void sg_add_bounds(const uint32_t *bound, int r, float x, float &B0, float &B1) {
-    const int lane = lane_id();
+__device__ __forceinline__ void sg_add_bounds(__amdgpu_buffer_rsrc_t bound, int r, float x, float &B0, float &B1) {
+    const int lane4 = lane_id() * 4;
     unsigned long long m = __ballot(r >= 0);
     while (m) {
         constexpr int NB = 8;
@@ -236,7 +309,7 @@ __device__ __forceinline__ void sg_add_bounds(const uint32_t *bound, int r, floa
             }
         }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) bq[j] = rq[j] >= 0 ? bound[static_cast<size_t>(rq[j]) * 64 + lane] : 0u;
+        for (int j = 0; j < NB; ++j) bq[j] = rq[j] >= 0 ? __builtin_amdgcn_raw_buffer_load_b32(bound, lane4, rq[j] * 256, 0) : 0u;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             B0 = __builtin_fmaf(aq[j], __uint_as_float(bq[j] << 16), B0);
@@ -257,11 +330,27 @@ __device__ __forceinline__ int sg_next_tile(float &B0, float &B1, float &bmax) {
     return 2 * ql + which;
 }
 
+// Diagnostic build (-DSCORE_PROFILE): shader-clock totals per phase of score_seg_kernel, summed over all waves
+// (rtrec_amd_seg_profile; not part of the release ABI).
+#ifdef SCORE_PROFILE
+enum { SP_JOBS, SP_CLAIM, SP_ITEMS, SP_BOUNDS, SP_NEXT, SP_FILTER, SP_SEGPTR, SP_ACC, SP_SCAN, SP_EMIT, SP_N_TILES, SP_N_SEGS, SP_TOTAL, SP_COUNT };
+__device__ unsigned long long g_seg_prof[16];
+#define SP_DECL unsigned long long sp_[16] = {0}; unsigned long long sp_t_ = __builtin_amdgcn_s_memtime(); const unsigned long long sp_start_ = sp_t_;
+#define SP_MARK(slot) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sp_[slot] += n_ - sp_t_; sp_t_ = n_; }
+#define SP_ADD(slot, v) { sp_[slot] += (v); }
+#define SP_FLUSH if (lane == 0) { sp_[SP_TOTAL] = __builtin_amdgcn_s_memtime() - sp_start_; for (int q_ = 0; q_ < SP_COUNT; ++q_) atomicAdd(&g_seg_prof[q_], sp_[q_]); }
+#else
+#define SP_DECL
+#define SP_MARK(slot)
+#define SP_ADD(slot, v)
+#define SP_FLUSH
+#endif
+
 template <typename IDX> struct SgNone;
 template <> struct SgNone<uint16_t> { static constexpr int value = 0xffff; };
 template <> struct SgNone<int> { static constexpr int value = -1; };
 
-template <int GROUP, typename IDX>
+template <int GROUP, typename IDX, bool T256>
 __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -270,7 +359,7 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
     unsigned char *wbase = smem + static_cast<size_t>(wave) * sg_wave_lds(T, sizeof(IDX));
     float *acc = reinterpret_cast<float *>(wbase);
     vf4 *acc4 = reinterpret_cast<vf4 *>(wbase);
-    float *rx = reinterpret_cast<float *>(wbase + static_cast<size_t>(T) * 4);      // rating of the j-th item that has a row in W
+    float *rx = reinterpret_cast<float *>(wbase + static_cast<size_t>(T + 64) * 4);  // rating of the j-th item that has a row in W
     IDX *lcl = reinterpret_cast<IDX *>(rx + kSgCap);                                  // layout column of the user's j-th item
     IDX *rr = lcl + kSgCap;                                                           // row of W of the j-th item that has one
     constexpr int none = SgNone<IDX>::value;
@@ -279,7 +368,10 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
     const int kk = a.kk;
     const unsigned long long kkmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
     for (int c = lane; c < (T >> 2); c += 64) acc4[c] = zero4;
+    const __amdgpu_buffer_rsrc_t went = sg_buffer(a.w_ent, static_cast<size_t>(a.nnz) * 8);
+    const __amdgpu_buffer_rsrc_t bnd = sg_buffer(a.bound, static_cast<size_t>(a.R) * 256);
 
+    SP_DECL
     int w_next = 0, w_end = 0;
     for (;;) {
         if (w_next >= w_end) {
@@ -297,6 +389,7 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
         const int n_a = readfirst_i(xok ? a.xb_ptr[xrow + 1] - a0 : 0);
         const bool in_lds = n_a <= kSgCap;
         if (!in_lds && a.xs) continue;          // a long user: score_seg_heavy_kernel takes it, one workgroup per user
+        SP_MARK(SP_CLAIM) SP_ADD(SP_JOBS, 1)
 
         // ---- 1. setup: rows of W the user rates, layout columns of its items, per-tile score bounds
         float B0 = 0.0f, B1 = 0.0f;
@@ -318,7 +411,9 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
                 rx[pos] = x;
             }
             n_r += static_cast<int>(__builtin_popcountll(m));
-            sg_add_bounds(a.bound, r, x, B0, B1);
+            SP_MARK(SP_ITEMS)
+            sg_add_bounds(bnd, r, x, B0, B1);
+            SP_MARK(SP_BOUNDS)
         }
         // without the heavy pass a long user's items are re-read from global per tile (slow, same answer)
         const int n_ch = in_lds ? (n_r + 63) >> 6 : (n_a + 63) >> 6;
@@ -335,6 +430,7 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
             if (L.n >= kk && bmax * slack < L.theta) break;
             const int t0 = t * T;
             const int ncol = min(T, a.n_cols - t0);
+            SP_MARK(SP_NEXT) SP_ADD(SP_N_TILES, 1)
 
             if (a.filter) {         // the user's own columns leave the race: -inf + p = -inf
                 for (int base = 0; base < n_a; base += 64) {
@@ -348,6 +444,7 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
                     if (lc >= 0 && lc < ncol) acc[lc] = ninf;
                 }
             }
+            SP_MARK(SP_FILTER)
             for (int ch = 0; ch < n_ch; ++ch) {
                 const int idx = (ch << 6) + lane;
                 int r = -1;
@@ -363,12 +460,19 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
                     const int *pp = a.seg_ptr + static_cast<size_t>(r) * (a.n_tiles + 1) + t;
                     s = pp[0]; e = pp[1];
                 }
-                sg_accumulate<GROUP>(acc, a.w_col, a.w_val, s, e, x);
+                SP_MARK(SP_SEGPTR) SP_ADD(SP_N_SEGS, __builtin_popcountll(__ballot((e & 0x7fffffff) > (s & 0x7fffffff))))
+                if constexpr (T256) sg_accumulate256(acc, went, s, e, x);
+                else sg_accumulate<GROUP>(acc, went, s, e, x);
+                SP_MARK(SP_ACC)
             }
             sg_scan_tile(acc4, T, t0, L, kk, kkmask, nullptr, ninf);
+            SP_MARK(SP_SCAN)
         }
+        SP_MARK(SP_NEXT)
         sg_emit(a, L, row);
+        SP_MARK(SP_EMIT)
     }
+    SP_FLUSH
 }
 
 // ---- heavy pass: one workgroup per long user ---------------------------------------------------------------------
@@ -385,9 +489,9 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
     const int nw = static_cast<int>(blockDim.x) >> 6;
     const int T = a.T;
     const float ninf = -__builtin_huge_valf();
-    float *acc = reinterpret_cast<float *>(smem + static_cast<size_t>(wave) * T * 4);
+    float *acc = reinterpret_cast<float *>(smem + static_cast<size_t>(wave) * (T + 64) * 4);
     vf4 *acc4 = reinterpret_cast<vf4 *>(acc);
-    float *bred = reinterpret_cast<float *>(smem + static_cast<size_t>(nw) * T * 4);      // [nw][128] partial bounds
+    float *bred = reinterpret_cast<float *>(smem + static_cast<size_t>(nw) * (T + 64) * 4);      // [nw][128] partial bounds
     float *lst_s = bred + nw * 128;                                                         // [nw][64] the waves' lists
     int *lst_c = reinterpret_cast<int *>(lst_s + nw * 64);
     int *shared = lst_c + nw * 64;                  // [0]: bits of the best full-list theta (> 0) any wave has reached
@@ -395,6 +499,8 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
     const int kk = a.kk;
     const unsigned long long kkmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
     for (int c = lane; c < (T >> 2); c += 64) acc4[c] = zero4;
+    const __amdgpu_buffer_rsrc_t went = sg_buffer(a.w_ent, static_cast<size_t>(a.nnz) * 8);
+    const __amdgpu_buffer_rsrc_t bnd = sg_buffer(a.bound, static_cast<size_t>(a.R) * 256);
     float *xs = a.xs + static_cast<size_t>(blockIdx.x) * a.n_items;
     unsigned char *fl = a.fl + static_cast<size_t>(blockIdx.x) * a.n_tiles * T;
     const int stride = static_cast<int>(blockDim.x);
@@ -428,7 +534,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
                     if (a.filter && f.y >= 0) fl[f.y] = 1;
                 }
             }
-            sg_add_bounds(a.bound, r, x, B0, B1);
+            sg_add_bounds(bnd, r, x, B0, B1);
         }
         bred[wave * 128 + 2 * lane] = B0;
         bred[wave * 128 + 2 * lane + 1] = B1;
@@ -460,7 +566,8 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
                     x = xs[rec.x];
                     if (x != 0.0f) { s = rec.y; e = rec.z; }
                 }
-                sg_accumulate<4>(acc, a.w_col, a.w_val, s, e, x);
+                if (T == 256) sg_accumulate256(acc, went, s, e, x);
+                else sg_accumulate<8>(acc, went, s, e, x);
             }
             sg_scan_tile(acc4, T, t0, L, kk, kkmask, a.filter ? fl + t0 : nullptr, floor);
             if (L.n >= kk && L.theta > 0.0f && lane == 0) atomicMax(shared, __float_as_int(L.theta));

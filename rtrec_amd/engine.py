@@ -594,7 +594,7 @@ class HipBackend:
                             int(fr.get("fr_n_frags", 0)), int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
                             fr.get("fr_scratch"),
                             row_order if (fr or sg) else None, int(timer), int(diagnostics), rescored, int(bool(row_order_grouped)),
-                            sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_col"), sg.get("sg_val"), sg.get("sg_bound"),
+                            sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_ent"), sg.get("sg_bound"),
                             sg.get("sg_col_ids"), int(sg.get("sg_T", 0)), int(sg.get("sg_n_tiles", 0)), int(sg.get("sg_rows", 0)),
                             int(sg.get("sg_n_cols", 0)), sg.get("sg_trow_ptr"), sg.get("sg_trow"),
                             sg.get("sg_scratch") if use_sg_heavy else None, int(bool(sg) and row_order is not None))

@@ -94,7 +94,7 @@ def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val
                fr_n_frags: int, fr_n_super: int,
                fr_buf_bytes: int, fr_scratch: Optional[Tensor], row_order: Optional[Tensor], timer: int,
                diagnostics: int, rescored: Optional[Tensor], row_order_grouped: int,
-               sg_info: Optional[Tensor], sg_ptr: Optional[Tensor], sg_col: Optional[Tensor], sg_val: Optional[Tensor],
+               sg_info: Optional[Tensor], sg_ptr: Optional[Tensor], sg_ent: Optional[Tensor],
                sg_bound: Optional[Tensor], sg_col_ids: Optional[Tensor], sg_tile_cols: int, sg_n_tiles: int, sg_rows: int,
                sg_n_cols: int, sg_trow_ptr: Optional[Tensor], sg_trow: Optional[Tensor], sg_scratch: Optional[Tensor],
                row_order_longest_first: int) -> None:
@@ -105,7 +105,7 @@ def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val
                              _p(fr_tile_rows), _p(fr_tile_off), _p(fr_super_kb), _p(fr_super_tile), _p(fr_frag_tile), fr_rows,
                              fr_tile_cols, fr_n_tiles, fr_n_frags, fr_n_super, fr_buf_bytes, _p(fr_scratch), fr_scratch.numel() if fr_scratch is not None else 0,
                              _p(row_order), C.c_void_p(timer or None), diagnostics, _p(rescored), row_order_grouped,
-                             _p(sg_info), _p(sg_ptr), _p(sg_col), _p(sg_val), _p(sg_bound), _p(sg_col_ids),
+                             _p(sg_info), _p(sg_ptr), _p(sg_ent), int(sg_ent.shape[0]) if sg_ent is not None else 0, _p(sg_bound), _p(sg_col_ids),
                              sg_tile_cols, sg_n_tiles, sg_rows, sg_n_cols, _p(sg_trow_ptr), _p(sg_trow), _p(sg_scratch),
                              sg_scratch.numel() if sg_scratch is not None else 0, row_order_longest_first)
     _native.check(lib.rtrec_slim_score_topk_opt(

@@ -10,8 +10,8 @@ neighbours.  The layout makes those blocks contiguous and prices them:
   * tiles of T columns (T = 256 unless that makes more than 128 tiles; at most 4096) -- a wave accumulates one
     (user, tile) at a time in T floats of LDS;
   * rows: only items that hold a weight have one (`info[item] = (row, layout column)`); a row's entries are sorted by
-    layout column, so its SEGMENT in tile t is the range seg_ptr[row][t] .. seg_ptr[row][t + 1] of (w_col, w_val)
-    (w_col = column inside the tile);
+    layout column, so its SEGMENT in tile t is the range seg_ptr[row][t] .. seg_ptr[row][t + 1] of the 8-byte records
+    ent = {column inside the tile, float32 bits of the weight};
   * bounds: bound[row][t] = max |w| of the segment, rounded UP to bfloat16 -- sum_i |x_ui| bound[i][t] bounds every
     score user u can have in tile t, so a tile that cannot beat the user's current (k+1)-th best is never opened.
 
@@ -30,6 +30,8 @@ SG_MIN_TILE = 256
 SG_MAX_TILE = 4096
 SG_MAX_TILES = 128           # two tiles per lane of the bound registers
 SG_LPA_ITERS = 8
+SG_DENSE_MIN = 64            # 256-column tiles: a segment with more entries than this is stored as 256 floats
+SG_MAX_RECORDS = 1 << 28     # 8-byte records the kernel's buffer view addresses
 _HASH_MUL = 2654435761
 
 
@@ -144,16 +146,48 @@ def build_seg_layout(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, labels: Opt
     up = up.reshape(R, SG_MAX_TILES // 2, 2)
     bound = (up[:, :, 0] | (up[:, :, 1] << 16)).astype(np.uint32).view(np.int32)
     info = np.stack([rmap, pos], axis=1).astype(np.int32)
+    # Records.  A segment is stored either SPARSE -- its {column, weight} records, padded with one {T, +0.0} record (the junk slot behind the
+    # tile's accumulators) to an even count -- or, in 256-column tiles when it has more than 64 entries, DENSE: 256 floats (128 record slots, 0 where
+    # W[row, column] is not stored; adding x * 0 never changes a sum), flagged by bit 31 of its begin pointer.  A sparse
+    # segment of a 256-column tile therefore never exceeds one 64-lane step.
+    seg_len = np.diff(seg_ptr.astype(np.int64), axis=1)                      # [R, n_tiles]
+    dense = (seg_len > SG_DENSE_MIN) if T == SG_MIN_TILE else np.zeros_like(seg_len, dtype=bool)
+    alloc = np.where(dense, T // 2, seg_len + (seg_len & 1)).ravel()
+    start = np.zeros(alloc.size + 1, dtype=np.int64)
+    np.cumsum(alloc, out=start[1:])
+    n_rec = int(start[-1])
+    if n_rec >= SG_MAX_RECORDS:
+        return None
+    ent = np.zeros((n_rec, 2), dtype=np.int32)
+    ent[:, 0] = T                                                            # pads update the junk slot behind the tile
+    seg_of = key // T                                                        # = row * n_tiles + tile
+    rank = np.arange(key.size, dtype=np.int64) - seg_ptr[:, :-1].astype(np.int64).ravel()[seg_of]
+    col_in = (pc[o] % T).astype(np.int64)
+    vbits = vals[o].view(np.int32)
+    is_d = dense.ravel()[seg_of]
+    dst = start[seg_of[~is_d]] + rank[~is_d]
+    ent[dst, 0] = col_in[~is_d]
+    ent[dst, 1] = vbits[~is_d]
+    dbase = np.flatnonzero(dense.ravel())
+    if dbase.size:                                                           # dense blocks are all weights: clear the pad columns
+        ent.reshape(-1)[(start[dbase] * 2)[:, None] + np.arange(T)[None, :]] = 0
+    ent.reshape(-1)[start[seg_of[is_d]] * 2 + col_in[is_d]] = vbits[is_d]
+    ptr2 = np.empty((R, n_tiles + 1), dtype=np.int64)
+    ptr2[:, :-1] = start[:-1].reshape(R, n_tiles)
+    ptr2[:, -1] = start[n_tiles::n_tiles]
+    flagged = ptr2.copy()
+    flagged[:, :-1] |= dense.astype(np.int64) << 31
+    seg_ptr2 = flagged.astype(np.uint32).view(np.int32)
     # the same segments from the tile's side (heavy pass): per tile its non-empty segments, ascending item
-    sr, st = np.nonzero(np.diff(seg_ptr, axis=1))
+    sr, st = np.nonzero(seg_len)
     o2 = np.lexsort((sr, st))
     sr, st = sr[o2], st[o2]
-    trow = np.stack([F[sr], seg_ptr[sr, st], seg_ptr[sr, st + 1], np.zeros_like(sr)], axis=1).astype(np.int32)
+    trow = np.stack([F[sr].astype(np.int32), seg_ptr2[sr, st], ptr2[sr, st + 1].astype(np.int32), np.zeros(len(sr), np.int32)], axis=1)
     trow_ptr = np.searchsorted(st, np.arange(n_tiles + 1)).astype(np.int32)
-    return dict(sg_trow=np.ascontiguousarray(trow).reshape(-1, 4), sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=np.ascontiguousarray(info),
-                sg_ptr=np.ascontiguousarray(seg_ptr), sg_col=(pc[o] % T).astype(np.uint16), sg_val=np.ascontiguousarray(vals[o]),
+    return dict(sg_trow=np.ascontiguousarray(trow).reshape(-1, 4), sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R,
+                sg_n_cols=n_cols, sg_info=np.ascontiguousarray(info), sg_ptr=np.ascontiguousarray(seg_ptr2), sg_ent=ent,
                 sg_bound=np.ascontiguousarray(bound), sg_col_ids=order.astype(np.int32), sg_nnz=int(key.size),
-                sg_segments=int(np.count_nonzero(np.diff(seg_ptr, axis=1))))
+                sg_segments=int(np.count_nonzero(seg_len)), sg_dense_segments=int(dense.sum()))
 
 
 def build_seg_layout_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int, labels=None,
@@ -195,12 +229,42 @@ def build_seg_layout_device(torch, rows, cols, vals, n_items: int, col_lo: int, 
     up = up.view(R, SG_MAX_TILES // 2, 2)
     bound = (up[:, :, 0] | (up[:, :, 1] << 16)).to(torch.int32).contiguous()        # sign bit clear: |w| is positive
     info = torch.stack([rmap, pos], dim=1).to(torch.int32).contiguous()
-    sr, st = torch.nonzero(seg_ptr[:, 1:] != seg_ptr[:, :-1], as_tuple=True)
+    # records: sparse segments padded to an even count, dense 256-float blocks (see build_seg_layout)
+    sp64 = seg_ptr.to(i64)
+    seg_len = sp64[:, 1:] - sp64[:, :-1]
+    dense = (seg_len > SG_DENSE_MIN) if T == SG_MIN_TILE else torch.zeros_like(seg_len, dtype=torch.bool)
+    alloc = torch.where(dense, torch.full_like(seg_len, T // 2), seg_len + (seg_len & 1)).reshape(-1)
+    start = torch.zeros(alloc.numel() + 1, dtype=i64, device=dev)
+    torch.cumsum(alloc, 0, out=start[1:])
+    n_rec = int(start[-1])
+    if n_rec >= SG_MAX_RECORDS:
+        return None
+    ent = torch.zeros((n_rec, 2), dtype=torch.int32, device=dev)
+    ent[:, 0] = T
+    seg_of = key // T
+    rank = torch.arange(key.numel(), dtype=i64, device=dev) - sp64[:, :-1].reshape(-1)[seg_of]
+    col_in = pc[o] % T
+    vbits = v[o].contiguous().view(torch.int32)
+    is_d = dense.reshape(-1)[seg_of]
+    dst = start[seg_of[~is_d]] + rank[~is_d]
+    ent[dst, 0] = col_in[~is_d].to(torch.int32)
+    ent[dst, 1] = vbits[~is_d]
+    dbase = torch.nonzero(dense.reshape(-1)).view(-1)
+    if dbase.numel():
+        ent.view(-1)[(start[dbase] * 2)[:, None] + torch.arange(T, device=dev)[None, :]] = 0
+    ent.view(-1)[start[seg_of[is_d]] * 2 + col_in[is_d]] = vbits[is_d]
+    ptr2 = torch.empty((R, n_tiles + 1), dtype=i64, device=dev)
+    ptr2[:, :-1] = start[:-1].view(R, n_tiles)
+    ptr2[:, -1] = start[n_tiles::n_tiles]
+    flagged = ptr2.clone()
+    flagged[:, :-1] |= dense.to(i64) << 31
+    seg_ptr2 = torch.where(flagged >= 2 ** 31, flagged - 2 ** 32, flagged).to(torch.int32).contiguous()
+    sr, st = torch.nonzero(seg_len, as_tuple=True)
     o2 = torch.argsort(st * R + sr)                          # by tile, then row (= item) ascending
     sr, st = sr[o2], st[o2]
-    trow = torch.stack([F[sr].to(torch.int32), seg_ptr[sr, st], seg_ptr[sr, st + 1], torch.zeros_like(sr, dtype=torch.int32)],
-                       dim=1).contiguous()
+    trow = torch.stack([F[sr].to(torch.int32), seg_ptr2[sr, st], ptr2[sr, st + 1].to(torch.int32),
+                        torch.zeros_like(sr, dtype=torch.int32)], dim=1).contiguous()
     trow_ptr = torch.searchsorted(st, torch.arange(n_tiles + 1, dtype=i64, device=dev)).to(torch.int32)
-    return dict(sg_trow=trow.view(-1, 4), sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info, sg_ptr=seg_ptr.contiguous(),
-                sg_col=(pc[o] % T).to(torch.int16).contiguous(), sg_val=v[o].contiguous(), sg_bound=bound,
-                sg_col_ids=order.to(torch.int32).contiguous(), sg_nnz=int(key.numel()), sg_labels=labels)
+    return dict(sg_trow=trow.view(-1, 4), sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info,
+                sg_ptr=seg_ptr2, sg_ent=ent, sg_bound=bound, sg_col_ids=order.to(torch.int32).contiguous(), sg_nnz=int(key.numel()),
+                sg_labels=labels)

@@ -25,6 +25,7 @@ def main() -> None:
     ap.add_argument("--save", default="")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--mode", default="exact")
+    ap.add_argument("--only-all", action="store_true", help="time the all-users pass only (profiling runs)")
     args = ap.parse_args()
     import torch
     from rtrec_amd import _native
@@ -65,6 +66,8 @@ def main() -> None:
     sets = [("all users", np.arange(U, dtype=np.int32)), ("16k users", np.arange(16384, dtype=np.int32))]
     for cap in (2048, 512, 256):
         sets.append((f"users with <= {cap} items", np.flatnonzero(lens <= cap).astype(np.int32)))
+    if args.only_all:
+        sets = sets[:1]
     for label, rows in sets:
         d_rows = eng.be.to_dev(rows)
         nrows = len(rows)
@@ -76,6 +79,19 @@ def main() -> None:
             o = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / args.steps * 1e3
+        prof = getattr(eng.be.lib, "rtrec_amd_seg_profile", None) if os.environ.get("RTREC_AMD_LIB") else None
+        if prof is not None:          # diagnostic build (-DSCORE_PROFILE): per-phase clocks of score_seg_kernel, one more pass
+            import ctypes as C
+            prof(None, 1)
+            eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
+            torch.cuda.synchronize()
+            buf = (C.c_uint64 * 16)()
+            prof(buf, 0)
+            names = ["jobs", "claim", "items", "bounds", "next", "filter", "segptr", "acc", "scan", "emit", "n_tiles", "n_segs", "total"]
+            v = dict(zip(names, [int(x) for x in buf]))
+            tot = max(v["total"], 1)
+            print("[seg profile] " + json.dumps({k: (v[k] if k in ("jobs", "total") or k.startswith("n_") else round(v[k] / tot, 4))
+                                                 for k in names}), flush=True)
         kms, kn = eng.be.timer_read(eng.score_timer)
         eng.be.timer_destroy(eng.score_timer)
         eng.score_timer = 0
