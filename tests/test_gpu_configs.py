@@ -282,3 +282,71 @@ def test_c5_decayed_fit_similar_items_for_all_items_and_recommend(c5, oracle):
     pos = rng.choice(len(users), 3000, replace=False)
     o_ids, o_sc, o_cnt = oracle.recommend_batch(X[users[pos]], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
     assert np.array_equal(ids[pos], o_ids) and np.array_equal(cnt[pos], o_cnt) and np.array_equal(bits(sc[pos]), bits(o_sc))
+
+
+# ------------------------------------------------------------------------------------------ C3S
+# The C3 shape with item-item structure (rtrec_amd.synth.clustered_pairs: 80 item clusters, 85 % of a user's draws inside
+# its home cluster): W has thousands of non-empty rows -- the general-W scoring path (csrc/score_seg.hip.h).
+C3S = dict(U=138_493, I=26_744, draws=46_000_000, K=50, gen="clustered", clusters=80, p_in=0.85)
+
+
+@pytest.fixture(scope="module")
+def c3s():
+    from rtrec_amd.synth import workload_matrix
+    I, K = C3S["I"], C3S["K"]
+    X = workload_matrix(C3S)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(Xc, X)
+    tg, items, coef, count, n_iter = eng.fit_columns(np.arange(I), nn_feature_selection=K)
+    W = merge_coefficients(None, I, *coefficients_to_updates(tg, items, coef, count))
+    eng.set_weights(W)
+    yield dict(X=X, Xc=Xc, eng=eng, W=W, tg=tg, items=items, coef=coef, count=count, n_iter=n_iter)
+    import torch
+    del eng
+    torch.cuda.empty_cache()
+
+
+def test_c3s_fit_sampled_columns_match_oracle(c3s, oracle):
+    rng = np.random.default_rng(12)
+    I, K = C3S["I"], C3S["K"]
+    nnz = np.diff(c3s["Xc"].indptr)
+    work = np.argsort(-c3s["n_iter"] * 1.0)[:6]
+    heavy = np.argsort(-nnz)[:8]
+    active = np.flatnonzero(np.diff(c3s["W"].indptr) > 0)
+    sample = np.unique(np.concatenate([c3s["tg"][work], heavy, rng.choice(active, 40, replace=False),
+                                       rng.choice(I, 60, replace=False)]))
+    check_fit_sample(oracle, c3s["Xc"], sample, c3s["tg"], c3s["items"], c3s["coef"], c3s["count"], c3s["n_iter"], K)
+
+
+def test_c3s_recommend_all_users_segment_kernel(c3s, oracle):
+    eng, X, W, U = c3s["eng"], c3s["X"], c3s["W"], C3S["U"]
+    assert np.count_nonzero(np.diff(W.tocsr().indptr)) > 1000, "the structured workload must give W thousands of rows"
+    rows = np.arange(U)
+    ids, sc, cnt = eng.recommend_rows(rows, top_k=10, filter_interacted=True, mode=_native.TOPK_SPARSE)
+    assert eng.last_score_path == "segments"
+    check_topk_properties(ids, sc, cnt, X, W, rows, 10)
+    ids2, sc2, cnt2 = eng.recommend_rows(rows, top_k=10)
+    assert np.array_equal(ids, ids2) and np.array_equal(bits(sc), bits(sc2)) and np.array_equal(cnt, cnt2), "idempotence"
+    # the segment kernel and the tiled-CSR kernel are two implementations of the same sums: ALL rows must agree
+    eng.use_seg_layout = False
+    try:
+        ids3, sc3, cnt3 = eng.recommend_rows(rows, top_k=10)
+        assert eng.last_score_path == "tiled"
+    finally:
+        eng.use_seg_layout = True
+    assert np.array_equal(ids, ids3) and np.array_equal(bits(sc), bits(sc3)) and np.array_equal(cnt, cnt3)
+    # oracle: random users plus the longest ones (the heavy pass) and the lists just below its threshold
+    lens = np.diff(X.indptr)
+    by_len = np.argsort(-lens)
+    sample = np.unique(np.concatenate([np.random.default_rng(3).choice(U, 3000, replace=False), by_len[:300],
+                                       np.flatnonzero((lens > 400) & (lens <= 512))[:300]]))
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
+    assert np.array_equal(ids[sample], o_ids) and np.array_equal(cnt[sample], o_cnt)
+    assert np.array_equal(bits(sc[sample]), bits(o_sc))
+    for k, filt in ((25, True), (10, False), (1, True)):
+        ids4, sc4, cnt4 = eng.recommend_rows(sample[:600], top_k=k, filter_interacted=filt)
+        assert eng.last_score_path == "segments"
+        o4, s4, c4 = oracle.recommend_batch(X[sample[:600]], W.tocsr(), top_k=k, filter_interacted=filt, n_threads=CPU_THREADS)
+        assert np.array_equal(ids4, o4) and np.array_equal(cnt4, c4) and np.array_equal(bits(sc4), bits(s4))
