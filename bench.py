@@ -64,6 +64,119 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def api_leg(X, K, top_k):
+    """SURVEY 8d's API-level figures (N = 1): the reference's own `len(train) / wall(bulk_fit)` including ingest
+    (recommender.py:81,126) and `B / wall(recommend_batch)` (recommender.py:141-151) through the drop-in DataFrame API --
+    Python lists in, Python lists out, one call for all users."""
+    import contextlib
+    import io
+    import pandas as pd
+    import torch
+    from rtrec_amd import SLIM, Recommender
+    U = X.shape[0]
+    coo = X.tocoo()
+    order = np.random.default_rng(0).permutation(coo.nnz)
+    df = pd.DataFrame({"user": coo.row[order].astype(int), "item": coo.col[order].astype(int),
+                       "tstamp": 1.7e9 + np.arange(coo.nnz, dtype=float), "rating": coo.data[order].astype(float)})
+    rec = Recommender(SLIM(min_value=0, max_value=15, nn_feature_selection=K))
+    sink = io.StringIO()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(sink):
+        rec.bulk_fit(df, parallel=True)
+    torch.cuda.synchronize()
+    t_fit = time.perf_counter() - t0
+    users = list(range(U))
+    rec.recommend_batch(users[:128], top_k=top_k)
+    t0 = time.perf_counter()
+    recs = rec.recommend_batch(users, top_k=top_k)
+    t_rec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for s0 in range(0, 20000, 100):            # the reference's evaluate() asks in 100-user batches (recommender.py:163-200)
+        rec.recommend_batch(users[s0:s0 + 100], top_k=top_k)
+    t_100 = time.perf_counter() - t0
+    out = {"bulk_fit_seconds": t_fit, "bulk_fit_samples_per_sec_incl_ingest": len(df) / t_fit,
+           "recommend_batch_users": U, "recommend_batch_seconds": t_rec, "api_users_per_sec": U / t_rec,
+           "recommend_batch_100_user_calls_users_per_sec": 20000 / t_100,
+           "mean_list_length": float(np.mean([len(r) for r in recs[:5000]])),
+           "note": "Recommender(SLIM(min_value=0, max_value=15, nn_feature_selection=K)).bulk_fit(DataFrame) and one "
+                   "recommend_batch(list of all users, top_k) call: id mapping, upload of the row ids, kernels, download and "
+                   "conversion to Python lists all inside the clock"}
+    del rec, df
+    torch.cuda.empty_cache()
+    return out
+
+
+def structured_leg(args, top_k):
+    """The C3 shape with item-item structure (workload c3s) on one GPU: exact fit, layouts, all-users scoring through the
+    general-W (segment) kernel, a sample of the answers checked against the C oracle.  Part of the default line so that the
+    driver-visible record does not rest on the popularity-only generator alone."""
+    import torch
+    from rtrec_amd import _native
+    from rtrec_amd.engine import SlimEngine
+    from rtrec_amd.synth import workload_matrix
+    wl = WORKLOADS["c3s"]
+    U, I, K = wl["U"], wl["I"], wl["K"]
+    X = workload_matrix(wl, seed=20251003, float_ratings=True)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    eng = SlimEngine(device="cuda:0", tile_cols=args.tile_cols)
+    eng.set_interactions(Xc, X)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    d_tg, d_items, d_coef, d_count, n_iter = eng.fit_columns(np.arange(I), nn_feature_selection=K, device_out=True)
+    torch.cuda.synchronize()
+    fit_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng.set_weights(eng.merge_fit(None, I, False, d_tg, d_items, d_coef, d_count))
+    lay = eng._layout(compact=True, top_k=top_k)
+    torch.cuda.synchronize()
+    to_score_s = time.perf_counter() - t0
+    d_rows = eng.be.to_dev(np.arange(U, dtype=np.int32))
+    xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
+    step = lambda: eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    eng.score_timer = eng.be.timer_create()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kms, kn = eng.be.timer_read(eng.score_timer)
+    eng.be.timer_destroy(eng.score_timer)
+    eng.score_timer = 0
+    W = eng.weights.to_csc(torch)
+    Wr = W.tocsr()
+    row_nnz_w = np.diff(Wr.indptr).astype(np.float64)
+    gathered = float(row_nnz_w[X.indices].sum())
+    algo_bytes = 8.0 * X.nnz + 8.0 * gathered + 8.0 * top_k * U + 4.0 * (U + 1)
+    res = {"workload": f"c3s: {wl['desc']}", "n_users": U, "n_items": I, "nnz": int(X.nnz),
+           "fit_seconds": fit_s, "fit_interactions_per_sec": X.nnz / fit_s, "mean_sweeps": float(n_iter.mean()),
+           "W_nnz": int(W.nnz), "w_rows": int(np.count_nonzero(row_nnz_w)), "active_columns": int(lay["n_cols"]),
+           "to_score_ms": to_score_s * 1e3, "score_path": eng.last_score_path,
+           "ms_per_step": dt / args.steps * 1e3, "users_per_sec": U * args.steps / dt, "cold_step_ms": cold_ms,
+           "kernel_ms_avg": kms / max(kn, 1),
+           "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_bytes / (kms / max(kn, 1) * 1e-3) / 1e9,
+           "algorithmic_frac_of_hbm_peak": algo_bytes / (kms / max(kn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "topk_ids_crc32": zlib.crc32(out[0].cpu().numpy().tobytes())}
+    if not args.no_cpu_baseline:
+        from oracle import slim_oracle as so
+        rows_s = np.sort(np.random.default_rng(7).choice(U, 1024, replace=False))
+        o_ids, o_sc, o_cnt = so.recommend_batch(X[rows_s], Wr, top_k=top_k, n_threads=max(1, min(16, len(os.sched_getaffinity(0)))))
+        res["oracle_sample_ids_identical"] = bool(np.array_equal(o_ids, out[0].cpu().numpy()[rows_s])
+                                                  and np.array_equal(o_sc.view(np.uint32), out[1].cpu().numpy()[rows_s].view(np.uint32)))
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -83,6 +196,10 @@ def main() -> None:
                          "per user, not per column, so dividing the users is what divides the work (DESIGN.md section 6); the "
                          "other division is timed right after and reported as `alt_sharding`")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget per cpu_baseline leg (4 legs)")
+    ap.add_argument("--no-structured", action="store_true",
+                    help="skip the `structured` leg of the default (c3) line: the same shape with item-item structure (c3s), "
+                         "fit + all-users scoring through the general-W kernel")
+    ap.add_argument("--no-api", action="store_true", help="skip the `api` leg (Recommender.bulk_fit / recommend_batch through the DataFrame API)")
     args = ap.parse_args()
     if args.score_shard == "auto":
         args.score_shard = "rows"
@@ -247,6 +364,23 @@ def main() -> None:
         # final lists; or, with --score-shard rows, this rank's slice of the users against all of W.
         return eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
 
+    # Honest step accounting: the first pass after a new X / W pays for the work order of the rows
+    # (SlimEngine._row_order: an index of X for the layout in use, cached afterwards) -- timed here on its own and as
+    # part of the first ("cold") step; the K timed steps below reuse the cached order.
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    out = step()
+    torch.cuda.synchronize()
+    cold_step_ms = (time.perf_counter() - t1) * 1e3
+    row_order_ms = None
+    if world == 1:
+        lay0 = eng._layout(True, top_k)
+        eng._X.pop("_orders", None)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng._row_order(d_rows, U, xb, lay0)
+        torch.cuda.synchronize()
+        row_order_ms = (time.perf_counter() - t1) * 1e3
     for _ in range(args.warmup):
         out = step()
     lib = eng.be.lib
@@ -418,7 +552,61 @@ def main() -> None:
                              "note": "W slices staged into LDS once per 64-user job (once per workgroup when resident) + the user rows"}}
             return bounds, kernel_name
 
-    if fr is not None and eng.use_feature_rows:
+    def segment_model():
+            """score_seg_kernel (general W): what it executes is estimated on a sample of users from the layout itself -- the
+            tiles a user must open (score bound >= its final (k+1)-th best score: a lower bound of what the kernel opens, which
+            learns that threshold as it goes) and the 8-byte records of the user's segments in them."""
+            sg = lay["sg"]
+            T, nt = int(sg["sg_T"]), int(sg["sg_n_tiles"])
+            info = sg["sg_info"].cpu().numpy()
+            ptr = sg["sg_ptr"].cpu().numpy().view(np.uint32).astype(np.int64) & 0x7fffffff
+            b = sg["sg_bound"].cpu().numpy().view(np.uint32)
+            Bm = np.empty((b.shape[0], 128), np.float32)
+            Bm[:, 0::2] = (b << 16).view(np.float32)
+            Bm[:, 1::2] = (b & 0xffff0000).view(np.float32)
+            rec = np.diff(ptr, axis=1).astype(np.float64)                           # records per (row, tile)
+            rs = np.random.default_rng(5)
+            Xall = X if n_scored == U else Xs
+            us = np.sort(rs.choice(n_scored, min(3000, n_scored), replace=False))
+            Xu = Xall[us]
+            sc_u = out[1].cpu().numpy()[us if n_scored == U else np.arange(rank, U, world)[us]]
+            theta = np.where(np.isfinite(sc_u[:, -1]), sc_u[:, -1], -np.inf)        # k-th best score (the (k+1)-th is <= it)
+            rows_u = info[:, 0][Xu.indices]
+            ok = rows_u >= 0
+            ui = np.repeat(np.arange(Xu.shape[0]), np.diff(Xu.indptr))
+            Bu = np.zeros((Xu.shape[0], 128))
+            np.add.at(Bu, ui[ok], np.abs(Xu.data[ok])[:, None] * Bm[rows_u[ok]])
+            need = (Bu[:, :nt] >= theta[:, None]) & (Bu[:, :nt] > 0)
+            Ru = np.zeros((Xu.shape[0], nt))
+            np.add.at(Ru, ui[ok], rec[rows_u[ok]])
+            scale = n_scored / Xu.shape[0]
+            rec_bytes = 8.0 * float((Ru * need).sum()) * scale
+            bound_bytes = 256.0 * float(ok.sum()) * scale
+            nnz_s = nnz if n_scored == U else int(Xs.nnz)
+            l2_bytes = rec_bytes + bound_bytes + (8.0 + 8.0) * nnz_s + 8.0 * float(ok.sum()) * scale * float(need.sum(1).mean())
+            name = "score_seg_kernel<8, unsigned short, true> (+ score_seg_heavy_kernel for users with more than 512 items)"
+            bounds = {"hbm_algorithmic": {"achieved": algo_bytes / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": algo_bytes,
+                                          "note": "SURVEY 8d: 8 B per (user item, stored weight of its row of W) + user rows + outputs, over the "
+                                                  "kernels' time.  W (a few MB) is served by L2 and the kernel skips every tile whose score "
+                                                  "bound cannot reach the user's list, so fewer bytes than this move: a rate of the path's "
+                                                  "algorithmic work against the HBM peak, not DRAM traffic"},
+                      "l2": {"achieved": l2_bytes / kern_s / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s",
+                             "frac": l2_bytes / kern_s / 1e9 / L2_PEAK_GBS, "bytes_per_launch": l2_bytes,
+                             "tiles_opened_per_user_at_least": float(need.sum(1).mean()), "tiles": nt, "tile_cols": T,
+                             "note": "estimate from a 3,000-user sample: records of the segments in the tiles a user must open, its bound "
+                                     "rows, segment pointers and its own row"}}
+            return bounds, name
+
+    score_path = eng.last_score_path
+    if score_path == "segments" and lay.get("sg") is not None:
+        try:
+            bounds, kernel_name = segment_model()
+        except Exception as exc:
+            log(f"[bench] segment bounds model failed ({exc!r}); falling back to the tiled-CSR model")
+            bounds, kernel_name = tiled_model()
+            kernel_name = "score_seg_kernel"
+    elif fr is not None and eng.use_feature_rows:
         try:
             bounds, kernel_name = feature_row_model()
         except Exception as exc:      # the model is bookkeeping: it must never cost the measurement
@@ -430,10 +618,15 @@ def main() -> None:
     bounds["hbm"] = {"achieved": compulsory_hbm / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": compulsory_hbm / kern_s / 1e9 / HBM_PEAK_GBS, "compulsory_bytes_per_launch": compulsory_hbm,
                      "note": "user rows + outputs: the only bytes that must come from / go to HBM"}
+    if "valu" in bounds:        # feature-row kernel: priced on USEFUL flops (2 per gathered W entry), not on the zero padding inside blocks
+        useful = bounds["valu"]["useful_flops_per_launch"] / kern_s / 1e12
+        bounds["valu"].update(block_flops_frac=bounds["valu"]["frac"], achieved=useful, frac=useful / VALU_PEAK_TFLOPS)
     bound = max(bounds, key=lambda k: bounds[k]["frac"])        # the bound the kernel is closest to
     algorithmic = {"bytes_per_launch": algo_bytes, "GBps": algo_bytes / kern_s / 1e9,
-                   "note": "SURVEY 8d figure (8 B per gathered W entry); it prices W entries that never reach DRAM, so it "
-                           "is NOT a fraction of any hardware limit and is kept for continuity with round 1 only"}
+                   "frac_of_hbm_peak": algo_bytes / kern_s / 1e9 / HBM_PEAK_GBS,
+                   "exceeds_hbm_peak": bool(algo_bytes / kern_s / 1e9 > HBM_PEAK_GBS),
+                   "note": "SURVEY 8d figure (8 B per gathered W entry); it prices W entries that never reach DRAM (W stays in L2 / LDS "
+                           "and most of it is pruned), so where it exceeds the peak it is NOT a physical fraction of any hardware limit"}
 
     # same value for every --gpus N: the sharded path returns the unsharded answer
     topk_crc = zlib.crc32(out[0].cpu().numpy().tobytes()) if rank == 0 else 0
@@ -481,7 +674,9 @@ def main() -> None:
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['desc']}", "n_users": U, "n_items": I, "nnz": nnz,
                    "nn_feature_selection": K, "top_k": top_k, "tile_cols": lay["tile_cols"], "n_tiles": lay["n_tiles"],
-                   "active_columns": lay["n_cols"], "w_rows": (fr["fr_rows"] if fr is not None else None),
+                   "active_columns": lay["n_cols"],
+                   "w_rows": (fr["fr_rows"] if fr is not None else (int(lay["sg"]["sg_rows"]) if lay.get("sg") else None)),
+                   "score_layout": ("feature rows" if fr is not None else "segments" if lay.get("sg") else "tiled CSR"),
                    "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
                                    else f"user-row shard x{world}, W replicated")},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend, "alt_sharding": alt_sharding,
@@ -498,10 +693,15 @@ def main() -> None:
                              "note": "rank 0's columns; compulsory bytes only (SURVEY 8d): the coordinate-descent sweeps "
                                      "re-read the K feature columns and stream the per-target residual, which is what "
                                      "`traffic` (PMC, profiles/) measures"}},
-        "roofline": {"kernel": kernel_name, "bound": bound, "achieved": best["achieved"], "peak": best["peak"],
+        "roofline": {"kernel": kernel_name, "bound": ("hbm" if bound.startswith("hbm") else bound), "achieved": best["achieved"], "peak": best["peak"],
                      "unit": best["unit"], "frac": best["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_vs_compulsory": (traffic / compulsory_hbm if traffic else None),
                      "kernel_ms_avg": kern_ms, "launches": int(n_launch.value), "bounds": bounds,
-                     "algorithmic": algorithmic, "counters": counters},
+                     "algorithmic": algorithmic, "counters": counters, "score_path": score_path},
+        "step_accounting": {"cold_step_ms": cold_step_ms, "row_order_ms": row_order_ms, "warm_ms_per_step": ms_per_step,
+                            "note": "cold = the first pass after a new X / W: it builds the work order of the rows (an index of X for the "
+                                    "layout in use: argsort by row length, or by feature-row pattern for the feature-row kernel), which the "
+                                    "timed steps reuse; row_order_ms is that build alone.  The layouts themselves are fit.to_score.layouts_ms"},
     }
 
     # ------------------------------------------------------------------ streaming leg (SURVEY 8 row S1 / BASELINE config 4 pattern)
@@ -510,6 +710,36 @@ def main() -> None:
         from stream_bench import SHAPES, run_stream
         if args.workload in ("c2", "c3") and args.workload in SHAPES:      # the c4 bulk load alone takes minutes
             line["streaming"] = run_stream(args.workload, batches=args.stream_batches, fit_modes=("exact", "gram"), log=log)
+
+    # ------------------------------------------------------------------ API-level figures and the structured workload
+    if world == 1 and not args.no_api and args.workload != "c4":          # (c4: 93 M DataFrame rows take minutes to ingest)
+        try:
+            line["api"] = api_leg(X, K, top_k)
+            log(f"[bench] api: bulk_fit {line['api']['bulk_fit_seconds']:.2f}s ({line['api']['bulk_fit_samples_per_sec_incl_ingest']:,.0f} samples/s "
+                f"incl. ingest), recommend_batch(all users) {line['api']['api_users_per_sec']:,.0f} users/s")
+        except Exception as exc:
+            log(f"[bench] api leg failed: {exc!r}")
+            line["api"] = {"error": repr(exc)}
+    if world == 1 and args.workload == "c3" and not args.no_structured:
+        try:
+            line["structured"] = structured_leg(args, top_k)
+            log(f"[bench] structured (c3s): fit {line['structured']['fit_seconds']:.2f}s, score {line['structured']['ms_per_step']:.2f} ms/step "
+                f"({line['structured']['users_per_sec']:,.0f} users/s) through {line['structured']['score_path']}")
+        except Exception as exc:
+            log(f"[bench] structured leg failed: {exc!r}")
+            line["structured"] = {"error": repr(exc)}
+    if world == 1 and args.workload in ("c2", "small", "smalls") and not args.no_fast_fit:
+        # the reference's DEFAULT model has no feature selection (nn_feature_selection=None, slim_elastic.py:182-190): every
+        # item is a feature of every target (reported for C1-C2)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        tg_a, items_a, coef_a, count_a, n_iter_a = eng.fit_columns(np.arange(I), nn_feature_selection=None)
+        torch.cuda.synchronize()
+        allf_s = time.perf_counter() - t1
+        line["fit"]["all_features"] = {"seconds": allf_s, "interactions_per_sec": nnz / allf_s, "columns_per_sec": I / allf_s,
+                                       "W_nnz": int(count_a.sum()), "mean_sweeps": float(n_iter_a.mean()),
+                                       "note": "nn_feature_selection=None: fit_columns_kernel<true>, exact mode"}
+        log(f"[bench] fit (K=None): {allf_s:.2f}s ({nnz / allf_s:,.0f} interactions/s)")
 
     # ------------------------------------------------------------------ cpu_baseline: the C oracle on this host,
     # one thread and all cores (POSIX threads over users / item columns: the reference's own parallel axis,
