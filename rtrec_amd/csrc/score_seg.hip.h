@@ -54,14 +54,22 @@ constexpr int kSgWaves = 4;          // waves per workgroup; they share nothing 
 constexpr int kSgCap = 512;          // items of a user a wave keeps in LDS (layout columns, rows of W, ratings); longer users: heavy pass
 constexpr int kSgQueueChunk = 4;     // users per queue claim
 constexpr int kSgMaxKk = 64;         // top_k + 1 list entries: one per lane
-constexpr int kSgHeavySlots = 512;   // workgroups (= scratch slots) of the heavy pass: two per CU
+#ifndef SG_HEAVY_SLOTS
+#define SG_HEAVY_SLOTS 1024
+#endif
+#ifndef SG_HEAVY_WAVES
+#define SG_HEAVY_WAVES 8
+#endif
+constexpr int kSgHeavySlots = SG_HEAVY_SLOTS;   // workgroups (= scratch slots) of the heavy pass: 8 waves each, three per CU
+                                               // (measured on the ML-20M-shape structured workload: 16 waves x 512 slots 0.95 ms,
+                                               // 8 x 1024 0.65 ms, 4 x 2048 0.76 ms for its 1,673 long users)
 
 // per wave: T accumulators, then per item a rating (float), a layout column and a row of W (IDX: uint16_t while both
 // counts stay below 65535, else int)
 __host__ __device__ constexpr size_t sg_wave_lds(int T, int idx_bytes) {
-    return static_cast<size_t>(T + 64) * 4 + static_cast<size_t>(kSgCap) * (4 + 2 * idx_bytes);        // + 64 junk slots
+    return static_cast<size_t>(T + 64) * 4 + static_cast<size_t>(kSgCap) * (4 + 2 * idx_bytes) + 64;   // + 64 junk slots, + claimed chunk
 }
-__host__ __device__ constexpr int sg_heavy_waves(int T) { return T <= 2048 ? 16 : 8; }
+__host__ __device__ constexpr int sg_heavy_waves(int T) { return T <= 2048 ? SG_HEAVY_WAVES : (SG_HEAVY_WAVES < 8 ? SG_HEAVY_WAVES : 8); }
 __host__ __device__ constexpr size_t sg_heavy_lds(int T) {
     return static_cast<size_t>(sg_heavy_waves(T)) * (static_cast<size_t>(T + 64) * 4 + 128 * 4 + 64 * 8) + 64;
 }
@@ -351,7 +359,7 @@ template <> struct SgNone<uint16_t> { static constexpr int value = 0xffff; };
 template <> struct SgNone<int> { static constexpr int value = -1; };
 
 template <int GROUP, typename IDX, bool T256>
-__global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
+__global__ __launch_bounds__(kSgWaves * 64, 7) void score_seg_kernel(SegArgs a) {       // 7 waves per SIMD: <= 72 VGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
     const int wave = static_cast<int>(threadIdx.x) >> 6;
@@ -372,21 +380,28 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
     const __amdgpu_buffer_rsrc_t bnd = sg_buffer(a.bound, static_cast<size_t>(a.R) * 256);
 
     SP_DECL
-    int w_next = 0, w_end = 0;
+    int w_next = 0, w_end = 0, w_base = 0;
+    int *claimed = reinterpret_cast<int *>(rr + kSgCap);       // [3][kSgQueueChunk]: output row, first entry, length of the chunk's users
     for (;;) {
         if (w_next >= w_end) {
             int w0 = 0;
             if (lane == 0) w0 = atomicAdd(a.queue, kSgQueueChunk);
-            w_next = readfirst_i(w0);
+            w_next = w_base = readfirst_i(w0);
             if (w_next >= a.n_rows) break;
             w_end = min(w_next + kSgQueueChunk, a.n_rows);
+            // the chunk's row pointers in one go: three dependent loads per chunk instead of three per user
+            if (w_next + lane < w_end) {
+                const int c_row = a.order ? a.order[w_next + lane] : w_next + lane;
+                const int xr = a.row_ids ? a.row_ids[c_row] : c_row;
+                int c_a0 = 0, c_na = 0;
+                if (xr >= 0 && xr < a.n_x_rows) { c_a0 = a.xb_ptr[xr]; c_na = a.xb_ptr[xr + 1] - c_a0; }      // anything else: an empty row
+                claimed[lane] = c_row; claimed[kSgQueueChunk + lane] = c_a0; claimed[2 * kSgQueueChunk + lane] = c_na;
+            }
         }
         const int p = w_next++;
-        const int row = a.order ? a.order[p] : p;
-        const int xrow = a.row_ids ? a.row_ids[row] : row;
-        const bool xok = xrow >= 0 && xrow < a.n_x_rows;       // anything else scores as an empty row
-        const int a0 = readfirst_i(xok ? a.xb_ptr[xrow] : 0);
-        const int n_a = readfirst_i(xok ? a.xb_ptr[xrow + 1] - a0 : 0);
+        const int row = readfirst_i(claimed[p - w_base]);
+        const int a0 = readfirst_i(claimed[kSgQueueChunk + p - w_base]);
+        const int n_a = readfirst_i(claimed[2 * kSgQueueChunk + p - w_base]);
         const bool in_lds = n_a <= kSgCap;
         if (!in_lds && a.xs) continue;          // a long user: score_seg_heavy_kernel takes it, one workgroup per user
         SP_MARK(SP_CLAIM) SP_ADD(SP_JOBS, 1)
@@ -445,6 +460,8 @@ __global__ __launch_bounds__(kSgWaves * 64) void score_seg_kernel(SegArgs a) {
                 }
             }
             SP_MARK(SP_FILTER)
+            // (measured and dropped: gathering the segment pointers of two chunks per step -- the second chunk's registers cost
+            // a wave per SIMD or spills, and users with several chunks got slower, not faster)
             for (int ch = 0; ch < n_ch; ++ch) {
                 const int idx = (ch << 6) + lane;
                 int r = -1;
