@@ -350,3 +350,33 @@ def test_c3s_recommend_all_users_segment_kernel(c3s, oracle):
         assert eng.last_score_path == "segments"
         o4, s4, c4 = oracle.recommend_batch(X[sample[:600]], W.tocsr(), top_k=k, filter_interacted=filt, n_threads=CPU_THREADS)
         assert np.array_equal(ids4, o4) and np.array_equal(cnt4, c4) and np.array_equal(bits(sc4), bits(s4))
+
+
+# ------------------------------------------------------------------------------------------ mid-size reference fixtures
+def test_midsize_reference_models_on_gpu(engine):
+    """tests/golden/midsize.json (real SLIMElastic at the ML-1M shape and on a structured 3000 x 1500 matrix): the HIP fit's W
+    has the reference's CSC checksums and scikit-learn's n_iter_ for every column."""
+    from test_oracle_golden import check_model_crc, midsize, midsize_matrix
+    for name in ("ml1m", "s3000"):
+        X = midsize_matrix(name)
+        I = X.shape[1]
+        engine.set_interactions(X, X.tocsr())
+        tg, items, coef, count, n_iter = engine.fit_columns(np.arange(I), nn_feature_selection=50)
+        W = merge_coefficients(None, I, *coefficients_to_updates(tg, items, coef, count))
+        order = np.argsort(tg)
+        check_model_crc(midsize()[name], W, n_iter[order])
+
+
+def test_midsize_long_columns_on_gpu(c3):
+    """80 long target columns (12k .. 128k entries) of the ML-20M shape: features, coefficient bits and sweep counts of the
+    full-size HIP fit equal scikit-learn's (fixture from the real reference)."""
+    from test_oracle_golden import midsize
+    ref = midsize()["long_columns"]
+    pos = {int(t): k for k, t in enumerate(c3["tg"])}
+    for n, j in enumerate(ref["targets"]):
+        k = pos[int(j)]
+        c = c3["count"][k]
+        o = np.argsort(c3["items"][k, :c], kind="stable")
+        assert c3["n_iter"][k] == ref["n_iter"][n], f"column {j}: sweeps"
+        assert np.array_equal(c3["items"][k, :c][o], ref["features"][n]), f"column {j}: features"
+        assert np.array_equal(bits(c3["coef"][k, :c][o]), np.asarray(ref["coef_bits"][n], dtype=np.uint32)), f"column {j}: coefficients"

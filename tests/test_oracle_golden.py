@@ -120,3 +120,64 @@ def test_similar_items_matches_reference(oracle):
         assert len(oi) == int(np.sum(zs["similar_ids"][j] >= 0))
         assert oi[:n].tolist() == zs["similar_ids"][j, :n].tolist()
         assert np.array_equal(bits(ov[:n]), bits(zs["similar_scores"][j, :n]))
+
+
+# ------------------------------------------------------------------ mid-size fixtures (tools/gen_golden.py --midsize)
+# Whole models at the ML-1M shape and at a structured 3000 x 1500 matrix (real SLIMElastic.partial_fit_items, K = 50) as CRC32 of
+# the CSC arrays + every column's n_iter_, and ElasticNet known answers for 80 long columns (12k .. 128k entries) of the ML-20M
+# shape: SURVEY 8c G3, where the BLAS reduction order of the duality gap (DESIGN D2) would show if it ever mattered.
+def _crc(a):
+    import zlib
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def midsize():
+    return json.load(open(os.path.join(G, "midsize.json")))
+
+
+def midsize_matrix(name):
+    from rtrec_amd.synth import interaction_matrix, structured_matrix
+    if name == "ml1m":
+        X = interaction_matrix(6040, 3706, 1_000_000, seed=20251003)
+    elif name == "s3000":
+        X = structured_matrix(3000, 1500, 200_000, seed=77, n_clusters=12)
+    else:
+        X = interaction_matrix(138_493, 26_744, 26_000_000, seed=20251003)
+    X = X.tocsc()
+    X.sort_indices()
+    return X
+
+
+def check_model_crc(ref, W, n_iter):
+    W = W.tocsc()
+    W.sort_indices()
+    assert W.nnz == ref["W_nnz"]
+    assert _crc(W.indptr.astype(np.int32)) == ref["crc_W_indptr"]
+    assert _crc(W.indices.astype(np.int32)) == ref["crc_W_indices"]
+    assert _crc(W.data.astype(np.float32).view(np.uint32)) == ref["crc_W_bits"], "coefficient bits differ from the reference's W"
+    assert np.array_equal(np.asarray(n_iter), np.asarray(ref["n_iter"])), "sweep counts differ from scikit-learn's n_iter_"
+
+
+@pytest.mark.parametrize("name", ["ml1m", "s3000"])
+def test_midsize_model_checksums(oracle, name):
+    ref = midsize()[name]
+    X = midsize_matrix(name)
+    assert [_crc(X.indptr.astype(np.int32)), _crc(X.indices.astype(np.int32)), _crc(X.data.astype(np.float32))] == ref["crc_X"], \
+        "the synthetic generator drifted: regenerate tests/golden/midsize.json"
+    I = X.shape[1]
+    ptr, idx, val, nit = oracle.fit_columns(X, np.arange(I), nn_feature_selection=50, n_threads=8)
+    W = merge_coefficients(None, I, idx.astype(np.int64), np.repeat(np.arange(I, dtype=np.int64), np.diff(ptr)), val)
+    check_model_crc(ref, W, nit)
+
+
+def test_midsize_long_columns(oracle):
+    ref = midsize()["long_columns"]
+    X = midsize_matrix("c3")
+    assert X.nnz == ref["nnz_X"]
+    tg = np.asarray(ref["targets"], dtype=np.int64)
+    assert np.array_equal(np.diff(X.indptr)[tg], ref["target_nnz"])
+    ptr, idx, val, nit = oracle.fit_columns(X, tg, nn_feature_selection=50, n_threads=8)
+    assert np.array_equal(nit, ref["n_iter"])
+    assert np.array_equal(np.diff(ptr), np.full(len(tg), 50))
+    assert np.array_equal(idx.reshape(len(tg), 50), np.asarray(ref["features"]))
+    assert np.array_equal(bits(val).reshape(len(tg), 50), np.asarray(ref["coef_bits"], dtype=np.uint32))

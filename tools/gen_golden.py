@@ -369,7 +369,86 @@ def gen_evaluate():
     json.dump(out, open(os.path.join(OUT, "evaluate.json"), "w"))
 
 
+# ------------------------------------------------------------------ G3 (mid-size): whole models as checksums + long-column known answers
+def _crc(a):
+    import zlib
+    return int(zlib.crc32(np.ascontiguousarray(a).tobytes()))
+
+
+def _column_sweeps(ref_model, X, cols):
+    """n_iter_ per target column, through the reference's own per-column objects (FeatureSelectionWrapper + ElasticNet,
+    slim_elastic.py:131-154,195-227) and its own column masking (CSCMatrixWrapper, :82-129)."""
+    from rtrec.models.internal.slim_elastic import CSCMatrixWrapper
+    Xw = CSCMatrixWrapper(X)
+    mdl = ref_model.get_model()
+    out = []
+    for j in cols:
+        y = Xw.get_col(j).toarray().ravel()
+        keep = X.data[X.indptr[j]:X.indptr[j + 1]].copy()
+        Xw.set_col(j, np.zeros_like(keep))
+        mdl.fit(X, y)
+        out.append(int(mdl.model.n_iter_))
+        Xw.set_col(j, keep)
+    return np.array(out, dtype=np.int32)
+
+
+def gen_midsize():
+    """VERDICT round 2 item 4 / SURVEY 8c G3: (i) whole-model W at the ML-1M shape and at a 3000 x 1500 structured matrix, K = 50,
+    from the real SLIMElastic.partial_fit_items -- stored as CRC32 of the CSC arrays (value BITS) plus every column's n_iter_;
+    (ii) ElasticNet known answers for 80 LONG target columns (12k .. 128k entries) of the ML-20M-shape matrix with their 50
+    selected features: coefficient bits and n_iter_, where the order of the BLAS reductions in the duality gap (DESIGN D2)
+    would bite if it ever did.  The inputs are regenerated from their seeds by the tests (rtrec_amd.synth)."""
+    from rtrec_amd.synth import structured_matrix
+    out = {}
+    for name, X in (("ml1m", interaction_matrix(6040, 3706, 1_000_000, seed=20251003)),
+                    ("s3000", structured_matrix(3000, 1500, 200_000, seed=77, n_clusters=12))):
+        X = X.tocsc()
+        X.sort_indices()
+        I = X.shape[1]
+        m = RefSLIMElastic({"nn_feature_selection": 50}).partial_fit_items(X.copy(), list(range(I)))
+        W = m.item_similarity.tocsc()
+        W.sort_indices()
+        out[name] = {"shape": list(X.shape), "nnz_X": int(X.nnz), "crc_X": [_crc(X.indptr.astype(np.int32)), _crc(X.indices.astype(np.int32)),
+                                                                           _crc(X.data.astype(np.float32))],
+                     "W_nnz": int(W.nnz), "W_dtype": str(W.dtype), "W_rows_nonempty": int(np.count_nonzero(np.diff(W.tocsr().indptr))),
+                     "crc_W_indptr": _crc(W.indptr.astype(np.int32)), "crc_W_indices": _crc(W.indices.astype(np.int32)),
+                     "crc_W_bits": _crc(W.data.astype(np.float32).view(np.uint32)),
+                     "n_iter": _column_sweeps(RefSLIMElastic({"nn_feature_selection": 50}), X.copy(), range(I)).tolist()}
+        print(f"[golden] {name}: W nnz {W.nnz}, rows {out[name]['W_rows_nonempty']}")
+    # (ii) long columns of the ML-20M shape
+    X = interaction_matrix(138_493, 26_744, 26_000_000, seed=20251003).tocsc()
+    X.sort_indices()
+    nnz = np.diff(X.indptr)
+    by_len = np.argsort(-nnz, kind="stable")
+    cand = by_len[nnz[by_len] >= 12_000]
+    pick = np.unique(np.concatenate([cand[:24], cand[np.linspace(0, len(cand) - 1, 56).astype(int)]]))[:80]
+    from rtrec.models.internal.slim_elastic import CSCMatrixWrapper
+    Xw = CSCMatrixWrapper(X)
+    mdl = RefSLIMElastic({"nn_feature_selection": 50}).get_model()
+    feats, coefs, iters = [], [], []
+    for j in pick:
+        y = Xw.get_col(int(j)).toarray().ravel()
+        keep = X.data[X.indptr[j]:X.indptr[j + 1]].copy()
+        Xw.set_col(int(j), np.zeros_like(keep))
+        mdl.fit(X, y)
+        c = mdl.sparse_coef_.tocsr()
+        o = np.argsort(c.indices, kind="stable")
+        feats.append(c.indices[o].astype(np.int32))
+        coefs.append(c.data[o].astype(np.float32))
+        iters.append(int(mdl.model.n_iter_))
+        Xw.set_col(int(j), keep)
+    out["long_columns"] = {"shape": [138_493, 26_744], "draws": 26_000_000, "seed": 20251003, "nnz_X": int(X.nnz),
+                           "targets": pick.astype(int).tolist(), "target_nnz": nnz[pick].astype(int).tolist(),
+                           "features": np.stack(feats).tolist(), "coef_bits": np.stack(coefs).view(np.uint32).tolist(),
+                           "n_iter": iters}
+    print(f"[golden] long columns: {len(pick)} targets, {nnz[pick].min()} .. {nnz[pick].max()} entries, sweeps {min(iters)} .. {max(iters)}")
+    json.dump(out, open(os.path.join(OUT, "midsize.json"), "w"))
+
+
 if __name__ == "__main__":
+    if "--midsize" in sys.argv:
+        gen_midsize()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "evaluate":     # adds evaluate.json without touching the other fixtures
         gen_evaluate()
         sys.exit(0)
