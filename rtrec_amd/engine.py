@@ -832,7 +832,7 @@ class SlimEngine:
         # exact mode: Gram TRACKING needs a non-negative X and pays on bulk calls; tolerance mode: Gram-form CD, any X
         if (K > 0 and min(K, I) <= 64 and getattr(be, "supports_gram", False) and gmode != "0"
                 and (fast == 2 or (fast == 0 and X.get("nonneg") and (n > FIT_MW_MAX_TARGETS or gmode == "force")))):
-            n_top = min(I, int(os.environ.get("RTREC_AMD_GRAM_ITEMS", GRAM_ITEMS)))
+            n_top = self._gram_items(targets, cfg, cap)
             if X.get("gram_n") != n_top:
                 X["gram"], X["gram_n"] = be.gram_matrix(X, U, I, n_top), n_top
             gram = X["gram"]
@@ -932,6 +932,63 @@ class SlimEngine:
             return (cat("t", (0,), torch.int32), cat("items", (0, cap), torch.int32), cat("coef", (0, cap), torch.float32),
                     cat("count", (0,), torch.int32), d_niter.cpu().numpy())
         return targets, items_out, coef_out, count_out, niter_out
+
+    GRAM_ITEMS_MAX = 4096       # rtrec_slim_gram_matrix's limit
+    GRAM_PILOT_TARGETS = 64
+    GRAM_PILOT_MIN_NNZ = 8_000_000      # smaller fits take a fraction of a second: the pilot (and a larger G) would not pay
+
+    def _gram_items(self, targets: np.ndarray, cfg, cap: int) -> int:
+        """How many of the most popular item columns the shared Gram matrix covers (RTREC_AMD_GRAM_ITEMS=<n> fixes it).
+        Gram tracking (exact mode) decides a zero coordinate without touching memory only while every UPDATED feature of the
+        target has a row in G, and the Gram-form coordinate descent (tolerance mode) needs ALL of a target's features there.
+        Which items are features depends on the co-occurrence structure, not on the popularity law: on popularity-only data
+        the features of every target are the ~100 most popular items, with item clusters they are each cluster's own
+        popular items and reach down to popularity rank ~5,000 (ML-20M shape, 80 clusters: top-512 holds 23 % of the
+        selected features, top-4096 97 % and every feature that ends up with a non-zero weight).  So the size is read off a
+        PILOT: the feature selection (one sweep) of 64 of the call's targets from the middle of the length-sorted
+        list -- the 90th percentile of the deepest popularity rank a target selects, rounded up to a power of two in
+        [512, 4096].  A matrix with few non-empty columns (a mini-batch's partial matrix, slim.py:33-36) gets them all.
+        The answer is cached with X."""
+        be, X = self.be, self._X
+        env = os.environ.get("RTREC_AMD_GRAM_ITEMS", "auto")
+        if env != "auto":
+            return min(self.n_items, int(env))
+        if "gram_auto" in X:
+            return X["gram_auto"]
+        col_nnz = X["col_nnz"]
+        nonempty = int(np.count_nonzero(col_nnz))
+        n_top = GRAM_ITEMS
+        if nonempty <= 1024:
+            n_top = max(64, min(self.n_items, nonempty))
+        elif (len(targets) > FIT_MW_MAX_TARGETS and isinstance(be, HipBackend) and int(cfg.top_features) > 0
+              and int(col_nnz.sum()) >= self.GRAM_PILOT_MIN_NNZ):
+            torch = be.torch
+            live = targets[col_nnz[targets] > 0]
+            # (not the head of the length-sorted list: a popular target's X^T y walks 100k user rows, and what it selects is no
+            # different -- the pilot costs a few ms this way instead of ~100)
+            pick = (live[np.linspace(0.05 * (len(live) - 1), 0.6 * (len(live) - 1), min(self.GRAM_PILOT_TARGETS, len(live))).astype(np.int64)]
+                    if len(live) else live)
+            if len(pick):
+                m = len(pick)
+                pcfg = _native.FitCfg(cfg.l1_reg, cfg.l2_reg, cfg.tol, 1, cfg.seed, cfg.positive, cfg.top_features)
+                key = (self.n_users, self.n_items, m, int(cfg.top_features), "pilot")
+                if key not in self._fit_ws:
+                    self._fit_ws[key] = be.fit_workspace(self.n_users, self.n_items, m, int(cfg.top_features))
+                ws, queue = self._fit_ws[key]
+                items = be.empty((m, cap), torch.int32)
+                coef = be.empty((m, cap), torch.float32)
+                count, niter = be.empty((m,), torch.int32), be.empty((m,), torch.int32)
+                be.fit_columns(self.n_users, self.n_items, X, be.to_dev(pick.astype(np.int32)), pcfg, items, coef, count, niter, cap,
+                               ws, queue, m, None, None, fast=0, one_pass_xty=False)
+                rank = np.empty(self.n_items, dtype=np.int64)
+                rank[np.argsort(-col_nnz, kind="stable")] = np.arange(self.n_items)
+                it, cn = items.cpu().numpy(), count.cpu().numpy()
+                deepest = np.array([rank[it[k, :cn[k]]].max() if cn[k] else 0 for k in range(m)])
+                need = int(np.percentile(deepest, 90)) + 1
+                n_top = GRAM_ITEMS if need <= GRAM_ITEMS else min(self.GRAM_ITEMS_MAX, 1 << int(need - 1).bit_length())
+                self._fit_ws.pop(key, None)
+        X["gram_auto"] = min(self.n_items, n_top)
+        return X["gram_auto"]
 
     def _one_pass_xty_pays(self, targets: np.ndarray) -> bool:
         """The one-pass X^T y of a small call (csrc/fit.hip, xty_batch_kernel) replaces one walk per target by one pass

@@ -32,10 +32,10 @@ def main():
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     from rtrec_amd import _native
     from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients
-    from rtrec_amd.synth import interaction_matrix
+    from rtrec_amd.synth import workload_matrix
     wl = WORKLOADS[args.workload]
     U, I, K = wl["U"], wl["I"], wl["K"]
-    X = interaction_matrix(U, I, wl["draws"], seed=20251003, float_ratings=True)
+    X = workload_matrix(wl, seed=20251003, float_ratings=True)
     Xc = X.tocsc(); Xc.sort_indices()
     out = {"workload": args.workload}
     ref = None

@@ -31,11 +31,11 @@ def main() -> None:
     args = ap.parse_args()
     import torch
     from rtrec_amd.engine import SlimEngine, shard_bounds
-    from rtrec_amd.synth import interaction_matrix
+    from rtrec_amd.synth import workload_matrix
 
     wl = WORKLOADS[args.workload]
     U, I, K = wl["U"], wl["I"], wl["K"]
-    X = interaction_matrix(U, I, wl["draws"], seed=20251003, float_ratings=True)
+    X = workload_matrix(wl, seed=20251003, float_ratings=True)
     Xc = X.tocsc()
     Xc.sort_indices()
     eng = SlimEngine(device="cuda:0")

@@ -34,11 +34,11 @@ def main() -> None:
     import torch
     from rtrec_amd import _native
     from rtrec_amd.engine import SlimEngine, coefficients_to_updates, merge_coefficients
-    from rtrec_amd.synth import interaction_matrix
+    from rtrec_amd.synth import workload_matrix
 
     wl = WORKLOADS[args.workload]
     U, I, K = wl["U"], wl["I"], wl["K"]
-    X = interaction_matrix(U, I, wl["draws"], seed=20251003, float_ratings=True)
+    X = workload_matrix(wl, seed=20251003, float_ratings=True)
     Xc = X.tocsc()
     Xc.sort_indices()
     eng = SlimEngine(device="cuda:0")

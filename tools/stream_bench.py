@@ -18,7 +18,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 SHAPES = {"small": (20_000, 5_000, 500_000), "c2": (100_000, 50_000, 5_000_000), "c3": (138_493, 26_744, 26_000_000),
-          "c4": (1_000_000, 500_000, 100_000_000)}
+          "c4": (1_000_000, 500_000, 100_000_000),
+          # structured variants (rtrec_amd.synth.clustered_pairs): (users, items, draws, item clusters)
+          "smalls": (20_000, 5_000, 900_000, 25), "c3s": (138_493, 26_744, 46_000_000, 80)}
+
+
+def workload_pairs(workload):
+    """(U, I, users, items) of the workload's distinct (user, item) pairs."""
+    from rtrec_amd.synth import clustered_pairs, zipf_pairs
+    shape = SHAPES[workload]
+    U, I, draws = shape[:3]
+    if len(shape) > 3:
+        u, i = clustered_pairs(U, I, draws, seed=20251003, n_clusters=shape[3])
+    else:
+        u, i = zipf_pairs(U, I, draws, seed=20251003)
+    return U, I, u, i
 
 
 def run_stream(workload="c2", batches=50, batch_size=1000, score_users=100, qps=0.0, fit_modes=("exact",),
@@ -27,11 +41,9 @@ def run_stream(workload="c2", batches=50, batch_size=1000, score_users=100, qps=
     (one entry per fit mode under "modes"; the first mode's figures are also at the top level)."""
     import torch
     from rtrec_amd import SLIM
-    from rtrec_amd.synth import zipf_pairs
 
-    U, I, draws = SHAPES[workload]
     rng = np.random.default_rng(5)
-    u, i = zipf_pairs(U, I, draws, seed=20251003)
+    U, I, u, i = workload_pairs(workload)
     n = len(u)
     order = rng.permutation(n)
     u, i = u[order], i[order]
