@@ -322,6 +322,12 @@ typedef struct {
     size_t         sg_scratch_bytes;
     int32_t        row_order_longest_first;   /* d_row_order is sorted by row length, longest first: the heavy pass then finds
                                      the long users at its head instead of walking all rows */
+    /* Scoring WITHOUT the tiled layout (d_tile_ptr == NULL; SPARSE mode, float32 accumulation, a usable feature-row or
+     * segment form above): the fast pass runs alone and, instead of re-scoring the rows whose lists hold an exact score tie,
+     * reports them: d_flagged[0] = their number, d_flagged[1 ..] = the rows (room for 1 + n_rows int32).  The caller scores
+     * exactly those rows again WITH the tiled layout (whose exact-tie pass orders them like the reference) -- and has to
+     * build that layout only when a call flags something. */
+    int32_t       *d_flagged;
 } rtrec_score_opts;
 
 size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols);

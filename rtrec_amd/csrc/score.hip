@@ -1867,7 +1867,7 @@ template <typename ACC>
 int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_ids, float *d_out_scores,
                double *d_out_scores64, uint32_t *d_out_aux, int32_t *d_out_count,
                unsigned char *ws, const ScoreWs &L, hipStream_t st, KernelTimer *tmr, const FrLayout &FR, const SgLayout &SG,
-               int n_x_rows, int32_t *d_rescored) {
+               int n_x_rows, int32_t *d_rescored, int32_t *d_flagged) {
     ScoreArgs a = base;
     const bool sparse = (a.mode == RTREC_TOPK_SPARSE);
     const bool single = (a.n_tiles == 1);
@@ -1877,9 +1877,13 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     a.cand_id = reinterpret_cast<int *>(ws + L.cand_id);
     a.cand_aux = reinterpret_cast<uint32_t *>(ws + L.cand_aux);
     a.cand_cnt = reinterpret_cast<int *>(ws + L.cand_cnt);
-    int *flag_list = reinterpret_cast<int *>(ws + L.flag_list);
-    int *flag_len = reinterpret_cast<int *>(ws + L.flag_len);
+    // Without the tiled layout (a fast layout only: rtrec_slim_score_topk_opt) there is no exact-tie pass here: the rows it
+    // would re-score are reported to the caller instead (d_flagged[0] = count, d_flagged[1 ..] = rows).
+    const bool have_tiled = base.tile_ptr != nullptr;
+    int *flag_list = have_tiled ? reinterpret_cast<int *>(ws + L.flag_list) : d_flagged + 1;
+    int *flag_len = have_tiled ? reinterpret_cast<int *>(ws + L.flag_len) : d_flagged;
     int *queue = reinterpret_cast<int *>(ws + L.queue);   // [0]: fast pass, [1]: exact-tie pass
+    if (!have_tiled && hipMemsetAsync(d_flagged, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     a.direct = single ? 1 : 0;
     a.out_id = d_out_ids; a.out_score = d_out_scores; a.out_score64 = d_out_scores64; a.out_aux = d_out_aux;
     a.out_cnt = d_out_count;
@@ -1888,7 +1892,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
     a.row_list = flag_list; a.row_list_len = flag_len;
     a.queue = queue;
     (void)hipGetLastError();   // drop stale errors of earlier, unrelated runtime calls
-    if (hipMemsetAsync(flag_len, 0, 16, st) != hipSuccess) return RTREC_ERR_LAUNCH;      // both list lengths and both queues
+    if (hipMemsetAsync(ws + L.flag_len, 0, 16, st) != hipSuccess) return RTREC_ERR_LAUNCH;      // both list lengths and both queues
 
     const long long total = static_cast<long long>(a.n_rows) * a.n_tiles;
     debug_stage(st, "score: begin");
@@ -1909,7 +1913,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.kk = a.kk; f.top_k = top_k; f.filter = a.filter;
         f.out_id = d_out_ids; f.out_score = d_out_scores; f.out_aux = d_out_aux; f.out_cnt = d_out_count;
         f.flag_list = flag_list; f.flag_len = flag_len; f.queue = queue;
-        f.tie_list = reinterpret_cast<int *>(ws + L.tie_list); f.tie_len = flag_len + 1;
+        f.tie_list = reinterpret_cast<int *>(ws + L.tie_list); f.tie_len = reinterpret_cast<int *>(ws + L.flag_len) + 1;
         // all slices in one super-tile that fits next to the setup scratch: W stays in LDS for the life of a 16-wave
         // workgroup; otherwise two 8-wave workgroups per CU stream the super-tiles (one computes while the other sets a
         // job up or waits at a super-tile barrier)
@@ -1973,6 +1977,8 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         else if (SG.T == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, uint16_t, true>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, uint16_t, false>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
         sg_done = true;
+    } else if (!have_tiled) {
+        return RTREC_ERR_INVALID_ARG;       // no tiled layout and no usable fast layout
     } else if (sparse) {
         const size_t lds = score_lds_bytes(a.tile_cols, acc_bytes, false, true, a.kk);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(score_sparse_kernel<ACC, false>), dim3(persistent_grid(lds, total)), dim3(64),
@@ -2007,7 +2013,9 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         debug_stage(st, "merge_topk_kernel");
     }
 
-    if (sparse) {
+    if (!have_tiled) {
+        if (d_rescored && hipMemsetAsync(d_rescored, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
+    } else if (sparse) {
         // exact reference tie order for the flagged rows only (first-touch tracking on)
         ScoreArgs f = a;
         f.kk = top_k;
@@ -2107,13 +2115,20 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
     if (n_rows < 0 || n_items <= 0 || n_cols <= 0 || top_k <= 0) return RTREC_ERR_INVALID_ARG;
     if (d_row_hdr && (reinterpret_cast<uintptr_t>(d_row_hdr) & 15u)) return RTREC_ERR_INVALID_ARG;
     if (n_rows == 0) return RTREC_OK;
-    if (!d_xb_ptr || !d_tile_ptr || !d_out_ids || !d_out_scores || !d_out_count || !d_workspace) return RTREC_ERR_INVALID_ARG;
+    if (!d_xb_ptr || !d_out_ids || !d_out_scores || !d_out_count || !d_workspace) return RTREC_ERR_INVALID_ARG;
+    if (!d_tile_ptr) {
+        // fast layout only (feature rows or segments): SPARSE mode, float32; the rows whose lists hold an exact score tie are
+        // handed back in opts->d_flagged for the caller to re-score against the tiled layout (which it may build only then)
+        if (!opts || !opts->d_flagged || mode != RTREC_TOPK_SPARSE || acc_f64) return RTREC_ERR_INVALID_ARG;
+        tile_cols = 256; n_tiles = 1;
+        d_w_col = nullptr; d_w_val = nullptr; d_dense_idx = nullptr; d_dense_val = nullptr; d_row_hdr = nullptr;
+    }
     if (mode < 0 || mode > 2) return RTREC_ERR_INVALID_ARG;
     if (mode == RTREC_TOPK_CANDIDATES && !d_col_rank) return RTREC_ERR_INVALID_ARG;
     if ((d_col_ids == nullptr) != (d_col_map == nullptr)) return RTREC_ERR_INVALID_ARG;
     if ((d_dense_idx == nullptr) != (d_dense_val == nullptr)) return RTREC_ERR_INVALID_ARG;
     if (tile_cols < 256 || tile_cols > 65536 || (tile_cols % 256) != 0) return RTREC_ERR_UNSUPPORTED;
-    if (n_tiles != (n_cols + tile_cols - 1) / tile_cols) return RTREC_ERR_INVALID_ARG;
+    if (d_tile_ptr && n_tiles != (n_cols + tile_cols - 1) / tile_cols) return RTREC_ERR_INVALID_ARG;
     const int acc_bytes = acc_f64 ? 8 : 4;
     // the exact-tie instantiation keeps an accumulator AND a first-touch word per column in LDS
     if (top_k > kMaxTopK || static_cast<long long>(n_tiles) * (top_k + 1) > 1024) return RTREC_ERR_UNSUPPORTED;
@@ -2166,9 +2181,9 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
     unsigned char *ws = static_cast<unsigned char *>(d_workspace);
     if (acc_f64)
         return score_impl<double>(a, top_k, 8, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
-                                  tmr, FR, SG, a.n_x_rows, opts ? opts->d_rescored : nullptr);
+                                  tmr, FR, SG, a.n_x_rows, opts ? opts->d_rescored : nullptr, opts ? opts->d_flagged : nullptr);
     return score_impl<float>(a, top_k, 4, d_out_ids, d_out_scores, d_out_scores64, d_out_aux, d_out_count, ws, L, st,
-                             tmr, FR, SG, a.n_x_rows, opts ? opts->d_rescored : nullptr);
+                             tmr, FR, SG, a.n_x_rows, opts ? opts->d_rescored : nullptr, opts ? opts->d_flagged : nullptr);
 }
 
 extern "C" int rtrec_slim_score_topk(int32_t n_rows, const int32_t *d_row_ids,

@@ -579,12 +579,12 @@ class HipBackend:
 
     def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
                    acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None, rescored=None, row_order_grouped=False,
-                   use_sg=True, use_sg_heavy=True):
+                   use_sg=True, use_sg_heavy=True, flagged=None):
         fr = lay if (use_fr and lay.get("fr_w") is not None) else {}
         sg = lay.get("sg") or {} if (use_sg and not fr) else {}
         self.ops.score_topk(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo,
-                            lay["col_ids"], lay["col_map"], lay["tile_cols"], lay["n_tiles"],
-                            lay["tile_ptr"], lay["w_col"], lay["w_val"], lay.get("dense_idx"), lay.get("dense_val"),
+                            lay.get("col_ids"), lay.get("col_map"), int(lay.get("tile_cols", 0)), int(lay.get("n_tiles", 0)),
+                            lay.get("tile_ptr"), lay.get("w_col"), lay.get("w_val"), lay.get("dense_idx"), lay.get("dense_val"),
                             lay.get("row_hdr"), col_rank, top_k, bool(filter_interacted), int(mode), bool(acc_f64),
                             ids, sc, sc64, aux, cnt, ws,
                             fr.get("fr_map"), fr.get("fr_col_ids"), fr.get("fr_col_map"), fr.get("fr_w"),
@@ -597,7 +597,7 @@ class HipBackend:
                             sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_ent"), sg.get("sg_bound"),
                             sg.get("sg_col_ids"), int(sg.get("sg_T", 0)), int(sg.get("sg_n_tiles", 0)), int(sg.get("sg_rows", 0)),
                             int(sg.get("sg_n_cols", 0)), sg.get("sg_trow_ptr"), sg.get("sg_trow"),
-                            sg.get("sg_scratch") if use_sg_heavy else None, int(bool(sg) and row_order is not None))
+                            sg.get("sg_scratch") if use_sg_heavy else None, int(bool(sg) and row_order is not None), flagged)
 
     def decay_f32(self, raw, ts, rate: float, now: float):
         """float32(raw * rate ** ((now - ts) / 86400)) for resident arrays: rtrec_store_decay_device, plus the host's libm
@@ -686,6 +686,7 @@ class SlimEngine:
         self.use_seg_layout = os.environ.get("RTREC_AMD_SEG_LAYOUT", "1") != "0"        # A/B switch of the general-W score kernel
         self.seg_cluster = os.environ.get("RTREC_AMD_SEG_CLUSTER", "1") != "0"          # ... and of its column clustering
         self.use_seg_heavy = os.environ.get("RTREC_AMD_SEG_HEAVY", "1") != "0"          # ... and of its workgroup-per-long-user pass
+        self.lazy_tiled = os.environ.get("RTREC_AMD_LAZY_TILED", "1") != "0"           # tiled layout only when a call flags exact ties
         self.last_score_path = ""     # which kernel family served the last _local_topk call (tests, bench.py)
         self._sg_labels = None        # (cluster labels of the last segment layout, n_items, nnz of W when they were computed)
 
@@ -1094,11 +1095,54 @@ class SlimEngine:
         key = key[order]
         return DeviceWeights(key % n_items, key // n_items, val[order].contiguous(), n_items, f64)
 
-    def _layout(self, compact: bool, top_k: int = 10) -> Optional[Dict[str, Any]]:
-        """Tiled layout of this rank's shard.  The tile width is self.tile_cols unless the merge of the
-        per-tile lists (n_tiles * (top_k + 1) <= 1024 candidates per user) needs wider tiles; it is
-        capped by what the exact-tie pass fits in LDS (accumulator + first-touch word per column)."""
+    def _fast_layout(self) -> Optional[Dict[str, Any]]:
+        """The fast SPARSE-mode form of this rank's shard (float32 W): feature rows when W has at most 128 non-empty rows
+        (popularity-only data), else segments (seg_layout.py).  Built once per W, on the device; None when neither applies
+        (float64 W, a backend without the kernels, an empty shard).  Independent of the tiled layout, which SPARSE-mode
+        scoring then needs only for the rows whose lists hold an exact score tie (see _local_topk)."""
         W, be = self._W, self.be
+        if "fast" in W:
+            return W["fast"]
+        fast = None
+        dw: DeviceWeights = W["dw"]
+        torch = be.torch
+        if W["col_hi"] > W["col_lo"] and not W["acc_f64"] and dw.nnz > 0:
+            if getattr(be, "supports_feature_rows", False):
+                fr = build_feature_rows_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"],
+                                               tile_cols=self.FR_TILE_COLS)
+                if fr is not None:
+                    nb = int(be.lib.rtrec_slim_score_fr_scratch_bytes(fr["fr_n_tiles"], fr["fr_tile_cols"]))
+                    fr["n_cols"] = int(fr.pop("col_ids_sorted").numel())
+                    fr["fr_scratch"] = be.empty((nb,), torch.uint8)      # fr_host: small host copies bench.py prices the kernel's work from
+                    fast = fr
+            # a W with many rows (item-item structure in the data): the segment layout; the cluster labels that order its
+            # columns are kept while W changes little (a mini-batch refits ~3 % of the columns)
+            if fast is None and self.use_seg_layout and getattr(be, "supports_seg_layout", False):
+                from .seg_layout import build_seg_layout_device
+                labels = None
+                kept = self._sg_labels
+                if kept is not None and kept[1] == W["n_items"] and abs(dw.nnz - kept[2]) <= 0.05 * max(kept[2], 1):
+                    labels = kept[0]
+                if not self.seg_cluster:
+                    labels = torch.arange(W["n_items"], dtype=torch.int64, device=dw.rows.device)
+                sg = build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels=labels)
+                if sg is not None:
+                    if labels is None:
+                        self._sg_labels = (sg["sg_labels"], W["n_items"], dw.nnz)
+                    # zeroed scratch of the heavy pass (long users, one workgroup each); the kernel leaves it zero
+                    nb = int(be.lib.rtrec_slim_score_sg_scratch_bytes(W["n_items"], sg["sg_n_tiles"], sg["sg_T"]))
+                    sg["sg_scratch"] = be.zeros((nb,), torch.uint8)
+                    fast = {"sg": sg, "n_cols": int(sg["sg_n_cols"])}
+        if fast is not None:
+            W["n_active"] = fast["n_cols"]
+        W["fast"] = fast
+        return fast
+
+    def _tile_width(self, compact: bool, top_k: int) -> int:
+        """Tile width of the tiled layout: self.tile_cols unless the merge of the per-tile lists (n_tiles * (top_k + 1) <= 1024
+        candidates per user) needs wider tiles; capped by what the exact-tie pass fits in LDS (accumulator + first-touch
+        word per column)."""
+        W = self._W
         acc = 8 if W["acc_f64"] else 4
         max_tile = 256
         while max_tile * 2 * (acc + 4) + 4096 + 16 * (top_k + 64) <= 160 * 1024 and max_tile < 32768:
@@ -1109,6 +1153,15 @@ class SlimEngine:
             width = W["n_active"]
         while tile < max_tile and -(-max(width, 1) // tile) * (top_k + 1) > 1024:
             tile *= 2
+        return tile
+
+    def _layout(self, compact: bool, top_k: int = 10) -> Optional[Dict[str, Any]]:
+        """Tiled layout of this rank's shard (built on the device on first use), with the fast SPARSE-mode form of the
+        shard (_fast_layout) merged in when compact."""
+        W, be = self._W, self.be
+        if compact:
+            self._fast_layout()               # (sets n_active, which the tile width of a compacted layout depends on)
+        tile = self._tile_width(compact, top_k)
         key = (compact, tile)
         if key not in W["layouts"]:
             lay = None
@@ -1119,33 +1172,9 @@ class SlimEngine:
                                            compact=compact, dense_fill=DENSE_ROW_FILL if compact else None)
                 if lay is not None and compact:
                     W["n_active"] = lay["n_cols"]
-                    if not W["acc_f64"] and getattr(be, "supports_feature_rows", False):
-                        fr = build_feature_rows_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"],
-                                                       tile_cols=self.FR_TILE_COLS)
-                        if fr is not None:
-                            nb = int(be.lib.rtrec_slim_score_fr_scratch_bytes(fr["fr_n_tiles"], fr["fr_tile_cols"]))
-                            fr.pop("col_ids_sorted")
-                            lay.update(fr)           # fr_host: small host copies bench.py prices the kernel's work from
-                            lay["fr_scratch"] = be.empty((nb,), torch.uint8)
-                    # a W with many rows (item-item structure in the data): the segment layout (seg_layout.py); the cluster
-                    # labels that order its columns are kept while W changes little (a mini-batch refits ~3 % of the columns)
-                    if (not W["acc_f64"] and lay.get("fr_w") is None and self.use_seg_layout
-                            and getattr(be, "supports_seg_layout", False)):
-                        from .seg_layout import build_seg_layout_device
-                        labels = None
-                        kept = self._sg_labels
-                        if kept is not None and kept[1] == W["n_items"] and abs(dw.nnz - kept[2]) <= 0.05 * max(kept[2], 1):
-                            labels = kept[0]
-                        if not self.seg_cluster:
-                            labels = torch.arange(W["n_items"], dtype=torch.int64, device=dw.rows.device)
-                        sg = build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels=labels)
-                        if sg is not None:
-                            if labels is None:
-                                self._sg_labels = (sg["sg_labels"], W["n_items"], dw.nnz)
-                            # zeroed scratch of the heavy pass (long users, one workgroup each); the kernel leaves it zero
-                            nb = int(be.lib.rtrec_slim_score_sg_scratch_bytes(W["n_items"], sg["sg_n_tiles"], sg["sg_T"]))
-                            sg["sg_scratch"] = be.zeros((nb,), torch.uint8)
-                            lay["sg"] = sg
+                    fast = self._fast_layout()
+                    if fast is not None:
+                        lay.update({k: v for k, v in fast.items() if k != "n_cols"})
             W["layouts"][key] = lay
         return W["layouts"][key]
 
@@ -1167,7 +1196,48 @@ class SlimEngine:
             ids._rtrec_pack = pack
         aux = be.empty((n_rows, top_k), torch.int32)
         sc64 = be.empty((n_rows, top_k), torch.float64) if W["acc_f64"] else None
-        lay = self._layout(compact=(mode == _native.TOPK_SPARSE), top_k=top_k)
+        sparse = mode == _native.TOPK_SPARSE
+        hip = isinstance(be, HipBackend)
+        # SPARSE mode, float32 W: the fast form of the shard (feature rows / segments).  The tiled layout is then needed only
+        # for the rows whose fast-pass list holds an exact score tie (the exact-tie pass orders those like the reference):
+        # with lazy_tiled it is built when a call first flags such a row -- after a mini-batch the first recommend builds one
+        # layout, not two -- at the price of reading one counter back per call while it does not exist.
+        fast = self._fast_layout() if (sparse and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0)) else None
+        use_fr = bool(fast is not None and self.use_feature_rows and fast.get("fr_w") is not None and n_rows >= self.FR_MIN_ROWS
+                      and top_k <= self.FR_MAX_TOP_K)
+        use_sg = bool(fast is not None and not use_fr and self.use_seg_layout and fast.get("sg") is not None
+                      and top_k <= self.SG_MAX_TOP_K)
+        tiled_key = (sparse, self._tile_width(sparse, top_k))
+        if hip and (use_fr or use_sg) and self.lazy_tiled and tiled_key not in W["layouts"]:
+            need = be.score_workspace_bytes(n_rows, 1, top_k)
+            if self._score_ws is None or self._score_ws.numel() < need:
+                self._score_ws = be.empty((need,), torch.uint8)
+            order = self._row_order(d_row_ids, n_rows, xb, fast)
+            self.last_score_path = "feature_rows" if use_fr else "segments"
+            flagged = be.empty((n_rows + 1,), torch.int32)
+            be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, top_k, filter_interacted,
+                          mode, False, ids, sc, None, aux, cnt, self._score_ws, timer=self.score_timer,
+                          diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8), use_fr=use_fr, row_order=order,
+                          rescored=None, row_order_grouped=(order is not None and use_fr and self._grouped_order(fast)),
+                          use_sg=use_sg, use_sg_heavy=self.use_seg_heavy, flagged=flagged)
+            n_flag = int(flagged[0].item())
+            if self.rescored is not None:
+                self.rescored.fill_(n_flag)
+            if n_flag:
+                # exact ties: those rows again, against the tiled layout (built now) -- its exact-tie pass orders them
+                lay = self._layout(compact=True, top_k=top_k)
+                rows_f = flagged[1:1 + n_flag].long()
+                sub_ids = d_row_ids[rows_f].contiguous() if d_row_ids is not None else rows_f.to(torch.int32)
+                t_ids, t_sc, t_aux = (be.empty((n_flag, top_k), dt) for dt in (torch.int32, torch.float32, torch.int32))
+                t_cnt = be.empty((n_flag,), torch.int32)
+                need = be.score_workspace_bytes(n_flag, lay["n_tiles"], top_k)
+                if self._score_ws.numel() < need:
+                    self._score_ws = be.empty((need,), torch.uint8)
+                be.score_topk(n_flag, sub_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
+                              mode, False, t_ids, t_sc, None, t_aux, t_cnt, self._score_ws, use_fr=False, use_sg=False)
+                ids[rows_f] = t_ids; sc[rows_f] = t_sc; aux[rows_f] = t_aux; cnt[rows_f] = t_cnt
+            return ids, sc, sc64, aux, cnt
+        lay = self._layout(compact=sparse, top_k=top_k)
         if lay is None:
             ids.fill_(-1); sc.fill_(float("-inf")); aux.zero_(); cnt.zero_()
             if sc64 is not None:
@@ -1176,11 +1246,7 @@ class SlimEngine:
         need = be.score_workspace_bytes(n_rows, lay["n_tiles"], top_k)
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = be.empty((need,), torch.uint8)
-        if isinstance(be, HipBackend):
-            use_fr = (self.use_feature_rows and mode == _native.TOPK_SPARSE and lay.get("fr_w") is not None
-                      and n_rows >= self.FR_MIN_ROWS)
-            use_sg = (not use_fr and self.use_seg_layout and mode == _native.TOPK_SPARSE and lay.get("sg") is not None
-                      and top_k <= self.SG_MAX_TOP_K)
+        if hip:
             order = self._row_order(d_row_ids, n_rows, xb, lay) if (use_fr or use_sg) else None
             self.last_score_path = "feature_rows" if use_fr else ("segments" if use_sg else "tiled")
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
@@ -1199,6 +1265,7 @@ class SlimEngine:
     # forms (chosen from the batch size inside rtrec_slim_score_topk) it is ahead at every batch size, one user included
     # (tools/score_batch_sweep.py: DESIGN.md section 3.1); the threshold is kept for A/B runs and the tests.
     FR_MIN_ROWS = 1
+    FR_MAX_TOP_K = 15           # kFrMaxKk - 1 of csrc/score.hip: a list of top_k + 1 entries fits one 16-lane DPP row
     SG_MAX_TOP_K = 63           # kSgMaxKk - 1 of csrc/score_seg.hip.h: the list of top_k + 1 entries is one register across the lanes
     FR_TILE_COLS = 256          # columns per tile of the feature-row layout (128: the narrow kernels, kept for A/B and tests)
     pattern_order = os.environ.get("RTREC_AMD_PATTERN_ORDER", "1") != "0"
@@ -1421,8 +1488,14 @@ class SlimEngine:
         callers fall back to score rows from the device + a host selection otherwise."""
         if top_k > self.MAX_TOP_K:
             return False
-        lay = self._layout(compact=(mode == _native.TOPK_SPARSE), top_k=top_k)
-        return lay is None or lay["n_tiles"] * (top_k + 1) <= self.MAX_MERGE_CANDIDATES
+        compact = mode == _native.TOPK_SPARSE
+        if compact:
+            self._fast_layout()
+        if compact and "n_active" not in self._W:
+            lay = self._layout(compact=True, top_k=top_k)
+            return lay is None or lay["n_tiles"] * (top_k + 1) <= self.MAX_MERGE_CANDIDATES
+        width = self._W["n_active"] if compact else self._W["col_hi"] - self._W["col_lo"]
+        return -(-max(width, 1) // self._tile_width(compact, top_k)) * (top_k + 1) <= self.MAX_MERGE_CANDIDATES
 
     def _check_rows(self, row_ids: np.ndarray) -> None:
         """Row ids index the resident X: anything outside [0, n_users) would be an out-of-bounds device read

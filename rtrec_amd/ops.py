@@ -80,11 +80,11 @@ def fit_columns(cptr: Tensor, crow: Tensor, cval: Tensor, rptr: Tensor, rcol: Te
         cap, _p(ws), ws.numel(), n_slots, _p(queue), _stream(out_items), C.byref(opts)), "rtrec_slim_fit_columns_opt")
 
 
-@custom_op("rtrec_amd::score_topk", mutates_args=("ids", "scores", "scores64", "aux", "count", "ws", "fr_scratch", "rescored", "sg_scratch"),
+@custom_op("rtrec_amd::score_topk", mutates_args=("ids", "scores", "scores64", "aux", "count", "ws", "fr_scratch", "rescored", "sg_scratch", "flagged"),
            device_types="cuda")
 def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val: Tensor, n_rows: int,
                n_items: int, n_cols: int, col_offset: int, col_ids: Optional[Tensor], col_map: Optional[Tensor],
-               tile_cols: int, n_tiles: int, tile_ptr: Tensor, w_col: Tensor, w_val: Tensor,
+               tile_cols: int, n_tiles: int, tile_ptr: Optional[Tensor], w_col: Optional[Tensor], w_val: Optional[Tensor],
                dense_idx: Optional[Tensor], dense_val: Optional[Tensor], row_hdr: Optional[Tensor],
                col_rank: Optional[Tensor], top_k: int, filter_interacted: bool, mode: int, acc_f64: bool,
                ids: Tensor, scores: Tensor, scores64: Optional[Tensor], aux: Tensor, count: Tensor, ws: Tensor,
@@ -97,7 +97,7 @@ def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val
                sg_info: Optional[Tensor], sg_ptr: Optional[Tensor], sg_ent: Optional[Tensor],
                sg_bound: Optional[Tensor], sg_col_ids: Optional[Tensor], sg_tile_cols: int, sg_n_tiles: int, sg_rows: int,
                sg_n_cols: int, sg_trow_ptr: Optional[Tensor], sg_trow: Optional[Tensor], sg_scratch: Optional[Tensor],
-               row_order_longest_first: int) -> None:
+               row_order_longest_first: int, flagged: Optional[Tensor]) -> None:
     """rtrec_slim_score_topk_opt.  n_x_rows is taken from xb_ptr; fr_* is the optional feature-row form of the
     shard, sg_* its optional segment form; `timer` is an rtrec_timer handle (0 = none)."""
     lib = _native.load()
@@ -107,7 +107,7 @@ def score_topk(row_ids: Optional[Tensor], xb_ptr: Tensor, xb_col: Tensor, xb_val
                              _p(row_order), C.c_void_p(timer or None), diagnostics, _p(rescored), row_order_grouped,
                              _p(sg_info), _p(sg_ptr), _p(sg_ent), int(sg_ent.shape[0]) if sg_ent is not None else 0, _p(sg_bound), _p(sg_col_ids),
                              sg_tile_cols, sg_n_tiles, sg_rows, sg_n_cols, _p(sg_trow_ptr), _p(sg_trow), _p(sg_scratch),
-                             sg_scratch.numel() if sg_scratch is not None else 0, row_order_longest_first)
+                             sg_scratch.numel() if sg_scratch is not None else 0, row_order_longest_first, _p(flagged))
     _native.check(lib.rtrec_slim_score_topk_opt(
         n_rows, _p(row_ids), _p(xb_ptr), _p(xb_col), _p(xb_val), n_items, n_cols, col_offset, _p(col_ids), _p(col_map),
         tile_cols, n_tiles, _p(tile_ptr), _p(w_col), _p(w_val), _p(dense_idx), _p(dense_val), _p(row_hdr), _p(col_rank),
