@@ -707,9 +707,13 @@ def main() -> None:
     # ------------------------------------------------------------------ streaming leg (SURVEY 8 row S1 / BASELINE config 4 pattern)
     if world == 1 and args.stream_batches > 0:
         sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-        from stream_bench import SHAPES, run_stream
-        if args.workload in ("c2", "c3") and args.workload in SHAPES:      # the c4 bulk load alone takes minutes
+        from stream_bench import SHAPES, run_open_loop, run_stream
+        if args.workload in ("c2", "c3", "c3s", "small", "smalls") and args.workload in SHAPES:      # the c4 bulk load alone takes minutes
             line["streaming"] = run_stream(args.workload, batches=args.stream_batches, fit_modes=("exact", "gram"), log=log)
+            # fixed-QPS open loop (BASELINE config 4's pattern): Poisson arrivals at 1k / 5k / 20k interactions per second,
+            # the consumer fits whatever has arrived and a recommend makes it visible
+            line["streaming"]["open_loop"] = run_open_loop(args.workload, rates=(1000.0, 5000.0, 20000.0), duration_s=3.0,
+                                                           fit_modes=("exact", "gram"), log=log)
 
     # ------------------------------------------------------------------ API-level figures and the structured workload
     if world == 1 and not args.no_api and args.workload != "c4":          # (c4: 93 M DataFrame rows take minutes to ingest)

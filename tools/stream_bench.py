@@ -112,6 +112,85 @@ def run_stream(workload="c2", batches=50, batch_size=1000, score_users=100, qps=
     return out
 
 
+def run_open_loop(workload="c3", rates=(1000.0, 5000.0, 20000.0), duration_s=3.0, fit_modes=("exact", "gram"), max_batch=10_000,
+                  score_users=100, bulk_chunk=4_000_000, model=None, held=None, log=lambda msg: print(msg, file=sys.stderr)):
+    """Fixed-QPS streaming (BASELINE.json config 4's pattern; the caller is the reference's Kinesis consumer,
+    examples/kinesis/kinesis_consumer.py:87-99: poll, SLIM.fit(whatever arrived), repeat; rtrec/serving/app.py:56-91 serves
+    recommend between updates).  OPEN LOOP: interactions arrive as a Poisson process at `rate` per second whether or not the
+    consumer keeps up.  The consumer takes everything that has arrived (at most max_batch), SLIM.fit()s it, and a
+    recommend_batch(score_users) follows -- the update is VISIBLE when that returns (it rebuilds the score layouts from the
+    refitted W).  Per interaction: update-to-visible latency = visible time - arrival time.  Reports, per rate and fit mode,
+    the sustained rate, batch sizes, p50 / p99 latency and whether the backlog stayed bounded."""
+    import torch
+    from rtrec_amd import SLIM
+    rng = np.random.default_rng(9)
+    if model is None:
+        U, I, u, i = workload_pairs(workload)
+        n = len(u)
+        order = rng.permutation(n)
+        u, i = u[order], i[order]
+        r = (rng.integers(1, 6, n) * np.exp(-rng.random(n) * 0.7)).astype(np.float64)
+        ts = 1.7e9 + np.arange(n, dtype=np.float64)
+        n_hold = int(min(n // 4, sum(rates) * duration_s * len(fit_modes) * 1.3 + 20_000))
+        n_bulk = n - n_hold
+        model = SLIM(min_value=0, max_value=15, nn_feature_selection=50, fit_mode=fit_modes[0])
+        for a in range(0, n_bulk, bulk_chunk):
+            b = min(a + bulk_chunk, n_bulk)
+            model.interactions.add_interactions_batch(model.user_ids.identify_many(u[a:b].astype(np.int64)),
+                                                      model.item_ids.identify_many(i[a:b].astype(np.int64)), ts[a:b], r[a:b])
+        model.bulk_fit(parallel=True, progress_bar=False)
+        torch.cuda.synchronize()
+        held = (u[n_bulk:], i[n_bulk:], ts[n_bulk:], r[n_bulk:], U)
+    hu, hi, hts, hr, U = held
+    model.recommend_batch(list(range(score_users)), top_k=10)
+    out = {"workload": workload, "max_batch": max_batch, "duration_s": duration_s, "score_users": score_users, "runs": []}
+    cursor = 0
+    for mode in fit_modes:
+        model.model.fit_mode = mode
+        for rate in rates:
+            n_arr = int(rate * duration_s)
+            if cursor + n_arr > len(hu):
+                break
+            arrive = np.cumsum(rng.exponential(1.0 / rate, n_arr))
+            a0 = cursor
+            cursor += n_arr
+            done, lat, sizes, fit_ms = 0, [], [], []
+            t0 = time.perf_counter()
+            while done < n_arr:
+                now = time.perf_counter() - t0
+                avail = int(np.searchsorted(arrive, now, side="right")) - done
+                if avail <= 0:
+                    time.sleep(max(0.0, min(0.002, arrive[done] - now)))
+                    continue
+                take = min(avail, max_batch)
+                sl = slice(a0 + done, a0 + done + take)
+                batch = list(zip(hu[sl].tolist(), hi[sl].tolist(), hts[sl].tolist(), hr[sl].tolist()))
+                t1 = time.perf_counter()
+                model.fit(batch, progress_bar=False)
+                torch.cuda.synchronize()
+                fit_ms.append((time.perf_counter() - t1) * 1e3)
+                model.recommend_batch(rng.integers(0, U, score_users).tolist(), top_k=10)
+                visible = time.perf_counter() - t0
+                lat.append(visible - arrive[done:done + take])
+                sizes.append(take)
+                done += take
+            wall = time.perf_counter() - t0
+            lat = np.concatenate(lat) * 1e3
+            third = max(1, len(sizes) // 3)
+            res = {"fit_mode": mode, "arrival_rate_per_sec": rate, "interactions": n_arr, "wall_s": wall,
+                   "sustained_interactions_per_sec": n_arr / wall, "batches": len(sizes),
+                   "batch_size": {"mean": float(np.mean(sizes)), "max": int(np.max(sizes))},
+                   "fit_ms": {"p50": float(np.median(fit_ms)), "max": float(np.max(fit_ms))},
+                   "update_to_visible_ms": {"p50": float(np.median(lat)), "p99": float(np.quantile(lat, 0.99)), "max": float(lat.max())},
+                   # the backlog is bounded when the last batches are no larger than the first ones
+                   "keeps_up": bool(np.mean(sizes[-third:]) <= 2.0 * max(np.mean(sizes[:third]), 1.0) and wall <= duration_s * 1.25 + 1.0)}
+            out["runs"].append(res)
+            log(f"[stream] open loop {mode} @ {rate:,.0f}/s: sustained {res['sustained_interactions_per_sec']:,.0f}/s, batch mean "
+                f"{res['batch_size']['mean']:.0f}, update-to-visible p50 {res['update_to_visible_ms']['p50']:.0f} ms p99 "
+                f"{res['update_to_visible_ms']['p99']:.0f} ms, keeps up: {res['keeps_up']}")
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c2", choices=sorted(SHAPES))
@@ -124,7 +203,14 @@ def main():
     ap.add_argument("--fit-mode", default="exact",
                     help="comma-separated SLIMElastic fit modes to stream with: exact (bit-identical to scikit-learn), gram, shuffle")
     ap.add_argument("--bulk-chunk", type=int, default=4_000_000, help="rows per vectorised bulk-ingest call")
+    ap.add_argument("--open-loop", default="", help="comma-separated arrival rates (interactions/s): run the fixed-QPS open-loop "
+                                                    "harness instead (Poisson arrivals, consumer takes what has arrived)")
+    ap.add_argument("--duration", type=float, default=3.0, help="seconds of arrivals per open-loop run")
     args = ap.parse_args()
+    if args.open_loop:
+        print(json.dumps(run_open_loop(args.workload, tuple(float(v) for v in args.open_loop.split(",")), args.duration,
+                                       tuple(args.fit_mode.split(",")), score_users=args.score_users)))
+        return
     print(json.dumps(run_stream(args.workload, args.batches, args.batch_size, args.score_users, args.qps,
                                 tuple(args.fit_mode.split(",")), args.bulk_chunk)))
 
