@@ -207,6 +207,16 @@ def _worker(rank, world, port, q, score_shard="columns"):
         m.item_similarity = sp.csc_matrix(load_csc(z, "W2_k50"), dtype=np.float64)
         out = m.recommend_batch(users, X.tocsr(), top_k=10, filter_interacted=True, dense_output=False, ret_scores=True)
         ok = ok and [o[0] for o in out] == [[x for x in row.tolist() if x >= 0] for row in zs["ids_f64_sparse_filter"]]
+        # resident X: two calls with DIFFERENT row sets of equal length must not share a cached slice / work order (ADVICE round
+        # 2: a cache keyed on the row tensor's address returned the first call's users for the second)
+        eng.set_weights(load_csc(z, "W2_k50"))
+        eng.set_interactions(None, X.tocsr(), need_csc=False)
+        solo = SlimEngine(backend=OracleBackend())
+        solo.set_interactions(None, X.tocsr(), need_csc=False)
+        solo.set_weights(load_csc(z, "W2_k50"))
+        for rows in ([5, 17, 40, 41, 300], [9, 3, 77, 78, 1100], [5, 17, 40, 41, 300], [1, 2, 3, 4, 6]):
+            got, ref = eng.recommend_rows(rows, top_k=5), solo.recommend_rows(rows, top_k=5)
+            ok = ok and all(np.array_equal(a, b) for a, b in zip(got, ref))
         q.put((rank, ok_w, ok, eng._layout(True)["n_cols"]))
     finally:
         dist.destroy_process_group()
