@@ -37,14 +37,47 @@ def is_stale() -> bool:
 
 
 def build_native(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
-        return LIB_PATH
+    if force or is_stale():
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd, cwd=CSRC)
+    build_ops(force=force, verbose=verbose)
+    return LIB_PATH
+
+
+# The PyTorch-ROCm custom ops (torch.ops.rtrec_amd.*) are registered from C++ (csrc/torch_ops.cpp, TORCH_LIBRARY): host
+# code only, built with the host compiler against the torch headers; it binds librtrec_amd.so at run time (dlopen).
+OPS_PATH = os.path.join(LIB_DIR, "librtrec_amd_ops.so")
+OPS_SOURCE = os.path.join(CSRC, "torch_ops.cpp")
+
+
+def ops_stale() -> bool:
+    if not os.path.exists(OPS_PATH):
+        return True
+    t = os.path.getmtime(OPS_PATH)
+    return any(os.path.getmtime(d) > t for d in (OPS_SOURCE, os.path.normpath(os.path.join(CSRC, HEADERS[-1]))))
+
+
+def build_ops(force: bool = False, verbose: bool = False) -> str:
+    if not force and not ops_stale():
+        return OPS_PATH
+    import torch
+    from torch.utils import cpp_extension
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cxx = shutil.which("g++") or "g++"
+    abi = int(getattr(torch._C, "_GLIBCXX_USE_CXX11_ABI", True))
+    cmd = ([cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            f"-D_GLIBCXX_USE_CXX11_ABI={abi}", "-I/opt/rocm/include"]
+           + [f"-I{p}" for p in cpp_extension.include_paths()]
+           + [OPS_SOURCE, "-o", OPS_PATH, f"-L{tlib}", "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", "-ldl",
+              f"-Wl,-rpath,{tlib}"])
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=CSRC)
-    return LIB_PATH
+    return OPS_PATH
 
 
 if __name__ == "__main__":

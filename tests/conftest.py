@@ -18,7 +18,7 @@ def pytest_sessionstart(session):
     store (merge / lookup / decay / LRU replay) live in the same library."""
     try:
         from rtrec_amd import build
-        if build.is_stale():
+        if build.is_stale() or build.ops_stale():
             build.build_native()
     except Exception as e:      # the tests that need the library then say so themselves
         print(f"[conftest] could not build librtrec_amd.so: {e}", file=sys.stderr)

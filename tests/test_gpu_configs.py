@@ -356,7 +356,7 @@ def test_c3s_recommend_all_users_segment_kernel(c3s, oracle):
 def test_midsize_reference_models_on_gpu(engine):
     """tests/golden/midsize.json (real SLIMElastic at the ML-1M shape and on a structured 3000 x 1500 matrix): the HIP fit's W
     has the reference's CSC checksums and scikit-learn's n_iter_ for every column."""
-    from test_oracle_golden import check_model_crc, midsize, midsize_matrix
+    from tests.test_oracle_golden import check_model_crc, midsize, midsize_matrix
     for name in ("ml1m", "s3000"):
         X = midsize_matrix(name)
         I = X.shape[1]
@@ -370,7 +370,7 @@ def test_midsize_reference_models_on_gpu(engine):
 def test_midsize_long_columns_on_gpu(c3):
     """80 long target columns (12k .. 128k entries) of the ML-20M shape: features, coefficient bits and sweep counts of the
     full-size HIP fit equal scikit-learn's (fixture from the real reference)."""
-    from test_oracle_golden import midsize
+    from tests.test_oracle_golden import midsize
     ref = midsize()["long_columns"]
     pos = {int(t): k for k, t in enumerate(c3["tg"])}
     for n, j in enumerate(ref["targets"]):
