@@ -21,7 +21,7 @@ def load(d, wl):
     for path in glob.glob(os.path.join(d, f"pmc*_{wl}_counter_collection.csv")):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                k = row["Kernel_Name"].split("(")[0]
+                k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
                 c = acc[k][row["Counter_Name"]]
                 c[0] += float(row["Counter_Value"])
                 c[1].add(row["Dispatch_Id"])
@@ -34,10 +34,17 @@ def main():
     stats = glob.glob(os.path.join(d, f"stats_{wl}_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(d, f"{tag}_{wl}_kernel_stats.csv"))
-    score = [k for k in per if "score_frows_kernel" in k] or [k for k in per if "score_sparse_kernel<float, false>" in k]
+    score = ([k for k in per if "score_seg_kernel" in k] or [k for k in per if "score_frows_kernel" in k]
+             or [k for k in per if "score_sparse_kernel<float, false>" in k])
     if score:
         k = max(score, key=lambda n: per[n].get("SQ_WAVE_CYCLES", (0, 0))[0])
         c = {n: v[0] for n, v in per[k].items()}
+        heavy = [h for h in per if "score_seg_heavy_kernel" in h] if "score_seg_kernel" in k else []
+        if heavy:       # the segment path is two launches per pass (long users first): byte counters are summed, the rest kept apart
+            hc = {n: v[0] for n, v in per[heavy[0]].items()}
+            for n in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"):
+                c[n] = c.get(n, 0.0) + hc.get(n, 0.0)
+            c.update({"heavy_" + n: v for n, v in hc.items() if n.startswith("SQ_")})
         launches = max(v[1] for v in per[k].values())
         fetch_kb, write_kb = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
         hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)

@@ -20,7 +20,7 @@ def main() -> None:
     for path in args:
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                k = row["Kernel_Name"]
+                k = row["Kernel_Name"].replace("(anonymous namespace)::", "")
                 if match and match not in k:
                     continue
                 k = k.split("(")[0]
