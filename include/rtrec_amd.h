@@ -163,6 +163,8 @@ typedef struct {
      * computes X^T y of ALL its targets in one pass over X (xty_batch_kernel: a wave per item column, the sums of every
      * target in LDS, products folded in the reference's ascending-user order) instead of one walk per target; results
      * are unchanged.  rtrec_slim_xty_workspace_bytes(n_users, n_items, nnz, n_targets) bytes, nnz = stored entries of X. */
+    /* PRECONDITION with d_xty_ws: the call's targets are DISTINCT (the one-pass X^T y maps a target to one slot of the call;
+     * a repeated target would be fitted without features).  Callers that may repeat a target pass NULL here. */
     void          *d_xty_ws;
     size_t         xty_ws_bytes;
     int64_t        nnz;

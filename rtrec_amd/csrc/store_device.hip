@@ -30,7 +30,14 @@ __global__ __launch_bounds__(256) void decay_kernel(const double *__restrict__ v
         out[k] = f;
         // distance of v to the nearest float32 rounding boundary (the midpoints between f and its neighbours)
         const double fd = static_cast<double>(f);
-        if (!(fabs(v) < 1e300) || fd == 0.0) continue;                       // inf / nan / zero: nothing to decide
+        if (!(fabs(v) < 1e300) || v == 0.0) continue;                        // inf / nan / an exact zero: nothing to decide
+        if (fd == 0.0 || fabs(v) < 0x1p-148) {
+            // at the underflow boundary (|v| around 2^-150: float32 rounds to 0 or to its smallest denormal): the spacing
+            // test below does not apply, the host decides with libm
+            const int slot = atomicAdd(unsafe_count, 1);
+            if (slot < cap) unsafe_idx[slot] = static_cast<int>(k);
+            continue;
+        }
         const float up = __uint_as_float(__float_as_uint(fabsf(f)) + 1u), dn = __uint_as_float(__float_as_uint(fabsf(f)) - 1u);
         const double a = fabs(v), m_up = 0.5 * (fabs(fd) + static_cast<double>(up)), m_dn = 0.5 * (fabs(fd) + static_cast<double>(dn));
         const double dist = fmin(fabs(a - m_up), fabs(a - m_dn));

@@ -775,6 +775,9 @@ class SlimEngine:
             raise RuntimeError("set_interactions() with the CSC orientation must be called before fit_columns()")
         U, I = self.n_users, self.n_items
         targets = np.asarray(targets, dtype=np.int64)
+        # the one-pass X^T y of small calls maps a target to ONE slot of the call (xty_tmap_kernel): a repeated target would lose
+        # its candidates there, so such a call takes the per-target walks (same results)
+        distinct_targets = len(np.unique(targets)) == len(targets)
         # longest columns first: the device work queue then ends on short jobs
         order = np.argsort(-X["col_nnz"][targets], kind="stable")
         targets = targets[order]
@@ -882,7 +885,7 @@ class SlimEngine:
                                ws_slots, d["trace"], gram, fast=fast,
                                # the heavy head of a bulk call starts its long ordered folds at once: its targets' own
                                # multi-wave walks overlap them, a one-pass X^T y up front would only delay the chain
-                               one_pass_xty=(role != "heavy" and self._one_pass_xty_pays(tg)))
+                               one_pass_xty=(role != "heavy" and distinct_targets and self._one_pass_xty_pays(tg)))
             else:
                 be.fit_columns(U, I, X, d["t"], cfg, d["items"], d["coef"], d["count"], d["niter"], cap, ws, queue,
                                ws_slots, d["trace"], gram)

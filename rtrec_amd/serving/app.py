@@ -20,6 +20,7 @@ from __future__ import annotations
 import logging
 import os
 import threading
+import time
 from typing import Any, Callable, Dict, List, Optional, Tuple
 
 from fastapi import APIRouter, FastAPI, Header, HTTPException
@@ -111,6 +112,7 @@ class RecommendCoalescer:
         self._queue: List[_Pending] = []
         self._leading = False
         self._full = threading.Event()
+        self._last_other = -1e9     # when a request last arrived while another was in flight
         self.rounds = 0             # recommend launches made on behalf of /recommend
         self.requests = 0           # /recommend calls answered
 
@@ -118,6 +120,8 @@ class RecommendCoalescer:
         p = _Pending(user, top_k, filter_interacted)
         with self._mu:
             self._queue.append(p)
+            if self._leading:
+                self._last_other = time.monotonic()      # a request arrived while another was being answered: callers overlap
             lead = not self._leading
             if lead:
                 self._leading = True
@@ -136,7 +140,12 @@ class RecommendCoalescer:
         return p.result
 
     def _round(self) -> None:
-        if self.max_wait_s > 0.0:
+        # the bounded wait collects concurrent callers; a request that is alone -- nothing else queued, no other request seen
+        # within the last window -- goes straight through (an isolated POST /recommend paid the whole wait)
+        now = time.monotonic()
+        with self._mu:
+            crowded = len(self._queue) > 1 or (now - self._last_other) < 4.0 * self.max_wait_s
+        if self.max_wait_s > 0.0 and crowded:
             self._full.wait(self.max_wait_s)
         batch: List[_Pending] = []
         try:

@@ -800,3 +800,66 @@ def test_device_resident_store_with_time_decay_tracks_the_host_store():
         items = np.unique(i).tolist()
         part = mir.partial(np.asarray(items))
         _assert_same_matrix(part, st.to_csc(items), "csc")
+
+
+def test_recommend_coalescer_promotion_failure_and_isolated_requests():
+    """RecommendCoalescer (serving/app.py): an isolated request does not pay the bounded wait; concurrent callers share
+    launches and a follower woken without an answer leads the next round; a failing model call reaches every caller of that
+    round and the coalescer keeps serving afterwards."""
+    import threading
+    import time
+    from rtrec_amd.serving.app import RecommendCoalescer
+
+    class FakeModel:
+        def __init__(self):
+            self.fail = False
+            self.calls = []
+
+        def recommend(self, user, top_k=10, filter_interacted=True):
+            if self.fail:
+                raise RuntimeError("boom")
+            time.sleep(0.005)
+            return [user, top_k]
+
+        def recommend_batch(self, users, top_k=10, filter_interacted=True):
+            self.calls.append(list(users))
+            if self.fail:
+                raise RuntimeError("boom")
+            time.sleep(0.005)
+            return [[u, top_k] for u in users]
+
+    class Gate:
+        def __init__(self, model):
+            self.model = model
+            self._lock = threading.RLock()
+
+    m = FakeModel()
+    co = RecommendCoalescer(Gate(m), max_wait_s=0.05, max_batch=4)
+    co._known = lambda model, user: True
+    t0 = time.perf_counter()
+    assert co.submit(7, 5, True) == [7, 5]
+    assert time.perf_counter() - t0 < 0.04, "an isolated request must not wait for company"
+    out, errs = {}, []
+
+    def call(u):
+        try:
+            out[u] = co.submit(u, 3, True)
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=call, args=(u,)) for u in range(10)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=10)
+    assert not errs and out == {u: [u, 3] for u in range(10)}
+    assert all(len(c) <= 4 for c in m.calls) and sum(len(c) for c in m.calls if len(c) > 1) >= 4      # batches were shared, several rounds led
+    m.fail = True
+    th = [threading.Thread(target=call, args=(100 + u,)) for u in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=10)
+    assert len(errs) == 3 and all(isinstance(e, RuntimeError) for e in errs)
+    m.fail = False
+    assert co.submit(9, 2, False) == [9, 2]
