@@ -469,3 +469,11 @@ def test_candidate_lists_follow_the_reference_ranking_on_the_oracle_backend():
         for u, g in zip(users, got):
             s = (X[m.user_ids.get_id(u)] @ W[:, cands]).toarray().ravel()
             assert g == [cands[i] for i in np.argsort(s, kind="stable")[-5:][::-1]]
+
+
+def test_hybrid_slimfm_call_sequence_on_the_facade():
+    """The calls HybridSlimFM makes on its SLIMElastic (hybrid.py:122 ... :477), in its order, with the real SLIMElastic's answers
+    (hybrid itself needs lightfm / implicit, its SLIM half is what rtrec_amd replaces)."""
+    from tests.hybrid_replay import replay
+    replay(lambda cfg: SLIMElastic(cfg, engine=SlimEngine(backend=OracleBackend())))
+

@@ -445,7 +445,63 @@ def gen_midsize():
     json.dump(out, open(os.path.join(OUT, "midsize.json"), "w"))
 
 
+# ------------------------------------------------------------------ N4: the call sequence HybridSlimFM makes on its SLIM half
+def gen_hybrid_calls():
+    """HybridSlimFM (rtrec/models/hybrid.py) drives a SLIMElastic through a fixed set of calls: :122 SLIMElastic(kwargs), :151 /
+    :196 partial_fit_items(coo.tocsc(), item_ids[, parallel]), :217 fit(csc, parallel), :225 recommend(...), :267 recommend(...,
+    ret_scores=True), :381 recommend_batch(..., ret_scores=False), :409 recommend_batch(..., ret_scores=True), :477
+    similar_items(q, top_k, ret_ndarrays=True).  hybrid.py itself needs lightfm / implicit (not installed); its SLIM half is
+    the real SLIMElastic, so the sequence is replayed on it and every answer recorded (float ratings: no score ties)."""
+    rng = np.random.default_rng(17)
+    X = interaction_matrix(260, 90, 5200, seed=404).tocoo()
+    order = rng.permutation(X.nnz)
+    u, i, v = X.row[order], X.col[order], X.data[order]
+    cut = int(X.nnz * 0.7)
+    out = {"u": u.tolist(), "i": i.tolist(), "v": v.astype(float).tolist(), "cut": cut, "kwargs": {"nn_feature_selection": 12, "alpha": 0.05}}
+    m = RefSLIMElastic(dict(out["kwargs"]))
+    A = sp.coo_matrix((v[:cut], (u[:cut], i[:cut])), shape=(260, 90), dtype=np.float32)
+    items_a = sorted(set(i[:cut].tolist()))
+    m.partial_fit_items(A.tocsc(copy=False), items_a, progress_bar=False)                       # hybrid.py:151
+    B = sp.coo_matrix((v, (u, i)), shape=(260, 90), dtype=np.float32)
+    items_b = sorted(set(i[cut:].tolist()))
+    m.partial_fit_items(B.tocsc(copy=False), items_b, parallel=True, progress_bar=False)        # hybrid.py:196
+    out["items_a"], out["items_b"] = items_a, items_b
+    out.update({k: (a.tolist() if hasattr(a, "tolist") else a) for k, a in csc_parts(m.item_similarity, "W_after_b").items()})
+    Br = B.tocsr()
+    users = [0, 7, 33, 120, 259]
+    cands = [3, 88, 17, 41, 5, 64, 70]
+    rec = {}
+    for uu in users:
+        row = Br          # (the reference indexes the matrix it is given with the user id: hybrid passes to_csr(select_users=[u]))
+        rec[str(uu)] = {
+            "plain": m.recommend(uu, row, candidate_item_ids=None, top_k=6, filter_interacted=True, dense_output=False),       # :225
+            "scores": [a.tolist() if hasattr(a, "tolist") else a for a in
+                       m.recommend(uu, row, candidate_item_ids=None, top_k=6, filter_interacted=True, dense_output=False, ret_scores=True)],  # :267
+            "cands": [a.tolist() if hasattr(a, "tolist") else a for a in
+                      m.recommend(uu, row, candidate_item_ids=cands, top_k=4, filter_interacted=False, dense_output=False, ret_scores=True)],
+            "dense": m.recommend(uu, row, candidate_item_ids=None, top_k=6, filter_interacted=True, dense_output=True)}
+    out["users"], out["cands"], out["recommend"] = users, cands, rec
+    sub = Br
+    out["batch_plain"] = m.recommend_batch(users, sub, candidate_item_ids=None, top_k=6, filter_interacted=True, dense_output=False,
+                                           ret_scores=False)                                                                      # :381
+    out["batch_scores"] = [[a.tolist() if hasattr(a, "tolist") else a for a in r] for r in
+                           m.recommend_batch(users, sub, candidate_item_ids=None, top_k=6, filter_interacted=False, dense_output=False,
+                                             ret_scores=True)]                                                                    # :409
+    sim = {}
+    for q in (0, 5, 41, 89):
+        a, b = m.similar_items(q, top_k=5, ret_ndarrays=True)                                                                      # :477
+        sim[str(q)] = [a.tolist(), b.astype(float).tolist()]
+    out["similar"] = sim
+    m.fit(B.tocsc(), parallel=False, progress_bar=False)                                                                            # :217
+    out.update({k: (a.tolist() if hasattr(a, "tolist") else a) for k, a in csc_parts(m.item_similarity, "W_after_fit").items()})
+    json.dump(out, open(os.path.join(OUT, "hybrid_calls.json"), "w"))
+    print("[golden] hybrid call sequence recorded")
+
+
 if __name__ == "__main__":
+    if "--hybrid" in sys.argv:
+        gen_hybrid_calls()
+        sys.exit(0)
     if "--midsize" in sys.argv:
         gen_midsize()
         sys.exit(0)
