@@ -397,6 +397,7 @@ def test_api_randomised_parity():
 def test_hybrid_slimfm_call_sequence_on_the_gpu():
     """HybridSlimFM's calls on its SLIM half (hybrid.py:122,151,196,217,225,267,381,409,477) replayed on the product path against the
     real SLIMElastic's answers (tests/golden/hybrid_calls.json)."""
+    from rtrec_amd.models.internal.slim_elastic import SLIMElastic
     from tests.hybrid_replay import replay
     replay(lambda cfg: SLIMElastic(cfg))
 
