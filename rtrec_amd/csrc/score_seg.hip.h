@@ -51,7 +51,10 @@ struct SegArgs {
 };
 
 constexpr int kSgWaves = 4;          // waves per workgroup; they share nothing (no barrier in the kernel)
-constexpr int kSgCap = 512;          // items of a user a wave keeps in LDS (layout columns, rows of W, ratings); longer users: heavy pass
+#ifndef SG_CAP
+#define SG_CAP 512
+#endif
+constexpr int kSgCap = SG_CAP;          // items of a user a wave keeps in LDS (layout columns, rows of W, ratings); longer users: heavy pass
 constexpr int kSgQueueChunk = 4;     // users per queue claim
 constexpr int kSgMaxKk = 64;         // top_k + 1 list entries: one per lane
 #ifndef SG_HEAVY_SLOTS

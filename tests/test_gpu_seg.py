@@ -164,3 +164,34 @@ def test_seg_small_and_empty_cases(oracle):
     check(eng, oracle, X, W, np.array([3]), 10, True)               # one user
     check(eng, oracle, X, W, np.arange(300), 63, True)              # k larger than most users' candidate sets
     check(eng, oracle, X, W, np.arange(300), 64, True, expect_path="tiled")     # beyond the kernel's list: the tiled path
+
+
+def test_seg_generic_path_at_scale_agrees_with_the_tiled_kernel(oracle):
+    """A 100k-item catalogue with 2 M block-structured weights over ~95k active columns: tiles of 1024 columns, the generic
+    accumulate loop (multi-step segments, no dense blocks), 16-bit LDS lists no longer possible (wide instantiation) -- all
+    40,000 users against the tiled-CSR kernel, a sample against the oracle."""
+    I = 100_000
+    rng = np.random.default_rng(8)
+    nnz = 2_000_000
+    r = rng.integers(0, I, nnz)
+    blk = 500
+    c = np.where(rng.random(nnz) < 0.85, (r // blk) * blk + rng.integers(0, blk, nnz), rng.integers(0, I, nnz)) % I
+    W = sp.csc_matrix(((rng.random(nnz) + 0.02).astype(np.float32), (r, c)), shape=(I, I))
+    W.sum_duplicates()
+    W.sort_indices()
+    X = interaction_matrix(40_000, I, 3_000_000, seed=61)
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    rows = np.arange(X.shape[0])
+    ids, sc, cnt = eng.recommend_rows(rows, top_k=10)
+    assert eng.last_score_path == "segments"
+    sg = eng._fast_layout()["sg"]
+    assert sg["sg_T"] == 1024 and sg["sg_rows"] > 65_535
+    eng.use_seg_layout = False
+    ids2, sc2, cnt2 = eng.recommend_rows(rows, top_k=10)
+    assert eng.last_score_path == "tiled"
+    assert np.array_equal(ids, ids2) and np.array_equal(bits(sc), bits(sc2)) and np.array_equal(cnt, cnt2)
+    sample = np.sort(rng.choice(X.shape[0], 1500, replace=False))
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], W.tocsr(), top_k=10, n_threads=8)
+    assert np.array_equal(ids[sample], o_ids) and np.array_equal(bits(sc[sample]), bits(o_sc)) and np.array_equal(cnt[sample], o_cnt)
