@@ -480,6 +480,17 @@ int rtrec_store_decay(const double *val, const double *ts, int64_t n, double rat
 int rtrec_store_decay_device(const double *d_val, const double *d_ts, int64_t n, double rate, double now,
                              float *d_out32, int32_t *d_unsafe_idx, int32_t *d_unsafe_count, int32_t cap, void *stream);
 
+/* Bulk ingest on the device (replaces one add_interaction per DataFrame row, rtrec/utils/interactions.py:81-119 as driven by
+ * rtrec/recommender.py:203-223).  Device pointers.  The batch is given sorted by (user, item, arrival): d_order[k] = arrival
+ * index of the k-th interaction in that order, d_start[n_groups + 1] = the runs of the distinct pairs.  Per pair, in arrival
+ * order: v = d_old ? d_old[g] : 0.0, then v = max(lo, min(v + d_delta[i], hi)) per occurrence with Python's min / max (a NaN
+ * sum ends as lo) -- or, with upsert != 0, v = the last occurrence's delta; d_out_ts[g] = the last occurrence's tstamp.
+ * d_out_val32 (may be NULL) receives (float)v, the value the resident matrix carries.  No time decay (the decayed current
+ * value of interactions.py:62-79 depends on the running max_timestamp: such stores ingest on the host). */
+int rtrec_store_fold_device(const int64_t *d_order, const int64_t *d_start, int64_t n_groups,
+                            const double *d_delta, const double *d_tstamp, const double *d_old, double lo, double hi,
+                            int32_t upsert, double *d_out_val, double *d_out_ts, float *d_out_val32, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ EXPORTS = [
     "rtrec_slim_score_topk", "rtrec_slim_score_rows", "rtrec_slim_merge_topk", "rtrec_slim_merge_topk_strided", "rtrec_slim_similar_topk",
     "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round", "rtrec_store_decay",
     "rtrec_store_decay_device",
+    "rtrec_store_fold_device",
 ]
 
 
@@ -141,6 +142,8 @@ def load() -> C.CDLL:
     L.rtrec_store_decay.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_double, vp, vp, i32]
     L.rtrec_store_decay_device.restype = C.c_int
     L.rtrec_store_decay_device.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_double, vp, vp, vp, i32, vp]
+    L.rtrec_store_fold_device.restype = C.c_int
+    L.rtrec_store_fold_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp, vp]
     _lib = L
     return L
 

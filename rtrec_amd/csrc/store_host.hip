@@ -170,7 +170,7 @@ extern "C" int rtrec_store_apply_round(const int64_t *order, int64_t n, const do
         for (int64_t k = k0; k < k1; ++k) {
             const int64_t i = order[k];
             double v = delta[i];
-            if (old) { v += old[k]; v = v < lo ? lo : (v > hi ? hi : v); }      // numpy.clip: NaN passes through
+            if (old) { v += old[k]; v = hi < v ? hi : v; v = v > lo ? v : lo; }      // Python's max(lo, min(v, hi)): a NaN ends as lo
             out_val[k] = v;
             out_ts[k] = tstamp[i];
         }

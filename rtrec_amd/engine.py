@@ -624,6 +624,18 @@ class HipBackend:
             out[sel] = torch.from_numpy(fix).to(out.device)
         return out
 
+    def fold_pairs(self, order, start, delta, tstamp, old, lo: float, hi: float, upsert: bool):
+        """(float64 values, float64 timestamps, float32 values) of a bulk batch's distinct pairs: rtrec_store_fold_device over
+        the batch sorted by (user, item, arrival) -- see DeviceInteractions.ingest."""
+        torch = self.torch
+        g = int(start.shape[0]) - 1
+        val, ts, v32 = self.empty((g,), torch.float64), self.empty((g,), torch.float64), self.empty((g,), torch.float32)
+        _native.check(self.lib.rtrec_store_fold_device(self.ptr(order), self.ptr(start), g, self.ptr(delta), self.ptr(tstamp),
+                                                       self.ptr(old) if old is not None else None, float(lo), float(hi),
+                                                       int(bool(upsert)), self.ptr(val), self.ptr(ts), self.ptr(v32), self.stream()),
+                      "rtrec_store_fold_device")
+        return val, ts, v32
+
     def timer_create(self) -> int:
         h = C.c_void_p()
         _native.check(self.lib.rtrec_timer_create(C.byref(h)), "rtrec_timer_create")

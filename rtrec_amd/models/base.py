@@ -115,10 +115,16 @@ class BaseModel(ABC):
         iid = self.item_ids.identify_many(items)
         tag0 = self._store_tag()
         self.interactions.add_interactions_batch(uid, iid, np.asarray(tstamps, dtype=np.float64),
-                                                 np.asarray(ratings, dtype=np.float64), upsert=update_interaction)
+                                                 np.asarray(ratings, dtype=np.float64), upsert=update_interaction,
+                                                 device_fold=self._bulk_folder(len(uid)))
         self._stored(tag0, uid, iid)
         if record_interactions:
             self._record_batch(uid, iid)
+
+    def _bulk_folder(self, n: int) -> Any:
+        """A device routine that reduces a bulk batch of n interactions to its distinct pairs (see
+        UserItemInteractions.add_interactions_batch), or None: models with a GPU backend override this."""
+        return None
 
     def _store_tag(self) -> Any:
         """What a copy of the store must match to be current (models with time decay add max_timestamp)."""

@@ -59,6 +59,37 @@ class SLIM(BaseModel):
 
     _MIRROR_APPLY_MAX = 1 << 18     # larger writes (bulk chunks) leave the mirror stale: it is rebuilt on demand
 
+    @property
+    def bulk_chunk_rows(self) -> Optional[int]:
+        """How many DataFrame rows Recommender hands over per add_interactions_columns call: with the device ingest one
+        chunk is one upload + one sort, so the whole frame goes in one piece (64 M rows = 2 GiB of columns)."""
+        return (1 << 26) if self._bulk_folder(1 << 26) is not None else None
+
+    def _bulk_folder(self, n: int) -> Any:
+        """Bulk batches are sorted, deduplicated and folded on the device (DeviceInteractions.ingest with the backend's
+        rtrec_store_fold_device kernel); a batch into an EMPTY store also leaves the mirror in step -- no upload later."""
+        from ..utils.interactions import _DEVICE_FOLD_MIN
+        st = self.interactions
+        if (n < _DEVICE_FOLD_MIN or st.decay_rate is not None or os.environ.get("RTREC_AMD_DEVICE_INGEST", "1") == "0"):
+            return None
+        if self.model._engine is None:
+            # ingest alone does not need the GPU (the host store is complete by itself): do not construct the engine --
+            # which fails loudly without one -- just to look for a folder
+            import torch
+            if not torch.cuda.is_available():
+                return None
+        mir = self._mirror(True)
+        fold_fn = None if mir is None else getattr(self.model.engine.be, "fold_pairs", None)
+        if fold_fn is None:
+            return None
+        was_empty = st.is_empty
+
+        def fold(users, items, ts, dl, upsert, lo, hi, lookup):
+            res = mir.ingest(users, items, ts, dl, upsert, lo, hi, lookup, fold_fn)
+            self._ingested_into_empty = was_empty
+            return res
+        return fold
+
     def _ingest(self, interactions: Iterable[Tuple[Any, Any, float, float]], update_interaction: bool
                 ) -> Tuple[np.ndarray, np.ndarray]:
         tag0 = self._store_tag()
@@ -70,6 +101,12 @@ class SLIM(BaseModel):
         """A mirror that was in step with the store is advanced by the batch's distinct (user, item)
         pairs -- their new (raw) values and timestamps come from the host store, which owns the semantics."""
         st, mir = self.interactions, self._dev_x
+        if mir is not None and mir.ingested is not None:       # the batch was folded on the device
+            into_empty, self._ingested_into_empty = getattr(self, "_ingested_into_empty", False), False
+            if self._store_tag() != tag_before and (into_empty or mir.version == tag_before):
+                mir.adopt_ingested(st.shape[0], st.shape[1], self._store_tag(), merge=not into_empty)
+                return
+            mir.ingested = None
         if (mir is None or mir.version != tag_before or self._store_tag() == tag_before
                 or len(user_ids) > self._MIRROR_APPLY_MAX or os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0"):
             return

@@ -53,8 +53,9 @@ class Recommender:
             # sequential semantics as one add_interaction per row, so mini-batch boundaries (batch_size)
             # do not change the result; only the per-row Python objects of the reference loop go away.
             u, i, t, r = (frame[c].to_numpy() for c in _COLUMNS)
-            for s in range(0, len(frame), _COLUMNAR_CHUNK):
-                e = s + _COLUMNAR_CHUNK
+            chunk = getattr(self.model, "bulk_chunk_rows", None) or _COLUMNAR_CHUNK
+            for s in range(0, len(frame), chunk):
+                e = s + chunk
                 columnar(u[s:e], i[s:e], t[s:e], r[s:e], update_interaction=update_interaction,
                          record_interactions=record)
             return

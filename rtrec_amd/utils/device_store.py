@@ -50,10 +50,15 @@ class DeviceInteractions:
         self._now: Optional[float] = None
         self._valued_at: Optional[float] = None
         self.decay_fn: Any = None           # (raw, ts, rate, now) -> float32 tensor; the GPU backend installs the HIP kernel
+        self.ingested: Optional[Dict[str, Any]] = None      # the block the last ingest() folded, still on the device
 
     # ------------------------------------------------------------------ build
-    def _dev(self, a: np.ndarray):
-        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+    def _dev(self, a: Any, dtype: Any = None):
+        """A host array uploaded (cast to `dtype` first) -- or a tensor that already lives on the device, as it is."""
+        if self.torch.is_tensor(a):
+            want = None if dtype is None else getattr(self.torch, np.dtype(dtype).name)
+            return a.to(self.device) if want is None or a.dtype == want else a.to(self.device, want)
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.device)
 
     def load_csr(self, indptr: np.ndarray, indices: np.ndarray, data: np.ndarray, n_users: int, n_items: int,
                  version: int) -> None:
@@ -92,17 +97,17 @@ class DeviceInteractions:
         stored values and -- for a store with time decay (rate, now = max_timestamp) -- the timestamps.  No host
         export: the values are cast (or decayed) on the device, the column-major copy is a device sort."""
         torch = self.torch
-        self._rk = self._dev(np.asarray(keys, dtype=np.int64))
+        self._rk = self._dev(keys, np.int64)
         ck = ((self._rk & _MASK) << _SHIFT) | (self._rk >> _SHIFT)
         self._ck, order = torch.sort(ck)
         self.rate = None if rate is None else float(rate)
         if self.rate is None:
-            self._rv = self._dev(np.asarray(raw, dtype=np.float32))
+            self._rv = self._dev(raw, np.float32)
             self._cv = self._rv[order]
             self._rraw = self._rts = self._craw = self._cts = None
             self._now = self._valued_at = None
         else:
-            self._rraw, self._rts = self._dev(np.asarray(raw, dtype=np.float64)), self._dev(np.asarray(ts, dtype=np.float64))
+            self._rraw, self._rts = self._dev(raw, np.float64), self._dev(ts, np.float64)
             self._craw, self._cts = self._rraw[order], self._rts[order]
             self._rv = self._cv = None
             self._now, self._valued_at = float(now), None
@@ -196,21 +201,87 @@ class DeviceInteractions:
         """Set X[users[k], items[k]] = values[k] for distinct pairs (the state the host store holds after a
         mini-batch) and grow the shape to (n_users, n_items).  With time decay `values` are the RAW stored values,
         `tstamps` their timestamps and `now` the store's max_timestamp after the batch."""
-        u = self._dev(np.asarray(users, dtype=np.int64))
-        i = self._dev(np.asarray(items, dtype=np.int64))
+        u = self._dev(users, np.int64)
+        i = self._dev(items, np.int64)
         if self.rate is None:
-            v = self._dev(np.asarray(values, dtype=np.float32))
+            v = self._dev(values, np.float32)
             if u.shape[0]:
                 self._rk, (self._rv,) = self._merge(self._rk, [self._rv], (u << _SHIFT) | i, [v])
                 self._ck, (self._cv,) = self._merge(self._ck, [self._cv], (i << _SHIFT) | u, [v])
         else:
-            v = self._dev(np.asarray(values, dtype=np.float64))
-            t = self._dev(np.asarray(tstamps, dtype=np.float64))
+            v = self._dev(values, np.float64)
+            t = self._dev(tstamps, np.float64)
             if u.shape[0]:
                 self._rk, (self._rraw, self._rts) = self._merge(self._rk, [self._rraw, self._rts], (u << _SHIFT) | i, [v, t])
                 self._ck, (self._craw, self._cts) = self._merge(self._ck, [self._craw, self._cts], (i << _SHIFT) | u, [v, t])
             self._now, self._valued_at = float(now), None      # every value is a function of max_timestamp
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
+
+    # ------------------------------------------------------------------ bulk ingest
+    def ingest(self, users: np.ndarray, items: np.ndarray, tstamps: np.ndarray, deltas: np.ndarray, upsert: bool,
+               lo: float, hi: float, lookup: Any, fold_fn: Any) -> Dict[str, Any]:
+        """A DataFrame-sized batch of interactions reduced to its distinct (user, item) pairs ON THE DEVICE, with the
+        sequential semantics of one add_interaction per row (rtrec/utils/interactions.py:81-119, no time decay):
+        the batch is uploaded once, sorted by (user, item, arrival) -- a value sort of the composite when it fits 63 bits,
+        like the host store's _stable_order -- cut into runs of equal pairs, and every run is folded in arrival order by
+        fold_fn (HipBackend.fold_pairs -> rtrec_store_fold_device) starting from the stored value `lookup(keys)` returns
+        (None: the store is empty).  Also counted on the device: the hot-item statistics (LRUFreqSet.add per positive
+        delta, interactions.py:115-116) as (item, hits, last arrival) triples and the set of items present.
+
+        Returns host arrays for the store (which stays the owner of the state) -- keys (ascending), val, ts, items_present,
+        hot = (items, hits, last_pos) or None -- and keeps the folded block on the device (self.ingested) so that a mirror of
+        a previously empty store can adopt it without an upload."""
+        torch = self.torch
+        n = int(len(users))
+        u, i = self._dev(users, np.int64), self._dev(items, np.int64)
+        t, d = self._dev(tstamps, np.float64), self._dev(deltas, np.float64)
+        u_hi, i_hi = int(u.max()), int(i.max())
+        ib, xb = i_hi.bit_length(), max(1, (n - 1).bit_length())
+        if u_hi.bit_length() + ib + xb <= 63:
+            comp = (u << (ib + xb)) | (i << xb) | torch.arange(n, dtype=torch.int64, device=self.device)
+            comp = torch.sort(comp)[0]          # distinct composites: the value sort IS the stable order
+            order = comp & ((1 << xb) - 1)
+            comp >>= xb
+            sk = ((comp >> ib) << _SHIFT) | (comp & ((1 << ib) - 1))
+        else:
+            sk, order = torch.sort((u << _SHIFT) | i, stable=True)
+        del u
+        first = torch.ones(n, dtype=torch.bool, device=self.device)
+        first[1:] = sk[1:] != sk[:-1]
+        begin = torch.nonzero(first).reshape(-1)
+        start = torch.cat([begin, torch.tensor([n], dtype=torch.int64, device=self.device)])
+        uk = sk[begin]
+        keys_h = uk.cpu().numpy()
+        old = None
+        if not upsert and lookup is not None:
+            old = self._dev(lookup(keys_h), np.float64)
+        val, ts_k, v32 = fold_fn(order, start, d, t, old, float(lo), float(hi), bool(upsert))
+        out: Dict[str, Any] = {"keys": keys_h, "user_max": u_hi, "item_max": i_hi, "hot": None, "items_present": None}
+        if i_hi <= max(4 * n, 1 << 22):         # dense id range: per-item counts by scatter (the host store's own criterion)
+            pos = d > 0
+            arrival = torch.arange(n, dtype=torch.int64, device=self.device)
+            hits = torch.bincount(i[pos], minlength=i_hi + 1)
+            last = torch.full((i_hi + 1,), -1, dtype=torch.int64, device=self.device)
+            last.scatter_reduce_(0, i[pos], arrival[pos], "amax")
+            seen = torch.bincount(i, minlength=i_hi + 1) > 0
+            hot_items = torch.nonzero(hits).reshape(-1)
+            out["hot"] = (hot_items.cpu().numpy(), hits[hot_items].cpu().numpy(), last[hot_items].cpu().numpy())
+            out["items_present"] = torch.nonzero(seen).reshape(-1).cpu().numpy()
+        out["val"], out["ts"] = val.cpu().numpy(), ts_k.cpu().numpy()
+        self.ingested = {"keys": uk, "val32": v32}
+        return out
+
+    def adopt_ingested(self, n_users: int, n_items: int, version: Any, merge: bool = False) -> bool:
+        """Take over the block the last ingest() folded (stores without time decay): as the whole matrix when the store
+        was empty before it, or (merge) as changed pairs of a mirror that was in step with the store."""
+        blk, self.ingested = self.ingested, None
+        if blk is None:
+            return False
+        if merge:
+            self.apply(blk["keys"] >> _SHIFT, blk["keys"] & _MASK, blk["val32"], n_users, n_items, version)
+        else:
+            self.load_store(blk["keys"], blk["val32"], None, n_users, n_items, version)
+        return True
 
     # ------------------------------------------------------------------ views
     @property

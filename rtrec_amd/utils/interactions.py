@@ -116,6 +116,7 @@ class _Block:
 _NATIVE_MERGE_MIN = 1 << 15
 _NATIVE_FIND_MIN = 1 << 14
 _NATIVE_APPLY_MIN = 1 << 16
+_DEVICE_FOLD_MIN = 1 << 18         # batches at least this long are reduced on the device when the caller offers one
 _MAX_ROUNDS = 32                   # occurrences of one (user, item) pair per batch that are applied as vectorised rounds
 _NATIVE_DECAY_MIN = 1
 _native_merge: Any = None          # False: the native library is not available (numpy merge instead)
@@ -355,9 +356,13 @@ class UserItemInteractions:
                                     np.array([tstamp], np.float64), np.array([delta], np.float64), upsert=upsert)
 
     def add_interactions_batch(self, users: Sequence[int], items: Sequence[int], tstamps: Sequence[float],
-                               deltas: Sequence[float], upsert: bool = False) -> None:
+                               deltas: Sequence[float], upsert: bool = False, device_fold: Any = None) -> None:
         """Apply interactions in order with exactly the sequential semantics of add_interaction
-        (interactions.py:81-119), vectorised over the interactions that touch distinct pairs."""
+        (interactions.py:81-119), vectorised over the interactions that touch distinct pairs.
+
+        device_fold (DeviceInteractions.ingest bound to a GPU backend) reduces a bulk batch to its distinct pairs on the
+        device instead -- sort, run detection, per-pair fold, hot-item counts -- and this store writes the result; it is
+        not used for stores with time decay (every step's current value depends on the running max_timestamp)."""
         users = np.asarray(users, dtype=np.int64)
         items = np.asarray(items, dtype=np.int64)
         ts = np.ascontiguousarray(tstamps, dtype=np.float64)
@@ -376,6 +381,24 @@ class UserItemInteractions:
         decaying = self.decay_rate is not None and not upsert
         seen = np.maximum.accumulate(np.concatenate(([self.max_timestamp], ts + 1.0)))[1:] if decaying else None
         max_ts_after = float(seen[-1]) if decaying else max(self.max_timestamp, float(ts.max()) + 1.0)
+
+        if device_fold is not None and not decaying and n >= _DEVICE_FOLD_MIN:
+            empty = self.is_empty
+            res = device_fold(users, items, ts, dl, upsert, float(self.min_value), float(self.max_value),
+                              None if empty else (lambda keys: self._lookup(keys)[1]))
+            self._write(res["keys"], res["val"], res["ts"], presorted=True)
+            self.max_timestamp = max_ts_after
+            if res["items_present"] is not None:
+                self.all_item_ids.update(res["items_present"].tolist())
+            else:
+                self.all_item_ids.update(np.unique(items).tolist())
+            if res["hot"] is None or not self.hot_items.add_counted(*res["hot"]):
+                pos = dl > 0
+                if pos.any():
+                    self.hot_items.add_many(items[pos])
+            self.max_user_id = max(self.max_user_id, int(res["user_max"]))
+            self.max_item_id = max(self.max_item_id, int(res["item_max"]))
+            return
 
         order, sk = _stable_order(users, items)
         tail_idx = tail_key = None
@@ -421,7 +444,9 @@ class UserItemInteractions:
                     cur = np.where(found & (old != 0.0), self._decay_array(old, old_ts, seen[idx]), 0.0)
                 else:
                     cur = old                 # 0.0 where the pair is new
-                new = np.clip(cur + dl[idx], self.min_value, self.max_value)
+                new = cur + dl[idx]       # max(lo, min(new, hi)) with Python's min / max (interactions.py:106): a NaN ends as lo
+                new = np.where(self.max_value < new, float(self.max_value), new)
+                new = np.where(new > self.min_value, new, float(self.min_value))
             self._write(k, new, ts[idx], presorted=True)     # every round is a subsequence of the key-sorted order
         if tail_idx is not None:
             self._fold_tail(tail_idx, tail_key, ts, dl, seen, upsert)
@@ -511,6 +536,10 @@ class UserItemInteractions:
     @property
     def nnz(self) -> int:
         return len(self._compact())
+
+    @property
+    def is_empty(self) -> bool:
+        return len(self._base) + len(self._delta) + len(self._l0) == 0
 
     def get_all_item_ids(self) -> List[int]:
         return list(self.all_item_ids)

@@ -72,6 +72,12 @@ class LRUFreqSet(MutableSet):
             last_all[shifted] = np.arange(n, dtype=np.int64)
             present = np.flatnonzero(counts_all)
             uniq, counts, last_pos = present + lo, counts_all[present], last_all[present]
+        return self.add_counted(uniq, counts, last_pos)
+
+    def add_counted(self, uniq: "np.ndarray", counts: "np.ndarray", last_pos: "np.ndarray") -> bool:
+        """The end state of add() for every value of a batch, given the batch's statistics: its distinct keys, how often each
+        occurs and where each occurs LAST (any increasing position).  False (nothing done) when the batch would overflow
+        the capacity."""
         keys = uniq.tolist()
         data = self.data
         fresh = sum(1 for k in keys if k not in data)

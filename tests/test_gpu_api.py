@@ -267,6 +267,54 @@ def test_bulk_fit_from_the_device_resident_store_equals_host_export(parallel, de
     assert rd == rh
 
 
+@pytest.mark.parametrize("upsert", [False, True])
+def test_device_bulk_ingest_equals_the_host_store(upsert, monkeypatch):
+    """Bulk batches are sorted, cut into runs of equal pairs and folded on the GPU (DeviceInteractions.ingest ->
+    rtrec_store_fold_device): the store, the hot items and the resident matrix must equal the host path's, for a batch into
+    an empty store (the mirror adopts the folded block), a second batch on top of it (merged into the mirror on the device),
+    a pair repeated 50,000 times, NaN ratings and clipping at both ends; then the same through Recommender.bulk_fit."""
+    import pandas as pd
+    from rtrec_amd import SLIM, Recommender
+    from rtrec_amd.utils import interactions as mod
+    from tests.test_host_logic import bits64, bulk_batches
+    monkeypatch.setattr(mod, "_DEVICE_FOLD_MIN", 1000)
+    u, i, ts, r = bulk_batches(n=400_000, n_users=9000, n_items=700)
+    u[::8], i[::8] = 5, 3                  # one long run: the kernel's eight-at-a-time loop
+    cut = 250_000
+
+    def run(device):
+        monkeypatch.setenv("RTREC_AMD_DEVICE_INGEST", "1" if device else "0")
+        m = SLIM(min_value=-3, max_value=10, nn_feature_selection=8)
+        m.add_interactions_columns(u[:cut], i[:cut], ts[:cut], r[:cut], update_interaction=upsert)
+        in_step = m._dev_x is not None and m._dev_x.version == m._store_tag()
+        m.add_interactions_columns(u[cut:], i[cut:], ts[cut:], r[cut:], update_interaction=upsert)
+        in_step = in_step and m._dev_x.version == m._store_tag()
+        return m, in_step
+
+    (md, dev_in_step), (mh, host_in_step) = run(True), run(False)
+    assert dev_in_step and not host_in_step
+    a, b = md.interactions._compact(), mh.interactions._compact()
+    assert np.array_equal(a.key, b.key) and np.array_equal(a.ts, b.ts) and np.array_equal(bits64(a.val), bits64(b.val))
+    assert md.interactions.max_timestamp == mh.interactions.max_timestamp and md.interactions.shape == mh.interactions.shape
+    assert md.interactions.all_item_ids == mh.interactions.all_item_ids
+    assert list(md.interactions.hot_items.data.items()) == list(mh.interactions.hot_items.data.items())
+    X, H = md._dev_x.full(), mh.interactions.to_csr()
+    assert np.array_equal(X["rptr"].cpu().numpy(), H.indptr) and np.array_equal(X["rcol"].cpu().numpy(), H.indices)
+    assert np.array_equal(bits(X["rval"].cpu().numpy()), bits(H.data))
+
+    # Recommender.bulk_fit on a DataFrame: one device-folded chunk, then the fit from the adopted mirror
+    ok = ~np.isnan(r)
+    df = pd.DataFrame({"user": u[ok], "item": i[ok], "tstamp": ts[ok], "rating": np.abs(r[ok])})
+    recs = []
+    for device in (True, False):
+        monkeypatch.setenv("RTREC_AMD_DEVICE_INGEST", "1" if device else "0")
+        rec = Recommender(SLIM(min_value=0, max_value=15, nn_feature_selection=8))
+        rec.bulk_fit(df, update_interaction=upsert)
+        recs.append((rec.model.model.item_similarity, rec.recommend_batch(list(range(0, 400, 9)), top_k=5)))
+    (Wd, rd), (Wh, rh) = recs
+    assert same_matrix(Wd, Wh) and rd == rh
+
+
 _RCCL_ONE_RANK = r"""
 import os, sys, numpy as np, scipy.sparse as sp, torch, torch.distributed as dist
 G = sys.argv[1]

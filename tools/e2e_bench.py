@@ -31,7 +31,7 @@ SHAPES = {"ml1m": (6040, 3706, 1_000_000), "c2": (100_000, 50_000, 5_000_000), "
 
 def main() -> None:
     ap = argparse.ArgumentParser()
-    ap.add_argument("--shape", default="ml1m", choices=sorted(SHAPES))
+    ap.add_argument("--shape", default="ml1m", choices=sorted(SHAPES) + ["c3s"])
     ap.add_argument("--stream", type=int, default=1000, help="interactions held back for the partial_fit step")
     ap.add_argument("--profile", action="store_true", help="cProfile the bulk_fit call (host-side breakdown to stderr)")
     ap.add_argument("--decay-days", type=int, default=0, help="SLIM(decay_in_days=...): BASELINE config 5 (0 = no time decay)")
@@ -40,9 +40,15 @@ def main() -> None:
     from rtrec_amd import SLIM, Recommender
     from rtrec_amd.synth import interaction_matrix
 
-    U, I, draws = SHAPES[args.shape]
     K = 50
-    X = interaction_matrix(U, I, draws, seed=20251003, float_ratings=True)
+    if args.shape == "c3s":                 # the structured C3 workload of bench.py (clustered items)
+        from bench import WORKLOADS
+        from rtrec_amd.synth import workload_matrix
+        X = workload_matrix(WORKLOADS["c3s"])
+        U, I = X.shape
+    else:
+        U, I, draws = SHAPES[args.shape]
+        X = interaction_matrix(U, I, draws, seed=20251003, float_ratings=True)
     coo = X.tocoo()
     rng = np.random.default_rng(0)
     order = rng.permutation(coo.nnz)
@@ -112,7 +118,7 @@ def main() -> None:
         "partial_fit_interactions": len(batch), "partial_fit_s": t_pf, "partial_fit_interactions_per_sec": len(batch) / t_pf,
         "recommend_100_after_update_ms": t_after * 1e3,
         "W_nnz": int(model.model.item_similarity.nnz), "mean_rec_len": float(np.mean([len(r) for r in recs])),
-        "host_cores": os.cpu_count()}))
+        "device_ingest": os.environ.get("RTREC_AMD_DEVICE_INGEST", "1") != "0", "host_cores": os.cpu_count()}))
 
 
 if __name__ == "__main__":

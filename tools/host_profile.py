@@ -43,11 +43,21 @@ def main():
     ts = 1.7e9 + np.arange(n, dtype=np.float64)
     n_bulk = n - (args.batches + 3) * 1000
     model = SLIM(min_value=0, max_value=15, nn_feature_selection=50, fit_mode=args.fit_mode)
+    torch.zeros(1, device="cuda")
+    from rtrec_amd.engine import HipBackend
+    HipBackend()
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
     for a in range(0, n_bulk, 4_000_000):
         b = min(a + 4_000_000, n_bulk)
         model.interactions.add_interactions_batch(model.user_ids.identify_many(u[a:b].astype(np.int64)),
                                                   model.item_ids.identify_many(i[a:b].astype(np.int64)), ts[a:b], r[a:b])
+    t_ing = time.perf_counter() - t0
     model.bulk_fit(parallel=True, progress_bar=False)
+    torch.cuda.synchronize()
+    pr.disable()
+    print(f"=== bulk ingest {t_ing:.2f}s + bulk_fit {time.perf_counter() - t0 - t_ing:.2f}s\n" + top(pr, 40))
     users = rng.integers(0, U, 300).tolist()
     model.recommend_batch(users[:64], top_k=10)
     for x in users[:20]:
