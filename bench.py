@@ -528,7 +528,7 @@ def main() -> None:
                 own_or = own[pos.reshape(8, n_wj)].any(axis=0)                      # [wave jobs, R]
             else:                              # jobs of 64 users: a wave takes 8 consecutive positions of the pattern-sorted
                 pos = np.concatenate([order, np.full((-n_scored) % 64, n_scored, dtype=np.int64)])      # order, else p % 8
-                own_or = own[pos.reshape(-1, 8, 8)].any(axis=2 if eng._grouped_order(lay) else 1)      # [jobs, 8 waves, R]
+                own_or = own[pos.reshape(-1, 8, 8)].any(axis=2 if getattr(eng, "_order_grouped", False) else 1)      # [jobs, 8 waves, R]
             nz_rt = np.array([[(int(tr[t, f // 64]) >> (f % 64)) & 1 for f in range(R)] for t in range(tr.shape[0])], dtype=np.int32)
             swept_rows = float((own_or.reshape(-1, R).astype(np.int32) @ nz_rt.T).sum())      # (wave, tile, row) reads of 1 slice row
             lds_bytes = swept_rows * tc * 4.0                 # upper bound: tiles pruned by the score bound are not read

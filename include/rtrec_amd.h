@@ -278,8 +278,10 @@ typedef struct {
     void          *timer;         /* rtrec_timer object or NULL */
     int32_t        diagnostics;   /* bits 0-7: ablation switches of tools/score_ablate.sh; honoured by diagnostic builds
                                      (-DRTREC_DIAGNOSTICS) only, ignored by the release library.  bits 8-11: users per wave
-                                     of the feature-row kernel (8, 4 or 2; 0 = chosen from the batch size) -- test / tuning
-                                     knob, results do not depend on it */
+                                     of the feature-row kernel (8, 4 or 2; 0 = chosen from the batch size); bits 12-23: v > 0
+                                     = the segment path gives users of more than v - 1 items (at most 512) a workgroup of
+                                     their own instead of a wave (0 = chosen from the batch size) -- test / tuning knobs,
+                                     results do not depend on them */
     int32_t       *d_rescored;    /* optional int32[1] on the device: receives the number of rows the exact-tie pass
                                      re-scored (SPARSE mode; rows whose fast-pass list held an exact tie reaching its
                                      (k+1)-th entry -- ties inside the leading k are ordered in place and not counted) */

@@ -1855,6 +1855,7 @@ struct SgLayout {
     int T = 0, n_tiles = 0, rows = 0, n_cols = 0, order_longest_first = 0;
     const int *trow_ptr = nullptr; const int4 *trow = nullptr;      // heavy pass (optional, with the scratch)
     unsigned char *scratch = nullptr; size_t scratch_bytes = 0;
+    int heavy_min = 0;          // tuning knob (rtrec_score_opts.diagnostics bits 12-23): 0 = chosen from the pass size
 };
 bool sg_usable(const SgLayout &S, int kk) {
     if (!S.info || !S.seg_ptr || !S.w_ent || S.nnz <= 0 || S.nnz >= (1ll << 28) || !S.bound || !S.col_ids) return false;
@@ -1959,8 +1960,15 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         waves_cu = waves_cu > 28 ? 28 : waves_cu;             // 7 waves per SIMD: the kernel's scalar registers
         int wg_cu = waves_cu / kSgWaves;
         wg_cu = wg_cu < 1 ? 1 : wg_cu;
-        const long long want = (static_cast<long long>(a.n_rows) + kSgWaves * kSgQueueChunk - 1) / (kSgWaves * kSgQueueChunk);
         const long long cap = 256ll * wg_cu;
+        // users per claim: kSgQueueChunk when the pass has that many for every wave slot of the chip, fewer for a smaller one
+        // (a request-sized batch must not queue four users behind one wave while the other slots idle)
+        long long chunk = a.n_rows / (cap * kSgWaves);
+        chunk = chunk < 1 ? 1 : (chunk > kSgQueueChunk ? kSgQueueChunk : chunk);
+        g.chunk = static_cast<int>(chunk);
+        g.heavy_min = SG.heavy_min > 0 ? (SG.heavy_min - 1 < kSgCap ? SG.heavy_min - 1 : kSgCap)
+                                       : sg_heavy_min_for(a.n_rows);
+        const long long want = (static_cast<long long>(a.n_rows) + kSgWaves * chunk - 1) / (kSgWaves * chunk);
         const unsigned grid = static_cast<unsigned>(want < cap ? (want > 0 ? want : 1) : cap);
         const bool heavy = SG.trow_ptr && SG.trow && SG.scratch &&
                            SG.scratch_bytes >= sg_heavy_scratch_bytes(a.n_items, SG.n_tiles, SG.T);
@@ -2174,6 +2182,7 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
         SG.order = opts->d_row_order; SG.order_longest_first = opts->row_order_longest_first;
         SG.trow_ptr = opts->d_sg_trow_ptr; SG.trow = reinterpret_cast<const int4 *>(opts->d_sg_trow);
         SG.scratch = static_cast<unsigned char *>(opts->d_sg_scratch); SG.scratch_bytes = opts->sg_scratch_bytes;
+        SG.heavy_min = (opts->diagnostics >> 12) & 0xfff;
         if (SG.n_cols != n_cols || (reinterpret_cast<uintptr_t>(opts->d_sg_trow) & 15u) ||
             (reinterpret_cast<uintptr_t>(opts->d_sg_scratch) & 15u)) return RTREC_ERR_INVALID_ARG;
     }

@@ -42,6 +42,8 @@ struct SegArgs {
     int *out_id; float *out_score; uint32_t *out_aux; int *out_cnt;
     int *flag_list; int *flag_len;
     int *queue;
+    int chunk;                 // users per queue claim (1 .. kSgQueueChunk): small passes claim fewer, so that every wave gets work
+    int heavy_min;             // users with more items than this go to score_seg_heavy_kernel (<= kSgCap; see kSgSmallPass)
     // long users (more items than a wave's LDS lists hold) are left to score_seg_heavy_kernel, one workgroup per user
     int order_longest_first;   // `order` is sorted by row length, longest first: the long users are its head
     const int *trow_ptr;       // [n_tiles + 1]: the segments of tile t, ascending item ...
@@ -55,8 +57,15 @@ constexpr int kSgWaves = 4;          // waves per workgroup; they share nothing 
 #define SG_CAP 512
 #endif
 constexpr int kSgCap = SG_CAP;          // items of a user a wave keeps in LDS (layout columns, rows of W, ratings); longer users: heavy pass
-constexpr int kSgQueueChunk = 4;     // users per queue claim
+constexpr int kSgQueueChunk = 4;     // users per queue claim of a full-size pass (SegArgs::chunk)
 constexpr int kSgMaxKk = 64;         // top_k + 1 list entries: one per lane
+// A pass with fewer users than the chip has wave slots (~7k) leaves most of it idle, and its latency is its longest
+// user's: there a user of more than n_rows / 16 items (at least 32) gets a whole workgroup (score_seg_heavy_kernel: eight
+// waves share the user's tiles) instead of one wave.  From 8192 rows on only users beyond a wave's LDS lists do.
+constexpr int kSgSmallHeavyMin = 32;
+__host__ __device__ constexpr int sg_heavy_min_for(int n_rows) {
+    return n_rows / 16 < kSgSmallHeavyMin ? kSgSmallHeavyMin : (n_rows / 16 > kSgCap ? kSgCap : n_rows / 16);
+}
 #ifndef SG_HEAVY_SLOTS
 #define SG_HEAVY_SLOTS 1024
 #endif
@@ -388,10 +397,10 @@ __global__ __launch_bounds__(kSgWaves * 64, 7) void score_seg_kernel(SegArgs a) 
     for (;;) {
         if (w_next >= w_end) {
             int w0 = 0;
-            if (lane == 0) w0 = atomicAdd(a.queue, kSgQueueChunk);
+            if (lane == 0) w0 = atomicAdd(a.queue, a.chunk);
             w_next = w_base = readfirst_i(w0);
             if (w_next >= a.n_rows) break;
-            w_end = min(w_next + kSgQueueChunk, a.n_rows);
+            w_end = min(w_next + a.chunk, a.n_rows);
             // the chunk's row pointers in one go: three dependent loads per chunk instead of three per user
             if (w_next + lane < w_end) {
                 const int c_row = a.order ? a.order[w_next + lane] : w_next + lane;
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(kSgWaves * 64, 7) void score_seg_kernel(SegArgs a) 
         const int a0 = readfirst_i(claimed[kSgQueueChunk + p - w_base]);
         const int n_a = readfirst_i(claimed[2 * kSgQueueChunk + p - w_base]);
         const bool in_lds = n_a <= kSgCap;
-        if (!in_lds && a.xs) continue;          // a long user: score_seg_heavy_kernel takes it, one workgroup per user
+        if (a.xs && n_a > a.heavy_min) continue;          // a long user: score_seg_heavy_kernel takes it, one workgroup per user
         SP_MARK(SP_CLAIM) SP_ADD(SP_JOBS, 1)
 
         // ---- 1. setup: rows of W the user rates, layout columns of its items, per-tile score bounds
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
         const bool xok = xrow >= 0 && xrow < a.n_x_rows;
         const int a0 = readfirst_i(xok ? a.xb_ptr[xrow] : 0);
         const int n_a = readfirst_i(xok ? a.xb_ptr[xrow + 1] - a0 : 0);
-        if (n_a <= kSgCap) {
+        if (n_a <= a.heavy_min) {
             if (a.order_longest_first) break;
             continue;
         }

@@ -478,12 +478,22 @@ class HipBackend:
         w = torch.ones(1, dtype=torch.float32, device=self.device)
         self.ops.column_sqnorms(torch.tensor([0, 1], dtype=torch.int32, device=self.device), w, torch.empty_like(w))
         from .utils.device_store import DeviceInteractions
-        DeviceInteractions(torch, self.device).warm_up()
+        DeviceInteractions(torch, self.device).warm_up(self.fold_pairs)
+        k = torch.arange(4, dtype=torch.int64, device=self.device)         # the tensor ops of SlimEngine.merge_fit
+        _ = (k // 2, k % 2, torch.isin(k, k[:2]), torch.argsort(k), k[k > 1], torch.cat([k, k]))
 
     # -- helpers -------------------------------------------------------------------------
     def to_dev(self, a: np.ndarray):
         t = self.torch.from_numpy(np.ascontiguousarray(a))
         return t.to(self.device, non_blocking=False)
+
+    def to_dev_small(self, a: np.ndarray):
+        """Upload of a request-sized array without a host-device round trip: staged in pinned memory (torch's caching host
+        allocator keeps the block until the copy has run) and copied asynchronously on the current stream."""
+        t = self.torch.from_numpy(np.ascontiguousarray(a))
+        if t.numel() > (1 << 16):
+            return t.to(self.device, non_blocking=False)
+        return t.pin_memory().to(self.device, non_blocking=True)
 
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=dtype, device=self.device)
@@ -695,6 +705,8 @@ class SlimEngine:
         # ablation switches of tools/score_ablate.sh: only a diagnostic build of the library looks at them
         self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0")) & 0xff
         self.fr_users_per_wave = int(os.environ.get("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
+        self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
+        self.sg_heavy_min = int(os.environ.get("RTREC_AMD_SG_HEAVY_MIN", "0"))   # v > 0: segment path, users of more than v - 1 items get a workgroup
         self.use_seg_layout = os.environ.get("RTREC_AMD_SEG_LAYOUT", "1") != "0"        # A/B switch of the general-W score kernel
         self.seg_cluster = os.environ.get("RTREC_AMD_SEG_CLUSTER", "1") != "0"          # ... and of its column clustering
         self.use_seg_heavy = os.environ.get("RTREC_AMD_SEG_HEAVY", "1") != "0"          # ... and of its workgroup-per-long-user pass
@@ -1132,26 +1144,49 @@ class SlimEngine:
                     fast = fr
             # a W with many rows (item-item structure in the data): the segment layout; the cluster labels that order its
             # columns are kept while W changes little (a mini-batch refits ~3 % of the columns)
-            if fast is None and self.use_seg_layout and getattr(be, "supports_seg_layout", False):
-                from .seg_layout import build_seg_layout_device
-                labels = None
-                kept = self._sg_labels
-                if kept is not None and kept[1] == W["n_items"] and abs(dw.nnz - kept[2]) <= 0.05 * max(kept[2], 1):
-                    labels = kept[0]
-                if not self.seg_cluster:
-                    labels = torch.arange(W["n_items"], dtype=torch.int64, device=dw.rows.device)
-                sg = build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels=labels)
-                if sg is not None:
-                    if labels is None:
-                        self._sg_labels = (sg["sg_labels"], W["n_items"], dw.nnz)
-                    # zeroed scratch of the heavy pass (long users, one workgroup each); the kernel leaves it zero
-                    nb = int(be.lib.rtrec_slim_score_sg_scratch_bytes(W["n_items"], sg["sg_n_tiles"], sg["sg_T"]))
-                    sg["sg_scratch"] = be.zeros((nb,), torch.uint8)
-                    fast = {"sg": sg, "n_cols": int(sg["sg_n_cols"])}
+            if fast is None:
+                fast = self._seg_form()
         if fast is not None:
             W["n_active"] = fast["n_cols"]
         W["fast"] = fast
         return fast
+
+    def _seg_form(self) -> Optional[Dict[str, Any]]:
+        """The segment layout of this rank's shard as a layout dict ({"sg": ..., "n_cols": ...}), or None."""
+        W, be = self._W, self.be
+        dw: DeviceWeights = W["dw"]
+        torch = be.torch
+        if not (self.use_seg_layout and getattr(be, "supports_seg_layout", False)):
+            return None
+        from .seg_layout import build_seg_layout_device
+        labels = None
+        kept = self._sg_labels
+        if kept is not None and kept[1] == W["n_items"] and abs(dw.nnz - kept[2]) <= 0.05 * max(kept[2], 1):
+            labels = kept[0]
+        if not self.seg_cluster:
+            labels = torch.arange(W["n_items"], dtype=torch.int64, device=dw.rows.device)
+        sg = build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels=labels)
+        if sg is None:
+            return None
+        if labels is None:
+            self._sg_labels = (sg["sg_labels"], W["n_items"], dw.nnz)
+        # zeroed scratch of the heavy pass (long users, one workgroup each); the kernel leaves it zero
+        nb = int(be.lib.rtrec_slim_score_sg_scratch_bytes(W["n_items"], sg["sg_n_tiles"], sg["sg_T"]))
+        sg["sg_scratch"] = be.zeros((nb,), torch.uint8)
+        return {"sg": sg, "n_cols": int(sg["sg_n_cols"])}
+
+    def _small_batch_layout(self, fast: Dict[str, Any]) -> Dict[str, Any]:
+        """The layout a request-sized batch is scored with.  The feature-row kernel gives a user to ONE wave that sweeps every
+        tile of W from LDS: 150 us per launch on the ML-20M shape however few the users (it is a throughput kernel -- a
+        full pass of 138k users is 1.4 ms).  The segment kernel touches only the user's own rows of W and prunes tiles by
+        their bounds: 25-45 us for one user.  So a W in feature-row form also gets its segment form, built when the first
+        small batch arrives (once per W), and batches below FR_SMALL_BATCH rows use that."""
+        W = self._W
+        if fast.get("fr_w") is None or "sg" in fast:
+            return fast
+        if "fast_small" not in W:
+            W["fast_small"] = self._seg_form() or fast
+        return W["fast_small"]
 
     def _tile_width(self, compact: bool, top_k: int) -> int:
         """Tile width of the tiled layout: self.tile_cols unless the merge of the per-tile lists (n_tiles * (top_k + 1) <= 1024
@@ -1195,15 +1230,17 @@ class SlimEngine:
 
     # ------------------------------------------------------------------------------ score
     def _local_topk(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
-                    d_col_rank, pad_rows: int = 0):
+                    d_col_rank, pad_rows: int = 0, host: bool = False):
         be, W = self.be, self._W
         torch = be.torch
         # ids | scores | counts are views of ONE buffer: a caller that wants them on the host downloads it in one copy
         # (_download: a single-user recommend is three device-to-host round trips otherwise), and the row-sharded path
         # all-gathers it as it is (pad_rows: the buffer is laid out for that many rows, so that every rank's has one size)
+        # (host: the caller downloads the lists; the lazy path below then reads its flag counter out of the same copy)
         cap = max(n_rows, int(pad_rows))
         nk = cap * top_k
-        pack = be.empty((2 * nk + cap,), torch.int32)
+        flag_words = n_rows + 1 if (host and not pad_rows) else 0
+        pack = be.empty((2 * nk + cap + flag_words,), torch.int32)
         ids = pack[:nk].view(cap, top_k)[:n_rows]
         sc = pack[nk:2 * nk].view(torch.float32).view(cap, top_k)[:n_rows]
         cnt = pack[2 * nk:2 * nk + n_rows]
@@ -1218,6 +1255,9 @@ class SlimEngine:
         # with lazy_tiled it is built when a call first flags such a row -- after a mini-batch the first recommend builds one
         # layout, not two -- at the price of reading one counter back per call while it does not exist.
         fast = self._fast_layout() if (sparse and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0)) else None
+        if (fast is not None and n_rows < self.FR_SMALL_BATCH and self.use_seg_layout and top_k <= self.SG_MAX_TOP_K
+                and getattr(be, "supports_seg_layout", False)):
+            fast = self._small_batch_layout(fast)
         use_fr = bool(fast is not None and self.use_feature_rows and fast.get("fr_w") is not None and n_rows >= self.FR_MIN_ROWS
                       and top_k <= self.FR_MAX_TOP_K)
         use_sg = bool(fast is not None and not use_fr and self.use_seg_layout and fast.get("sg") is not None
@@ -1229,13 +1269,19 @@ class SlimEngine:
                 self._score_ws = be.empty((need,), torch.uint8)
             order = self._row_order(d_row_ids, n_rows, xb, fast)
             self.last_score_path = "feature_rows" if use_fr else "segments"
-            flagged = be.empty((n_rows + 1,), torch.int32)
+            flagged = pack[2 * nk + cap:] if flag_words else be.empty((n_rows + 1,), torch.int32)
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, top_k, filter_interacted,
                           mode, False, ids, sc, None, aux, cnt, self._score_ws, timer=self.score_timer,
-                          diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8), use_fr=use_fr, row_order=order,
-                          rescored=None, row_order_grouped=(order is not None and use_fr and self._grouped_order(fast)),
+                          diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8) | ((self.sg_heavy_min & 0xfff) << 12), use_fr=use_fr, row_order=order,
+                          rescored=None, row_order_grouped=(order is not None and use_fr and self._order_grouped),
                           use_sg=use_sg, use_sg_heavy=self.use_seg_heavy, flagged=flagged)
-            n_flag = int(flagged[0].item())
+            if flag_words:                # one download: the lists and the counter
+                h = pack.cpu().numpy()
+                n_flag = int(h[2 * nk + cap])
+                if n_flag == 0:
+                    ids._rtrec_host = h
+            else:
+                n_flag = int(flagged[0].item())
             if self.rescored is not None:
                 self.rescored.fill_(n_flag)
             if n_flag:
@@ -1266,9 +1312,9 @@ class SlimEngine:
             self.last_score_path = "feature_rows" if use_fr else ("segments" if use_sg else "tiled")
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws, timer=self.score_timer,
-                          diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8), use_fr=use_fr, row_order=order,
+                          diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8) | ((self.sg_heavy_min & 0xfff) << 12), use_fr=use_fr, row_order=order,
                           rescored=self.rescored,
-                          row_order_grouped=(order is not None and use_fr and self._grouped_order(lay)), use_sg=use_sg,
+                          row_order_grouped=(order is not None and use_fr and self._order_grouped), use_sg=use_sg,
                           use_sg_heavy=self.use_seg_heavy)
         else:
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
@@ -1276,22 +1322,25 @@ class SlimEngine:
         return ids, sc, sc64, aux, cnt
 
     ROW_ORDER_MIN = 2048        # batches below this are one or two waves of jobs: nothing to level
+    GROUPED_ORDER_MIN = 32768   # the pattern-grouped order (~1 ms to compute, kept per row set) pays for bulk passes only
     # Batches below this many rows go to the tiled-CSR kernel.  Since the feature-row kernel has its 4- and 2-users-per-wave
     # forms (chosen from the batch size inside rtrec_slim_score_topk) it is ahead at every batch size, one user included
     # (tools/score_batch_sweep.py: DESIGN.md section 3.1); the threshold is kept for A/B runs and the tests.
     FR_MIN_ROWS = 1
+    FR_SMALL_BATCH = 513              # batches below this many rows are scored from the segment form (_small_batch_layout)
     FR_MAX_TOP_K = 15           # kFrMaxKk - 1 of csrc/score.hip: a list of top_k + 1 entries fits one 16-lane DPP row
     SG_MAX_TOP_K = 63           # kSgMaxKk - 1 of csrc/score_seg.hip.h: the list of top_k + 1 entries is one register across the lanes
     FR_TILE_COLS = 256          # columns per tile of the feature-row layout (128: the narrow kernels, kept for A/B and tests)
     pattern_order = os.environ.get("RTREC_AMD_PATTERN_ORDER", "1") != "0"
     rescored = None             # optional int32[1] device tensor: rows the exact-tie pass re-scored in the last call
 
-    def _grouped_order(self, lay) -> bool:
+    def _grouped_order(self, lay, n_rows: Optional[int] = None) -> bool:
         """Pattern-sorted work order with eight consecutive rows per wave: for the STREAMING feature-row layout (C3:
         2.37 -> 2.26 ms).  The resident layout keeps the longest-first order dealt out in strides: its waves claim jobs
         on their own, and evenly mixed jobs matter more there than small unions (C2: 0.41 ms against 0.57 ms grouped)."""
         host = (lay or {}).get("fr_host") or {}
-        return bool(self.pattern_order and host and not host.get("fr_resident"))
+        return bool(self.pattern_order and host and not host.get("fr_resident")
+                    and (n_rows is None or n_rows >= self.GROUPED_ORDER_MIN))
 
     def _row_order(self, d_row_ids, n_rows: int, xb, lay=None):
         """Work order for the feature-row kernel (rtrec_score_opts.d_row_order).  Default: the batch's rows by descending
@@ -1308,12 +1357,22 @@ class SlimEngine:
         fr_host = (lay or {}).get("fr_host")
         # One entry per (row-id tensor, layout), matched by IDENTITY: the entry keeps the tensor and the layout alive, so a
         # recycled address can never stand for another row set; a temporary row tensor simply misses.
+        # The pattern-grouped order costs milliseconds to compute: a row set gets it the SECOND time it is scored (a caller
+        # that keeps its row tensor -- bulk scoring, bench.py); a row set seen once (an API batch) runs in the length order.
         cache = self._X.setdefault("_orders", []) if resident else None
+        want_grouped = bool(fr_host is not None and lay.get("fr_map") is not None and self._grouped_order(lay, n_rows))
+        seen = None
+        self._order_grouped = False
         if cache is not None:
             for ent in cache:
                 if (ent[0] is d_row_ids and ent[1] == (None if d_row_ids is None else d_row_ids._version) and ent[2] == n_rows
                         and ent[3] is fr_host):
-                    return ent[4]
+                    if ent[5] or not want_grouped:
+                        self._order_grouped = ent[5]
+                        return ent[4]
+                    seen = ent
+                    break
+        grouped = want_grouped and (seen is not None or d_row_ids is None)
         ptr, col = xb[0], xb[1]
         if d_row_ids is None:
             rows = None
@@ -1321,7 +1380,7 @@ class SlimEngine:
         else:
             rows = d_row_ids[:n_rows].long().clamp_(0, ptr.shape[0] - 2)
             lens = ptr[rows + 1] - ptr[rows]
-        if fr_host is None or lay.get("fr_map") is None or not self._grouped_order(lay):
+        if not grouped:
             order = torch.argsort(lens, descending=True, stable=True).to(torch.int32)
         else:
             R = int(fr_host["fr_rows"])
@@ -1352,14 +1411,17 @@ class SlimEngine:
                 order = order[torch.argsort(words[order, w], descending=True, stable=True)]
             order = order.to(torch.int32)
         if cache is not None:
+            if seen is not None:
+                cache.remove(seen)
             if len(cache) >= 32:
                 cache.clear()
-            cache.append((d_row_ids, None if d_row_ids is None else d_row_ids._version, n_rows, fr_host, order))
+            cache.append((d_row_ids, None if d_row_ids is None else d_row_ids._version, n_rows, fr_host, order, grouped))
             self._X["_order"] = order          # the most recent one (bench.py's bounds model reads it)
+        self._order_grouped = grouped
         return order
 
     def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
-                          mode: int, col_rank: Optional[np.ndarray] = None, xb=None, d_rows=None):
+                          mode: int, col_rank: Optional[np.ndarray] = None, xb=None, d_rows=None, host: bool = False):
         """Device tensors (ids, scores, counts) of the GLOBAL top-k for the given rows of X
         (or of the CSR batch `xb` = (ptr, col, val) device tensors).  `d_rows` may pass the row ids
         as a device tensor that is already resident (bench.py reuses it across steps).
@@ -1377,11 +1439,12 @@ class SlimEngine:
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
         if xb is None:
             xb = (self._X["rptr"], self._X["rcol"], self._X["rval"])
+        up = getattr(be, "to_dev_small", be.to_dev)
         if d_rows is None and row_ids is not None:
-            d_rows = be.to_dev(np.asarray(row_ids, dtype=np.int32))
-        d_rank = be.to_dev(np.asarray(col_rank, dtype=np.int32)) if col_rank is not None else None
+            d_rows = up(np.asarray(row_ids, dtype=np.int32))
+        d_rank = up(np.asarray(col_rank, dtype=np.int32)) if col_rank is not None else None
         if self.world_size == 1 and not self.force_exchange:
-            ids, sc, sc64, aux, cnt = self._local_topk(d_rows, n_rows, xb, top_k, filter_interacted, mode, d_rank)
+            ids, sc, sc64, aux, cnt = self._local_topk(d_rows, n_rows, xb, top_k, filter_interacted, mode, d_rank, host=host)
             return ids, sc, cnt
         import torch.distributed as dist
         torch = be.torch
@@ -1549,7 +1612,7 @@ class SlimEngine:
             return (np.empty((0, top_k), np.int32), np.empty((0, top_k), np.float32), np.empty((0,), np.int32))
         self._check_rows(row_ids)
         row_ids = row_ids.astype(np.int32)
-        return self._download(*self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank))
+        return self._download(*self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank, host=True))
 
     @staticmethod
     def _download(ids, sc, cnt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -1558,8 +1621,10 @@ class SlimEngine:
         if pack is None:
             return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
         n, k = ids.shape
-        h = pack.cpu().numpy()
-        return h[:n * k].reshape(n, k), h[n * k:2 * n * k].view(np.float32).reshape(n, k), h[2 * n * k:]
+        h = getattr(ids, "_rtrec_host", None)
+        if h is None:
+            h = pack.cpu().numpy()
+        return h[:n * k].reshape(n, k), h[n * k:2 * n * k].view(np.float32).reshape(n, k), h[2 * n * k:2 * n * k + n]
 
     def recommend_csr(self, Xb: sp.csr_matrix, top_k: int = 10, filter_interacted: bool = True,
                       mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None

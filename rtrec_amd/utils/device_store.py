@@ -149,7 +149,7 @@ class DeviceInteractions:
         self.rate = self._rraw = self._rts = self._craw = self._cts = self._now = self._valued_at = None
         self.n_users, self.n_items, self.version, self._full = int(n_users), int(n_items), version, None
 
-    def warm_up(self) -> None:
+    def warm_up(self, fold_fn: Any = None) -> None:
         """Run every tensor op of this class once on a four-entry matrix: the first use of a sort /
         searchsorted / scatter kernel loads its code object (~0.1-0.3 s per process), which belongs to
         backend construction, not to the first bulk_fit or mini-batch."""
@@ -161,6 +161,11 @@ class DeviceInteractions:
         self.load_store(np.array([0, 1, (1 << 32) | 1]), np.ones(3), np.zeros(3), 2, 2, 4, rate=0.99, now=86400.0)
         self.apply(np.array([0]), np.array([1]), np.ones(1), 2, 2, 5, tstamps=np.zeros(1), now=2 * 86400.0)
         self.full()
+        if fold_fn is not None:
+            for wide in (1 << 31, 0):       # both sort keys of ingest()
+                self.ingest(np.array([0, 1, 0]) + wide, np.array([1, 0, 1]) + wide, np.zeros(3), np.ones(3), False, 0.0, 5.0,
+                            lambda keys: np.zeros(len(keys)), fold_fn)
+            self.adopt_ingested(2, 2, 6)
 
     # ------------------------------------------------------------------ update
     def _merge(self, keys, vals, new_k, new_v):

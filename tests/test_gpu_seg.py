@@ -114,6 +114,54 @@ def test_seg_long_users_and_foreign_rows(oracle, heavy_pass):
     assert np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc)) and np.array_equal(cnt, o_cnt)
 
 
+@pytest.mark.parametrize("knob", [0, 1, 17, 513])
+def test_seg_request_sized_passes_give_users_a_workgroup(oracle, knob):
+    """Passes of at most 256 rows hand every user of more than 32 items to the workgroup-per-user kernel (its latency is
+    the longest user's); the knob (rtrec_score_opts.diagnostics bits 12-23) moves that threshold for any pass size.  Same
+    answers whichever kernel scores a user: one user per call, request-sized batches, and a full pass with the knob."""
+    I = 2000
+    W = random_w(I, 0.006, seed=9, n_blocks=8, signed=True)
+    X = interaction_matrix(900, I, 60000, seed=23).tolil()
+    rng = np.random.default_rng(3)
+    for u, n in ((5, 1900), (6, 1025), (7, 33), (8, 32), (9, 300), (10, 1)):
+        X[u, :] = 0
+        cols = rng.choice(I, n, replace=False)
+        X[u, cols] = (rng.random(n) * 4 + 0.5).astype(np.float32)
+    X[11, :] = 0                                  # an empty row
+    X = X.tocsr().astype(np.float32)
+    X.eliminate_zeros()
+    X.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.sg_heavy_min = knob
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    for u in (5, 6, 7, 8, 9, 10, 11, 100):
+        check(eng, oracle, X, W, np.array([u]), 10, True)
+    check(eng, oracle, X, W, np.arange(0, 256), 10, True)
+    check(eng, oracle, X, W, np.arange(0, 256), 10, True)           # again: the scratch was left zeroed
+    check(eng, oracle, X, W, np.array([5, 11, 6, 7, 8, 9, 10, 5]), 63, False)
+    check(eng, oracle, X, W, np.arange(X.shape[0]), 5, True)
+
+
+def test_feature_row_w_scores_request_sized_batches_from_its_segment_form(oracle):
+    """A W with at most 128 rows has the feature-row form (a throughput kernel: one wave sweeps all of W per user); batches
+    below SlimEngine.FR_SMALL_BATCH rows are scored from the segment form of the same W instead -- same answers."""
+    I = 3000
+    rng = np.random.default_rng(12)
+    rows = np.sort(rng.choice(I, 100, replace=False))
+    nnz = 60_000
+    W = sp.csc_matrix(((rng.random(nnz) + 0.01).astype(np.float32), (rng.choice(rows, nnz), rng.integers(0, I, nnz))), shape=(I, I))
+    W.sum_duplicates(); W.setdiag(0); W.eliminate_zeros(); W.sort_indices()
+    X = interaction_matrix(1200, I, 90000, seed=5).astype(np.float32)
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    check(eng, oracle, X, W, np.arange(X.shape[0]), 10, True, expect_path="feature_rows")
+    for b in (1, 5, eng.FR_SMALL_BATCH - 1):
+        check(eng, oracle, X, W, np.arange(7, 7 + b), 10, True, expect_path="segments")
+    check(eng, oracle, X, W, np.arange(eng.FR_SMALL_BATCH), 10, False, expect_path="feature_rows")
+
+
 def test_seg_exact_ties_go_through_the_exact_pass(oracle):
     """Integer ratings and duplicated columns of W: exact score ties inside and at the edge of the list; the flagged rows
     are re-scored by the first-touch kernel and come out in the reference's order."""

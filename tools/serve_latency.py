@@ -19,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SHAPES = {"small": (20_000, 5_000, 500_000), "c2": (100_000, 50_000, 5_000_000), "c3": (138_493, 26_744, 26_000_000)}
+from tools.stream_bench import SHAPES  # noqa: E402
 
 
 def pct(a, q):
@@ -32,15 +32,15 @@ def main():
     ap.add_argument("--requests", type=int, default=2000)
     ap.add_argument("--clients", type=int, default=32)
     ap.add_argument("--coalesce-ms", type=float, default=1.0)
+    ap.add_argument("--single-only", action="store_true", help="only the one-caller loop (for tracing)")
     args = ap.parse_args()
     import torch
     from rtrec_amd import SLIM
     from rtrec_amd.serving.app import ModelGate
-    from rtrec_amd.synth import zipf_pairs
+    from tools.stream_bench import workload_pairs
 
-    U, I, draws = SHAPES[args.workload]
     rng = np.random.default_rng(5)
-    u, i = zipf_pairs(U, I, draws, seed=20251003)
+    U, I, u, i = workload_pairs(args.workload)
     n = len(u)
     r = (rng.integers(1, 6, n) * np.exp(-rng.random(n) * 0.7)).astype(np.float64)
     ts = 1.7e9 + np.arange(n, dtype=np.float64)
@@ -63,6 +63,10 @@ def main():
         model.recommend(user=x, top_k=10)
         lat.append((time.perf_counter() - t) * 1e3)
     single = {"requests": len(users), "p50_ms": pct(lat, .5), "p99_ms": pct(lat, .99), "requests_per_sec": len(users) / (time.perf_counter() - t0)}
+
+    if args.single_only:
+        print(json.dumps({"workload": args.workload, "one_caller": single}))
+        return
 
     def concurrent(gate):
         lat_c, lock = [], threading.Lock()
