@@ -1145,7 +1145,7 @@ class SlimEngine:
             # a W with many rows (item-item structure in the data): the segment layout; the cluster labels that order its
             # columns are kept while W changes little (a mini-batch refits ~3 % of the columns)
             if fast is None:
-                fast = self._seg_form()
+                fast = W.get("fast_small") or self._seg_form()       # (a small batch may have built it already)
         if fast is not None:
             W["n_active"] = fast["n_cols"]
         W["fast"] = fast
@@ -1175,18 +1175,22 @@ class SlimEngine:
         sg["sg_scratch"] = be.zeros((nb,), torch.uint8)
         return {"sg": sg, "n_cols": int(sg["sg_n_cols"])}
 
-    def _small_batch_layout(self, fast: Dict[str, Any]) -> Dict[str, Any]:
-        """The layout a request-sized batch is scored with.  The feature-row kernel gives a user to ONE wave that sweeps every
-        tile of W from LDS: 150 us per launch on the ML-20M shape however few the users (it is a throughput kernel -- a
-        full pass of 138k users is 1.4 ms).  The segment kernel touches only the user's own rows of W and prunes tiles by
-        their bounds: 25-45 us for one user.  So a W in feature-row form also gets its segment form, built when the first
-        small batch arrives (once per W), and batches below FR_SMALL_BATCH rows use that."""
-        W = self._W
-        if fast.get("fr_w") is None or "sg" in fast:
-            return fast
+    def _small_batch_layout(self) -> Optional[Dict[str, Any]]:
+        """The layout a request-sized batch is scored with: the segment form, whatever the shape of W.  The feature-row kernel
+        gives a user to ONE wave that sweeps every tile of W from LDS: 150 us per launch on the ML-20M shape however few
+        the users (it is a throughput kernel -- a full pass of 138k users is 1.4 ms).  The segment kernels touch only the
+        user's own rows of W, prune tiles by their bounds and give a long user a workgroup: 10-25 us for one user.  So the
+        segment form is what a small batch builds (once per W; after a mini-batch the first recommend builds this one
+        layout), and the feature-row form waits for the first large pass."""
+        W, be = self._W, self.be
+        if "fast" in W and (W["fast"] is None or "sg" in W["fast"]):
+            return W["fast"]
         if "fast_small" not in W:
-            W["fast_small"] = self._seg_form() or fast
-        return W["fast_small"]
+            ok = W["col_hi"] > W["col_lo"] and not W["acc_f64"] and W["dw"].nnz > 0
+            W["fast_small"] = self._seg_form() if ok else None
+            if W["fast_small"] is not None:
+                W.setdefault("n_active", W["fast_small"]["n_cols"])
+        return W["fast_small"] or self._fast_layout()
 
     def _tile_width(self, compact: bool, top_k: int) -> int:
         """Tile width of the tiled layout: self.tile_cols unless the merge of the per-tile lists (n_tiles * (top_k + 1) <= 1024
@@ -1254,10 +1258,11 @@ class SlimEngine:
         # for the rows whose fast-pass list holds an exact score tie (the exact-tie pass orders those like the reference):
         # with lazy_tiled it is built when a call first flags such a row -- after a mini-batch the first recommend builds one
         # layout, not two -- at the price of reading one counter back per call while it does not exist.
-        fast = self._fast_layout() if (sparse and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0)) else None
-        if (fast is not None and n_rows < self.FR_SMALL_BATCH and self.use_seg_layout and top_k <= self.SG_MAX_TOP_K
-                and getattr(be, "supports_seg_layout", False)):
-            fast = self._small_batch_layout(fast)
+        fast = None
+        if sparse and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
+            small = (n_rows < self.FR_SMALL_BATCH and self.use_seg_layout and top_k <= self.SG_MAX_TOP_K
+                     and getattr(be, "supports_seg_layout", False))
+            fast = self._small_batch_layout() if small else self._fast_layout()
         use_fr = bool(fast is not None and self.use_feature_rows and fast.get("fr_w") is not None and n_rows >= self.FR_MIN_ROWS
                       and top_k <= self.FR_MAX_TOP_K)
         use_sg = bool(fast is not None and not use_fr and self.use_seg_layout and fast.get("sg") is not None
@@ -1308,6 +1313,8 @@ class SlimEngine:
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = be.empty((need,), torch.uint8)
         if hip:
+            if use_sg and lay.get("sg") is None:          # a small batch against a feature-row W: its segment form
+                lay = dict(lay, sg=fast["sg"])
             order = self._row_order(d_row_ids, n_rows, xb, lay) if (use_fr or use_sg) else None
             self.last_score_path = "feature_rows" if use_fr else ("segments" if use_sg else "tiled")
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,

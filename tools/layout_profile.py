@@ -58,6 +58,14 @@ def main():
         eng.set_weights(dw)
         return eng._layout(True, 10)
     rep["engine_layout_total_ms"], _ = timed(whole)
+    rows = np.arange(0, 100 * 97, 97)
+
+    def after_update():
+        eng.set_weights(dw)
+        return eng.recommend_rows(rows, top_k=10)
+    rep["recommend_100_after_set_weights_ms"], _ = timed(after_update, n=9)
+    rep["recommend_100_path"] = eng.last_score_path
+    rep["recommend_100_warm_ms"], _ = timed(lambda: eng.recommend_rows(rows, top_k=10), n=9)
     print(json.dumps(rep))
 
 
