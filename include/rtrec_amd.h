@@ -482,6 +482,36 @@ int rtrec_store_decay(const double *val, const double *ts, int64_t n, double rat
 int rtrec_store_decay_device(const double *d_val, const double *d_ts, int64_t n, double rate, double now,
                              float *d_out32, int32_t *d_unsafe_idx, int32_t *d_unsafe_count, int32_t cap, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * SEGMENT LAYOUT BUILDER  (the d_sg_* arrays of rtrec_score_opts from a W resident on the device; what has to happen
+ * between a mini-batch refit -- rtrec/models/slim.py:29-43 writes W's columns, slim_elastic.py:371-374 -- and the next
+ * recommend -- slim_elastic.py:707-708).  Specification: rtrec_amd/seg_layout.py::build_seg_layout.
+ * W as COO triples sorted by (column, row): d_rows / d_cols int64[nnz], d_vals float32[nnz]; the shard is the columns
+ * [col_lo, col_hi); d_labels int64[n_items] in [0, n_items) orders the shard's columns (stable by label, then item id).
+ *
+ * rtrec_slim_seg_plan   marks the shard's columns and rows, orders the columns, and SYNCHRONISES the stream once to
+ *                       return h_out[4] = {n_cols, n_rows (items that hold a weight), tile_cols (0: more than 128 tiles
+ *                       of 4096 columns -- no segment layout), n_tiles}.  The workspace must stay untouched until
+ *                       rtrec_slim_seg_fill has been enqueued.
+ * rtrec_slim_seg_fill   enqueues the rest (no synchronisation) into caller-allocated arrays:
+ *                       d_info int32[n_items][2] (8-byte aligned), d_seg_ptr int32[n_rows][n_tiles + 1],
+ *                       d_ent int32[ent_capacity][2] with ent_capacity >= 2 * nnz (the records in use are the first
+ *                       d_seg_ptr[n_rows - 1][n_tiles]; the rest are pads), d_bound uint32[n_rows][64],
+ *                       d_col_ids int32[n_cols], d_trow_ptr int32[n_tiles + 1], d_trow int32[trow_capacity][4] (16-byte
+ *                       aligned) with trow_capacity >= min(nnz, n_rows * n_tiles).
+ * Requires nnz < 2^27.  RTREC_OK or a negative RTREC_ERR_* code.
+ * ------------------------------------------------------------------------------------- */
+size_t rtrec_slim_seg_plan_workspace_bytes(int32_t n_items);
+size_t rtrec_slim_seg_fill_workspace_bytes(int32_t n_items, int64_t nnz, int32_t n_rows, int32_t n_tiles);
+int rtrec_slim_seg_plan(int32_t n_items, int64_t nnz, const int64_t *d_rows, const int64_t *d_cols,
+                        int32_t col_lo, int32_t col_hi, const int64_t *d_labels, void *d_workspace, size_t workspace_bytes,
+                        int32_t *h_out, void *stream);
+int rtrec_slim_seg_fill(int32_t n_items, int64_t nnz, const int64_t *d_rows, const int64_t *d_cols, const float *d_vals,
+                        int32_t col_lo, int32_t col_hi, const void *d_plan_workspace, int32_t n_cols, int32_t n_rows,
+                        int32_t tile_cols, int32_t n_tiles, void *d_workspace, size_t workspace_bytes,
+                        int32_t *d_info, int32_t *d_seg_ptr, int32_t *d_ent, int64_t ent_capacity, uint32_t *d_bound,
+                        int32_t *d_col_ids, int32_t *d_trow_ptr, int32_t *d_trow, int64_t trow_capacity, void *stream);
+
 /* Bulk ingest on the device (replaces one add_interaction per DataFrame row, rtrec/utils/interactions.py:81-119 as driven by
  * rtrec/recommender.py:203-223).  Device pointers.  The batch is given sorted by (user, item, arrival): d_order[k] = arrival
  * index of the k-th interaction in that order, d_start[n_groups + 1] = the runs of the distinct pairs.  Per pair, in arrival

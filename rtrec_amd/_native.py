@@ -27,6 +27,10 @@ EXPORTS = [
     "rtrec_store_merge_sorted", "rtrec_store_find_sorted", "rtrec_lru_replay", "rtrec_store_apply_round", "rtrec_store_decay",
     "rtrec_store_decay_device",
     "rtrec_store_fold_device",
+    "rtrec_slim_seg_plan_workspace_bytes",
+    "rtrec_slim_seg_fill_workspace_bytes",
+    "rtrec_slim_seg_plan",
+    "rtrec_slim_seg_fill",
 ]
 
 
@@ -142,6 +146,15 @@ def load() -> C.CDLL:
     L.rtrec_store_decay.argtypes = [vp, vp, C.c_int64, C.c_double, vp, C.c_double, vp, vp, i32]
     L.rtrec_store_decay_device.restype = C.c_int
     L.rtrec_store_decay_device.argtypes = [vp, vp, C.c_int64, C.c_double, C.c_double, vp, vp, vp, i32, vp]
+    L.rtrec_slim_seg_plan_workspace_bytes.restype = C.c_size_t
+    L.rtrec_slim_seg_plan_workspace_bytes.argtypes = [i32]
+    L.rtrec_slim_seg_fill_workspace_bytes.restype = C.c_size_t
+    L.rtrec_slim_seg_fill_workspace_bytes.argtypes = [i32, C.c_int64, i32, i32]
+    L.rtrec_slim_seg_plan.restype = C.c_int
+    L.rtrec_slim_seg_plan.argtypes = [i32, C.c_int64, vp, vp, i32, i32, vp, vp, C.c_size_t, vp, vp]
+    L.rtrec_slim_seg_fill.restype = C.c_int
+    L.rtrec_slim_seg_fill.argtypes = [i32, C.c_int64, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, C.c_size_t,
+                                      vp, vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp]
     L.rtrec_store_fold_device.restype = C.c_int
     L.rtrec_store_fold_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp, vp]
     _lib = L

@@ -705,6 +705,8 @@ class SlimEngine:
         # ablation switches of tools/score_ablate.sh: only a diagnostic build of the library looks at them
         self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0")) & 0xff
         self.fr_users_per_wave = int(os.environ.get("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
+        self.native_seg_builder = os.environ.get("RTREC_AMD_NATIVE_SEG_BUILD", "1") != "0"   # csrc/seg_build.hip (else tensor ops)
+        self._sg_scratch = None           # zeroed scratch of the segment path's workgroup-per-user kernel
         self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
         self.sg_heavy_min = int(os.environ.get("RTREC_AMD_SG_HEAVY_MIN", "0"))   # v > 0: segment path, users of more than v - 1 items get a workgroup
         self.use_seg_layout = os.environ.get("RTREC_AMD_SEG_LAYOUT", "1") != "0"        # A/B switch of the general-W score kernel
@@ -1165,14 +1167,26 @@ class SlimEngine:
             labels = kept[0]
         if not self.seg_cluster:
             labels = torch.arange(W["n_items"], dtype=torch.int64, device=dw.rows.device)
-        sg = build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels=labels)
+        if self.native_seg_builder and hasattr(be, "lib") and dw.nnz < (1 << 27):
+            from .seg_layout import build_seg_layout_native, cluster_labels_device
+            fresh = labels is None
+            if fresh:       # first layout of a model (or W has changed a lot): label propagation over the shard's graph
+                sel = (dw.cols >= W["col_lo"]) & (dw.cols < W["col_hi"])
+                labels = cluster_labels_device(torch, dw.rows[sel], dw.cols[sel], dw.vals[sel], W["n_items"])
+            sg = build_seg_layout_native(be, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels)
+            labels = None if fresh else labels
+        else:
+            sg = build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"], labels=labels)
         if sg is None:
             return None
         if labels is None:
             self._sg_labels = (sg["sg_labels"], W["n_items"], dw.nnz)
         # zeroed scratch of the heavy pass (long users, one workgroup each); the kernel leaves it zero
+        # (kept across layouts of the same size: 130 MB for the ML-20M shape)
         nb = int(be.lib.rtrec_slim_score_sg_scratch_bytes(W["n_items"], sg["sg_n_tiles"], sg["sg_T"]))
-        sg["sg_scratch"] = be.zeros((nb,), torch.uint8)
+        if self._sg_scratch is None or self._sg_scratch.numel() != nb:
+            self._sg_scratch = be.zeros((nb,), torch.uint8)
+        sg["sg_scratch"] = self._sg_scratch
         return {"sg": sg, "n_cols": int(sg["sg_n_cols"])}
 
     def _small_batch_layout(self) -> Optional[Dict[str, Any]]:

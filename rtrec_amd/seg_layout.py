@@ -268,3 +268,40 @@ def build_seg_layout_device(torch, rows, cols, vals, n_items: int, col_lo: int, 
     return dict(sg_trow=trow.view(-1, 4), sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info,
                 sg_ptr=seg_ptr2, sg_ent=ent, sg_bound=bound, sg_col_ids=order.to(torch.int32).contiguous(), sg_nnz=int(key.numel()),
                 sg_labels=labels)
+
+
+def build_seg_layout_native(be, rows, cols, vals, n_items: int, col_lo: int, col_hi: int, labels) -> Optional[Dict[str, Any]]:
+    """build_seg_layout_device through the library's own builder (csrc/seg_build.hip: rtrec_slim_seg_plan + _fill): a dozen
+    kernels and one host round trip instead of ~45 tensor ops and five -- what a recommend right after a mini-batch waits
+    for.  `labels` must be given (int64 device tensor with values in [0, n_items): the cached cluster labels, or arange).
+    Returns None when the shard is empty or too wide for the layout; raises when the library refuses the arguments.
+    sg_ent / sg_trow are allocated for the worst case (2 nnz records / min(nnz, segments) list entries): the entries in
+    use are the first sg_ptr[-1, -1] / sg_trow_ptr[-1]; the rest is padding the kernels never address."""
+    import ctypes as C
+    from . import _native
+    torch, lib = be.torch, be.lib
+    nnz = int(rows.numel())
+    if nnz == 0 or nnz >= (1 << 27):
+        return None
+    rows, cols, vals = rows.contiguous(), cols.contiguous(), vals.contiguous()
+    labels = labels.contiguous()
+    p = be.ptr
+    pws = be.empty((int(lib.rtrec_slim_seg_plan_workspace_bytes(n_items)),), torch.uint8)
+    out = (C.c_int32 * 4)()
+    _native.check(lib.rtrec_slim_seg_plan(n_items, nnz, p(rows), p(cols), int(col_lo), int(col_hi), p(labels), p(pws), pws.numel(),
+                                          C.cast(out, C.c_void_p), be.stream()), "rtrec_slim_seg_plan")
+    n_cols, R, T, n_tiles = (int(x) for x in out)
+    if n_cols == 0 or R == 0 or T == 0:
+        return None
+    i32 = torch.int32
+    fws = be.empty((int(lib.rtrec_slim_seg_fill_workspace_bytes(n_items, nnz, R, n_tiles)),), torch.uint8)
+    info, seg_ptr = be.empty((n_items, 2), i32), be.empty((R, n_tiles + 1), i32)
+    ent, bound = be.empty((2 * nnz, 2), i32), be.empty((R, 64), i32)
+    col_ids, trow_ptr = be.empty((n_cols,), i32), be.empty((n_tiles + 1,), i32)
+    trow = be.empty((min(nnz, R * n_tiles), 4), i32)
+    _native.check(lib.rtrec_slim_seg_fill(n_items, nnz, p(rows), p(cols), p(vals), int(col_lo), int(col_hi), p(pws), n_cols, R, T, n_tiles,
+                                          p(fws), fws.numel(), p(info), p(seg_ptr), p(ent), ent.shape[0], p(bound), p(col_ids),
+                                          p(trow_ptr), p(trow), trow.shape[0], be.stream()), "rtrec_slim_seg_fill")
+    return dict(sg_trow=trow, sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info,
+                sg_ptr=seg_ptr, sg_ent=ent, sg_bound=bound, sg_col_ids=col_ids, sg_nnz=nnz, sg_labels=labels,
+                _workspaces=(pws, fws))        # the fill is only enqueued: its workspaces live as long as the layout

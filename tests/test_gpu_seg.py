@@ -162,6 +162,48 @@ def test_feature_row_w_scores_request_sized_batches_from_its_segment_form(oracle
     check(eng, oracle, X, W, np.arange(eng.FR_SMALL_BATCH), 10, False, expect_path="feature_rows")
 
 
+@pytest.mark.parametrize("case", ["blocks", "wide", "shard", "dense_rows"])
+def test_native_layout_builder_equals_the_numpy_specification(case):
+    """csrc/seg_build.hip (rtrec_slim_seg_plan + rtrec_slim_seg_fill: what a recommend right after a mini-batch waits for)
+    against seg_layout.build_seg_layout, array by array: cluster-ordered columns, tiles wider than 256, a column shard
+    of a larger W, rows dense enough for 256-float blocks."""
+    import torch
+    from rtrec_amd.engine import HipBackend
+    from rtrec_amd.seg_layout import build_seg_layout, build_seg_layout_native, cluster_labels
+    if case == "wide":
+        I, W, lo, hi = 70_000, random_w(70_000, 0.00004, seed=3), 0, 70_000
+    elif case == "dense_rows":
+        I, lo, hi = 3000, 0, 3000
+        rng = np.random.default_rng(12)
+        rows = np.sort(rng.choice(I, 60, replace=False))
+        nnz = 90_000
+        W = sp.csc_matrix(((rng.random(nnz) + 0.01).astype(np.float32), (rng.choice(rows, nnz), rng.integers(0, I, nnz))), shape=(I, I))
+        W.sum_duplicates(); W.eliminate_zeros(); W.sort_indices()
+    else:
+        I, W = 2000, random_w(2000, 0.006, seed=9, n_blocks=8, signed=True)
+        lo, hi = (0, I) if case == "blocks" else (700, 1500)
+    coo = W.tocoo()
+    order = np.lexsort((coo.row, coo.col))
+    r, c, v = coo.row[order].astype(np.int64), coo.col[order].astype(np.int64), coo.data[order].astype(np.float32)
+    for labels in (np.arange(I, dtype=np.int64), cluster_labels(r, c, v, I)):
+        ref = build_seg_layout(W, lo, hi, labels=labels)
+        be = HipBackend("cuda:0")
+        got = build_seg_layout_native(be, be.to_dev(r), be.to_dev(c), be.to_dev(v), I, lo, hi, be.to_dev(labels))
+        torch.cuda.synchronize()
+        for k in ("sg_T", "sg_n_tiles", "sg_rows", "sg_n_cols"):
+            assert got[k] == ref[k], k
+        if case == "wide":
+            assert got["sg_T"] > 256
+        n_rec, n_list = int(ref["sg_ent"].shape[0]), int(ref["sg_trow"].shape[0])
+        assert int(got["sg_ptr"][-1, -1]) == n_rec and int(got["sg_trow_ptr"][-1]) == n_list
+        for k in ("sg_info", "sg_ptr", "sg_bound", "sg_col_ids", "sg_trow_ptr"):
+            assert np.array_equal(got[k].cpu().numpy(), np.asarray(ref[k])), k
+        assert np.array_equal(got["sg_ent"][:n_rec].cpu().numpy(), ref["sg_ent"])
+        assert np.array_equal(got["sg_trow"][:n_list].cpu().numpy(), ref["sg_trow"])
+        if case == "dense_rows":
+            assert ref["sg_dense_segments"] > 0
+
+
 def test_seg_exact_ties_go_through_the_exact_pass(oracle):
     """Integer ratings and duplicated columns of W: exact score ties inside and at the edge of the list; the flagged rows
     are re-scored by the first-touch kernel and come out in the reference's order."""

@@ -50,6 +50,7 @@ def main():
     rep["feature_rows_built"] = fr is not None
     rep["cluster_labels_ms"], lab = timed(lambda: S.cluster_labels_device(torch, dw.rows, dw.cols, dw.vals, I))
     rep["segments_with_labels_ms"], sg = timed(lambda: S.build_seg_layout_device(torch, dw.rows, dw.cols, dw.vals, I, 0, I, labels=lab))
+    rep["segments_native_ms"], _ = timed(lambda: S.build_seg_layout_native(eng.be, dw.rows, dw.cols, dw.vals, I, 0, I, lab), n=9)
     nb = int(eng.be.lib.rtrec_slim_score_sg_scratch_bytes(I, sg["sg_n_tiles"], sg["sg_T"])) if sg else 0
     rep["heavy_scratch_bytes"] = nb
     rep["heavy_scratch_zero_ms"], _ = timed(lambda: eng.be.zeros((nb,), torch.uint8))
