@@ -1588,8 +1588,18 @@ class SlimEngine:
         if top_k > self.MAX_TOP_K:
             return False
         compact = mode == _native.TOPK_SPARSE
-        if compact:
-            self._fast_layout()
+        W = self._W
+        if compact and "n_active" not in W:
+            # a shard as wide as ALL its columns is an upper bound: when even that fits the merge, no count is needed
+            full = W["col_hi"] - W["col_lo"]
+            if -(-max(full, 1) // self._tile_width(False, top_k)) * (top_k + 1) <= self.MAX_MERGE_CANDIDATES:
+                return True
+        if compact and "n_active" not in W and not W["acc_f64"] and W["dw"].nnz > 0 and W["col_hi"] > W["col_lo"]:
+            # the number of columns that hold a weight (what every compacted layout is as wide as): counted from the sorted
+            # COO -- no layout is built just to answer this question (the feature-row form alone is 2 ms)
+            cols = W["dw"].cols
+            inside = cols[(cols >= W["col_lo"]) & (cols < W["col_hi"])]
+            W["n_active"] = int((inside[1:] != inside[:-1]).sum()) + 1 if inside.numel() else 0
         if compact and "n_active" not in self._W:
             lay = self._layout(compact=True, top_k=top_k)
             return lay is None or lay["n_tiles"] * (top_k + 1) <= self.MAX_MERGE_CANDIDATES

@@ -31,11 +31,9 @@ def main():
     args = ap.parse_args()
     import torch
     from rtrec_amd import SLIM
-    from rtrec_amd.synth import zipf_pairs
-    from stream_bench import SHAPES
-    U, I, draws = SHAPES[args.workload]
+    from stream_bench import workload_pairs
     rng = np.random.default_rng(5)
-    u, i = zipf_pairs(U, I, draws, seed=20251003)
+    U, I, u, i = workload_pairs(args.workload)
     n = len(u)
     order = rng.permutation(n)
     u, i = u[order], i[order]
@@ -84,6 +82,18 @@ def main():
         torch.cuda.synchronize()
     pr.disable()
     print(f"=== {args.batches} x SLIM.fit(1000 interactions), fit_mode={args.fit_mode}: {(time.perf_counter() - t0) / args.batches * 1e3:.1f} ms each\n" + top(pr, 60))
+
+    pr = cProfile.Profile()
+    t_rec = 0.0
+    for k in range(3 + args.batches, 3 + 2 * args.batches):
+        model.fit(batch(k), progress_bar=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pr.enable()
+        model.recommend_batch(users[:100], top_k=10)
+        pr.disable()
+        t_rec += time.perf_counter() - t0
+    print(f"=== {args.batches} x recommend_batch(100 users) right after a fit: {t_rec / args.batches * 1e3:.2f} ms each\n" + top(pr, 45))
 
 
 if __name__ == "__main__":
