@@ -332,6 +332,10 @@ typedef struct {
      * exactly those rows again WITH the tiled layout (whose exact-tie pass orders them like the reference) -- and has to
      * build that layout only when a call flags something. */
     int32_t       *d_flagged;
+    /* Optional second HIP stream of the caller (NULL: none).  The segment path then runs its workgroup-per-long-user kernel
+     * on it, beside the main kernel, for passes of 8192 rows or more: forked from and joined to `stream` by events inside the
+     * call, so the caller sees the usual stream-ordered semantics on `stream` and need not synchronise anything itself. */
+    void          *aux_stream;
 } rtrec_score_opts;
 
 size_t rtrec_slim_score_fr_scratch_bytes(int32_t fr_n_tiles, int32_t fr_tile_cols);

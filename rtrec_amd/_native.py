@@ -58,7 +58,7 @@ class ScoreOpts(C.Structure):
                 ("d_sg_bound", C.c_void_p), ("d_sg_col_ids", C.c_void_p),
                 ("sg_tile_cols", C.c_int32), ("sg_n_tiles", C.c_int32), ("sg_rows", C.c_int32), ("sg_n_cols", C.c_int32),
                 ("d_sg_trow_ptr", C.c_void_p), ("d_sg_trow", C.c_void_p), ("d_sg_scratch", C.c_void_p), ("sg_scratch_bytes", C.c_size_t),
-                ("row_order_longest_first", C.c_int32), ("d_flagged", C.c_void_p)]
+                ("row_order_longest_first", C.c_int32), ("d_flagged", C.c_void_p), ("aux_stream", C.c_void_p)]
 
 
 class NativeLibraryError(RuntimeError):

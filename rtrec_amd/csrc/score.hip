@@ -1855,6 +1855,7 @@ struct SgLayout {
     int T = 0, n_tiles = 0, rows = 0, n_cols = 0, order_longest_first = 0;
     const int *trow_ptr = nullptr; const int4 *trow = nullptr;      // heavy pass (optional, with the scratch)
     unsigned char *scratch = nullptr; size_t scratch_bytes = 0;
+    void *aux_stream = nullptr; // rtrec_score_opts.aux_stream
     int heavy_min = 0;          // tuning knob (rtrec_score_opts.diagnostics bits 12-23): 0 = chosen from the pass size
 };
 bool sg_usable(const SgLayout &S, int kk) {
@@ -1980,10 +1981,26 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         }
         // users too long for a wave's LDS lists first, one workgroup each (a percent of the rows): the launch is over
         // at once when there are none
-        if (heavy) hipLaunchKernelGGL(score_seg_heavy_kernel, dim3(kSgHeavySlots), dim3(sg_heavy_waves(SG.T) * 64), sg_heavy_lds(SG.T), st, g);
+        // With an auxiliary stream the heavy pass runs BESIDE the main kernel (fork / join by events): it is short of
+        // parallelism (a thousand-odd users, its end is its longest user's critical path), the main kernel's tail too.
+        hipStream_t aux = static_cast<hipStream_t>(SG.aux_stream);
+        hipEvent_t e_fork = nullptr, e_join = nullptr;
+        bool forked = false;
+        if (heavy && aux && aux != st && a.n_rows >= kSgForkMinRows &&
+            hipEventCreateWithFlags(&e_fork, hipEventDisableTiming) == hipSuccess) {
+            if (hipEventCreateWithFlags(&e_join, hipEventDisableTiming) == hipSuccess) {
+                forked = hipEventRecord(e_fork, st) == hipSuccess && hipStreamWaitEvent(aux, e_fork, 0) == hipSuccess;
+            }
+        }
+        if (heavy) hipLaunchKernelGGL(score_seg_heavy_kernel, dim3(kSgHeavySlots), dim3(sg_heavy_waves(SG.T) * 64), sg_heavy_lds(SG.T),
+                                      forked ? aux : st, g);
+        if (forked) (void)hipEventRecord(e_join, aux);
         if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, int, false>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
         else if (SG.T == 256) hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, uint16_t, true>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(score_seg_kernel<SG_GROUP, uint16_t, false>), dim3(grid), dim3(kSgWaves * 64), kSgWaves * wave_lds, st, g);
+        if (forked) (void)hipStreamWaitEvent(st, e_join, 0);
+        if (e_fork) (void)hipEventDestroy(e_fork);          // (released when the recorded work has completed)
+        if (e_join) (void)hipEventDestroy(e_join);
         sg_done = true;
     } else if (!have_tiled) {
         return RTREC_ERR_INVALID_ARG;       // no tiled layout and no usable fast layout
@@ -2183,6 +2200,7 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
         SG.trow_ptr = opts->d_sg_trow_ptr; SG.trow = reinterpret_cast<const int4 *>(opts->d_sg_trow);
         SG.scratch = static_cast<unsigned char *>(opts->d_sg_scratch); SG.scratch_bytes = opts->sg_scratch_bytes;
         SG.heavy_min = (opts->diagnostics >> 12) & 0xfff;
+        SG.aux_stream = opts->aux_stream;
         if (SG.n_cols != n_cols || (reinterpret_cast<uintptr_t>(opts->d_sg_trow) & 15u) ||
             (reinterpret_cast<uintptr_t>(opts->d_sg_scratch) & 15u)) return RTREC_ERR_INVALID_ARG;
     }

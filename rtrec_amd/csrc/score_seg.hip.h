@@ -63,6 +63,7 @@ constexpr int kSgMaxKk = 64;         // top_k + 1 list entries: one per lane
 // user's: there a user of more than n_rows / 16 items (at least 32) gets a whole workgroup (score_seg_heavy_kernel: eight
 // waves share the user's tiles) instead of one wave.  From 8192 rows on only users beyond a wave's LDS lists do.
 constexpr int kSgSmallHeavyMin = 32;
+constexpr int kSgForkMinRows = 8192;      // passes from this size on run the heavy pass on the caller's auxiliary stream
 __host__ __device__ constexpr int sg_heavy_min_for(int n_rows) {
     return n_rows / 16 < kSgSmallHeavyMin ? kSgSmallHeavyMin : (n_rows / 16 > kSgCap ? kSgCap : n_rows / 16);
 }

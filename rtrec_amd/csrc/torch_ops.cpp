@@ -127,7 +127,7 @@ void score_topk(const OT &row_ids, const at::Tensor &xb_ptr, const at::Tensor &x
                 int64_t fr_n_frags, int64_t fr_n_super, int64_t fr_buf_bytes, OT fr_scratch, const OT &row_order, int64_t timer,
                 int64_t diagnostics, OT rescored, int64_t row_order_grouped, const OT &sg_info, const OT &sg_ptr, const OT &sg_ent,
                 const OT &sg_bound, const OT &sg_col_ids, int64_t sg_tile_cols, int64_t sg_n_tiles, int64_t sg_rows, int64_t sg_n_cols,
-                const OT &sg_trow_ptr, const OT &sg_trow, OT sg_scratch, int64_t row_order_longest_first, OT flagged) {
+                const OT &sg_trow_ptr, const OT &sg_trow, OT sg_scratch, OT flagged, int64_t aux_stream) {
     rtrec_score_opts o{};
     o.n_x_rows = static_cast<int32_t>(xb_ptr.size(0)) - 1;
     o.d_fr_map = ptr<const int32_t>(fr_map);
@@ -148,7 +148,8 @@ void score_topk(const OT &row_ids, const at::Tensor &xb_ptr, const at::Tensor &x
     o.timer = reinterpret_cast<void *>(static_cast<intptr_t>(timer));
     o.diagnostics = static_cast<int32_t>(diagnostics);
     o.d_rescored = ptr<int32_t>(rescored);
-    o.row_order_grouped = static_cast<int32_t>(row_order_grouped);
+    o.row_order_grouped = static_cast<int32_t>(row_order_grouped & 1);      // the schema holds 64 arguments at most: two flags in one
+    o.row_order_longest_first = static_cast<int32_t>((row_order_grouped >> 1) & 1);
     o.d_sg_info = ptr<const int32_t>(sg_info);
     o.d_sg_ptr = ptr<const int32_t>(sg_ptr);
     o.d_sg_ent = ptr<const uint32_t>(sg_ent);
@@ -161,8 +162,8 @@ void score_topk(const OT &row_ids, const at::Tensor &xb_ptr, const at::Tensor &x
     o.d_sg_trow = ptr<const int32_t>(sg_trow);
     o.d_sg_scratch = ptr(sg_scratch);
     o.sg_scratch_bytes = (sg_scratch.has_value() && sg_scratch->defined()) ? static_cast<size_t>(sg_scratch->numel()) : 0;
-    o.row_order_longest_first = static_cast<int32_t>(row_order_longest_first);
     o.d_flagged = ptr<int32_t>(flagged);
+    o.aux_stream = reinterpret_cast<void *>(static_cast<intptr_t>(aux_stream));
     check(abi().score_topk_opt(static_cast<int32_t>(n_rows), ptr<const int32_t>(row_ids), ptr<const int32_t>(xb_ptr),
                                ptr<const int32_t>(xb_col), ptr<const float>(xb_val), static_cast<int32_t>(n_items),
                                static_cast<int32_t>(n_cols), static_cast<int32_t>(col_offset), ptr<const int32_t>(col_ids),
@@ -253,7 +254,7 @@ TORCH_LIBRARY(rtrec_amd, m) {
           "int fr_buf_bytes, Tensor(g!)? fr_scratch, Tensor? row_order, int timer, int diagnostics, Tensor(h!)? rescored, "
           "int row_order_grouped, Tensor? sg_info, Tensor? sg_ptr, Tensor? sg_ent, Tensor? sg_bound, Tensor? sg_col_ids, int sg_tile_cols, "
           "int sg_n_tiles, int sg_rows, int sg_n_cols, Tensor? sg_trow_ptr, Tensor? sg_trow, Tensor(i!)? sg_scratch, "
-          "int row_order_longest_first, Tensor(j!)? flagged) -> ()");
+          "Tensor(j!)? flagged, int aux_stream) -> ()");
     m.def("score_rows(Tensor? row_ids, Tensor xb_ptr, Tensor xb_col, Tensor xb_val, int n_rows, int n_items, int n_cols, int col_offset, "
           "int tile_cols, int n_tiles, Tensor tile_ptr, Tensor w_col, Tensor w_val, bool acc_f64, Tensor(a!) out) -> ()");
     m.def("merge_topk(Tensor in_ids, Tensor in_scores, Tensor? in_scores64, Tensor in_aux, Tensor in_count, int top_k, "

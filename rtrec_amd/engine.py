@@ -473,6 +473,7 @@ class HipBackend:
         from . import ops as _ops  # noqa: F401  (registers torch.ops.rtrec_amd.*)
         self.ops = torch.ops.rtrec_amd
         self._xty_ws = None              # scratch of the one-pass X^T y of small fit calls (grown on demand)
+        self._aux_stream = None
         # one-time costs of a process (custom-op dispatcher set-up, loading the gfx950 code objects)
         # belong here, next to the HIP context creation, not inside the first fit or recommend call
         w = torch.ones(1, dtype=torch.float32, device=self.device)
@@ -603,11 +604,24 @@ class HipBackend:
                             int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)), int(fr.get("fr_n_tiles", 0)),
                             int(fr.get("fr_n_frags", 0)), int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
                             fr.get("fr_scratch"),
-                            row_order if (fr or sg) else None, int(timer), int(diagnostics), rescored, int(bool(row_order_grouped)),
+                            row_order if (fr or sg) else None, int(timer), int(diagnostics), rescored,
+                            int(bool(row_order_grouped)) | (int(bool(sg) and row_order is not None) << 1),       # bit 1: longest first
                             sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_ent"), sg.get("sg_bound"),
                             sg.get("sg_col_ids"), int(sg.get("sg_T", 0)), int(sg.get("sg_n_tiles", 0)), int(sg.get("sg_rows", 0)),
                             int(sg.get("sg_n_cols", 0)), sg.get("sg_trow_ptr"), sg.get("sg_trow"),
-                            sg.get("sg_scratch") if use_sg_heavy else None, int(bool(sg) and row_order is not None), flagged)
+                            sg.get("sg_scratch") if use_sg_heavy else None, flagged,
+                            self.aux_stream_handle() if (sg and use_sg_heavy and n_rows >= self.SG_FORK_MIN_ROWS) else 0)
+
+    SG_FORK_MIN_ROWS = 8192          # = kSgForkMinRows (csrc/score_seg.hip.h)
+
+    def aux_stream_handle(self) -> int:
+        """A second stream of this backend (created on first use): the segment path's workgroup-per-long-user kernel runs on
+        it beside the main kernel (rtrec_score_opts.aux_stream).  RTREC_AMD_SG_FORK=0 turns that off (A/B)."""
+        if os.environ.get("RTREC_AMD_SG_FORK", "1") == "0":
+            return 0
+        if self._aux_stream is None:
+            self._aux_stream = self.torch.cuda.Stream(device=self.device)
+        return int(self._aux_stream.cuda_stream)
 
     def decay_f32(self, raw, ts, rate: float, now: float):
         """float32(raw * rate ** ((now - ts) / 86400)) for resident arrays: rtrec_store_decay_device, plus the host's libm
@@ -706,6 +720,7 @@ class SlimEngine:
         self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0")) & 0xff
         self.fr_users_per_wave = int(os.environ.get("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
         self.native_seg_builder = os.environ.get("RTREC_AMD_NATIVE_SEG_BUILD", "1") != "0"   # csrc/seg_build.hip (else tensor ops)
+        self.FR_SMALL_BATCH = int(os.environ.get("RTREC_AMD_FR_SMALL_BATCH", self.FR_SMALL_BATCH))     # A/B: segments for larger passes
         self._sg_scratch = None           # zeroed scratch of the segment path's workgroup-per-user kernel
         self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
         self.sg_heavy_min = int(os.environ.get("RTREC_AMD_SG_HEAVY_MIN", "0"))   # v > 0: segment path, users of more than v - 1 items get a workgroup
