@@ -1958,7 +1958,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         const bool wide = SG.n_cols >= 0xffff || SG.rows >= 0xffff;        // the LDS lists hold 16-bit columns / rows otherwise
         const size_t wave_lds = sg_wave_lds(SG.T, wide ? 4 : 2);
         int waves_cu = static_cast<int>((160u * 1024u) / wave_lds);
-        waves_cu = waves_cu > 28 ? 28 : waves_cu;             // 7 waves per SIMD: the kernel's scalar registers
+        waves_cu = waves_cu > 4 * SG_OCC ? 4 * SG_OCC : waves_cu;             // SG_OCC (7) waves per SIMD: the kernel's registers
         int wg_cu = waves_cu / kSgWaves;
         wg_cu = wg_cu < 1 ? 1 : wg_cu;
         const long long cap = 256ll * wg_cu;

@@ -67,6 +67,9 @@ constexpr int kSgForkMinRows = 8192;      // passes from this size on run the he
 __host__ __device__ constexpr int sg_heavy_min_for(int n_rows) {
     return n_rows / 16 < kSgSmallHeavyMin ? kSgSmallHeavyMin : (n_rows / 16 > kSgCap ? kSgCap : n_rows / 16);
 }
+#ifndef SG_OCC
+#define SG_OCC 7          // waves per SIMD the main kernel is compiled for (72 VGPRs)
+#endif
 #ifndef SG_HEAVY_SLOTS
 #define SG_HEAVY_SLOTS 1024
 #endif
@@ -372,7 +375,7 @@ template <> struct SgNone<uint16_t> { static constexpr int value = 0xffff; };
 template <> struct SgNone<int> { static constexpr int value = -1; };
 
 template <int GROUP, typename IDX, bool T256>
-__global__ __launch_bounds__(kSgWaves * 64, 7) void score_seg_kernel(SegArgs a) {       // 7 waves per SIMD: <= 72 VGPRs
+__global__ __launch_bounds__(kSgWaves * 64, SG_OCC) void score_seg_kernel(SegArgs a) {       // 7 waves per SIMD: <= 72 VGPRs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
     const int wave = static_cast<int>(threadIdx.x) >> 6;
@@ -475,6 +478,9 @@ __global__ __launch_bounds__(kSgWaves * 64, 7) void score_seg_kernel(SegArgs a) 
             SP_MARK(SP_FILTER)
             // (measured and dropped: gathering the segment pointers of two chunks per step -- the second chunk's registers cost
             // a wave per SIMD or spills, and users with several chunks got slower, not faster)
+            // (also measured and dropped, round 3 late: requesting chunk ch + 1's pointers before chunk ch's records, so that
+            // the two gathers of a step overlap -- 4-8 spilled VGPRs at 7 waves per SIMD (2.06-2.09 ms per c3s pass against
+            // 1.95), and no better without spills at 6 waves per SIMD (1.99 ms): occupancy hides those round trips already)
             for (int ch = 0; ch < n_ch; ++ch) {
                 const int idx = (ch << 6) + lane;
                 int r = -1;
