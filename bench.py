@@ -95,7 +95,15 @@ def api_leg(X, K, top_k):
     for s0 in range(0, 20000, 100):            # the reference's evaluate() asks in 100-user batches (recommender.py:163-200)
         rec.recommend_batch(users[s0:s0 + 100], top_k=top_k)
     t_100 = time.perf_counter() - t0
-    out = {"bulk_fit_seconds": t_fit, "bulk_fit_samples_per_sec_incl_ingest": len(df) / t_fit,
+    lat = []
+    probe = np.random.default_rng(3).integers(0, U, 330).tolist()
+    for x in probe:                                # the /recommend boundary (rtrec/serving/app.py:77-93): one user per call
+        t0 = time.perf_counter()
+        rec.recommend(x, top_k=top_k)
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.asarray(lat[30:])
+    out = {"single_user_recommend_ms": {"p50": float(np.quantile(lat, .5)), "p99": float(np.quantile(lat, .99)), "requests": int(lat.size)},
+           "bulk_fit_seconds": t_fit, "bulk_fit_samples_per_sec_incl_ingest": len(df) / t_fit,
            "recommend_batch_users": U, "recommend_batch_seconds": t_rec, "api_users_per_sec": U / t_rec,
            "recommend_batch_100_user_calls_users_per_sec": 20000 / t_100,
            "mean_list_length": float(np.mean([len(r) for r in recs[:5000]])),
@@ -236,6 +244,10 @@ def main() -> None:
     # RTREC_BENCH_SAME_GPU=1 (functional test only): every rank drives cuda:0 and the collectives
     # run over gloo, so the sharded path can be exercised on a single-GPU box.
     same_gpu = os.environ.get("RTREC_BENCH_SAME_GPU") == "1"
+    if same_gpu:
+        # several PROCESSES time-slice one GPU here: the fork / join of the segment path's second stream then waits a
+        # scheduling slice per event (measured: 6 ms -> 307 ms per c3s step at two ranks).  One rank per GPU is unaffected.
+        os.environ.setdefault("RTREC_AMD_SG_FORK", "0")
     if same_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
