@@ -11,6 +11,7 @@ import os
 from typing import Optional
 
 from . import build as _build
+from . import settings
 
 _lib: Optional[C.CDLL] = None
 
@@ -67,7 +68,7 @@ class NativeLibraryError(RuntimeError):
 
 def lib_path() -> str:
     # RTREC_AMD_LIB: load another build of the same ABI (A/B timing of kernel variants, tools/ab_build.sh)
-    return os.environ.get("RTREC_AMD_LIB") or _build.LIB_PATH
+    return settings.raw("RTREC_AMD_LIB") or _build.LIB_PATH
 
 
 def load() -> C.CDLL:

@@ -23,6 +23,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import _native
+from . import settings
 
 DEFAULT_TILE_COLS = 4096   # 16 KB of float accumulators: 8 persistent waves per CU (2 per SIMD) hide each other's latency
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
@@ -531,11 +532,11 @@ class HipBackend:
     def fit_knobs() -> Dict[str, int]:
         """Tuning / test knobs of rtrec_fit_opts, read from the environment HERE (the library itself reads none):
         RTREC_AMD_FIT_MODE=sw|mw, RTREC_AMD_COLWALK_MIN, RTREC_AMD_SCREEN_MIN, RTREC_AMD_LANE_MAX."""
-        mode = os.environ.get("RTREC_AMD_FIT_MODE", "")
-        lane_max = os.environ.get("RTREC_AMD_LANE_MAX")
+        mode = settings.raw("RTREC_AMD_FIT_MODE", "")
+        lane_max = settings.raw("RTREC_AMD_LANE_MAX")
         return dict(kernel=2 if mode.startswith("m") else 1 if mode.startswith("s") else 0,
-                    colwalk_min_rows=int(os.environ.get("RTREC_AMD_COLWALK_MIN", 0)),
-                    screen_min=int(os.environ.get("RTREC_AMD_SCREEN_MIN", 0)),
+                    colwalk_min_rows=int(settings.raw("RTREC_AMD_COLWALK_MIN", 0)),
+                    screen_min=int(settings.raw("RTREC_AMD_SCREEN_MIN", 0)),
                     lane_max=0 if lane_max is None else (-1 if int(lane_max) == 0 else int(lane_max)))
 
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
@@ -546,7 +547,7 @@ class HipBackend:
         xty = None
         n_t, nnz = int(targets.shape[0]), int(X["rcol"].shape[0])
         if (one_pass_xty and 0 < n_t <= FIT_MW_MAX_TARGETS and int(cfg.top_features) > 0 and int(fast) != 1 and k["kernel"] != 1 and nnz > 0
-                and os.environ.get("RTREC_AMD_XTY_BATCH", "1") != "0"):
+                and settings.raw("RTREC_AMD_XTY_BATCH", "1") != "0"):
             need = int(self.lib.rtrec_slim_xty_workspace_bytes(n_users, n_items, nnz, n_t))
             if 0 < need <= XTY_SCRATCH_MAX_BYTES:
                 if self._xty_ws is None or self._xty_ws.numel() < need:
@@ -617,7 +618,7 @@ class HipBackend:
     def aux_stream_handle(self) -> int:
         """A second stream of this backend (created on first use): the segment path's workgroup-per-long-user kernel runs on
         it beside the main kernel (rtrec_score_opts.aux_stream).  RTREC_AMD_SG_FORK=0 turns that off (A/B)."""
-        if os.environ.get("RTREC_AMD_SG_FORK", "1") == "0":
+        if settings.raw("RTREC_AMD_SG_FORK", "1") == "0":
             return 0
         if self._aux_stream is None:
             self._aux_stream = self.torch.cuda.Stream(device=self.device)
@@ -698,12 +699,12 @@ class SlimEngine:
         # 1/G slice of the users against all of W and only the final lists are all-gathered -- for
         # catalogues whose W is so small that a pass is bound by reading the user rows (C4: 3.2k active
         # columns), which column sharding does not divide.
-        self.score_shard = (score_shard or os.environ.get("RTREC_AMD_SCORE_SHARD", "columns")).lower()
+        self.score_shard = (score_shard or settings.raw("RTREC_AMD_SCORE_SHARD", "columns")).lower()
         if self.score_shard not in ("columns", "rows"):
             raise ValueError(f"score_shard must be 'columns' or 'rows': {self.score_shard}")
         # testing aid: run the multi-GPU exchange (collectives, strided merge) even with a single rank, so that
         # the RCCL code path can be exercised on a one-GPU box through a 1-rank process group
-        self.force_exchange = os.environ.get("RTREC_AMD_FORCE_EXCHANGE") == "1"
+        self.force_exchange = settings.raw("RTREC_AMD_FORCE_EXCHANGE") == "1"
         self.tile_cols = int(tile_cols or DEFAULT_TILE_COLS)
         self.be = backend if backend is not None else HipBackend(device)
         self.n_users = 0
@@ -715,19 +716,19 @@ class SlimEngine:
         self.gather_chunk_rows = GATHER_CHUNK_ROWS
         self.last_fit_stats: Dict[str, Any] = {}
         self.score_timer = 0          # rtrec_timer handle (HipBackend.timer_create) bracketing the dominant score kernel
-        self.use_feature_rows = os.environ.get("RTREC_AMD_FEATURE_ROWS", "1") != "0"     # A/B switch of the score kernel
+        self.use_feature_rows = settings.raw("RTREC_AMD_FEATURE_ROWS", "1") != "0"     # A/B switch of the score kernel
         # ablation switches of tools/score_ablate.sh: only a diagnostic build of the library looks at them
-        self.diagnostics = int(os.environ.get("RTREC_AMD_ABLATE", "0")) & 0xff
-        self.fr_users_per_wave = int(os.environ.get("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
-        self.native_seg_builder = os.environ.get("RTREC_AMD_NATIVE_SEG_BUILD", "1") != "0"   # csrc/seg_build.hip (else tensor ops)
-        self.FR_SMALL_BATCH = int(os.environ.get("RTREC_AMD_FR_SMALL_BATCH", self.FR_SMALL_BATCH))     # A/B: segments for larger passes
+        self.diagnostics = int(settings.raw("RTREC_AMD_ABLATE", "0")) & 0xff
+        self.fr_users_per_wave = int(settings.raw("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
+        self.native_seg_builder = settings.raw("RTREC_AMD_NATIVE_SEG_BUILD", "1") != "0"   # csrc/seg_build.hip (else tensor ops)
+        self.FR_SMALL_BATCH = int(settings.raw("RTREC_AMD_FR_SMALL_BATCH", self.FR_SMALL_BATCH))     # A/B: segments for larger passes
         self._sg_scratch = None           # zeroed scratch of the segment path's workgroup-per-user kernel
         self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
-        self.sg_heavy_min = int(os.environ.get("RTREC_AMD_SG_HEAVY_MIN", "0"))   # v > 0: segment path, users of more than v - 1 items get a workgroup
-        self.use_seg_layout = os.environ.get("RTREC_AMD_SEG_LAYOUT", "1") != "0"        # A/B switch of the general-W score kernel
-        self.seg_cluster = os.environ.get("RTREC_AMD_SEG_CLUSTER", "1") != "0"          # ... and of its column clustering
-        self.use_seg_heavy = os.environ.get("RTREC_AMD_SEG_HEAVY", "1") != "0"          # ... and of its workgroup-per-long-user pass
-        self.lazy_tiled = os.environ.get("RTREC_AMD_LAZY_TILED", "1") != "0"           # tiled layout only when a call flags exact ties
+        self.sg_heavy_min = int(settings.raw("RTREC_AMD_SG_HEAVY_MIN", "0"))   # v > 0: segment path, users of more than v - 1 items get a workgroup
+        self.use_seg_layout = settings.raw("RTREC_AMD_SEG_LAYOUT", "1") != "0"        # A/B switch of the general-W score kernel
+        self.seg_cluster = settings.raw("RTREC_AMD_SEG_CLUSTER", "1") != "0"          # ... and of its column clustering
+        self.use_seg_heavy = settings.raw("RTREC_AMD_SEG_HEAVY", "1") != "0"          # ... and of its workgroup-per-long-user pass
+        self.lazy_tiled = settings.raw("RTREC_AMD_LAZY_TILED", "1") != "0"           # tiled layout only when a call flags exact ties
         self.last_score_path = ""     # which kernel family served the last _local_topk call (tests, bench.py)
         self._sg_labels = None        # (cluster labels of the last segment layout, n_items, nnz of W when they were computed)
 
@@ -827,7 +828,7 @@ class SlimEngine:
             raise AssertionError(f"n_neighbors must be a positive integer: {K}")
         # K = None: a column's solution is sparse, so the output block is sized for ALLF_OUTPUT_CAP
         # coefficients per target and the rare target that has more is refitted with room for all I
-        cap = min(K, I) if K > 0 else min(I, int(os.environ.get("RTREC_AMD_ALLF_CAP", ALLF_OUTPUT_CAP)))
+        cap = min(K, I) if K > 0 else min(I, int(settings.raw("RTREC_AMD_ALLF_CAP", ALLF_OUTPUT_CAP)))
         cfg = _native.FitCfg(np.float32(alpha * l1_ratio * U), np.float32(alpha * (1.0 - l1_ratio) * U),
                              np.float32(tol), int(max_iter), sklearn_seed(random_state), int(bool(positive)), K)
         torch = be.torch
@@ -835,13 +836,13 @@ class SlimEngine:
             X["sqn"] = be.empty((I,), torch.float32)
             be.column_sqnorms(I, X["cptr"], X["cval"], X["sqn"])
         n = len(targets)
-        slots = int(n_slots or min(int(os.environ.get("RTREC_AMD_FIT_SLOTS", MAX_SLOTS)), max(1, n)))
+        slots = int(n_slots or min(int(settings.raw("RTREC_AMD_FIT_SLOTS", MAX_SLOTS)), max(1, n)))
         # Per-slot scratch is R (U floats) + s/touched/candidates (I each).  The X^T y step is a random
         # read-modify-write over s, i.e. bound by cache lines moved, and measured faster with FEWER
         # targets in flight once a slot is several MB (C4: 1024 slots 7.3 s, 5120 slots 9.2 s): keep
         # the total near 16 GiB but never below 1024 slots.
         per_slot = 4 * (U + (5 if K <= 0 else 4) * I)
-        scratch_gib = float(os.environ.get("RTREC_AMD_FIT_SCRATCH_GIB", FIT_SCRATCH_GIB))
+        scratch_gib = float(settings.raw("RTREC_AMD_FIT_SCRATCH_GIB", FIT_SCRATCH_GIB))
         slots = max(1, min(slots, max(1024, int(scratch_gib * (1 << 30)) // max(per_slot, 1))))
 
         # Bulk calls end on their heaviest targets: a popular item's X^T y is a walk over tens of
@@ -856,18 +857,18 @@ class SlimEngine:
             # ends with its slowest target: more of it goes to the multi-wave kernel, two workgroups per CU
             # (C3, an eighth of the targets: 0.77 -> 0.59 s; tools/fit_shard_model.py).
             small_call = n <= 2 * FIT_MW_MAX_TARGETS
-            want = int(os.environ.get("RTREC_AMD_FIT_HEAVY", 4 * FIT_HEAVY_TARGETS if small_call else FIT_HEAVY_TARGETS))
+            want = int(settings.raw("RTREC_AMD_FIT_HEAVY", 4 * FIT_HEAVY_TARGETS if small_call else FIT_HEAVY_TARGETS))
             heavy_slots = 2 * FIT_HEAVY_SLOTS if small_call else FIT_HEAVY_SLOTS
             heavy_min_rows = FIT_HEAVY_MIN_ROWS // 8 if small_call else FIT_HEAVY_MIN_ROWS
             nnz_sorted = X["col_nnz"][targets]
-            n_heavy = int(min(want, n - FIT_MW_MAX_TARGETS - 1, np.searchsorted(-nnz_sorted, -int(os.environ.get("RTREC_AMD_FIT_HEAVY_MIN_ROWS", heavy_min_rows)),
+            n_heavy = int(min(want, n - FIT_MW_MAX_TARGETS - 1, np.searchsorted(-nnz_sorted, -int(settings.raw("RTREC_AMD_FIT_HEAVY_MIN_ROWS", heavy_min_rows)),
                                                                                  side="right")))
             n_heavy = max(n_heavy, 0)
 
         # Gram tracking (csrc/fit.hip): bulk calls on a non-negative X get the Gram matrix of the most
         # popular items, which lets the kernel decide most zero coordinates without a pass over memory.
         gram = None
-        gmode = os.environ.get("RTREC_AMD_GRAM", "auto")
+        gmode = settings.raw("RTREC_AMD_GRAM", "auto")
         mode_ = mode or ("exact" if exact else "gram")
         if mode_ not in ("exact", "shuffle", "gram"):
             raise ValueError(f"fit mode must be 'exact', 'shuffle' or 'gram': {mode_}")
@@ -952,7 +953,7 @@ class SlimEngine:
             side = self._side_stream = getattr(self, "_side_stream", None) or torch.cuda.Stream(be.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                heavy = launch(0, n_heavy, min(n_heavy, int(os.environ.get("RTREC_AMD_FIT_HEAVY_SLOTS", heavy_slots))), role="heavy")
+                heavy = launch(0, n_heavy, min(n_heavy, int(settings.raw("RTREC_AMD_FIT_HEAVY_SLOTS", heavy_slots))), role="heavy")
         for s in range(n_heavy, n, chunk):
             collect(launch(s, min(n, s + chunk), min(slots, max(1, min(n, s + chunk) - s))))
         if heavy is not None:
@@ -995,7 +996,7 @@ class SlimEngine:
         [512, 4096].  A matrix with few non-empty columns (a mini-batch's partial matrix, slim.py:33-36) gets them all.
         The answer is cached with X."""
         be, X = self.be, self._X
-        env = os.environ.get("RTREC_AMD_GRAM_ITEMS", "auto")
+        env = settings.raw("RTREC_AMD_GRAM_ITEMS", "auto")
         if env != "auto":
             return min(self.n_items, int(env))
         if "gram_auto" in X:
@@ -1041,7 +1042,7 @@ class SlimEngine:
         column).  Targets with >= 1024 users walk all of X each (kColWalkMinRows), so it pays when that traffic is
         large (targets x entries of the matrix being fitted): measured between C2 (175 such targets x 1.1 M entries: 16 -> 23 ms with
         it) and C3 (450 x 5.0 M: 58 -> 44 ms)."""
-        if os.environ.get("RTREC_AMD_XTY_BATCH") == "force":      # parity tests: small matrices through this path
+        if settings.raw("RTREC_AMD_XTY_BATCH") == "force":      # parity tests: small matrices through this path
             return True
         col_nnz = self._X["col_nnz"]
         big = int(np.count_nonzero(col_nnz[targets] >= 1024))
@@ -1049,7 +1050,7 @@ class SlimEngine:
         # ... and its own fixed cost is one scan of the target sums per item column: a wide catalogue (C4: 500k columns,
         # 879 -> 957 ms with it) pays more for that than the walks cost
         scans = float(self.n_items) * -(-len(targets) // 64)
-        if os.environ.get("RTREC_AMD_DEBUG_XTY"):
+        if settings.raw("RTREC_AMD_DEBUG_XTY"):
             print(f"[xty] targets={len(targets)} big={big} nnz={int(col_nnz.sum())} walks={walks:.3g} scans={scans:.3g}", flush=True)
         if walks < 2000.0 * scans:
             return False
@@ -1367,7 +1368,7 @@ class SlimEngine:
     FR_MAX_TOP_K = 15           # kFrMaxKk - 1 of csrc/score.hip: a list of top_k + 1 entries fits one 16-lane DPP row
     SG_MAX_TOP_K = 63           # kSgMaxKk - 1 of csrc/score_seg.hip.h: the list of top_k + 1 entries is one register across the lanes
     FR_TILE_COLS = 256          # columns per tile of the feature-row layout (128: the narrow kernels, kept for A/B and tests)
-    pattern_order = os.environ.get("RTREC_AMD_PATTERN_ORDER", "1") != "0"
+    pattern_order = settings.raw("RTREC_AMD_PATTERN_ORDER", "1") != "0"
     rescored = None             # optional int32[1] device tensor: rows the exact-tie pass re-scored in the last call
 
     def _grouped_order(self, lay, n_rows: Optional[int] = None) -> bool:

@@ -15,7 +15,7 @@ import numpy as np
 from ..utils.device_store import DeviceInteractions
 from .base import BaseModel
 from .internal.slim_elastic import SLIMElastic
-
+from .. import settings
 
 class SLIM(BaseModel):
     def __init__(self, **kwargs: Any):
@@ -36,7 +36,7 @@ class SLIM(BaseModel):
         """The device-resident copy of X, or None where it does not apply (a backend without device arrays).
         Stores with time decay keep their raw values and timestamps resident too and are re-valued on the device
         at every new max_timestamp (utils/device_store.py).  RTREC_AMD_DEVICE_STORE=0 forces the host-export path."""
-        if os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0":
+        if settings.raw("RTREC_AMD_DEVICE_STORE", "1") == "0":
             return None
         be = self.model.engine.be
         if not getattr(be, "supports_device_store", False):
@@ -70,7 +70,7 @@ class SLIM(BaseModel):
         rtrec_store_fold_device kernel); a batch into an EMPTY store also leaves the mirror in step -- no upload later."""
         from ..utils.interactions import _DEVICE_FOLD_MIN
         st = self.interactions
-        if (n < _DEVICE_FOLD_MIN or st.decay_rate is not None or os.environ.get("RTREC_AMD_DEVICE_INGEST", "1") == "0"):
+        if (n < _DEVICE_FOLD_MIN or st.decay_rate is not None or settings.raw("RTREC_AMD_DEVICE_INGEST", "1") == "0"):
             return None
         if self.model._engine is None:
             # ingest alone does not need the GPU (the host store is complete by itself): do not construct the engine --
@@ -108,7 +108,7 @@ class SLIM(BaseModel):
                 return
             mir.ingested = None
         if (mir is None or mir.version != tag_before or self._store_tag() == tag_before
-                or len(user_ids) > self._MIRROR_APPLY_MAX or os.environ.get("RTREC_AMD_DEVICE_STORE", "1") == "0"):
+                or len(user_ids) > self._MIRROR_APPLY_MAX or settings.raw("RTREC_AMD_DEVICE_STORE", "1") == "0"):
             return
         keys = np.unique(st._keys(user_ids, item_ids))
         _, val, ts = st._lookup(keys)

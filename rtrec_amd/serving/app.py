@@ -26,6 +26,7 @@ from typing import Any, Callable, Dict, List, Optional, Tuple
 from fastapi import APIRouter, FastAPI, Header, HTTPException
 from fastapi.middleware.cors import CORSMiddleware
 from pydantic import BaseModel
+from .. import settings
 
 SECRET_TOKEN = os.getenv("X_TOKEN", "fake_secret_token")
 log = logging.getLogger("rtrec_amd.serving")
@@ -67,7 +68,7 @@ class ModelGate:
     def __init__(self, model: Any, coalesce_ms: Optional[float] = None):
         self.model = model
         self._lock = threading.Lock()
-        ms = float(os.getenv("RTREC_AMD_COALESCE_MS", "1")) if coalesce_ms is None else float(coalesce_ms)
+        ms = float(settings.raw("RTREC_AMD_COALESCE_MS", "1")) if coalesce_ms is None else float(coalesce_ms)
         self.coalescer = RecommendCoalescer(self, max_wait_s=ms * 1e-3) if ms >= 0 else None
 
     def recommend(self, user: Any, top_k: int, filter_interacted: bool) -> Any:

@@ -930,3 +930,23 @@ def test_recommend_coalescer_promotion_failure_and_isolated_requests():
     assert len(errs) == 3 and all(isinstance(e, RuntimeError) for e in errs)
     m.fail = False
     assert co.submit(9, 2, False) == [9, 2]
+
+
+def test_every_environment_switch_is_in_the_settings_table():
+    """rtrec_amd/settings.py is the one table of RTREC_AMD_* switches: no module of the package reads the environment for one
+    directly, and every name the code asks for is documented there."""
+    import glob
+    import re
+    from rtrec_amd import settings
+    root = os.path.join(os.path.dirname(os.path.dirname(__file__)), "rtrec_amd")
+    asked = set()
+    for path in glob.glob(os.path.join(root, "**", "*.py"), recursive=True):
+        src = open(path).read()
+        if not path.endswith("settings.py"):
+            assert not re.search(r'os\.(environ\.get|getenv|environ\[)\(?"RTREC_AMD_', src), path
+        asked |= set(re.findall(r'settings\.raw\("(RTREC_AMD_[A-Z_]+)"', src))
+    assert asked and asked <= set(settings.TABLE)
+    assert set(settings.TABLE) <= asked | {"RTREC_AMD_LIB"}
+    with pytest.raises(KeyError):
+        settings.raw("RTREC_AMD_NO_SUCH_SWITCH")
+    assert "RTREC_AMD_SG_FORK" in settings.describe()
