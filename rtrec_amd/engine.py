@@ -1179,7 +1179,7 @@ class SlimEngine:
         from .seg_layout import build_seg_layout_device
         labels = None
         kept = self._sg_labels
-        if kept is not None and kept[1] == W["n_items"] and abs(dw.nnz - kept[2]) <= 0.05 * max(kept[2], 1):
+        if kept is not None and kept[1] == W["n_items"] and abs(dw.nnz - kept[2]) <= self.SG_RELABEL_FRACTION * max(kept[2], 1):
             labels = kept[0]
         if not self.seg_cluster:
             labels = torch.arange(W["n_items"], dtype=torch.int64, device=dw.rows.device)
@@ -1364,6 +1364,8 @@ class SlimEngine:
     # forms (chosen from the batch size inside rtrec_slim_score_topk) it is ahead at every batch size, one user included
     # (tools/score_batch_sweep.py: DESIGN.md section 3.1); the threshold is kept for A/B runs and the tests.
     FR_MIN_ROWS = 1
+    SG_RELABEL_FRACTION = 0.2        # the cluster labels that order the segment layout's columns are kept until W's nnz has
+                                     # moved by this much (they decide locality only, never a result; label propagation is 3.4 ms)
     FR_SMALL_BATCH = 513              # batches below this many rows are scored from the segment form (_small_batch_layout)
     FR_MAX_TOP_K = 15           # kFrMaxKk - 1 of csrc/score.hip: a list of top_k + 1 entries fits one 16-lane DPP row
     SG_MAX_TOP_K = 63           # kSgMaxKk - 1 of csrc/score_seg.hip.h: the list of top_k + 1 entries is one register across the lanes

@@ -50,11 +50,10 @@ def main():
     from rtrec_amd import SLIM
     from rtrec_amd import engine as engine_mod
     from rtrec_amd.models.internal import slim_elastic as se
-    from rtrec_amd.synth import zipf_pairs
+    from tools.stream_bench import workload_pairs
 
-    U, I, draws = SHAPES[args.workload]
     rng = np.random.default_rng(5)
-    u, i = zipf_pairs(U, I, draws, seed=20251003)
+    U, I, u, i = workload_pairs(args.workload)
     n = len(u)
     order = rng.permutation(n)
     u, i = u[order], i[order]
