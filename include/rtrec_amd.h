@@ -330,7 +330,11 @@ typedef struct {
      * segment form above): the fast pass runs alone and, instead of re-scoring the rows whose lists hold an exact score tie,
      * reports them: d_flagged[0] = their number, d_flagged[1 ..] = the rows (room for 1 + n_rows int32).  The caller scores
      * exactly those rows again WITH the tiled layout (whose exact-tie pass orders them like the reference) -- and has to
-     * build that layout only when a call flags something. */
+     * build that layout only when a call flags something.
+     * DENSE mode (mode = RTREC_TOPK_DENSE, every column competes -- slim_elastic.py:745-778) may be asked for in the same way:
+     * the fast pass then also flags every row whose leading top_k scores are not all POSITIVE (positives outrank every
+     * zero-score column and zeros outrank negatives, so any other row's list is final) and every tie (DENSE mode orders ties
+     * by item id, not by first touch); the flagged rows are the caller's to score with the tiled layout in DENSE mode. */
     int32_t       *d_flagged;
     /* Optional second HIP stream of the caller (NULL: none).  The segment path then runs its workgroup-per-long-user kernel
      * on it, beside the main kernel, for passes of 8192 rows or more: forked from and joined to `stream` by events inside the

@@ -1045,6 +1045,7 @@ struct FrArgs {
     unsigned long long *mscratch;   // [gridDim.x][waves][users][n_tiles * REGS] interacted-column lane masks
     int kk, top_k, filter;
     int *out_id; float *out_score; uint32_t *out_aux; int *out_cnt;
+    int dense_rule;                  // DENSE mode through this pass (see sg_emit): short-of-positives rows and every tie are flagged
     int *flag_list; int *flag_len;   // rows for the exact-tie pass
     int *tie_list; int *tie_len;     // rows whose ties fr_ties_kernel orders
     int *queue;
@@ -1638,14 +1639,19 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                 a.out_score[o] = ok ? s : ninf;
                 if (a.out_aux) a.out_aux[o] = 0u;
             }
+            const bool short_of_positives = a.dense_rule &&
+                static_cast<int>(__builtin_popcountll(__ballot(rel >= 0 && rel < n_fin && s > 0.0f))) < a.top_k;
             if (lane == lb) {
                 a.out_cnt[r] = n_fin;
-                if (tie) {
+                if (short_of_positives) {
+                    a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+                } else if (tie) {
                     // A tie that reaches the (k+1)-th entry may have lost equal columns at the list's threshold: the row is
                     // re-scored by the exact-tie pass.  Otherwise the answer's SET is right and only the order of the tied
-                    // entries is open: fr_ties_kernel settles it from W.
+                    // entries is open: fr_ties_kernel settles it from W (SPARSE mode's first-touch order; DENSE mode orders
+                    // ties by item id: such a row is re-scored too).
                     const bool boundary = n_valid == kk && ((tie >> (lb + kk - 2)) & 1ull);
-                    if (boundary) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
+                    if (boundary || a.dense_rule) a.flag_list[atomicAdd(a.flag_len, 1)] = r;
                     else a.tie_list[atomicAdd(a.tie_len, 1)] = r;
                 }
             }
@@ -1871,7 +1877,10 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
                unsigned char *ws, const ScoreWs &L, hipStream_t st, KernelTimer *tmr, const FrLayout &FR, const SgLayout &SG,
                int n_x_rows, int32_t *d_rescored, int32_t *d_flagged) {
     ScoreArgs a = base;
-    const bool sparse = (a.mode == RTREC_TOPK_SPARSE);
+    // DENSE mode without the tiled layout: the fast pass runs as for SPARSE mode (non-zero sums, k + 1 entries) and flags
+    // what DENSE semantics could change -- see sg_emit
+    const bool dense_fast = (a.mode == RTREC_TOPK_DENSE) && base.tile_ptr == nullptr;
+    const bool sparse = (a.mode == RTREC_TOPK_SPARSE) || dense_fast;
     const bool single = (a.n_tiles == 1);
     a.top_k = top_k;
     a.kk = sparse ? top_k + 1 : top_k;
@@ -1912,7 +1921,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         f.frag_tile = FR.frag_tile;
         f.consecutive = FR.consecutive;
         f.mscratch = FR.scratch;
-        f.kk = a.kk; f.top_k = top_k; f.filter = a.filter;
+        f.kk = a.kk; f.top_k = top_k; f.filter = a.filter; f.dense_rule = dense_fast ? 1 : 0;
         f.out_id = d_out_ids; f.out_score = d_out_scores; f.out_aux = d_out_aux; f.out_cnt = d_out_count;
         f.flag_list = flag_list; f.flag_len = flag_len; f.queue = queue;
         f.tie_list = reinterpret_cast<int *>(ws + L.tie_list); f.tie_len = reinterpret_cast<int *>(ws + L.flag_len) + 1;
@@ -1952,7 +1961,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         g.xb_ptr = a.xb_ptr; g.xb_col = a.xb_col; g.xb_val = a.xb_val; g.n_items = a.n_items;
         g.info = SG.info; g.seg_ptr = SG.seg_ptr; g.w_ent = SG.w_ent; g.nnz = SG.nnz; g.bound = SG.bound;
         g.col_ids = SG.col_ids; g.n_cols = SG.n_cols; g.T = SG.T; g.n_tiles = SG.n_tiles; g.R = SG.rows;
-        g.kk = a.kk; g.top_k = top_k; g.filter = a.filter;
+        g.kk = a.kk; g.top_k = top_k; g.filter = a.filter; g.dense_rule = dense_fast ? 1 : 0;
         g.out_id = d_out_ids; g.out_score = d_out_scores; g.out_aux = d_out_aux; g.out_cnt = d_out_count;
         g.flag_list = flag_list; g.flag_len = flag_len; g.queue = queue;
         const bool wide = SG.n_cols >= 0xffff || SG.rows >= 0xffff;        // the LDS lists hold 16-bit columns / rows otherwise
@@ -2144,7 +2153,7 @@ extern "C" int rtrec_slim_score_topk_opt(int32_t n_rows, const int32_t *d_row_id
     if (!d_tile_ptr) {
         // fast layout only (feature rows or segments): SPARSE mode, float32; the rows whose lists hold an exact score tie are
         // handed back in opts->d_flagged for the caller to re-score against the tiled layout (which it may build only then)
-        if (!opts || !opts->d_flagged || mode != RTREC_TOPK_SPARSE || acc_f64) return RTREC_ERR_INVALID_ARG;
+        if (!opts || !opts->d_flagged || (mode != RTREC_TOPK_SPARSE && mode != RTREC_TOPK_DENSE) || acc_f64) return RTREC_ERR_INVALID_ARG;
         tile_cols = 256; n_tiles = 1;
         d_w_col = nullptr; d_w_val = nullptr; d_dense_idx = nullptr; d_dense_val = nullptr; d_row_hdr = nullptr;
     }

@@ -44,6 +44,7 @@ struct SegArgs {
     int *queue;
     int chunk;                 // users per queue claim (1 .. kSgQueueChunk): small passes claim fewer, so that every wave gets work
     int heavy_min;             // users with more items than this go to score_seg_heavy_kernel (<= kSgCap; see kSgSmallPass)
+    int dense_rule;            // DENSE mode through this pass: a row with fewer than top_k POSITIVE scores is flagged as well
     // long users (more items than a wave's LDS lists hold) are left to score_seg_heavy_kernel, one workgroup per user
     int order_longest_first;   // `order` is sorted by row length, longest first: the long users are its head
     const int *trow_ptr;       // [n_tiles + 1]: the segments of tile t, ascending item ...
@@ -307,9 +308,13 @@ __device__ __forceinline__ void sg_emit(const SegArgs &a, const SgList &L, int r
     }
     const float below = fr_shift_down(L.ls, ninf);
     const unsigned long long tie = __ballot(lane + 1 < L.n && L.ls == below);
+    // DENSE mode (every column competes, zeros included): the list is the answer only when its leading top_k scores are all
+    // positive -- positives outrank every zero-score column, zeros outrank negatives; any other row is the caller's to re-score
+    const bool short_of_positives = a.dense_rule &&
+        static_cast<int>(__builtin_popcountll(__ballot(lane < n_fin && L.ls > 0.0f))) < a.top_k;
     if (lane == 0) {
         a.out_cnt[row] = n_fin;
-        if (tie) a.flag_list[atomicAdd(a.flag_len, 1)] = row;
+        if (tie || short_of_positives) a.flag_list[atomicAdd(a.flag_len, 1)] = row;
     }
 }
 

@@ -722,6 +722,7 @@ class SlimEngine:
         self.fr_users_per_wave = int(settings.raw("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
         self.native_seg_builder = settings.raw("RTREC_AMD_NATIVE_SEG_BUILD", "1") != "0"   # csrc/seg_build.hip (else tensor ops)
         self.FR_SMALL_BATCH = int(settings.raw("RTREC_AMD_FR_SMALL_BATCH", self.FR_SMALL_BATCH))     # A/B: segments for larger passes
+        self.dense_fast = settings.raw("RTREC_AMD_DENSE_FAST", "1") != "0"    # DENSE mode through the fast SPARSE-style pass
         self._sg_scratch = None           # zeroed scratch of the segment path's workgroup-per-user kernel
         self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
         self.sg_heavy_min = int(settings.raw("RTREC_AMD_SG_HEAVY_MIN", "0"))   # v > 0: segment path, users of more than v - 1 items get a workgroup
@@ -1288,8 +1289,14 @@ class SlimEngine:
         # for the rows whose fast-pass list holds an exact score tie (the exact-tie pass orders those like the reference):
         # with lazy_tiled it is built when a call first flags such a row -- after a mini-batch the first recommend builds one
         # layout, not two -- at the price of reading one counter back per call while it does not exist.
+        # DENSE mode (string ids: every column competes, slim_elastic.py:745-778) takes the same fast pass when this rank holds
+        # all of W's columns: a row whose leading top_k scores are all positive is final (positives outrank every zero-score
+        # column, zeros outrank negatives); the kernel flags the others, and every tie (DENSE orders ties by item id), for the
+        # tiled DENSE kernel below.
+        dense_fast = bool(mode == _native.TOPK_DENSE and hip and self.dense_fast and self.lazy_tiled and not W["acc_f64"]
+                          and W.get("col_lo", 0) == 0 and W.get("col_hi", 0) == W["n_items"])
         fast = None
-        if sparse and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
+        if (sparse or dense_fast) and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
             small = (n_rows < self.FR_SMALL_BATCH and self.use_seg_layout and top_k <= self.SG_MAX_TOP_K
                      and getattr(be, "supports_seg_layout", False))
             fast = self._small_batch_layout() if small else self._fast_layout()
@@ -1298,7 +1305,7 @@ class SlimEngine:
         use_sg = bool(fast is not None and not use_fr and self.use_seg_layout and fast.get("sg") is not None
                       and top_k <= self.SG_MAX_TOP_K)
         tiled_key = (sparse, self._tile_width(sparse, top_k))
-        if hip and (use_fr or use_sg) and self.lazy_tiled and tiled_key not in W["layouts"]:
+        if hip and (use_fr or use_sg) and self.lazy_tiled and (dense_fast or tiled_key not in W["layouts"]):
             need = be.score_workspace_bytes(n_rows, 1, top_k)
             if self._score_ws is None or self._score_ws.numel() < need:
                 self._score_ws = be.empty((need,), torch.uint8)
@@ -1321,7 +1328,7 @@ class SlimEngine:
                 self.rescored.fill_(n_flag)
             if n_flag:
                 # exact ties: those rows again, against the tiled layout (built now) -- its exact-tie pass orders them
-                lay = self._layout(compact=True, top_k=top_k)
+                lay = self._layout(compact=not dense_fast, top_k=top_k)
                 rows_f = flagged[1:1 + n_flag].long()
                 sub_ids = d_row_ids[rows_f].contiguous() if d_row_ids is not None else rows_f.to(torch.int32)
                 t_ids, t_sc, t_aux = (be.empty((n_flag, top_k), dt) for dt in (torch.int32, torch.float32, torch.int32))

@@ -204,6 +204,47 @@ def test_native_layout_builder_equals_the_numpy_specification(case):
             assert ref["sg_dense_segments"] > 0
 
 
+@pytest.mark.parametrize("shape", ["general", "feature_rows"])
+@pytest.mark.parametrize("filt", [True, False])
+def test_dense_mode_through_the_fast_pass(oracle, shape, filt):
+    """DENSE mode (string item ids: every column competes, zeros included; slim_elastic.py:745-778) runs the fast pass too:
+    rows whose leading top_k scores are all positive are final, the kernel flags the rest (short users, negative scores,
+    exact ties -- DENSE orders ties by item id) for the tiled DENSE kernel.  Against the oracle's dense mode, bit for bit."""
+    I = 2500
+    rng = np.random.default_rng(4)
+    if shape == "general":
+        W = random_w(I, 0.005, seed=21, n_blocks=10, signed=True)
+    else:
+        rows = np.sort(rng.choice(I, 90, replace=False))
+        nnz = 50_000
+        v = (rng.random(nnz) + 0.01).astype(np.float32) * np.where(rng.random(nnz) < 0.2, -1, 1)
+        W = sp.csc_matrix((v.astype(np.float32), (rng.choice(rows, nnz), rng.integers(0, I, nnz))), shape=(I, I))
+        W.sum_duplicates(); W.setdiag(0); W.eliminate_zeros(); W.sort_indices()
+    X = interaction_matrix(1500, I, 80000, seed=6).tolil()
+    X[3, :] = 0                                            # no items at all: the highest ids, all zeros
+    X[4, :] = 0; X[4, 17] = 2.0                            # one item: a handful of non-zero scores, then zeros by id
+    X[5, :] = 0; X[5, [100, 200]] = [1.0, 1.0]             # equal ratings: exact ties likely
+    X = X.tocsr().astype(np.float32)
+    X.eliminate_zeros(); X.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    for rows, k in ((np.arange(X.shape[0]), 10), (np.arange(0, 40), 5), (np.array([3, 4, 5, 700]), 15), (np.array([4]), 10)):
+        ids, sc, cnt = eng.recommend_rows(rows, top_k=k, filter_interacted=filt, mode=_native.TOPK_DENSE)
+        assert eng.last_score_path in ("segments", "feature_rows")
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], W.tocsr(), top_k=k, filter_interacted=filt, dense=True)
+        assert np.array_equal(cnt, o_cnt)
+        bad = np.flatnonzero((ids != o_ids).any(axis=1))
+        assert bad.size == 0, f"ids differ for rows {rows[bad][:8]}: {ids[bad[0]]} vs {o_ids[bad[0]]}"
+        assert np.array_equal(bits(sc), bits(o_sc))
+    # the same through the tiled kernel alone (the A/B switch)
+    eng.dense_fast = False
+    ids2, sc2, cnt2 = eng.recommend_rows(np.arange(X.shape[0]), top_k=10, filter_interacted=filt, mode=_native.TOPK_DENSE)
+    assert eng.last_score_path == "tiled"
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X, W.tocsr(), top_k=10, filter_interacted=filt, dense=True)
+    assert np.array_equal(ids2, o_ids) and np.array_equal(bits(sc2), bits(o_sc)) and np.array_equal(cnt2, o_cnt)
+
+
 def test_seg_exact_ties_go_through_the_exact_pass(oracle):
     """Integer ratings and duplicated columns of W: exact score ties inside and at the edge of the list; the flagged rows
     are re-scored by the first-touch kernel and come out in the reference's order."""
