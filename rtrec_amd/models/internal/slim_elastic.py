@@ -359,7 +359,10 @@ class SLIMElastic:
 
     @staticmethod
     def _format(ids: ndarray, scores: ndarray, counts: ndarray, ret_scores: bool):
-        rows, cnt = ids.tolist(), counts.tolist()          # one conversion for the whole batch
+        rows = ids.tolist()                                # one conversion for the whole batch
+        if not ret_scores and (len(rows) == 0 or int(counts.min()) == ids.shape[1]):
+            return rows                                    # every list is full (the usual case): nothing to cut
+        cnt = counts.tolist()
         if not ret_scores:
             return [row[:c] for row, c in zip(rows, cnt)]
         return [(row[:c], scores[r, :c].copy()) for r, (row, c) in enumerate(zip(rows, cnt))]
