@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised parity run of the SPARSE-mode score path (feature-row kernel: resident and streaming layouts, fragments,
-tile test, exact-tie pass) against the C oracle: random numbers of rows of W, columns, densities, users, top_k, filter,
-integer / float / negative values, 256- and 128-column tiles.   python tools/fuzz_score.py --iters 60 --seed 1
+"""Randomised parity run of the score path (feature-row kernel: resident and streaming layouts, fragments, tile test,
+exact-tie pass; segment kernels: wave per user and workgroup per user; SPARSE and DENSE mode; request-sized and full
+batches) against the C oracle: random numbers of rows of W, columns, densities, users, top_k, filter, integer / float /
+negative values, 256- and 128-column tiles.   python tools/fuzz_score.py --iters 60 --seed 1
 """
 import argparse
 import os
@@ -18,14 +19,15 @@ sys.path.insert(0, ROOT)
 def run(iters: int, seed: int, log=print) -> int:
     """Number of (configuration, call) pairs whose ids, score bits or counts differ from the oracle's."""
     from oracle import slim_oracle as so
+    from rtrec_amd import _native
     from rtrec_amd.engine import SlimEngine
     rng = np.random.default_rng(seed)
     bad = 0
     t0 = time.time()
     for it in range(iters):
-        R = int(rng.choice([1, 3, 17, 40, 64, 65, 66, 90, 128]))
+        R = int(rng.choice([1, 3, 17, 40, 64, 65, 66, 90, 128, 129, 300, 1500]))
         n_cols = int(rng.choice([8, 100, 700, 3000, 9000, 20000]))
-        I = max(n_cols + int(rng.integers(50, 3000)), R + 10)
+        I = max(n_cols + int(rng.integers(50, 3000)), R + 10, 2 * R)
         U = int(rng.choice([97, 700, 3000, 9000]))
         per_col = int(rng.integers(1, max(2, min(R, 40)) + 1))
         integer = bool(rng.integers(0, 2))
@@ -57,17 +59,23 @@ def run(iters: int, seed: int, log=print) -> int:
         eng.set_weights(W)
         lay = eng._layout(True)
         Wr = W.tocsr()
-        for _ in range(2):
-            top_k = int(rng.integers(1, 16))
+        for _ in range(3):
+            top_k = int(rng.integers(1, 16)) if rng.integers(0, 3) else int(rng.integers(16, 40))
             filt = bool(rng.integers(0, 2))
-            rows = np.arange(U) if rng.integers(0, 2) else rng.permutation(U)[:int(rng.integers(1, U + 1))]
-            ids, sc, cnt = eng.recommend_rows(rows, top_k=top_k, filter_interacted=filt)
-            o_ids, o_sc, o_cnt = so.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt)
+            dense = bool(rng.integers(0, 3) == 0)
+            pick = int(rng.integers(0, 3))
+            rows = (np.arange(U) if pick == 0 else rng.permutation(U)[:int(rng.integers(1, U + 1))] if pick == 1
+                    else rng.permutation(U)[:int(rng.integers(1, 60))])
+            eng.sg_heavy_min = int(rng.choice([0, 0, 1, 9, 300]))
+            ids, sc, cnt = eng.recommend_rows(rows, top_k=top_k, filter_interacted=filt,
+                                              mode=_native.TOPK_DENSE if dense else _native.TOPK_SPARSE)
+            o_ids, o_sc, o_cnt = so.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt, dense=dense)
             ok = np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(sc.view(np.uint32), o_sc.view(np.uint32))
             if not ok:
                 bad += 1
                 wrong = np.flatnonzero((ids != o_ids).any(axis=1) | (cnt != o_cnt))
-                log(f"MISMATCH it={it} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} integer={integer} tc={eng.FR_TILE_COLS} "
+                log(f"MISMATCH it={it} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} dense={dense} n_rows={len(rows)} path={eng.last_score_path} "
+                    f"heavy_min={eng.sg_heavy_min} integer={integer} tc={eng.FR_TILE_COLS} "
                     f"fr={lay.get('fr_w') is not None} rows_wrong={len(wrong)} first={wrong[:5].tolist()}")
         if it % 50 == 49:
             log(f"[fuzz] {it + 1} configurations, {bad} mismatches, {time.time() - t0:.0f}s")
@@ -80,7 +88,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     args = ap.parse_args()
     bad = run(args.iters, args.seed, log=lambda m: print(m, flush=True))
-    print(f"fuzz done: {args.iters} configurations x 2 calls, mismatches: {bad}")
+    print(f"fuzz done: {args.iters} configurations x 3 calls, mismatches: {bad}")
     sys.exit(1 if bad else 0)
 
 
