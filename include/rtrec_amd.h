@@ -491,6 +491,27 @@ int rtrec_store_decay_device(const double *d_val, const double *d_ts, int64_t n,
                              float *d_out32, int32_t *d_unsafe_idx, int32_t *d_unsafe_count, int32_t cap, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * FLOAT64 ANSWERS FROM THE FLOAT32 FAST PASS  (SPARSE mode; a W that is float64 on the host -- the reference's serial fit,
+ * slim_elastic.py:252 -- whose values are float32 numbers; ratings and weights all >= 0 and large enough that no product
+ * underflows in float32: the CALLER checks both).
+ * d_in_ids / d_in_scores [n_rows][top_k + 1], d_in_count [n_rows]: the lists of rtrec_slim_score_topk_opt asked for
+ * top_k + 1 columns with float32 accumulation (item ids, scores descending).  Every candidate's float64 score is recomputed
+ * like the reference's csr_matmat (W in CSC form d_wc_*, rows ascending; one rounded product and one rounded add per
+ * addend, ascending item order), the candidates are sorted, and d_out_* [n_rows][top_k] receive ids, float32 casts and the
+ * float64 scores.  A row is final when its top_k-th float64 score exceeds m32 * (1 + rel_margin), m32 = the list's
+ * (top_k + 1)-th float32 score -- no column outside the list can then reach it (rel_margin >= 2 (n + 1) 2^-24 for columns
+ * of at most n weights) -- or when the list holds every non-zero column (d_in_count <= top_k).  Other rows, and rows with
+ * two equal float64 scores among the candidates, are appended to d_flagged (d_flagged[0] = running count, rows from
+ * d_flagged[1]; room for every row on top of what is there) for the caller to score with the float64 tiled kernel.
+ * ------------------------------------------------------------------------------------- */
+int rtrec_slim_refine_topk_f64(int32_t n_rows, const int32_t *d_row_ids, const int32_t *d_xb_ptr, const int32_t *d_xb_col,
+                               const float *d_xb_val, int32_t n_x_rows, int32_t n_items, const int32_t *d_wc_ptr,
+                               const int32_t *d_wc_row, const float *d_wc_val, int32_t top_k, const int32_t *d_in_ids,
+                               const float *d_in_scores, const int32_t *d_in_count, double rel_margin,
+                               int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64, int32_t *d_out_count,
+                               int32_t *d_flagged, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * SEGMENT LAYOUT BUILDER  (the d_sg_* arrays of rtrec_score_opts from a W resident on the device; what has to happen
  * between a mini-batch refit -- rtrec/models/slim.py:29-43 writes W's columns, slim_elastic.py:371-374 -- and the next
  * recommend -- slim_elastic.py:707-708).  Specification: rtrec_amd/seg_layout.py::build_seg_layout.

@@ -722,6 +722,7 @@ class SlimEngine:
         self.fr_users_per_wave = int(settings.raw("RTREC_AMD_FR_USERS", "0"))      # 8 / 4 / 2: force the feature-row kernel's form
         self.native_seg_builder = settings.raw("RTREC_AMD_NATIVE_SEG_BUILD", "1") != "0"   # csrc/seg_build.hip (else tensor ops)
         self.FR_SMALL_BATCH = int(settings.raw("RTREC_AMD_FR_SMALL_BATCH", self.FR_SMALL_BATCH))     # A/B: segments for larger passes
+        self.f64_refine = settings.raw("RTREC_AMD_F64_REFINE", "1") != "0"      # float64 W: float32 fast pass + float64 refine
         self.dense_fast = settings.raw("RTREC_AMD_DENSE_FAST", "1") != "0"    # DENSE mode through the fast SPARSE-style pass
         self._sg_scratch = None           # zeroed scratch of the segment path's workgroup-per-user kernel
         self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
@@ -1152,7 +1153,7 @@ class SlimEngine:
         fast = None
         dw: DeviceWeights = W["dw"]
         torch = be.torch
-        if W["col_hi"] > W["col_lo"] and not W["acc_f64"] and dw.nnz > 0:
+        if W["col_hi"] > W["col_lo"] and self._fast_dtype_ok() and dw.nnz > 0:
             if getattr(be, "supports_feature_rows", False):
                 fr = build_feature_rows_device(torch, dw.rows, dw.cols, dw.vals, W["n_items"], W["col_lo"], W["col_hi"],
                                                tile_cols=self.FR_TILE_COLS)
@@ -1169,6 +1170,39 @@ class SlimEngine:
             W["n_active"] = fast["n_cols"]
         W["fast"] = fast
         return fast
+
+    def _fast_dtype_ok(self) -> bool:
+        """The fast layouts hold float32 weights and their kernels accumulate float32: right for a float32 W, and usable for a
+        float64 W whose values are float32 numbers and all positive (the serial fit's output) through the refine step of
+        _local_topk (rtrec_slim_refine_topk_f64)."""
+        W = self._W
+        if not W["acc_f64"]:
+            return True
+        return self._f64_refine_w_ok()
+
+    def _f64_refine_w_ok(self) -> bool:
+        W = self._W
+        if "f64_refine" not in W:
+            dw: DeviceWeights = W["dw"]
+            ok = bool(self.f64_refine and isinstance(self.be, HipBackend) and not dw.lossy and dw.nnz > 0
+                      and float(dw.vals.min()) >= self.F64_REFINE_MIN_VALUE)
+            if ok:
+                ptr = dw.csc_arrays(self.be.torch)[0]
+                W["col_nnz_max"] = int((ptr[1:] - ptr[:-1]).max())
+            W["f64_refine"] = ok
+        return W["f64_refine"]
+
+    def _f64_refine_x_ok(self, xb) -> bool:
+        """Ratings all >= F64_REFINE_MIN_VALUE (no negative addend, no float32 underflow of a product); cached for the
+        resident X."""
+        val = xb[2]
+        if val.numel() == 0:
+            return True
+        if self._X.get("rval") is val:
+            if "rval_min_ok" not in self._X:
+                self._X["rval_min_ok"] = bool(float(val.min()) >= self.F64_REFINE_MIN_VALUE)
+            return self._X["rval_min_ok"]
+        return bool(float(val.min()) >= self.F64_REFINE_MIN_VALUE)
 
     def _seg_form(self) -> Optional[Dict[str, Any]]:
         """The segment layout of this rank's shard as a layout dict ({"sg": ..., "n_cols": ...}), or None."""
@@ -1217,7 +1251,7 @@ class SlimEngine:
         if "fast" in W and (W["fast"] is None or "sg" in W["fast"]):
             return W["fast"]
         if "fast_small" not in W:
-            ok = W["col_hi"] > W["col_lo"] and not W["acc_f64"] and W["dw"].nnz > 0
+            ok = W["col_hi"] > W["col_lo"] and self._fast_dtype_ok() and W["dw"].nnz > 0
             W["fast_small"] = self._seg_form() if ok else None
             if W["fast_small"] is not None:
                 W.setdefault("n_active", W["fast_small"]["n_cols"])
@@ -1297,13 +1331,26 @@ class SlimEngine:
                           and W.get("col_lo", 0) == 0 and W.get("col_hi", 0) == W["n_items"])
         fast = None
         if (sparse or dense_fast) and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
-            small = (n_rows < self.FR_SMALL_BATCH and self.use_seg_layout and top_k <= self.SG_MAX_TOP_K
-                     and getattr(be, "supports_seg_layout", False))
+            # (a float64 W asks its fast pass for one column more: see f64_fast below)
+            k_need = top_k + 1 if (W["acc_f64"] and self._f64_refine_w_ok()) else top_k
+            # the segment form: request-sized batches, and any batch whose top_k the feature-row kernel's lists do not hold
+            small = ((n_rows < self.FR_SMALL_BATCH or k_need > self.FR_MAX_TOP_K) and self.use_seg_layout
+                     and k_need <= self.SG_MAX_TOP_K and getattr(be, "supports_seg_layout", False))
             fast = self._small_batch_layout() if small else self._fast_layout()
+        # float64 W (serial fit): the float32 fast pass for top_k + 1 columns, then the candidates' float64 scores
+        # (rtrec_slim_refine_topk_f64) -- when W and X are all positive; otherwise the float64 tiled kernel as before
+        f64_fast = bool(sparse and hip and W["acc_f64"] and fast is not None and self.lazy_tiled and self._f64_refine_w_ok()
+                        and self._f64_refine_x_ok(xb))
+        if W["acc_f64"] and not f64_fast:
+            fast = None
+        k_fast = top_k + 1 if f64_fast else top_k
         use_fr = bool(fast is not None and self.use_feature_rows and fast.get("fr_w") is not None and n_rows >= self.FR_MIN_ROWS
-                      and top_k <= self.FR_MAX_TOP_K)
+                      and k_fast <= self.FR_MAX_TOP_K)
         use_sg = bool(fast is not None and not use_fr and self.use_seg_layout and fast.get("sg") is not None
-                      and top_k <= self.SG_MAX_TOP_K)
+                      and k_fast <= self.SG_MAX_TOP_K)
+        if f64_fast and (use_fr or use_sg):
+            return self._local_topk_f64(d_row_ids, n_rows, xb, top_k, filter_interacted, d_col_rank, fast, use_fr, use_sg,
+                                        ids, sc, sc64, aux, cnt)
         tiled_key = (sparse, self._tile_width(sparse, top_k))
         if hip and (use_fr or use_sg) and self.lazy_tiled and (dense_fast or tiled_key not in W["layouts"]):
             need = be.score_workspace_bytes(n_rows, 1, top_k)
@@ -1363,6 +1410,57 @@ class SlimEngine:
         else:
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws)
+        return ids, sc, sc64, aux, cnt
+
+    F64_REFINE_MIN_VALUE = 1e-18     # ratings and weights at least this large: a product is a normal float32 number
+
+    def _local_topk_f64(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, d_col_rank, fast, use_fr: bool,
+                        use_sg: bool, ids, sc, sc64, aux, cnt):
+        """SPARSE mode, float64 W with positive float32-valued weights, positive ratings: the float32 fast pass for top_k + 1
+        columns, the float64 scores of those candidates (csrc/score_refine.hip), and the float64 tiled kernel for the rows
+        either step flags (float32 ties; a top_k-th float64 score too close to what a column outside the list could reach;
+        float64 ties)."""
+        be, W = self.be, self._W
+        torch = be.torch
+        k1 = top_k + 1
+        ids1, sc1 = be.empty((n_rows, k1), torch.int32), be.empty((n_rows, k1), torch.float32)
+        aux1, cnt1 = be.empty((n_rows, k1), torch.int32), be.empty((n_rows,), torch.int32)
+        flagged = be.empty((2 * n_rows + 2,), torch.int32)
+        need = be.score_workspace_bytes(n_rows, 1, k1)
+        if self._score_ws is None or self._score_ws.numel() < need:
+            self._score_ws = be.empty((need,), torch.uint8)
+        order = self._row_order(d_row_ids, n_rows, xb, fast)
+        self.last_score_path = ("feature_rows" if use_fr else "segments") + "+f64"
+        be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, k1, filter_interacted,
+                      _native.TOPK_SPARSE, False, ids1, sc1, None, aux1, cnt1, self._score_ws, timer=self.score_timer,
+                      diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8) | ((self.sg_heavy_min & 0xfff) << 12),
+                      use_fr=use_fr, row_order=order, rescored=None,
+                      row_order_grouped=(order is not None and use_fr and self._order_grouped),
+                      use_sg=use_sg, use_sg_heavy=self.use_seg_heavy, flagged=flagged)
+        wc_ptr, wc_row, wc_val = W["dw"].csc_arrays(torch)
+        margin = 2.0 * (W["col_nnz_max"] + 2) * 2.0 ** -24
+        p = be.ptr
+        _native.check(be.lib.rtrec_slim_refine_topk_f64(n_rows, p(d_row_ids), p(xb[0]), p(xb[1]), p(xb[2]), int(xb[0].shape[0]) - 1,
+                                                        W["n_items"], p(wc_ptr), p(wc_row), p(wc_val), top_k, p(ids1), p(sc1), p(cnt1),
+                                                        float(margin), p(ids), p(sc), p(sc64), p(cnt), p(flagged), be.stream()),
+                      "rtrec_slim_refine_topk_f64")
+        aux.zero_()
+        n_flag = int(flagged[0].item())
+        if self.rescored is not None:
+            self.rescored.fill_(n_flag)
+        if n_flag:
+            rows_f = torch.unique(flagged[1:1 + n_flag].long())
+            n_f = int(rows_f.numel())
+            lay = self._layout(compact=True, top_k=top_k)
+            sub_ids = d_row_ids[rows_f].contiguous() if d_row_ids is not None else rows_f.to(torch.int32)
+            t_ids, t_sc, t_aux = (be.empty((n_f, top_k), dt) for dt in (torch.int32, torch.float32, torch.int32))
+            t_sc64, t_cnt = be.empty((n_f, top_k), torch.float64), be.empty((n_f,), torch.int32)
+            need = be.score_workspace_bytes(n_f, lay["n_tiles"], top_k)
+            if self._score_ws.numel() < need:
+                self._score_ws = be.empty((need,), torch.uint8)
+            be.score_topk(n_f, sub_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
+                          _native.TOPK_SPARSE, True, t_ids, t_sc, t_sc64, t_aux, t_cnt, self._score_ws, use_fr=False, use_sg=False)
+            ids[rows_f] = t_ids; sc[rows_f] = t_sc; sc64[rows_f] = t_sc64; aux[rows_f] = t_aux; cnt[rows_f] = t_cnt
         return ids, sc, sc64, aux, cnt
 
     ROW_ORDER_MIN = 2048        # batches below this are one or two waves of jobs: nothing to level

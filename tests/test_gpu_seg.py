@@ -245,6 +245,51 @@ def test_dense_mode_through_the_fast_pass(oracle, shape, filt):
     assert np.array_equal(ids2, o_ids) and np.array_equal(bits(sc2), bits(o_sc)) and np.array_equal(cnt2, o_cnt)
 
 
+@pytest.mark.parametrize("shape", ["general", "feature_rows", "signed"])
+def test_float64_w_through_the_fast_pass_and_the_refine_step(oracle, shape):
+    """A W that is float64 on the host (the reference's serial fit, slim_elastic.py:252; float32-valued) accumulates float64
+    scores.  With positive weights and ratings the float32 fast pass (top_k + 1 columns) + rtrec_slim_refine_topk_f64 gives
+    the float64 answer: ids, float32 casts of the float64 scores and counts equal the oracle's use_f64 mode; rows the margin
+    test or a tie flags go to the float64 tiled kernel.  A W with negative weights takes the tiled kernel as before."""
+    I = 2500
+    rng = np.random.default_rng(8)
+    if shape == "feature_rows":
+        rows = np.sort(rng.choice(I, 90, replace=False))
+        nnz = 50_000
+        W = sp.csc_matrix(((rng.random(nnz) + 0.01).astype(np.float32), (rng.choice(rows, nnz), rng.integers(0, I, nnz))), shape=(I, I))
+        W.sum_duplicates(); W.setdiag(0); W.eliminate_zeros(); W.sort_indices()
+    else:
+        W = random_w(I, 0.005, seed=31, n_blocks=10, signed=(shape == "signed"))
+    X = interaction_matrix(1500, I, 80000, seed=6).tolil()
+    X[3, :] = 0
+    X[4, :] = 0; X[4, 17] = 2.0
+    X[5, :] = 0; X[5, [100, 200]] = [1.0, 1.0]
+    X = X.tocsr().astype(np.float32)
+    X.eliminate_zeros(); X.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W.astype(np.float64), acc_f64=True)
+    Wr = W.tocsr()
+    for rows_, k, filt in ((np.arange(X.shape[0]), 10, True), (np.arange(0, 40), 5, False), (np.array([3, 4, 5, 700]), 14, True),
+                           (np.array([4]), 10, True), (np.arange(X.shape[0]), 30, True)):
+        ids, sc, cnt = eng.recommend_rows(rows_, top_k=k, filter_interacted=filt, mode=_native.TOPK_SPARSE)
+        assert eng.last_score_path == ("tiled" if shape == "signed" else eng.last_score_path)
+        if shape != "signed":
+            assert eng.last_score_path.endswith("+f64"), eng.last_score_path
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows_], Wr, top_k=k, filter_interacted=filt, use_f64=True)
+        assert np.array_equal(cnt, o_cnt)
+        bad = np.flatnonzero((ids != o_ids).any(axis=1))
+        assert bad.size == 0, f"ids differ for rows {rows_[bad][:8]}: {ids[bad[0]]} vs {o_ids[bad[0]]}"
+        assert np.array_equal(bits(sc), bits(o_sc))
+    if shape != "signed":       # A/B: the tiled float64 kernel alone gives the same arrays
+        a = eng.recommend_rows(np.arange(X.shape[0]), top_k=10)
+        eng.f64_refine = False
+        eng.set_weights(W.astype(np.float64), acc_f64=True)
+        b = eng.recommend_rows(np.arange(X.shape[0]), top_k=10)
+        assert eng.last_score_path == "tiled"
+        assert all(np.array_equal(x.view(np.int32), y.view(np.int32)) for x, y in zip(a, b))
+
+
 def test_seg_exact_ties_go_through_the_exact_pass(oracle):
     """Integer ratings and duplicated columns of W: exact score ties inside and at the edge of the list; the flagged rows
     are re-scored by the first-touch kernel and come out in the reference's order."""

@@ -47,6 +47,23 @@ def main():
         rep[name] = {"all_users_ms": float(np.median(ts)), "users_per_sec": U / (float(np.median(ts)) * 1e-3), "path": eng.last_score_path,
                      "rows_rescored": int(eng.rescored.item()) if eng.rescored is not None else None,
                      "single_user_p50_ms": float(np.quantile(lat[30:], .5))}
+    # float64 W (the reference's serial fit): float32 fast pass + float64 refine step vs the float64 tiled kernel alone
+    dw = eng.weights
+    f64 = {}
+    for name, flag in (("refine", True), ("tiled_only", False)):
+        eng.f64_refine = flag
+        eng.set_weights(dw, acc_f64=True)
+        step = lambda: eng.score_topk_device(None, U, 10, True, _native.TOPK_SPARSE, d_rows=d_rows)
+        eng.rescored = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        o = step(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(6):
+            t0 = time.perf_counter(); o = step(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
+        f64[name] = tuple(t.cpu().numpy() for t in o)
+        rep["f64_" + name] = {"all_users_ms": float(np.median(ts)), "users_per_sec": U / (float(np.median(ts)) * 1e-3),
+                              "path": eng.last_score_path, "rows_to_tiled_kernel": int(eng.rescored.item())}
+        eng.rescored = None
+    rep["f64_identical"] = bool(all(np.array_equal(x.view(np.int32), y.view(np.int32)) for x, y in zip(f64["refine"], f64["tiled_only"])))
     a, b = res["fast_pass"], res["tiled_only"]
     rep["identical"] = bool(all(np.array_equal(x.view(np.int32) if x.dtype == np.float32 else x, y.view(np.int32) if y.dtype == np.float32 else y)
                                 for x, y in zip(a, b)))

@@ -56,7 +56,8 @@ def run(iters: int, seed: int, log=print) -> int:
         eng.FR_TILE_COLS = int(rng.choice([256, 256, 128]))
         eng.FR_MIN_ROWS = int(rng.choice([0, 32]))
         eng.set_interactions(None, X, need_csc=False)
-        eng.set_weights(W)
+        f64 = bool(rng.integers(0, 4) == 0)              # a float64 W (float32-valued): float64 accumulation
+        eng.set_weights(W.astype(np.float64) if f64 else W, acc_f64=f64)
         lay = eng._layout(True)
         Wr = W.tocsr()
         for _ in range(3):
@@ -69,12 +70,12 @@ def run(iters: int, seed: int, log=print) -> int:
             eng.sg_heavy_min = int(rng.choice([0, 0, 1, 9, 300]))
             ids, sc, cnt = eng.recommend_rows(rows, top_k=top_k, filter_interacted=filt,
                                               mode=_native.TOPK_DENSE if dense else _native.TOPK_SPARSE)
-            o_ids, o_sc, o_cnt = so.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt, dense=dense)
+            o_ids, o_sc, o_cnt = so.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt, dense=dense, use_f64=f64)
             ok = np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(sc.view(np.uint32), o_sc.view(np.uint32))
             if not ok:
                 bad += 1
                 wrong = np.flatnonzero((ids != o_ids).any(axis=1) | (cnt != o_cnt))
-                log(f"MISMATCH it={it} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} dense={dense} n_rows={len(rows)} path={eng.last_score_path} "
+                log(f"MISMATCH it={it} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} dense={dense} f64={f64} n_rows={len(rows)} path={eng.last_score_path} "
                     f"heavy_min={eng.sg_heavy_min} integer={integer} tc={eng.FR_TILE_COLS} "
                     f"fr={lay.get('fr_w') is not None} rows_wrong={len(wrong)} first={wrong[:5].tolist()}")
         if it % 50 == 49:
