@@ -944,7 +944,7 @@ def test_every_environment_switch_is_in_the_settings_table():
         src = open(path).read()
         if not path.endswith("settings.py"):
             assert not re.search(r'os\.(environ\.get|getenv|environ\[)\(?"RTREC_AMD_', src), path
-        asked |= set(re.findall(r'settings\.raw\("(RTREC_AMD_[A-Z_]+)"', src))
+        asked |= set(re.findall(r'settings\.raw\("(RTREC_AMD_[A-Z0-9_]+)"', src))
     assert asked and asked <= set(settings.TABLE)
     assert set(settings.TABLE) <= asked | {"RTREC_AMD_LIB"}
     with pytest.raises(KeyError):
