@@ -1327,7 +1327,8 @@ class SlimEngine:
         # all of W's columns: a row whose leading top_k scores are all positive is final (positives outrank every zero-score
         # column, zeros outrank negatives); the kernel flags the others, and every tie (DENSE orders ties by item id), for the
         # tiled DENSE kernel below.
-        dense_fast = bool(mode == _native.TOPK_DENSE and hip and self.dense_fast and self.lazy_tiled and not W["acc_f64"]
+        dense_fast = bool(mode == _native.TOPK_DENSE and hip and self.dense_fast and self.lazy_tiled
+                          and (not W["acc_f64"] or self._f64_refine_w_ok())
                           and W.get("col_lo", 0) == 0 and W.get("col_hi", 0) == W["n_items"])
         fast = None
         if (sparse or dense_fast) and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
@@ -1339,8 +1340,8 @@ class SlimEngine:
             fast = self._small_batch_layout() if small else self._fast_layout()
         # float64 W (serial fit): the float32 fast pass for top_k + 1 columns, then the candidates' float64 scores
         # (rtrec_slim_refine_topk_f64) -- when W and X are all positive; otherwise the float64 tiled kernel as before
-        f64_fast = bool(sparse and hip and W["acc_f64"] and fast is not None and self.lazy_tiled and self._f64_refine_w_ok()
-                        and self._f64_refine_x_ok(xb))
+        f64_fast = bool((sparse or dense_fast) and hip and W["acc_f64"] and fast is not None and self.lazy_tiled
+                        and self._f64_refine_w_ok() and self._f64_refine_x_ok(xb))
         if W["acc_f64"] and not f64_fast:
             fast = None
         k_fast = top_k + 1 if f64_fast else top_k
@@ -1350,7 +1351,7 @@ class SlimEngine:
                       and k_fast <= self.SG_MAX_TOP_K)
         if f64_fast and (use_fr or use_sg):
             return self._local_topk_f64(d_row_ids, n_rows, xb, top_k, filter_interacted, d_col_rank, fast, use_fr, use_sg,
-                                        ids, sc, sc64, aux, cnt)
+                                        ids, sc, sc64, aux, cnt, mode)
         tiled_key = (sparse, self._tile_width(sparse, top_k))
         if hip and (use_fr or use_sg) and self.lazy_tiled and (dense_fast or tiled_key not in W["layouts"]):
             need = be.score_workspace_bytes(n_rows, 1, top_k)
@@ -1415,11 +1416,13 @@ class SlimEngine:
     F64_REFINE_MIN_VALUE = 1e-18     # ratings and weights at least this large: a product is a normal float32 number
 
     def _local_topk_f64(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, d_col_rank, fast, use_fr: bool,
-                        use_sg: bool, ids, sc, sc64, aux, cnt):
+                        use_sg: bool, ids, sc, sc64, aux, cnt, mode: int = _native.TOPK_SPARSE):
         """SPARSE mode, float64 W with positive float32-valued weights, positive ratings: the float32 fast pass for top_k + 1
         columns, the float64 scores of those candidates (csrc/score_refine.hip), and the float64 tiled kernel for the rows
         either step flags (float32 ties; a top_k-th float64 score too close to what a column outside the list could reach;
-        float64 ties)."""
+        float64 ties).  DENSE mode likewise: its fast pass also flags the rows with fewer than top_k + 1 positive scores (every
+        non-zero score is positive here), which the DENSE float64 tiled kernel then scores."""
+        dense = mode == _native.TOPK_DENSE
         be, W = self.be, self._W
         torch = be.torch
         k1 = top_k + 1
@@ -1432,7 +1435,7 @@ class SlimEngine:
         order = self._row_order(d_row_ids, n_rows, xb, fast)
         self.last_score_path = ("feature_rows" if use_fr else "segments") + "+f64"
         be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, k1, filter_interacted,
-                      _native.TOPK_SPARSE, False, ids1, sc1, None, aux1, cnt1, self._score_ws, timer=self.score_timer,
+                      mode, False, ids1, sc1, None, aux1, cnt1, self._score_ws, timer=self.score_timer,
                       diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8) | ((self.sg_heavy_min & 0xfff) << 12),
                       use_fr=use_fr, row_order=order, rescored=None,
                       row_order_grouped=(order is not None and use_fr and self._order_grouped),
@@ -1451,7 +1454,7 @@ class SlimEngine:
         if n_flag:
             rows_f = torch.unique(flagged[1:1 + n_flag].long())
             n_f = int(rows_f.numel())
-            lay = self._layout(compact=True, top_k=top_k)
+            lay = self._layout(compact=not dense, top_k=top_k)
             sub_ids = d_row_ids[rows_f].contiguous() if d_row_ids is not None else rows_f.to(torch.int32)
             t_ids, t_sc, t_aux = (be.empty((n_f, top_k), dt) for dt in (torch.int32, torch.float32, torch.int32))
             t_sc64, t_cnt = be.empty((n_f, top_k), torch.float64), be.empty((n_f,), torch.int32)
@@ -1459,7 +1462,7 @@ class SlimEngine:
             if self._score_ws.numel() < need:
                 self._score_ws = be.empty((need,), torch.uint8)
             be.score_topk(n_f, sub_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
-                          _native.TOPK_SPARSE, True, t_ids, t_sc, t_sc64, t_aux, t_cnt, self._score_ws, use_fr=False, use_sg=False)
+                          mode, True, t_ids, t_sc, t_sc64, t_aux, t_cnt, self._score_ws, use_fr=False, use_sg=False)
             ids[rows_f] = t_ids; sc[rows_f] = t_sc; sc64[rows_f] = t_sc64; aux[rows_f] = t_aux; cnt[rows_f] = t_cnt
         return ids, sc, sc64, aux, cnt
 

@@ -281,6 +281,11 @@ def test_float64_w_through_the_fast_pass_and_the_refine_step(oracle, shape):
         bad = np.flatnonzero((ids != o_ids).any(axis=1))
         assert bad.size == 0, f"ids differ for rows {rows_[bad][:8]}: {ids[bad[0]]} vs {o_ids[bad[0]]}"
         assert np.array_equal(bits(sc), bits(o_sc))
+    for rows_, k in ((np.arange(X.shape[0]), 10), (np.array([3, 4, 5, 700]), 7)):         # DENSE mode with the float64 W
+        ids, sc, cnt = eng.recommend_rows(rows_, top_k=k, filter_interacted=True, mode=_native.TOPK_DENSE)
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows_], Wr, top_k=k, filter_interacted=True, dense=True, use_f64=True)
+        assert np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc))
+        assert (shape == "signed") == (eng.last_score_path == "tiled")
     if shape != "signed":       # A/B: the tiled float64 kernel alone gives the same arrays
         a = eng.recommend_rows(np.arange(X.shape[0]), top_k=10)
         eng.f64_refine = False
