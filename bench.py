@@ -174,6 +174,26 @@ def structured_leg(args, top_k):
            "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_bytes / (kms / max(kn, 1) * 1e-3) / 1e9,
            "algorithmic_frac_of_hbm_peak": algo_bytes / (kms / max(kn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "topk_ids_crc32": zlib.crc32(out[0].cpu().numpy().tobytes())}
+    # the other forms the reference scores in: DENSE mode (string item ids: every column competes, slim_elastic.py:745-778)
+    # and a float64 W (its serial fit, :252) -- both through the fast pass plus the rows it flags
+    other = {}
+
+    def timed_mode(name, mode):
+        stepm = lambda: eng.score_topk_device(None, U, top_k, True, mode, d_rows=d_rows, xb=xb)
+        o = stepm()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            o = stepm()
+        torch.cuda.synchronize()
+        other[name] = {"ms_per_step": (time.perf_counter() - t1) / 3 * 1e3, "score_path": eng.last_score_path}
+        return o
+    timed_mode("dense_mode", _native.TOPK_DENSE)
+    eng.set_weights(eng.weights, acc_f64=True)
+    o64 = timed_mode("float64_w", _native.TOPK_SPARSE)
+    other["float64_w"]["same_ids_as_float32"] = bool(np.array_equal(o64[0].cpu().numpy(), out[0].cpu().numpy()))
+    eng.set_weights(eng.weights, acc_f64=False)
+    res["other_modes"] = other
     if not args.no_cpu_baseline:
         from oracle import slim_oracle as so
         rows_s = np.sort(np.random.default_rng(7).choice(U, 1024, replace=False))
