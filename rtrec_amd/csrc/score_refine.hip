@@ -25,6 +25,7 @@ namespace rtrec {
 namespace {
 
 constexpr int kRfWaves = 4;
+constexpr int kRfItems = 1024;      // items of a row staged in LDS per wave (8 KB); longer rows are searched in global memory
 
 __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
     int n_rows, const int *__restrict__ row_ids, const int *__restrict__ xb_ptr, const int *__restrict__ xb_col,
@@ -32,7 +33,11 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
     const float *__restrict__ wc_val, int top_k, const int *__restrict__ in_ids, const float *__restrict__ in_scores,
     const int *__restrict__ in_count, double rel_margin, int *__restrict__ out_ids, float *__restrict__ out_scores,
     double *__restrict__ out_scores64, int *__restrict__ out_count, int *__restrict__ flagged) {
+    __shared__ int s_col[kRfWaves][kRfItems];
+    __shared__ float s_val[kRfWaves][kRfItems];
     const int lane = lane_id();
+    int *lcol = s_col[static_cast<int>(threadIdx.x) >> 6];
+    float *lval = s_val[static_cast<int>(threadIdx.x) >> 6];
     const int wave = (static_cast<int>(blockIdx.x) * kRfWaves) + (static_cast<int>(threadIdx.x) >> 6);
     const int n_waves = static_cast<int>(gridDim.x) * kRfWaves;
     const int kin = top_k + 1;
@@ -42,6 +47,9 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
         int a0 = 0, n_a = 0;
         if (xrow >= 0 && xrow < n_x_rows) { a0 = xb_ptr[xrow]; n_a = xb_ptr[xrow + 1] - a0; }
         const int n = min(in_count[row], kin);
+        // the row's items in LDS: every candidate's entries are looked up in them (a wave's LDS traffic is program-ordered)
+        const bool staged = n_a <= kRfItems;
+        if (staged) for (int q = lane; q < n_a; q += 64) { lcol[q] = xb_col[a0 + q]; lval[q] = xb_val[a0 + q]; }
         // ---- exact float64 score of candidate `lane`
         double e = ninf;
         int c = -1;
@@ -52,12 +60,21 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
                 for (int q = wc_ptr[c]; q < wc_ptr[c + 1]; ++q) {
                     const int i = wc_row[q];
                     int lo = 0, hi = n_a;                                   // first position with item >= i
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (xb_col[a0 + mid] < i) lo = mid + 1; else hi = mid;
+                    if (staged) {
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (lcol[mid] < i) lo = mid + 1; else hi = mid;
+                        }
+                        if (lo < n_a && lcol[lo] == i)
+                            acc = __dadd_rn(acc, __dmul_rn(static_cast<double>(lval[lo]), static_cast<double>(wc_val[q])));
+                    } else {
+                        while (lo < hi) {
+                            const int mid = (lo + hi) >> 1;
+                            if (xb_col[a0 + mid] < i) lo = mid + 1; else hi = mid;
+                        }
+                        if (lo < n_a && xb_col[a0 + lo] == i)
+                            acc = __dadd_rn(acc, __dmul_rn(static_cast<double>(xb_val[a0 + lo]), static_cast<double>(wc_val[q])));
                     }
-                    if (lo < n_a && xb_col[a0 + lo] == i)
-                        acc = __dadd_rn(acc, __dmul_rn(static_cast<double>(xb_val[a0 + lo]), static_cast<double>(wc_val[q])));
                 }
             }
             e = acc;
