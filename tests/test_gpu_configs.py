@@ -352,6 +352,45 @@ def test_c3s_recommend_all_users_segment_kernel(c3s, oracle):
         assert np.array_equal(ids4, o4) and np.array_equal(cnt4, c4) and np.array_equal(bits(sc4), bits(s4))
 
 
+def test_c3s_dense_mode_and_float64_w_at_full_size(c3s, oracle):
+    """The other two forms the reference scores in, at full size: DENSE mode (string item ids, slim_elastic.py:745-778) and a
+    float64 W (the serial fit, :252).  Both run the fast pass plus the rows it flags; ALL rows must equal the tiled kernel
+    of the same mode, and samples (random users, the longest, the shortest) the oracle."""
+    eng, X, W, U = c3s["eng"], c3s["X"], c3s["W"], C3S["U"]
+    rows = np.arange(U)
+    lens = np.diff(X.indptr)
+    sample = np.unique(np.concatenate([np.random.default_rng(4).choice(U, 1500, replace=False), np.argsort(-lens)[:150],
+                                       np.argsort(lens)[:300]]))
+    Wr = W.tocsr()
+    # DENSE
+    d = eng.recommend_rows(rows, top_k=10, mode=_native.TOPK_DENSE)
+    assert eng.last_score_path == "segments"
+    eng.dense_fast = False
+    try:
+        t = eng.recommend_rows(rows, top_k=10, mode=_native.TOPK_DENSE)
+        assert eng.last_score_path == "tiled"
+    finally:
+        eng.dense_fast = True
+    assert all(np.array_equal(a.view(np.int32), b.view(np.int32)) for a, b in zip(d, t))
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], Wr, top_k=10, dense=True, n_threads=CPU_THREADS)
+    assert np.array_equal(d[0][sample], o_ids) and np.array_equal(bits(d[1][sample]), bits(o_sc)) and np.array_equal(d[2][sample], o_cnt)
+    # float64 W
+    try:
+        eng.set_weights(W.astype(np.float64), acc_f64=True)
+        f = eng.recommend_rows(rows, top_k=10)
+        assert eng.last_score_path == "segments+f64"
+        eng.f64_refine = False
+        eng.set_weights(W.astype(np.float64), acc_f64=True)
+        t = eng.recommend_rows(rows, top_k=10)
+        assert eng.last_score_path == "tiled"
+        assert all(np.array_equal(a.view(np.int32), b.view(np.int32)) for a, b in zip(f, t))
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], Wr, top_k=10, use_f64=True, n_threads=CPU_THREADS)
+        assert np.array_equal(f[0][sample], o_ids) and np.array_equal(bits(f[1][sample]), bits(o_sc)) and np.array_equal(f[2][sample], o_cnt)
+    finally:
+        eng.f64_refine = True
+        eng.set_weights(W)
+
+
 # ------------------------------------------------------------------------------------------ mid-size reference fixtures
 def test_midsize_reference_models_on_gpu(engine):
     """tests/golden/midsize.json (real SLIMElastic at the ML-1M shape and on a structured 3000 x 1500 matrix): the HIP fit's W
