@@ -1559,7 +1559,7 @@ class SlimEngine:
             order = order.to(torch.int32)
         if cache is not None:
             if seen is not None:
-                cache.remove(seen)
+                cache[:] = [ent for ent in cache if ent is not seen]       # (by identity: the entries hold tensors)
             if len(cache) >= 32:
                 cache.clear()
             cache.append((d_row_ids, None if d_row_ids is None else d_row_ids._version, n_rows, fr_host, order, grouped))

@@ -148,6 +148,23 @@ def _bulk_ingest(model, u, i, ts, r, n_bulk, chunk=4_000_000):
         model.add_interactions_columns(u[a:b], i[a:b], ts[a:b], r[a:b])
 
 
+def test_c3_row_sets_scored_again_get_the_grouped_order(c3):
+    """A row tensor scored a second time gets the pattern-grouped work order (SlimEngine._row_order keeps one entry per row
+    tensor: several live at once here); the answers do not depend on the order."""
+    eng = c3["eng"]
+    U = eng.n_users
+    sets = [eng.be.to_dev(np.arange(a, a + 40_000, dtype=np.int32)) for a in (0, 30_000, U - 40_000)]
+    first = []
+    for d in sets:                                     # first sight: the length order
+        o = eng.score_topk_device(None, 40_000, 10, True, _native.TOPK_SPARSE, d_rows=d)
+        first.append([t.cpu().numpy() for t in o])
+    for rep in range(2):                               # second sight builds the grouped order, third reuses it
+        for d, f in zip(sets, first):
+            o = eng.score_topk_device(None, 40_000, 10, True, _native.TOPK_SPARSE, d_rows=d)
+            assert eng.last_score_path == "feature_rows"
+            assert all(np.array_equal(a.cpu().numpy().view(np.int32), b.view(np.int32)) for a, b in zip(o, f))
+
+
 @pytest.fixture(scope="module")
 def c4():
     from rtrec_amd import SLIM
