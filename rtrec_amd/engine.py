@@ -15,6 +15,7 @@ followed by the merge kernel.
 from __future__ import annotations
 
 import ctypes as C
+import logging
 import os
 from dataclasses import dataclass
 from typing import Any, Dict, List, Optional, Sequence, Tuple
@@ -690,8 +691,11 @@ class HipBackend:
 class SlimEngine:
     """Fit / score / similar-items on one GPU (one shard of W)."""
 
+    _process_warm: set = set()          # devices whose code objects this process has loaded (see _process_warm_up)
+
     def __init__(self, device: Any = None, rank: int = 0, world_size: int = 1, process_group: Any = None,
-                 tile_cols: Optional[int] = None, backend: Any = None, score_shard: Optional[str] = None):
+                 tile_cols: Optional[int] = None, backend: Any = None, score_shard: Optional[str] = None,
+                 warm_up: bool = True):
         self.rank, self.world_size, self.group = rank, world_size, process_group
         # How a multi-GPU scoring pass is divided.  "columns" (default; BASELINE.json's configuration): every
         # rank scores all users against its item-column shard of W, lists are exchanged and merged.
@@ -733,6 +737,50 @@ class SlimEngine:
         self.lazy_tiled = settings.raw("RTREC_AMD_LAZY_TILED", "1") != "0"           # tiled layout only when a call flags exact ties
         self.last_score_path = ""     # which kernel family served the last _local_topk call (tests, bench.py)
         self._sg_labels = None        # (cluster labels of the last segment layout, n_items, nnz of W when they were computed)
+        if warm_up and isinstance(self.be, HipBackend) and str(self.be.device) not in SlimEngine._process_warm:
+            SlimEngine._process_warm.add(str(self.be.device))
+            self._process_warm_up()
+
+    def _process_warm_up(self) -> None:
+        """Once per process and device: a toy model through the whole path (fit, write-back, every layout builder, every
+        scoring mode) on a throw-away engine.  The first use of a kernel -- ours or one of the tensor ops of the builders --
+        loads its code object (tens of milliseconds each: the first W write-back of a process took 120-320 ms, the first
+        layouts 60-90 ms); that belongs next to the creation of the HIP context, not inside the first fit or recommend."""
+        rng = np.random.default_rng(0)
+        U, I = 96, 48
+        X = sp.random(U, I, density=0.3, random_state=rng, format="csr", dtype=np.float32)
+        X.data[:] = rng.integers(1, 6, X.nnz).astype(np.float32)
+        Xc = X.tocsc()
+        Xc.sort_indices()
+        X.sort_indices()
+        toy = SlimEngine(backend=self.be, rank=0, world_size=1, warm_up=False)
+        try:
+            toy.set_interactions(Xc, X)
+            for mode in ("exact", "gram"):
+                out = toy.fit_columns(np.arange(I), nn_feature_selection=8, device_out=True, mode=mode)
+            dw = toy.merge_fit(None, I, False, *out[:4])
+            dw = toy.merge_fit(dw, I, False, *out[:4])                      # the merge into an existing W as well
+            rows = np.arange(U)
+            for f64 in (False, True):
+                toy.set_weights(dw, acc_f64=f64)
+                for md in (_native.TOPK_SPARSE, _native.TOPK_DENSE):
+                    toy.recommend_rows(rows, top_k=5, mode=md)              # fast layouts, flagged rows -> tiled layouts
+                    toy.recommend_rows(rows[:3], top_k=5, mode=md)          # the request-sized path
+            toy.set_weights(dw, acc_f64=False)
+            toy._layout(True, 5)
+            toy._layout(False, 5)
+            # the tensor ops of the write-back and the builders pick other kernel configurations for real sizes (radix sort,
+            # scans, compaction): once more on a quarter of a million elements
+            torch = self.be.torch
+            big = torch.arange(1 << 18, dtype=torch.int64, device=self.be.device).flip(0)
+            srt, order = torch.sort(big)
+            _ = (torch.argsort(big), torch.unique(big % 1000), big[big % 2 == 0], torch.isin(big, big[:100]), torch.cumsum(big, 0),
+                 torch.searchsorted(srt, big[:1000]), torch.nonzero(big % 3 == 0), torch.repeat_interleave(big[:1000] % 7),
+                 torch.bincount(big % 1000), big.to(torch.int32).to(torch.float32).abs().max(), torch.cat([big, big]),
+                 torch.sort(big.to(torch.float32), descending=True), torch.argsort(big % 977, stable=True))
+            self.be.synchronize()
+        except Exception as e:          # a warm-up must never keep an engine from being constructed
+            logging.debug(f"rtrec_amd warm-up skipped: {e}")
 
     # ------------------------------------------------------------------------------ X
     def set_interactions(self, X_csc: sp.csc_matrix, X_csr: Optional[sp.csr_matrix] = None,
