@@ -25,36 +25,55 @@ namespace rtrec {
 namespace {
 
 constexpr int kRfWaves = 4;
-constexpr int kRfItems = 1024;      // items of a row staged in LDS per wave (8 KB); longer rows are searched in global memory
+constexpr int kRfItems = 1024;      // item slots staged in LDS per wave (8 KB), divided among the rows the wave works on; a longer
+                                    // row is searched in global memory
 
+__device__ __forceinline__ double rf_shfl_d(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl(static_cast<int>(b & 0xffffffffll), src, 64);
+    const int hi = __shfl(static_cast<int>(b >> 32), src, 64);
+    return __longlong_as_double((static_cast<long long>(hi) << 32) | static_cast<unsigned int>(lo));
+}
+
+// P lanes per row (the smallest power of two >= top_k + 1), 64 / P rows per wave: lane = slot * P + candidate.
+template <int P>
 __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
     int n_rows, const int *__restrict__ row_ids, const int *__restrict__ xb_ptr, const int *__restrict__ xb_col,
     const float *__restrict__ xb_val, int n_x_rows, int n_items, const int *__restrict__ wc_ptr, const int *__restrict__ wc_row,
     const float *__restrict__ wc_val, int top_k, const int *__restrict__ in_ids, const float *__restrict__ in_scores,
     const int *__restrict__ in_count, double rel_margin, int *__restrict__ out_ids, float *__restrict__ out_scores,
     double *__restrict__ out_scores64, int *__restrict__ out_count, int *__restrict__ flagged) {
+    constexpr int RPW = 64 / P;                 // rows per wave
+    constexpr int CAP = kRfItems / RPW;         // staged items per row
     __shared__ int s_col[kRfWaves][kRfItems];
     __shared__ float s_val[kRfWaves][kRfItems];
     const int lane = lane_id();
-    int *lcol = s_col[static_cast<int>(threadIdx.x) >> 6];
-    float *lval = s_val[static_cast<int>(threadIdx.x) >> 6];
-    const int wave = (static_cast<int>(blockIdx.x) * kRfWaves) + (static_cast<int>(threadIdx.x) >> 6);
-    const int n_waves = static_cast<int>(gridDim.x) * kRfWaves;
+    const int slot = lane / P, cand = lane % P;
+    int *lcol = s_col[static_cast<int>(threadIdx.x) >> 6] + slot * CAP;
+    float *lval = s_val[static_cast<int>(threadIdx.x) >> 6] + slot * CAP;
+    const long long wave = (static_cast<long long>(blockIdx.x) * kRfWaves) + (static_cast<int>(threadIdx.x) >> 6);
+    const long long n_waves = static_cast<long long>(gridDim.x) * kRfWaves;
     const int kin = top_k + 1;
     const double ninf = -__builtin_huge_val();
-    for (int row = wave; row < n_rows; row += n_waves) {
-        const int xrow = row_ids ? row_ids[row] : row;
-        int a0 = 0, n_a = 0;
-        if (xrow >= 0 && xrow < n_x_rows) { a0 = xb_ptr[xrow]; n_a = xb_ptr[xrow + 1] - a0; }
-        const int n = min(in_count[row], kin);
-        // the row's items in LDS: every candidate's entries are looked up in them (a wave's LDS traffic is program-ordered)
-        const bool staged = n_a <= kRfItems;
-        if (staged) for (int q = lane; q < n_a; q += 64) { lcol[q] = xb_col[a0 + q]; lval[q] = xb_val[a0 + q]; }
-        // ---- exact float64 score of candidate `lane`
+    const unsigned long long gmask = (P == 64 ? ~0ull : ((1ull << P) - 1ull)) << (slot * P);
+    for (long long base = wave * RPW; base < n_rows; base += n_waves * RPW) {
+        const long long row = base + slot;
+        const bool live = row < n_rows;
+        int a0 = 0, n_a = 0, n = 0;
+        if (live) {
+            const int xrow = row_ids ? row_ids[row] : static_cast<int>(row);
+            if (xrow >= 0 && xrow < n_x_rows) { a0 = xb_ptr[xrow]; n_a = xb_ptr[xrow + 1] - a0; }
+            n = min(in_count[row], kin);
+        }
+        // the row's items in LDS: its candidates' entries are looked up in them (a wave's LDS traffic is program-ordered)
+        const bool staged = n_a <= CAP;
+        if (staged) for (int q = cand; q < n_a; q += P) { lcol[q] = xb_col[a0 + q]; lval[q] = xb_val[a0 + q]; }
+        // ---- exact float64 score of candidate `cand` of row `slot`
+        const bool has = live && cand < n;
         double e = ninf;
         int c = -1;
-        if (lane < n) {
-            c = in_ids[static_cast<long long>(row) * kin + lane];
+        if (has) {
+            c = in_ids[row * kin + cand];
             double acc = 0.0;
             if (c >= 0 && c < n_items) {
                 for (int q = wc_ptr[c]; q < wc_ptr[c + 1]; ++q) {
@@ -79,41 +98,43 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
             }
             e = acc;
         }
-        // ---- rank by (score descending, list position ascending); exact ties among the candidates are the tiled kernel's
+        // ---- rank inside the row's lane group by (score descending, list position ascending); exact ties are the tiled kernel's
         int rank = 0;
         bool tie = false;
-        for (int j = 0; j < n; ++j) {
-            const double o = readlane_d(e, j);
-            if (lane < n && j != lane) {
-                rank += (o > e || (o == e && j < lane)) ? 1 : 0;
+        for (int j = 0; j < P; ++j) {
+            const int src = slot * P + j;
+            const double o = rf_shfl_d(e, src);
+            const bool ov = __shfl(has ? 1 : 0, src, 64) != 0;
+            if (has && ov && j != cand) {
+                rank += (o > e || (o == e && j < cand)) ? 1 : 0;
                 tie = tie || (o == e);
             }
         }
-        const bool any_tie = __ballot(lane < n && tie) != 0ull;
+        const bool any_tie = (__ballot(has && tie) & gmask) != 0ull;
         // the top_k-th best float64 score against what a column outside the list can reach
+        const unsigned long long at = __ballot(has && rank == top_k - 1) & gmask;
+        const double e_k = rf_shfl_d(e, at ? static_cast<int>(__builtin_ctzll(at)) : lane);
         bool unsafe = false;
-        if (n == kin) {
-            const unsigned long long at = __ballot(lane < n && rank == top_k - 1);
-            const double e_k = readlane_d(e, static_cast<int>(__builtin_ctzll(at)));
-            const double m32 = static_cast<double>(in_scores[static_cast<long long>(row) * kin + top_k]);
+        if (live && n == kin) {
+            const double m32 = static_cast<double>(in_scores[row * kin + top_k]);
             unsafe = !(e_k > m32 * (1.0 + rel_margin));
         }
         const int n_fin = min(n, top_k);
-        if (lane < n && rank < top_k) {
-            const long long o = static_cast<long long>(row) * top_k + rank;
+        if (has && rank < top_k) {
+            const long long o = row * top_k + rank;
             out_ids[o] = c;
             out_scores[o] = static_cast<float>(e);
             out_scores64[o] = e;
         }
-        if (lane >= n_fin && lane < top_k) {
-            const long long o = static_cast<long long>(row) * top_k + lane;
+        if (live && cand >= n_fin && cand < top_k) {
+            const long long o = row * top_k + cand;
             out_ids[o] = -1;
             out_scores[o] = -__builtin_huge_valf();
             out_scores64[o] = ninf;
         }
-        if (lane == 0) {
+        if (live && cand == 0) {
             out_count[row] = n_fin;
-            if (any_tie || unsafe) flagged[1 + atomicAdd(flagged, 1)] = row;
+            if (any_tie || unsafe) flagged[1 + atomicAdd(flagged, 1)] = static_cast<int>(row);
         }
     }
 }
@@ -133,10 +154,24 @@ extern "C" int rtrec_slim_refine_topk_f64(int32_t n_rows, const int32_t *d_row_i
         !d_out_ids || !d_out_scores || !d_out_scores64 || !d_out_count || !d_flagged)
         return RTREC_ERR_INVALID_ARG;
     (void)hipGetLastError();
-    const long long want = (static_cast<long long>(n_rows) + rtrec::kRfWaves - 1) / rtrec::kRfWaves;
+    int P = 2;
+    while (P < top_k + 1) P *= 2;                       // lanes per row
+    const long long rows_per_wg = static_cast<long long>(rtrec::kRfWaves) * (64 / P);
+    const long long want = (static_cast<long long>(n_rows) + rows_per_wg - 1) / rows_per_wg;
     const unsigned grid = static_cast<unsigned>(want < 16384 ? want : 16384);
-    hipLaunchKernelGGL(rtrec::refine_f64_kernel, dim3(grid), dim3(rtrec::kRfWaves * 64), 0, static_cast<hipStream_t>(stream), n_rows,
-                       d_row_ids, d_xb_ptr, d_xb_col, d_xb_val, n_x_rows, n_items, d_wc_ptr, d_wc_row, d_wc_val, top_k, d_in_ids,
-                       d_in_scores, d_in_count, rel_margin, d_out_ids, d_out_scores, d_out_scores64, d_out_count, d_flagged);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define RTREC_RF_LAUNCH(P_)                                                                                                      \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(rtrec::refine_f64_kernel<P_>), dim3(grid), dim3(rtrec::kRfWaves * 64), 0, st, n_rows, d_row_ids,  \
+                       d_xb_ptr, d_xb_col, d_xb_val, n_x_rows, n_items, d_wc_ptr, d_wc_row, d_wc_val, top_k, d_in_ids, d_in_scores,     \
+                       d_in_count, rel_margin, d_out_ids, d_out_scores, d_out_scores64, d_out_count, d_flagged)
+    switch (P) {
+        case 2: RTREC_RF_LAUNCH(2); break;
+        case 4: RTREC_RF_LAUNCH(4); break;
+        case 8: RTREC_RF_LAUNCH(8); break;
+        case 16: RTREC_RF_LAUNCH(16); break;
+        case 32: RTREC_RF_LAUNCH(32); break;
+        default: RTREC_RF_LAUNCH(64); break;
+    }
+#undef RTREC_RF_LAUNCH
     return rtrec::launch_status();
 }
