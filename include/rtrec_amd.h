@@ -491,6 +491,23 @@ int rtrec_store_decay_device(const double *d_val, const double *d_ts, int64_t n,
                              float *d_out32, int32_t *d_unsafe_idx, int32_t *d_unsafe_count, int32_t cap, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * CANDIDATES MODE FOR REQUEST-SIZED CALLS  (replaces recommend_batch(..., candidate_item_ids=...),
+ * rtrec/models/internal/slim_elastic.py:723-735: scores = X[users] @ W[:, candidates], argsort()[-top_k:][::-1]; zeros compete,
+ * filter_interacted is ignored, ties: the later candidate first -- DESIGN.md D1).
+ * d_cands[n_cands] item ids in the caller's order (duplicates allowed: every position competes, as in the reference;
+ * n_cands <= 8192); W in CSC form d_wc_* (rows ascending, float32 values).  One wave per row computes the candidates'
+ * scores with the reference's summation order (ascending item; one rounded product and one rounded add per addend; float32,
+ * or float64 accumulation when acc_f64: then d_out_scores64 is required) and emits the best top_k:
+ * d_out_ids / d_out_scores [n_rows][top_k] (-1 / -inf beyond min(top_k, n_cands)), d_out_count[n_rows].  Meant for
+ * n_rows x n_cands of a request; rtrec_slim_score_topk in RTREC_TOPK_CANDIDATES mode serves bulk calls.
+ * ------------------------------------------------------------------------------------- */
+int rtrec_slim_score_candidates(int32_t n_rows, const int32_t *d_row_ids, const int32_t *d_xb_ptr, const int32_t *d_xb_col,
+                                const float *d_xb_val, int32_t n_x_rows, int32_t n_items, const int32_t *d_wc_ptr,
+                                const int32_t *d_wc_row, const float *d_wc_val, const int32_t *d_cands, int32_t n_cands,
+                                int32_t top_k, int32_t acc_f64, int32_t *d_out_ids, float *d_out_scores,
+                                double *d_out_scores64, int32_t *d_out_count, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * FLOAT64 ANSWERS FROM THE FLOAT32 FAST PASS  (SPARSE mode; a W that is float64 on the host -- the reference's serial fit,
  * slim_elastic.py:252 -- whose values are float32 numbers; ratings and weights all >= 0 and large enough that no product
  * underflows in float32: the CALLER checks both).

@@ -33,6 +33,7 @@ EXPORTS = [
     "rtrec_slim_seg_plan",
     "rtrec_slim_seg_fill",
     "rtrec_slim_refine_topk_f64",
+    "rtrec_slim_score_candidates",
 ]
 
 
@@ -160,6 +161,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_refine_topk_f64.restype = C.c_int
     L.rtrec_slim_refine_topk_f64.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, C.c_double,
                                              vp, vp, vp, vp, vp, vp]
+    L.rtrec_slim_score_candidates.restype = C.c_int
+    L.rtrec_slim_score_candidates.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
     L.rtrec_store_fold_device.restype = C.c_int
     L.rtrec_store_fold_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp, vp]
     _lib = L

@@ -727,6 +727,7 @@ class SlimEngine:
         self.native_seg_builder = settings.raw("RTREC_AMD_NATIVE_SEG_BUILD", "1") != "0"   # csrc/seg_build.hip (else tensor ops)
         self.FR_SMALL_BATCH = int(settings.raw("RTREC_AMD_FR_SMALL_BATCH", self.FR_SMALL_BATCH))     # A/B: segments for larger passes
         self.f64_refine = settings.raw("RTREC_AMD_F64_REFINE", "1") != "0"      # float64 W: float32 fast pass + float64 refine
+        self.cands_direct = settings.raw("RTREC_AMD_CANDS_DIRECT", "1") != "0"   # request-sized CANDIDATES calls: csrc/score_cands.hip
         self.dense_fast = settings.raw("RTREC_AMD_DENSE_FAST", "1") != "0"    # DENSE mode through the fast SPARSE-style pass
         self._sg_scratch = None           # zeroed scratch of the segment path's workgroup-per-user kernel
         self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
@@ -1616,7 +1617,8 @@ class SlimEngine:
         return order
 
     def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
-                          mode: int, col_rank: Optional[np.ndarray] = None, xb=None, d_rows=None, host: bool = False):
+                          mode: int, col_rank: Optional[np.ndarray] = None, xb=None, d_rows=None, host: bool = False,
+                          candidates: Optional[np.ndarray] = None):
         """Device tensors (ids, scores, counts) of the GLOBAL top-k for the given rows of X
         (or of the CSR batch `xb` = (ptr, col, val) device tensors).  `d_rows` may pass the row ids
         as a device tensor that is already resident (bench.py reuses it across steps).
@@ -1637,6 +1639,13 @@ class SlimEngine:
         up = getattr(be, "to_dev_small", be.to_dev)
         if d_rows is None and row_ids is not None:
             d_rows = up(np.asarray(row_ids, dtype=np.int32))
+        if mode == _native.TOPK_CANDIDATES and candidates is not None:
+            direct = self._candidates_direct(d_rows, n_rows, xb, top_k, candidates)
+            if direct is not None:
+                return direct
+            if col_rank is None:          # the bulk form: a rank per column of W (the later of two equal candidates wins)
+                col_rank = np.full(self._W["n_items"], -1, dtype=np.int32)
+                col_rank[np.asarray(candidates, dtype=np.int64)] = np.arange(len(candidates), dtype=np.int32)
         d_rank = up(np.asarray(col_rank, dtype=np.int32)) if col_rank is not None else None
         if self.world_size == 1 and not self.force_exchange:
             ids, sc, sc64, aux, cnt = self._local_topk(d_rows, n_rows, xb, top_k, filter_interacted, mode, d_rank, host=host)
@@ -1780,6 +1789,42 @@ class SlimEngine:
         width = self._W["n_active"] if compact else self._W["col_hi"] - self._W["col_lo"]
         return -(-max(width, 1) // self._tile_width(compact, top_k)) * (top_k + 1) <= self.MAX_MERGE_CANDIDATES
 
+    CANDS_DIRECT_MAX = 4096             # candidates of a request ranked by rtrec_slim_score_candidates ...
+    CANDS_DIRECT_MAX_PAIRS = 1 << 21    # ... while rows x candidates stays a request, not a bulk pass
+
+    def _candidates_direct(self, d_rows, n_rows: int, xb, top_k: int, candidates: np.ndarray):
+        """CANDIDATES mode for a request-sized call (csrc/score_cands.hip): the candidates' scores straight from W's CSC
+        columns, no pass over all columns and no n_items-sized rank array.  None: not applicable (bulk call, a backend or a
+        W it does not serve, several column shards) -- the caller takes the tiled kernel."""
+        be, W = self.be, self._W
+        n_c = int(len(candidates))
+        dw: DeviceWeights = W["dw"]
+        if (not isinstance(be, HipBackend) or not self.cands_direct or n_c == 0 or n_c > self.CANDS_DIRECT_MAX
+                or n_rows * n_c > self.CANDS_DIRECT_MAX_PAIRS or (self.world_size > 1 and self.score_shard != "rows")
+                or self.force_exchange or dw.lossy or dw.nnz == 0 or top_k > n_c):
+            return None
+        cands = np.asarray(candidates)
+        if int(cands.min()) < 0 or int(cands.max()) >= W["n_items"]:
+            return None                       # (the rank-array path raises like the reference's W[:, candidates])
+        torch = be.torch
+        f64 = bool(W["acc_f64"])
+        d_c = be.to_dev_small(cands.astype(np.int32))
+        wc_ptr, wc_row, wc_val = dw.csc_arrays(torch)
+        nk = n_rows * top_k
+        pack = be.empty((2 * nk + n_rows,), torch.int32)
+        ids = pack[:nk].view(n_rows, top_k)
+        sc = pack[nk:2 * nk].view(torch.float32).view(n_rows, top_k)
+        cnt = pack[2 * nk:]
+        ids._rtrec_pack = pack
+        sc64 = be.empty((n_rows, top_k), torch.float64) if f64 else None
+        p = be.ptr
+        _native.check(be.lib.rtrec_slim_score_candidates(n_rows, p(d_rows), p(xb[0]), p(xb[1]), p(xb[2]), int(xb[0].shape[0]) - 1,
+                                                         W["n_items"], p(wc_ptr), p(wc_row), p(wc_val), p(d_c), n_c, top_k, int(f64),
+                                                         p(ids), p(sc), p(sc64), p(cnt), be.stream()),
+                      "rtrec_slim_score_candidates")
+        self.last_score_path = "candidates_direct"
+        return ids, sc, cnt
+
     def _check_rows(self, row_ids: np.ndarray) -> None:
         """Row ids index the resident X: anything outside [0, n_users) would be an out-of-bounds device read
         (the reference's scipy indexing raises IndexError for it)."""
@@ -1809,15 +1854,17 @@ class SlimEngine:
         return sp.csr_matrix((vals, cols, indptr), shape=(len(row_ids), self.n_items))
 
     def recommend_rows(self, row_ids: Sequence[int], top_k: int = 10, filter_interacted: bool = True,
-                       mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None
-                       ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """Top-k for rows of the resident X.  Returns numpy (ids[B,k], scores[B,k], counts[B])."""
+                       mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None,
+                       candidates: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """Top-k for rows of the resident X.  Returns numpy (ids[B,k], scores[B,k], counts[B]).  CANDIDATES mode: either the
+        rank array `col_rank` (n_items entries, -1 = not a candidate) or the list `candidates` itself."""
         row_ids = np.asarray(row_ids, dtype=np.int64)
         if len(row_ids) == 0:
             return (np.empty((0, top_k), np.int32), np.empty((0, top_k), np.float32), np.empty((0,), np.int32))
         self._check_rows(row_ids)
         row_ids = row_ids.astype(np.int32)
-        return self._download(*self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank, host=True))
+        return self._download(*self.score_topk_device(row_ids, len(row_ids), top_k, filter_interacted, mode, col_rank, host=True,
+                                                      candidates=candidates))
 
     @staticmethod
     def _download(ids, sc, cnt) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
@@ -1832,8 +1879,8 @@ class SlimEngine:
         return h[:n * k].reshape(n, k), h[n * k:2 * n * k].view(np.float32).reshape(n, k), h[2 * n * k:2 * n * k + n]
 
     def recommend_csr(self, Xb: sp.csr_matrix, top_k: int = 10, filter_interacted: bool = True,
-                      mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None
-                      ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+                      mode: int = _native.TOPK_SPARSE, col_rank: Optional[np.ndarray] = None,
+                      candidates: Optional[np.ndarray] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """Top-k for the rows of a host CSR batch (the SLIMElastic.recommend_batch boundary)."""
         be = self.be
         B = Xb.shape[0]
@@ -1843,7 +1890,7 @@ class SlimEngine:
             Xb = Xb.sorted_indices()
         xb = (be.to_dev(np.asarray(Xb.indptr, dtype=np.int32)), be.to_dev(np.asarray(Xb.indices, dtype=np.int32)),
               be.to_dev(np.asarray(Xb.data, dtype=np.float32)))
-        return self._download(*self.score_topk_device(None, B, top_k, filter_interacted, mode, col_rank, xb=xb))
+        return self._download(*self.score_topk_device(None, B, top_k, filter_interacted, mode, col_rank, xb=xb, candidates=candidates))
 
     # ------------------------------------------------------------------------------ score vectors
     def predict_csr(self, Xb: sp.csr_matrix) -> np.ndarray:

@@ -256,11 +256,10 @@ class SLIMElastic:
         """(ids[B,k], scores[B,k], counts[B]) for the rows of Xb (or rows `row_ids` of the resident X)."""
         self._sync_weights()
         n_items = self.n_items_fitted
-        col_rank = None
+        col_rank = cands = None
         if candidate_item_ids is not None:
             mode = _native.TOPK_CANDIDATES
-            col_rank = np.full(n_items, -1, dtype=np.int32)
-            col_rank[np.asarray(candidate_item_ids, dtype=np.int64)] = np.arange(len(candidate_item_ids), dtype=np.int32)
+            cands = np.asarray(candidate_item_ids, dtype=np.int64)        # (the engine builds the rank array when it needs one)
             top_k = min(top_k, len(candidate_item_ids))
         else:
             mode = _native.TOPK_DENSE if dense_output else _native.TOPK_SPARSE
@@ -275,11 +274,11 @@ class SLIMElastic:
                 Xb = self.engine.rows_csr(row_ids)
             return self._topk_host(Xb, candidate_item_ids, top_k, filter_interacted, mode)
         if row_ids is not None:
-            return self.engine.recommend_rows(row_ids, top_k, filter_interacted, mode, col_rank)
+            return self.engine.recommend_rows(row_ids, top_k, filter_interacted, mode, col_rank, candidates=cands)
         if Xb.shape[1] != n_items:   # the reference would fail inside scipy on a shape mismatch
             Xb = Xb.copy()
             Xb.resize((Xb.shape[0], n_items))
-        return self.engine.recommend_csr(Xb, top_k, filter_interacted, mode, col_rank)
+        return self.engine.recommend_csr(Xb, top_k, filter_interacted, mode, col_rank, candidates=cands)
 
     def _topk_host(self, Xb: sp.csr_matrix, candidate_item_ids: Optional[List[int]], top_k: int,
                    filter_interacted: bool, mode: int, chunk_rows: int = 256):

@@ -228,6 +228,48 @@ def test_candidate_mode(oracle):
         assert cnt[r] == 5
 
 
+@pytest.mark.parametrize("f64", [False, True])
+def test_candidate_mode_request_sized_calls_take_the_direct_kernel(oracle, f64):
+    """A request (few rows x a candidate list) is ranked by rtrec_slim_score_candidates -- scores from W's CSC columns in the
+    reference's summation order, no pass over all columns: ids, score bits and counts equal the scipy product ranked by the
+    stable-argsort rule (later candidate first on ties, zeros compete, duplicates compete), and the tiled kernel's answer."""
+    X, W = make_model(oracle, U=400, I=300, draws=8000, K=10)
+    X = X.tolil()
+    X[7, :] = 0                                            # an empty row: every score 0, candidates by position descending
+    X = X.tocsr().astype(np.float32)
+    X.eliminate_zeros(); X.sort_indices()
+    eng = SlimEngine(device="cuda:0", tile_cols=256)
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W.astype(np.float64) if f64 else W, acc_f64=f64)
+    rng = np.random.default_rng(2)
+    Wr = W.tocsr()
+    for cands, k, rows in (([5, 17, 250, 3, 99, 100, 101, 42], 5, np.arange(50)), (rng.permutation(300)[:200].tolist(), 10, np.array([7, 3, 11])),
+                           ([9, 9, 40, 9], 4, np.arange(20)), (list(range(300)), 300, np.array([0])), ([123], 3, np.arange(5))):
+        ids, sc, cnt = eng.recommend_rows(rows, top_k=min(k, len(cands)), mode=_native.TOPK_CANDIDATES, candidates=np.asarray(cands))
+        assert eng.last_score_path == "candidates_direct"
+        kk = min(k, len(cands))
+        if f64:
+            S = (X[rows].astype(np.float64) @ Wr.astype(np.float64)[:, cands]).toarray()
+        else:
+            S = (X[rows] @ Wr[:, cands]).toarray().astype(np.float32)
+        for r in range(len(rows)):
+            order = sorted(range(len(cands)), key=lambda c: (-S[r, c], -c))[:kk]
+            assert ids[r].tolist() == [cands[c] for c in order], (cands[:8], r)
+            assert np.array_equal(bits(sc[r]), bits(S[r, order].astype(np.float32)))
+            assert cnt[r] == kk
+        if len(set(cands)) == len(cands):                  # (the rank-array form keeps one position per item)
+            eng.cands_direct = False
+            t = eng.recommend_rows(rows, top_k=kk, mode=_native.TOPK_CANDIDATES, candidates=np.asarray(cands))
+            eng.cands_direct = True
+            assert eng.last_score_path != "candidates_direct"
+            assert np.array_equal(t[0], ids) and np.array_equal(bits(t[1]), bits(sc)) and np.array_equal(t[2], cnt)
+    got = eng.recommend_csr(X[[3, 7, 9]], top_k=3, mode=_native.TOPK_CANDIDATES, candidates=np.array([5, 17, 250, 3]))
+    ref = eng.recommend_rows(np.array([3, 7, 9]), top_k=3, mode=_native.TOPK_CANDIDATES, candidates=np.array([5, 17, 250, 3]))
+    assert all(np.array_equal(a.view(np.int32), b.view(np.int32)) for a, b in zip(got, ref))
+    with pytest.raises(IndexError):
+        eng.recommend_rows(np.array([1]), top_k=2, mode=_native.TOPK_CANDIDATES, candidates=np.array([5, 300]))
+
+
 def test_similar_items(engine, oracle):
     X, W = make_model(oracle, U=800, I=300, draws=15000, K=30)
     engine.set_weights(W)

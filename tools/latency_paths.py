@@ -59,6 +59,19 @@ def main():
         out["paths"][name] = res
         for k, v in saved.items():
             setattr(eng, k, v)
+    # CANDIDATES mode: one user, 200 candidates (a re-ranking request): direct kernel against the tiled kernel
+    cands = rng.permutation(I)[:200].tolist()
+    cres = {}
+    for name, flag in (("direct", True), ("tiled", False)):
+        eng.cands_direct = flag
+        lat = []
+        for q in range(330):
+            t = time.perf_counter()
+            model.recommend(user=users[q], candidate_items=cands, top_k=10)
+            lat.append((time.perf_counter() - t) * 1e3)
+        cres[name] = {"p50_ms": float(np.quantile(lat[30:], .5)), "p99_ms": float(np.quantile(lat[30:], .99)), "path": eng.last_score_path}
+    eng.cands_direct = True
+    out["candidates_200_single_user"] = cres
     print(json.dumps(out))
 
 
