@@ -17,14 +17,25 @@ from collections import defaultdict
 
 
 def load(d, wl):
-    acc = defaultdict(lambda: defaultdict(lambda: [0.0, set()]))
+    """Per kernel and counter: (mean per launch, launches) over the launches of the kernel's LARGEST grid -- a bench run also
+    launches the score kernels for small row sets (flagged rows, warm-ups of other modes), which are not the pass priced here."""
+    rows = []
     for path in glob.glob(os.path.join(d, f"pmc*_{wl}_counter_collection.csv")):
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
-                k = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
-                c = acc[k][row["Counter_Name"]]
-                c[0] += float(row["Counter_Value"])
-                c[1].add(row["Dispatch_Id"])
+                row["_k"] = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+                rows.append(row)
+    top_grid = defaultdict(int)
+    for row in rows:
+        top_grid[row["_k"]] = max(top_grid[row["_k"]], int(row.get("Grid_Size") or 0))
+    acc = defaultdict(lambda: defaultdict(lambda: [0.0, set()]))
+    for row in rows:
+        k = row["_k"]
+        if int(row.get("Grid_Size") or 0) != top_grid[k]:
+            continue
+        c = acc[k][row["Counter_Name"]]
+        c[0] += float(row["Counter_Value"])
+        c[1].add(row["Dispatch_Id"])
     return {k: {c: (v[0] / max(len(v[1]), 1), len(v[1])) for c, v in cs.items()} for k, cs in acc.items()}
 
 
@@ -50,7 +61,7 @@ def main():
         hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
         json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, "
                              f"tools/profile_round.sh {tag} {wl}) -- python3 bench.py --steps 3 --no-cpu-baseline",
-                   "kernel": k.replace("void rtrec::", "").replace(" ", ""), "launches_averaged": launches,
+                   "kernel": k.replace("void rtrec::", "").replace("void ", "").replace(" ", ""), "launches_averaged": launches,
                    "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
                    "hbm_bytes_per_launch_corrected": int(fetch_kb * 1024 * 2 + write_kb * 1024),
                    "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
@@ -58,7 +69,7 @@ def main():
                            "Infinity-Cache hits are counted, so this is an upper bound of DRAM traffic"},
                   open(os.path.join(d, f"{tag}_{wl}_pmc_traffic.json"), "w"), indent=1)
         wave_cyc = c.get("SQ_WAVE_CYCLES", 0.0)
-        json.dump({"kernel": k.replace("void rtrec::", "").replace(" ", ""), "launches_averaged": launches,
+        json.dump({"kernel": k.replace("void rtrec::", "").replace("void ", "").replace(" ", ""), "launches_averaged": launches,
                    "per_launch": c,
                    "derived": {"valu_busy_frac_of_wave_cycles": c.get("SQ_ACTIVE_INST_VALU", 0.0) / wave_cyc if wave_cyc else None,
                                "wait_any_frac": c.get("SQ_WAIT_ANY", 0.0) / wave_cyc if wave_cyc else None,
@@ -75,7 +86,7 @@ def main():
             c = {n: v[0] for n, v in cs.items()}
             fetch_kb, write_kb = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
             hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
-            out[k.replace("void rtrec::", "").replace(" ", "")] = {
+            out[k.replace("void rtrec::", "").replace("void ", "").replace(" ", "")] = {
                 "launches_averaged": max(v[1] for v in cs.values()), "per_launch": c,
                 "hbm_bytes_per_launch_corrected": int(fetch_kb * 1024 * 2 + write_kb * 1024),
                 "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
