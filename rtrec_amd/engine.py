@@ -607,7 +607,8 @@ class HipBackend:
                             int(fr.get("fr_n_frags", 0)), int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
                             fr.get("fr_scratch"),
                             row_order if (fr or sg) else None, int(timer), int(diagnostics), rescored,
-                            int(bool(row_order_grouped)) | (int(bool(sg) and row_order is not None) << 1),       # bit 1: longest first
+                            # bit 1: the order is by descending length (the segment kernels rely on it: _row_order(allow_grouped=False))
+                            int(bool(row_order_grouped)) | (int(bool(sg) and row_order is not None and not row_order_grouped) << 1),
                             sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_ent"), sg.get("sg_bound"),
                             sg.get("sg_col_ids"), int(sg.get("sg_T", 0)), int(sg.get("sg_n_tiles", 0)), int(sg.get("sg_rows", 0)),
                             int(sg.get("sg_n_cols", 0)), sg.get("sg_trow_ptr"), sg.get("sg_trow"),
@@ -1406,7 +1407,7 @@ class SlimEngine:
             need = be.score_workspace_bytes(n_rows, 1, top_k)
             if self._score_ws is None or self._score_ws.numel() < need:
                 self._score_ws = be.empty((need,), torch.uint8)
-            order = self._row_order(d_row_ids, n_rows, xb, fast)
+            order = self._row_order(d_row_ids, n_rows, xb, fast, allow_grouped=use_fr)
             self.last_score_path = "feature_rows" if use_fr else "segments"
             flagged = pack[2 * nk + cap:] if flag_words else be.empty((n_rows + 1,), torch.int32)
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, top_k, filter_interacted,
@@ -1449,7 +1450,7 @@ class SlimEngine:
         if hip:
             if use_sg and lay.get("sg") is None:          # a small batch against a feature-row W: its segment form
                 lay = dict(lay, sg=fast["sg"])
-            order = self._row_order(d_row_ids, n_rows, xb, lay) if (use_fr or use_sg) else None
+            order = self._row_order(d_row_ids, n_rows, xb, lay, allow_grouped=use_fr) if (use_fr or use_sg) else None
             self.last_score_path = "feature_rows" if use_fr else ("segments" if use_sg else "tiled")
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], lay, d_col_rank, top_k, filter_interacted,
                           mode, W["acc_f64"], ids, sc, sc64, aux, cnt, self._score_ws, timer=self.score_timer,
@@ -1481,7 +1482,7 @@ class SlimEngine:
         need = be.score_workspace_bytes(n_rows, 1, k1)
         if self._score_ws is None or self._score_ws.numel() < need:
             self._score_ws = be.empty((need,), torch.uint8)
-        order = self._row_order(d_row_ids, n_rows, xb, fast)
+        order = self._row_order(d_row_ids, n_rows, xb, fast, allow_grouped=use_fr)
         self.last_score_path = ("feature_rows" if use_fr else "segments") + "+f64"
         be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, k1, filter_interacted,
                       mode, False, ids1, sc1, None, aux1, cnt1, self._score_ws, timer=self.score_timer,
@@ -1538,19 +1539,23 @@ class SlimEngine:
         return bool(self.pattern_order and host and not host.get("fr_resident")
                     and (n_rows is None or n_rows >= self.GROUPED_ORDER_MIN))
 
-    def _row_order(self, d_row_ids, n_rows: int, xb, lay=None):
+    def _row_order(self, d_row_ids, n_rows: int, xb, lay=None, allow_grouped: bool = True):
         """Work order for the feature-row kernel (rtrec_score_opts.d_row_order).  Default: the batch's rows by descending
         length.  Streaming layout (_grouped_order): a wave sweeps, per tile, the UNION of the rows of W its eight users
         rate, so users with the same rated feature items should share a wave -- the rows are sorted by their feature-row
         pattern as one big integer, the row of W that holds a weight in the most tiles most significant, descending
         (heavy patterns first: the tail of the launch is light): 13 % fewer swept rows on C3.  A function of X, the row set and
         the layout only: kept with the resident X and reused while the same row-id tensor is scored against the same
-        layout (bulk scoring, bench.py); small batches go in the order given."""
+        layout (bulk scoring, bench.py); small batches go in the order given.
+        `allow_grouped=False` (the segment kernels): always the length order -- they are told "longest first" and stop at the
+        first short user (a pattern-grouped order there left long users unscored); such a call neither reads
+        nor writes the feature-row entries of the cache (its entries carry no layout)."""
         if n_rows < self.ROW_ORDER_MIN:
+            self._order_grouped = False
             return None
         torch = self.be.torch
         resident = self._X.get("rptr") is xb[0]
-        fr_host = (lay or {}).get("fr_host")
+        fr_host = (lay or {}).get("fr_host") if allow_grouped else None
         # One entry per (row-id tensor, layout), matched by IDENTITY: the entry keeps the tensor and the layout alive, so a
         # recycled address can never stand for another row set (ADVICE round 2); a temporary row tensor simply misses.
         # The pattern-grouped order costs milliseconds to compute: a row set gets it the SECOND time it is scored (a caller

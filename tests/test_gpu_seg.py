@@ -376,3 +376,54 @@ def test_seg_generic_path_at_scale_agrees_with_the_tiled_kernel(oracle):
     sample = np.sort(rng.choice(X.shape[0], 1500, replace=False))
     o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], W.tocsr(), top_k=10, n_threads=8)
     assert np.array_equal(ids[sample], o_ids) and np.array_equal(bits(sc[sample]), bits(o_sc)) and np.array_equal(cnt[sample], o_cnt)
+
+
+def test_segment_pass_never_gets_the_pattern_grouped_order(oracle):
+    """a feature-row shaped STREAMING W, top_k beyond the feature-row kernel's lists (so the segment
+    kernels score it), >= GROUPED_ORDER_MIN rows, the tiled layout already built, and the same resident row tensor scored
+    three times: the cached work order must stay the length order (the segment kernels stop looking for long users at
+    the first short one), never the feature-row kernel's pattern-grouped order.  Long users sit in the middle of the row
+    set; every row is compared with the tiled kernel, the long ones with the oracle."""
+    import torch
+    I, U = 3000, 34000
+    rng = np.random.default_rng(12)
+    wrows = np.sort(rng.choice(I, 100, replace=False))
+    nnz = 60_000
+    W = sp.csc_matrix(((rng.random(nnz) + 0.01).astype(np.float32), (rng.choice(wrows, nnz), rng.integers(0, I, nnz))), shape=(I, I))
+    W.sum_duplicates(); W.setdiag(0); W.eliminate_zeros(); W.sort_indices()
+    X = interaction_matrix(U, I, 700_000, seed=5).astype(np.float32).tolil()
+    long_users = np.sort(rng.choice(np.arange(5000, U - 5000), 40, replace=False))
+    for u in long_users:
+        items = rng.choice(I, int(rng.integers(600, 1400)), replace=False)
+        X[u, items] = (rng.integers(1, 6, items.size)).astype(np.float32)
+    X = X.tocsr().astype(np.float32)
+    X.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    assert U >= eng.GROUPED_ORDER_MIN
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    d_rows = torch.arange(U, dtype=torch.int32, device="cuda:0")
+    S = _native.TOPK_SPARSE
+    for _ in range(3):                                                  # the feature-row pass: its order becomes the grouped one
+        eng.score_topk_device(None, U, 10, True, S, d_rows=d_rows)
+    assert eng.last_score_path == "feature_rows"
+    fast = eng._fast_layout()
+    assert fast.get("fr_host") is not None and not fast["fr_host"].get("fr_resident"), "the test needs the streaming layout"
+    assert eng._order_grouped, "the test needs the pattern-grouped order in the cache"
+    eng._layout(compact=True, top_k=20)                                 # the tiled layout exists (as after an exact-tie call)
+    outs = []
+    for _ in range(3):
+        ids, sc, cnt = eng.score_topk_device(None, U, 20, True, S, d_rows=d_rows)
+        assert eng.last_score_path == "segments" and not eng._order_grouped
+        outs.append((ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()))
+    eng.use_seg_layout = eng.use_feature_rows = False
+    t_ids, t_sc, t_cnt = eng.score_topk_device(None, U, 20, True, S, d_rows=d_rows)
+    assert eng.last_score_path == "tiled"
+    t_ids, t_sc, t_cnt = t_ids.cpu().numpy(), t_sc.cpu().numpy(), t_cnt.cpu().numpy()
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[long_users], W.tocsr(), top_k=20, filter_interacted=True)
+    for ids, sc, cnt in outs:
+        assert np.array_equal(cnt, t_cnt)
+        m = np.arange(20)[None, :] < cnt[:, None]
+        assert np.array_equal(ids[m], t_ids[m]) and np.array_equal(bits(sc)[m], bits(t_sc)[m])
+        assert np.array_equal(ids[long_users], o_ids) and np.array_equal(cnt[long_users], o_cnt)
+        assert np.array_equal(bits(sc[long_users]), bits(o_sc))

@@ -1,8 +1,9 @@
 #!/bin/bash
-# Build the current csrc/ into rtrec_amd/lib/ab_<name>.so (select it with RTREC_AMD_LIB=<path>).
+# Build the current csrc/ into ab/ab_<name>.so (select it with RTREC_AMD_LIB=<path>). ab/ is scratch: it ships with a gpurun
+# snapshot (gpurun_out/ does not), so delete it when the A/B is over (rm -rf ab).
 set -e
 cd "$(dirname "$0")/.."
-mkdir -p rtrec_amd/lib
+mkdir -p ab
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared $AB_FLAGS \
-  -o rtrec_amd/lib/ab_$1.so rtrec_amd/csrc/score.hip rtrec_amd/csrc/fit.hip rtrec_amd/csrc/store_host.hip rtrec_amd/csrc/store_device.hip rtrec_amd/csrc/seg_build.hip rtrec_amd/csrc/score_refine.hip rtrec_amd/csrc/score_cands.hip
-echo rtrec_amd/lib/ab_$1.so
+  -o ab/ab_$1.so rtrec_amd/csrc/score.hip rtrec_amd/csrc/fit.hip rtrec_amd/csrc/store_host.hip rtrec_amd/csrc/store_device.hip rtrec_amd/csrc/seg_build.hip rtrec_amd/csrc/score_refine.hip rtrec_amd/csrc/score_cands.hip
+echo ab/ab_$1.so

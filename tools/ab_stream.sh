@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 W=$1; shift
 for rep in 1 2; do for V in "$@"; do
-RTREC_AMD_LIB=$GRAFT_REPO_ROOT/rtrec_amd/lib/ab_$V.so python tools/stream_profile.py --workload $W --batches 3 2>/dev/null | python -c "
+RTREC_AMD_LIB=$GRAFT_REPO_ROOT/ab/ab_$V.so python tools/stream_profile.py --workload $W --batches 3 2>/dev/null | python -c "
 import sys, json
 rows = [json.loads(l) for l in sys.stdin if l.startswith('{')][1:]
 for d in rows:

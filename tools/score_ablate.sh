@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-# NOTE: needs a diagnostic build of the library (AB_FLAGS=-DRTREC_DIAGNOSTICS bash tools/ab_build.sh diag; RTREC_AMD_LIB=rtrec_amd/lib/ab_diag.so):
+# NOTE: needs a diagnostic build of the library (AB_FLAGS=-DRTREC_DIAGNOSTICS bash tools/ab_build.sh diag; RTREC_AMD_LIB=ab/ab_diag.so):
 # the release library ignores rtrec_score_opts.diagnostics.
 for W in c3 c2; do
 for A in 0 1 2 4 8 15; do
