@@ -91,6 +91,17 @@ def api_leg(X, K, top_k):
     t0 = time.perf_counter()
     recs = rec.recommend_batch(users, top_k=top_k)
     t_rec = time.perf_counter() - t0
+    # the array-returning form of the same call (round 4: rtrec_amd extension, BaseModel.recommend_batch(as_arrays=True)):
+    # an id array in, (ids[B, k], counts[B]) out -- no Python object per user or item on either side
+    users_arr = np.arange(U, dtype=np.int64)
+    rec.recommend_batch(users_arr, top_k=top_k, as_arrays=True)
+    t_arr = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        a_ids, a_cnt = rec.recommend_batch(users_arr, top_k=top_k, as_arrays=True)
+        t_arr.append(time.perf_counter() - t0)
+    t_arr = float(np.median(t_arr))
+    arrays_equal_lists = bool(all(a_ids[b, :a_cnt[b]].tolist() == recs[b] for b in range(0, U, max(1, U // 4000))))
     t0 = time.perf_counter()
     for s0 in range(0, 20000, 100):            # the reference's evaluate() asks in 100-user batches (recommender.py:163-200)
         rec.recommend_batch(users[s0:s0 + 100], top_k=top_k)
@@ -105,6 +116,8 @@ def api_leg(X, K, top_k):
     out = {"single_user_recommend_ms": {"p50": float(np.quantile(lat, .5)), "p99": float(np.quantile(lat, .99)), "requests": int(lat.size)},
            "bulk_fit_seconds": t_fit, "bulk_fit_samples_per_sec_incl_ingest": len(df) / t_fit,
            "recommend_batch_users": U, "recommend_batch_seconds": t_rec, "api_users_per_sec": U / t_rec,
+           "recommend_batch_as_arrays_seconds": t_arr, "api_users_per_sec_arrays": U / t_arr,
+           "arrays_equal_lists_on_sample": arrays_equal_lists,
            "recommend_batch_100_user_calls_users_per_sec": 20000 / t_100,
            "mean_list_length": float(np.mean([len(r) for r in recs[:5000]])),
            "note": "Recommender(SLIM(min_value=0, max_value=15, nn_feature_selection=K)).bulk_fit(DataFrame) and one "
@@ -694,7 +707,11 @@ def main() -> None:
     cpath = latest(f"r*_{args.workload}_score_counters.json")
     if world == 1 and cpath:
         try:
-            counters = dict(json.load(open(cpath)), source=os.path.relpath(cpath, ROOT))
+            cj = json.load(open(cpath))       # only a summary of THIS line's dominant kernel may be attached
+            if cj.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
+                counters = dict(cj, source=os.path.relpath(cpath, ROOT))
+            else:
+                log(f"[bench] {os.path.relpath(cpath, ROOT)} describes {cj.get('kernel')!r}, not {kernel_name.split('<')[0]}: not attached")
         except Exception:
             counters = None
     fpath = latest(f"r*_{args.workload}_fit_pmc.json")
@@ -759,7 +776,8 @@ def main() -> None:
         try:
             line["api"] = api_leg(X, K, top_k)
             log(f"[bench] api: bulk_fit {line['api']['bulk_fit_seconds']:.2f}s ({line['api']['bulk_fit_samples_per_sec_incl_ingest']:,.0f} samples/s "
-                f"incl. ingest), recommend_batch(all users) {line['api']['api_users_per_sec']:,.0f} users/s")
+                f"incl. ingest), recommend_batch(all users) {line['api']['api_users_per_sec']:,.0f} users/s as lists, "
+                f"{line['api']['api_users_per_sec_arrays']:,.0f} users/s as arrays")
         except Exception as exc:
             log(f"[bench] api leg failed: {exc!r}")
             line["api"] = {"error": repr(exc)}

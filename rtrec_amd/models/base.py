@@ -219,7 +219,18 @@ class BaseModel(ABC):
 
     def recommend_batch(self, users: List[Any], candidate_items: Optional[List[Any]] = None,
                         users_tags: Optional[List[List[str]]] = None, top_k: int = 10,
-                        filter_interacted: bool = True) -> List[List[Any]]:
+                        filter_interacted: bool = True, as_arrays: bool = False) -> Any:
+        """rtrec/models/base.py:188-269: hot / cold split, candidates mapped and bounded, one list of raw item ids per user.
+
+        Integer (pass-through) user ids take a vectorised route: ONE compare of the id array against `max_user_id` instead of
+        a `get_id` per user, and the array goes to the model's array hook (`_recommend_hot_arrays`) as it is -- the
+        per-user Python of the reference's loop is what bounded `B / wall(recommend_batch)` (SURVEY 8d's score metric).
+
+        `as_arrays=True` (an extension; the reference returns lists only) returns `(ids[B, top_k], counts[B])` numpy arrays
+        instead of B Python lists: row b's answer is `ids[b, :counts[b]]`, the rest of the row is -1 (None for mapped ids)."""
+        arr = self._int_user_array(users) if not users_tags else None
+        if arr is not None:
+            return self._recommend_batch_int_users(arr, candidate_items, top_k, filter_interacted, as_arrays)
         hot_pos: List[int] = []
         hot_ids: List[int] = []
         cold_pos: List[int] = []
@@ -240,9 +251,10 @@ class BaseModel(ABC):
             return [[self.item_ids.get(i) for i in row] for row in rows]
 
         if not cold_ids:
-            return to_items(self._recommend_hot_batch(hot_ids, candidate_item_ids=candidate_item_ids,
-                                                      users_tags=users_tags, top_k=top_k,
-                                                      filter_interacted=filter_interacted))
+            results = to_items(self._recommend_hot_batch(hot_ids, candidate_item_ids=candidate_item_ids,
+                                                         users_tags=users_tags, top_k=top_k,
+                                                         filter_interacted=filter_interacted))
+            return self._lists_as_arrays(results, top_k) if as_arrays else results
         results: List[List[Any]] = [[] for _ in users]
         cold_tags = [users_tags[p] for p in cold_pos] if users_tags else None
         cold = to_items(self._recommend_cold_batch(cold_ids, candidate_item_ids=candidate_item_ids,
@@ -256,7 +268,91 @@ class BaseModel(ABC):
                                                      filter_interacted=filter_interacted))
             for p, row in zip(hot_pos, hot):
                 results[p] = row
-        return results
+        return self._lists_as_arrays(results, top_k) if as_arrays else results
+
+    def _int_user_array(self, users: Any) -> Optional[np.ndarray]:
+        """`users` as an int64 array when every element is an integer that passes through unmapped (then `get_id` is the
+        identity and the hot / cold split is one compare), else None -> the per-user loop with the reference's checks."""
+        ident = self.user_ids
+        if ident.force_identify or ident.pass_through is not True:
+            return None
+        if (type(self).handle_unknown_user is not BaseModel.handle_unknown_user
+                or type(self)._recommend_cold_batch is not BaseModel._recommend_cold_batch):
+            return None                  # a subclass maps / serves unknown users itself: keep its per-user hooks
+        if isinstance(users, np.ndarray):
+            return users.astype(np.int64, copy=False) if (users.ndim == 1 and users.dtype.kind in "iu") else None
+        if isinstance(users, range):
+            return np.arange(users.start, users.stop, users.step, dtype=np.int64)
+        if not isinstance(users, (list, tuple)) or len(users) == 0 or not isinstance(users[0], (int, np.integer)):
+            return None
+        try:
+            arr = np.asarray(users)
+        except Exception:
+            return None
+        # (a str / float / None among the ints makes numpy choose another dtype: those batches keep the loop)
+        return arr.astype(np.int64, copy=False) if (arr.ndim == 1 and arr.dtype.kind in "iu") else None
+
+    def _recommend_batch_int_users(self, uid: np.ndarray, candidate_items: Optional[List[Any]], top_k: int,
+                                   filter_interacted: bool, as_arrays: bool) -> Any:
+        candidate_item_ids = self._candidate_ids(candidate_items)
+        B = int(uid.shape[0])
+        cold = uid > self.interactions.max_user_id       # an integer id the store has never seen is a cold-start user
+        n_cold = int(np.count_nonzero(cold))
+        mapped = not self.item_ids.pass_through          # string item ids: internal -> raw through id_to_obj
+        if n_cold == 0:
+            ids, counts = self._recommend_hot_arrays(uid, candidate_item_ids, top_k, filter_interacted)
+        else:
+            hot_rows = self._recommend_cold_batch([None], candidate_item_ids=candidate_item_ids, top_k=top_k)[0]
+            width = max(top_k, len(hot_rows))
+            if n_cold < B:
+                h_ids, h_counts = self._recommend_hot_arrays(uid[~cold], candidate_item_ids, top_k, filter_interacted)
+                width = max(width, h_ids.shape[1])
+            ids = np.full((B, width), -1, dtype=np.int64)
+            counts = np.zeros(B, dtype=np.int32)
+            if n_cold < B:
+                hot_pos = np.flatnonzero(~cold)
+                ids[hot_pos, :h_ids.shape[1]] = h_ids
+                counts[hot_pos] = h_counts
+            ids[cold, :len(hot_rows)] = np.asarray(hot_rows, dtype=np.int64)[None, :] if hot_rows else -1
+            counts[cold] = len(hot_rows)
+        if as_arrays:
+            if mapped:
+                lut = np.empty(len(self.item_ids.id_to_obj) + 1, dtype=object)
+                lut[:-1] = self.item_ids.id_to_obj
+                lut[-1] = None
+                live = np.arange(ids.shape[1])[None, :] < counts[:, None]
+                bad = live & ((ids < 0) | (ids >= len(lut) - 1))
+                if bad.any():
+                    from ..utils.identifiers import IdentifierError
+                    raise IdentifierError(self.item_ids.name, int(ids[bad][0]))
+                ids = lut[np.where(live, ids, -1)]
+            return ids, counts
+        rows = ids.tolist()                               # one conversion for the whole batch
+        if B and int(counts.min()) < ids.shape[1]:
+            rows = [row[:c] for row, c in zip(rows, counts.tolist())]
+        if mapped:
+            get = self.item_ids.get
+            rows = [[get(i) for i in row] for row in rows]
+        return rows
+
+    def _recommend_hot_arrays(self, user_ids: np.ndarray, candidate_item_ids: Optional[List[int]], top_k: int,
+                              filter_interacted: bool) -> Tuple[np.ndarray, np.ndarray]:
+        """Array form of _recommend_hot_batch: (ids[B, k'], counts[B]), internal item ids, row b valid up to counts[b].
+        The default goes through the list hook; models with a batched scorer override it."""
+        rows = self._recommend_hot_batch(user_ids.tolist(), candidate_item_ids=candidate_item_ids, top_k=top_k,
+                                         filter_interacted=filter_interacted)
+        return self._lists_as_arrays(rows, top_k)
+
+    @staticmethod
+    def _lists_as_arrays(rows: List[List[Any]], top_k: int) -> Tuple[np.ndarray, np.ndarray]:
+        counts = np.fromiter((len(r) for r in rows), dtype=np.int32, count=len(rows))
+        width = max(int(top_k), int(counts.max()) if len(rows) else 0)
+        ints = all(isinstance(x, (int, np.integer)) for r in rows for x in r)
+        ids = np.full((len(rows), width), -1, dtype=np.int64) if ints else np.full((len(rows), width), None, dtype=object)
+        for b, r in enumerate(rows):
+            if r:
+                ids[b, :len(r)] = r
+        return ids, counts
 
     def handle_unknown_user(self, user: Any) -> Optional[int]:
         return None

@@ -191,32 +191,49 @@ class SLIM(BaseModel):
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
         if len(user_ids) == 0:
             return []
+        n_users = self.interactions.shape[0]
+        ids_arr = np.asarray(user_ids, dtype=np.int64)
+        if int(ids_arr.min()) < 0 or int(ids_arr.max()) >= n_users:
+            return self._recommend_odd_ids(ids_arr, n_users, candidate_item_ids, top_k, filter_interacted)
+        ids, scores, counts = self._hot_topk(ids_arr, candidate_item_ids, top_k, filter_interacted)
+        return self.model._format(ids, scores, counts, ret_scores=False)
+
+    def _recommend_hot_arrays(self, user_ids: np.ndarray, candidate_item_ids: Optional[List[int]], top_k: int,
+                              filter_interacted: bool) -> Tuple[np.ndarray, np.ndarray]:
+        """The kernels' own output -- ids[B, k] and counts[B] as they come off the device in one copy -- with no Python
+        object per user or per item (BaseModel.recommend_batch's vectorised route)."""
+        if not self.model.is_fitted:
+            raise RuntimeError("Model must be fitted before calling batch_recommend.")
+        if len(user_ids) == 0:
+            return np.empty((0, top_k), np.int32), np.zeros(0, np.int32)
+        n_users = self.interactions.shape[0]
+        if int(user_ids.min()) < 0 or int(user_ids.max()) >= n_users:
+            return super()._recommend_hot_arrays(user_ids, candidate_item_ids, top_k, filter_interacted)
+        ids, _, counts = self._hot_topk(user_ids, candidate_item_ids, top_k, filter_interacted)
+        return ids, counts
+
+    def _hot_topk(self, ids_arr: np.ndarray, candidate_item_ids: Optional[List[int]], top_k: int, filter_interacted: bool):
+        """(ids, scores, counts) arrays for internal user ids inside [0, n_users)."""
         dense_output = not self.item_ids.pass_through
         stamp = (self.interactions.version, self.interactions.max_timestamp)
         n_users = self.interactions.shape[0]
-        ids_arr = np.asarray(user_ids, dtype=np.int64)
-        if len(ids_arr) and (int(ids_arr.min()) < 0 or int(ids_arr.max()) >= n_users):
-            return self._recommend_odd_ids(ids_arr, n_users, candidate_item_ids, top_k, filter_interacted)
         resident = self._dev_x is not None and self._dev_x.version == self._store_tag()
-        if self._x_on_device == stamp or resident or len(user_ids) * 16 >= n_users:
+        if self._x_on_device == stamp or resident or len(ids_arr) * 16 >= n_users:
             # bulk scoring: (re)upload all of X once and score it in place by row id
             self._sync_interactions()
-            ids, scores, counts = self.model._topk(None, candidate_item_ids, top_k, filter_interacted, dense_output,
-                                                   row_ids=user_ids)
-        else:
-            # online serving after an update: ship only the requested users' rows (like the
-            # reference's to_csr(select_users=...), but without the empty rows)
-            uniq, inverse = np.unique(np.asarray(user_ids, dtype=np.int64), return_inverse=True)
-            rows, cols, data = self.interactions._triples(select_users=uniq)
-            indptr = np.zeros(len(uniq) + 1, dtype=np.int64)
-            indptr[1:] = np.bincount(np.searchsorted(uniq, rows), minlength=len(uniq))
-            np.cumsum(indptr, out=indptr)
-            from scipy.sparse import csr_matrix
-            Xb = csr_matrix((data.astype(np.float32), cols.astype(np.int32), indptr.astype(np.int32)),
-                            shape=(len(uniq), self.interactions.shape[1]))
-            ids, scores, counts = self.model._topk(Xb, candidate_item_ids, top_k, filter_interacted, dense_output)
-            ids, scores, counts = ids[inverse], scores[inverse], counts[inverse]
-        return self.model._format(ids, scores, counts, ret_scores=False)
+            return self.model._topk(None, candidate_item_ids, top_k, filter_interacted, dense_output, row_ids=ids_arr)
+        # online serving after an update: ship only the requested users' rows (like the
+        # reference's to_csr(select_users=...), but without the empty rows)
+        uniq, inverse = np.unique(ids_arr, return_inverse=True)
+        rows, cols, data = self.interactions._triples(select_users=uniq)
+        indptr = np.zeros(len(uniq) + 1, dtype=np.int64)
+        indptr[1:] = np.bincount(np.searchsorted(uniq, rows), minlength=len(uniq))
+        np.cumsum(indptr, out=indptr)
+        from scipy.sparse import csr_matrix
+        Xb = csr_matrix((data.astype(np.float32), cols.astype(np.int32), indptr.astype(np.int32)),
+                        shape=(len(uniq), self.interactions.shape[1]))
+        ids, scores, counts = self.model._topk(Xb, candidate_item_ids, top_k, filter_interacted, dense_output)
+        return ids[inverse], scores[inverse], counts[inverse]
 
     def _recommend_odd_ids(self, ids: np.ndarray, n_users: int, candidate_item_ids: Optional[List[int]], top_k: int,
                            filter_interacted: bool) -> List[List[int]]:

@@ -94,7 +94,11 @@ class Recommender:
 
     def recommend_batch(self, users: List[Any], candidate_items: Optional[List[Any]] = None,
                         users_tags: Optional[List[List[str]]] = None, top_k: int = 10,
-                        filter_interacted: bool = True) -> List[List[Any]]:
+                        filter_interacted: bool = True, as_arrays: bool = False) -> Any:
+        """rtrec/recommender.py:141-151.  `as_arrays=True` (extension): (ids[B, top_k], counts[B]) numpy arrays instead of B
+        Python lists -- see BaseModel.recommend_batch."""
+        if as_arrays:
+            return self.model.recommend_batch(users, candidate_items, users_tags, top_k, filter_interacted, as_arrays=True)
         return self.model.recommend_batch(users, candidate_items, users_tags, top_k, filter_interacted)
 
     def similar_items(self, query_items: List[Any], query_item_tags: Optional[List[str]] = None, top_k: int = 10,

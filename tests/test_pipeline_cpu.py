@@ -477,3 +477,54 @@ def test_hybrid_slimfm_call_sequence_on_the_facade():
     from tests.hybrid_replay import replay
     replay(lambda cfg: SLIMElastic(cfg, engine=SlimEngine(backend=OracleBackend())))
 
+
+
+@pytest.mark.parametrize("item_kind", ["int", "str"])
+def test_vectorised_recommend_batch_equals_the_per_user_loop(item_kind, monkeypatch):
+    """BaseModel.recommend_batch with integer users takes one array compare instead of get_id per user
+    (rtrec/models/base.py:188-269 is the per-user loop): same lists for hot / cold mixes, candidates, numpy / range / list
+    inputs, ids beyond and below the matrix; `as_arrays=True` carries the same answers as (ids, counts)."""
+    rng = np.random.default_rng(4)
+    n = 5000
+    u, i = rng.integers(0, 150, n), (rng.zipf(1.3, n) - 1) % 400
+    r = rng.integers(1, 6, n).astype(float) + rng.random(n)
+    conv = (lambda x: int(x)) if item_kind == "int" else (lambda x: f"i{int(x)}")
+    m = cpu_slim(nn_feature_selection=10)
+    m.add_interactions([(int(a), conv(b), 1.7e9 + t, float(c)) for t, (a, b, c) in enumerate(zip(u, i, r))])
+    m.bulk_fit(progress_bar=False)
+    n_users = m.interactions.shape[0]
+    cands = [conv(x) for x in (3, 1, 7, 399, 12, 5000)] + ([10 ** 7] if item_kind == "int" else ["never seen"])
+    cases = [list(range(n_users)), [5, 900, 3, 901, 5], [900, 901], np.arange(0, n_users, 3), range(10, 40),
+             np.array([2, 10 ** 6], dtype=np.int32), [7], (1, 2, 3)]
+
+    def loop(users, **kw):
+        with monkeypatch.context() as mp:
+            mp.setattr(type(m), "_int_user_array", lambda self, users: None)
+            return m.recommend_batch(list(users) if not isinstance(users, list) else users, **kw)
+
+    for users in cases:
+        for kw in (dict(top_k=5), dict(top_k=4, filter_interacted=False), dict(top_k=3, candidate_items=cands),
+                   dict(top_k=50)):
+            want = loop(users, **kw)
+            assert m._int_user_array(users) is not None
+            got = m.recommend_batch(users, **kw)
+            assert got == want, (users, kw)
+            ids, counts = m.recommend_batch(users, as_arrays=True, **kw)
+            assert counts.tolist() == [len(x) for x in want]
+            assert [ids[b, :c].tolist() for b, c in enumerate(counts.tolist())] == want
+            a_ids, a_counts = loop(users, as_arrays=True, **kw)
+            assert a_counts.tolist() == counts.tolist()
+            assert [a_ids[b, :c].tolist() for b, c in enumerate(a_counts.tolist())] == want
+    # batches that must keep the per-user loop: mixed kinds, floats, per-user tags, a negative (wrapping) id stays correct
+    assert m._int_user_array([1, "x"]) is None and m._int_user_array([1.0, 2.0]) is None and m._int_user_array([]) is None
+    assert m.recommend_batch([0, -1, 2], top_k=5) == loop([0, -1, 2], top_k=5)
+    with pytest.raises(IndexError):
+        m.recommend_batch([0, -n_users - 1], top_k=5)
+    assert m.recommend_batch([], top_k=5) == [] and m.recommend_batch(np.empty(0, np.int64), top_k=5) == []
+    rec = Recommender(m)
+    assert rec.recommend_batch([1, 2], top_k=3) == m.recommend_batch([1, 2], top_k=3)
+    assert rec.recommend_batch([1, 2], top_k=3, as_arrays=True)[1].tolist() == [3, 3]
+    # string users never take the array route
+    s = cpu_slim()
+    s.fit([("a", 1, 1.7e9, 3.0), ("b", 2, 1.7e9, 2.0), ("a", 2, 1.7e9, 1.0)], progress_bar=False)
+    assert s._int_user_array(["a", "b"]) is None and s._int_user_array([1, 2]) is None

@@ -45,10 +45,20 @@ def main():
     stats = glob.glob(os.path.join(d, f"stats_{wl}_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(d, f"{tag}_{wl}_kernel_stats.csv"))
-    score = ([k for k in per if "score_seg_kernel" in k] or [k for k in per if "score_frows_kernel" in k]
-             or [k for k in per if "score_sparse_kernel<float, false>" in k])
+    # The kernel summarised is the one the bench line of the same run names as dominant (roofline.kernel), else the score
+    # kernel with the most wave cycles over ALL candidates -- never "any segment kernel first": the C3 run also launches
+    # score_seg_kernel for a few request-sized calls, and round 3's summaries described those.
+    score = [k for k in per if any(n in k for n in ("score_seg_kernel", "score_frows_kernel", "score_sparse_kernel<float, false>"))]
+    named = None
+    try:
+        named = json.load(open(os.path.join(d, f"bench_{wl}.json")))["roofline"]["kernel"].split("<")[0].split(" ")[0]
+    except Exception:
+        pass
+    if named and [k for k in score if named in k]:
+        score = [k for k in score if named in k]
     if score:
-        k = max(score, key=lambda n: per[n].get("SQ_WAVE_CYCLES", (0, 0))[0])
+        k = max(score, key=lambda n: per[n].get("SQ_WAVE_CYCLES", (0, 0))[0] * per[n].get("SQ_WAVE_CYCLES", (0, 0))[1] or
+                per[n].get("FETCH_SIZE", (0, 0))[0])
         c = {n: v[0] for n, v in per[k].items()}
         heavy = [h for h in per if "score_seg_heavy_kernel" in h] if "score_seg_kernel" in k else []
         if heavy:       # the segment path is two launches per pass (long users first): byte counters are summed, the rest kept apart
