@@ -89,8 +89,14 @@ def api_leg(X, K, top_k):
     users = list(range(U))
     rec.recommend_batch(users[:128], top_k=top_k)
     t0 = time.perf_counter()
-    recs = rec.recommend_batch(users, top_k=top_k)
-    t_rec = time.perf_counter() - t0
+    recs = rec.recommend_batch(users, top_k=top_k)          # first full-size call of the model: builds the large-pass layout
+    t_first = time.perf_counter() - t0
+    t_rec = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        recs = rec.recommend_batch(users, top_k=top_k)
+        t_rec.append(time.perf_counter() - t0)
+    t_rec = float(np.median(t_rec))
     # the array-returning form of the same call (round 4: rtrec_amd extension, BaseModel.recommend_batch(as_arrays=True)):
     # an id array in, (ids[B, k], counts[B]) out -- no Python object per user or item on either side
     users_arr = np.arange(U, dtype=np.int64)
@@ -116,6 +122,7 @@ def api_leg(X, K, top_k):
     out = {"single_user_recommend_ms": {"p50": float(np.quantile(lat, .5)), "p99": float(np.quantile(lat, .99)), "requests": int(lat.size)},
            "bulk_fit_seconds": t_fit, "bulk_fit_samples_per_sec_incl_ingest": len(df) / t_fit,
            "recommend_batch_users": U, "recommend_batch_seconds": t_rec, "api_users_per_sec": U / t_rec,
+           "recommend_batch_first_call_seconds": t_first,
            "recommend_batch_as_arrays_seconds": t_arr, "api_users_per_sec_arrays": U / t_arr,
            "arrays_equal_lists_on_sample": arrays_equal_lists,
            "recommend_batch_100_user_calls_users_per_sec": 20000 / t_100,

@@ -755,6 +755,14 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
 
     const long long tr0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
     long long tr_folded = 0;
+#ifdef RTREC_FIT_PHASES      // diagnostic build (tools/fit_trace.py --phases): where a target's coordinate descent spends its time
+    long long ph_fold = 0, ph_upd = 0, ph_screen = 0, ph_gap = 0;
+#define FIT_PH_T0 const long long ph_t0 = static_cast<long long>(wall_clock64());
+#define FIT_PH_ADD(acc) acc += static_cast<long long>(wall_clock64()) - ph_t0;
+#else
+#define FIT_PH_T0
+#define FIT_PH_ADD(acc)
+#endif
     const Prep P = prep_target<ALLF>(a, j, K, s, touched, cand_s, cand_i, F);
     const long long tr1 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
     const float yy = P.yy, tol_s = P.tol_s;
@@ -862,11 +870,17 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                     if (!ALLF && gram_interval(p, e - b, S)) screened = screen_stays_zero(S, alpha, positive, w_new);
                     if (!screened && e - b >= a.screen_min && e - b <= kScreenMaxLen) {
                         float ps, pa;
+                        FIT_PH_T0
                         screen_pass(a.crow, a.cval, R, b, e, ps, pa);
+                        FIT_PH_ADD(ph_screen)
                         screened = screen_stays_zero(screen_interval(ps, pa, e - b), alpha, positive, w_new);
                     }
                 }
-                if (!screened && !a.fast) { tmp = dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf); tr_folded += e - b; }
+                if (!screened && !a.fast) {
+                    FIT_PH_T0
+                    tmp = dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf); tr_folded += e - b;
+                    FIT_PH_ADD(ph_fold)
+                }
             }
             if (!screened) w_new = cd_update(tmp, alpha, beta, nrm, positive);
             if (w_old != 0.0f || w_new != 0.0f) {
@@ -874,7 +888,11 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                     for (int o = yb + lane; o < ye; o += 64) R[a.crow[o]] = a.cval[o];
                     dirty = true;
                 }
-                update_pass(a.crow, a.cval, R, b, e, w_old, w_new);
+                {
+                    FIT_PH_T0
+                    update_pass(a.crow, a.cval, R, b, e, w_old, w_new);
+                    FIT_PH_ADD(ph_upd)
+                }
                 if (!ALLF) gram_update(p, w_old, w_new);
                 if (ALLF) {
                     if (ever_flag[p] == 0) { if (lane == 0) { ever_flag[p] = 1; ever_list[n_ever] = p; } n_ever++; }
@@ -892,6 +910,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
         }
 
         if (w_max == 0.0f || __fdiv_rn(d_w_max, w_max) < a.cfg.tol || n_iter == max_iter - 1) {
+            FIT_PH_T0
             // dual norm of XtA = X^T R - beta w
             float dn = 0.0f;
             bool dn_init = false;
@@ -1011,6 +1030,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
             const double t3 = 0.5 * static_cast<double>(beta) * static_cast<double>(__fadd_rn(1.0f, __fmul_rn(cst, cst))) *
                               static_cast<double>(w_norm2);
             gap = static_cast<float>(static_cast<double>(gap) + (static_cast<double>(t12) + t3));
+            FIT_PH_ADD(ph_gap)
             if (gap < tol_s) break;
         }
     }
@@ -1068,8 +1088,13 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
     if (a.trace && lane == 0) {
         long long *tr = a.trace + static_cast<size_t>(t) * 8;
         tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
+#ifdef RTREC_FIT_PHASES
+        tr[4] = ph_fold; tr[5] = ph_upd; tr[6] = ph_screen; tr[7] = ph_gap;
+#endif
     }
 }
+#undef FIT_PH_T0
+#undef FIT_PH_ADD
 
 
 // =============================================================================================

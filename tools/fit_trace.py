@@ -76,6 +76,21 @@ def main() -> None:
         "busy_slots_at_5pct_steps": busy,
         "dur_percentiles_s": {str(p): float(np.percentile(dur, p)) for p in (50, 90, 99, 99.9, 100)},
     }
+    if tr.shape[1] >= 8 and tr[:, 4:8].any():
+        # phase clocks (a library built with -DRTREC_FIT_PHASES: tools/ab_build.sh with AB_FLAGS): the single-wave kernel's
+        # targets are those after the heavy head (engine.last_fit_stats["n_heavy"]; the head runs fit_columns_mw_kernel, whose
+        # slots 4..7 mean fold / update / gap / cycles)
+        nh = int(eng.last_fit_stats.get("n_heavy", 0))
+        sw = slice(nh, None)
+        ph = tr[sw, 4:8].sum(axis=0) * tick
+        cd_sw = float(cd[sw].sum())
+        rep["single_wave_phases_wave_seconds"] = {
+            "targets": int(len(tg) - nh), "prep (X^T y + selection)": float(prep[sw].sum()), "coordinate descent": cd_sw,
+            "ordered folds (dot_pass)": float(ph[0]), "residual updates (update_pass)": float(ph[1]),
+            "screening passes (screen_pass)": float(ph[2]), "duality gaps": float(ph[3]),
+            "rest of the descent (draws, Gram-tracked screens, bookkeeping)": cd_sw - float(ph.sum()),
+            "folded_entries": float(folded[sw].sum()),
+            "fold_ns_per_entry_in_dot_pass": float(ph[0] / max(folded[sw].sum(), 1) * 1e9)}
     print(json.dumps(rep, indent=1))
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
