@@ -432,10 +432,11 @@ class DeviceWeights:
     records that the host-visible matrix is float64 (serial fit, slim_elastic.py:252), which selects the float64
     accumulator of the score kernels."""
 
-    __slots__ = ("rows", "cols", "vals", "n_items", "f64", "lossy", "_host", "_csc")
+    __slots__ = ("rows", "cols", "vals", "n_items", "f64", "lossy", "_host", "_csc", "shard")
 
     def __init__(self, rows, cols, vals, n_items: int, f64: bool, host: Optional[sp.csc_matrix] = None, lossy: bool = False):
         self.rows, self.cols, self.vals, self.n_items, self.f64 = rows, cols, vals, int(n_items), bool(f64)
+        self.shard = None              # (rank, world): only this rank's column block of W is held (SlimEngine.shard_w)
         self.lossy = bool(lossy)       # uploaded from a float64 host matrix whose values are not float32 numbers
         self._host = host
         self._csc = None
@@ -696,7 +697,7 @@ class SlimEngine:
 
     def __init__(self, device: Any = None, rank: int = 0, world_size: int = 1, process_group: Any = None,
                  tile_cols: Optional[int] = None, backend: Any = None, score_shard: Optional[str] = None,
-                 warm_up: bool = True):
+                 warm_up: bool = True, shard_w: Optional[bool] = None):
         self.rank, self.world_size, self.group = rank, world_size, process_group
         # How a multi-GPU scoring pass is divided.  "columns" (default; BASELINE.json's configuration): every
         # rank scores all users against its item-column shard of W, lists are exchanged and merged.
@@ -707,6 +708,15 @@ class SlimEngine:
         self.score_shard = (score_shard or settings.raw("RTREC_AMD_SCORE_SHARD", "columns")).lower()
         if self.score_shard not in ("columns", "rows"):
             raise ValueError(f"score_shard must be 'columns' or 'rows': {self.score_shard}")
+        # shard_w (round 4; BASELINE.json: "W shards by item column across the 8 GPUs"): every rank FITS the item columns of its
+        # own scoring shard [lo, hi) and keeps only those -- the fit output is the score input and W never moves.
+        # Without it (the default) the targets are dealt out by column length and the coefficient triples are all-gathered, so
+        # that every rank holds all of W: right while W is a few MB, not a design for a W that is not degenerate (500k
+        # items x K=50 = 200 MB per copy and 8x the merge work).  Column-sharded scoring only; `item_similarity`,
+        # `similar_items` and pickling gather on demand (collective calls: every rank must make them).
+        if shard_w is None:
+            shard_w = settings.raw("RTREC_AMD_SHARD_W", "0") == "1"
+        self.shard_w = bool(shard_w) and world_size > 1 and self.score_shard == "columns"
         # testing aid: run the multi-GPU exchange (collectives, strided merge) even with a single rank, so that
         # the RCCL code path can be exercised on a one-GPU box through a 1-rank process group
         self.force_exchange = settings.raw("RTREC_AMD_FORCE_EXCHANGE") == "1"
@@ -843,6 +853,9 @@ class SlimEngine:
         columns = np.asarray(columns, dtype=np.int64)
         if self.world_size == 1:
             return columns
+        if self.shard_w:        # the rank that scores a column fits it: W never moves
+            lo, hi = shard_bounds(self.n_items, self.world_size, self.rank)
+            return np.sort(columns[(columns >= lo) & (columns < hi)])
         nnz = self._X["col_nnz"][columns] if "col_nnz" in self._X else np.zeros(len(columns), dtype=np.int64)
         order = np.lexsort((columns, -nnz))            # nnz descending, ties by id: identical on all ranks
         pos = np.arange(len(columns))
@@ -1166,7 +1179,7 @@ class SlimEngine:
         mask = torch.arange(cap, device=d_items.device)[None, :] < d_count[:, None]
         key = (d_targets.to(torch.int64)[:, None] * n_items + d_items.to(torch.int64))[mask]
         val = d_coef[mask]
-        if self.world_size > 1:
+        if self.world_size > 1 and not self.shard_w:
             import torch.distributed as dist
             sizes = torch.zeros(self.world_size, dtype=torch.int64, device=key.device)
             dist.all_gather_into_tensor(sizes, torch.tensor([key.numel()], dtype=torch.int64, device=key.device), group=self.group)
@@ -1180,6 +1193,13 @@ class SlimEngine:
             dist.all_gather_into_tensor(va, vp, group=self.group)
             key = torch.cat([ka[r * m:r * m + s] for r, s in enumerate(sizes)])
             val = torch.cat([va[r * m:r * m + s] for r, s in enumerate(sizes)])
+        if self.shard_w and old is not None and (getattr(old, "shard", None) is None or old.n_items != n_items):
+            # the catalogue grew (the block boundaries moved) or the old W was not sharded: every rank keeps the old entries
+            # of ITS columns under the new boundaries
+            old = self.gather_weights(old)
+            lo, hi = shard_bounds(n_items, self.world_size, self.rank)
+            sel = (old.cols >= lo) & (old.cols < hi)
+            old = DeviceWeights(old.rows[sel], old.cols[sel], old.vals[sel], old.n_items, old.f64)
         if old is not None and old.nnz:
             inside = (old.rows < n_items) & (old.cols < n_items)
             o_key = (old.cols * n_items + old.rows)[inside]
@@ -1190,7 +1210,34 @@ class SlimEngine:
         key, val = key[nz], val[nz]
         order = torch.argsort(key)
         key = key[order]
-        return DeviceWeights(key % n_items, key // n_items, val[order].contiguous(), n_items, f64)
+        dw = DeviceWeights(key % n_items, key // n_items, val[order].contiguous(), n_items, f64)
+        if self.shard_w:
+            dw.shard = (self.rank, self.world_size)
+        return dw
+
+    def gather_weights(self, dw: "DeviceWeights") -> "DeviceWeights":
+        """All of W from its column shards (shard_w): the ranks' triples concatenated in rank order = (column, row) order,
+        because the shards are contiguous column blocks.  A COLLECTIVE: every rank calls it (reading `item_similarity`,
+        pickling).  A W that is not sharded is returned as it is."""
+        if getattr(dw, "shard", None) is None or self.world_size == 1:
+            return dw
+        import torch.distributed as dist
+        torch = self.be.torch
+        dev = dw.vals.device
+        sizes = torch.zeros(self.world_size, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(sizes, torch.tensor([dw.nnz], dtype=torch.int64, device=dev), group=self.group)
+        sizes = sizes.cpu().tolist()
+        m = max(max(sizes), 1)
+        key = dw.cols * dw.n_items + dw.rows
+        kp = torch.zeros(m, dtype=torch.int64, device=dev); kp[:dw.nnz] = key
+        vp = torch.zeros(m, dtype=torch.float32, device=dev); vp[:dw.nnz] = dw.vals
+        ka = torch.empty(m * self.world_size, dtype=torch.int64, device=dev)
+        va = torch.empty(m * self.world_size, dtype=torch.float32, device=dev)
+        dist.all_gather_into_tensor(ka, kp, group=self.group)
+        dist.all_gather_into_tensor(va, vp, group=self.group)
+        key = torch.cat([ka[r * m:r * m + n] for r, n in enumerate(sizes)])
+        val = torch.cat([va[r * m:r * m + n] for r, n in enumerate(sizes)])
+        return DeviceWeights(key % dw.n_items, key // dw.n_items, val.contiguous(), dw.n_items, dw.f64)
 
     def _fast_layout(self) -> Optional[Dict[str, Any]]:
         """The fast SPARSE-mode form of this rank's shard (float32 W): feature rows when W has at most 128 non-empty rows
@@ -1941,6 +1988,18 @@ class SlimEngine:
         cnt = be.empty((n,), torch.int32)
         cptr, crow, cval = W["dw"].csc_arrays(torch)
         be.similar_topk(d_q, {"cptr": cptr, "crow": crow, "cval": cval}, top_k, ids, sc, cnt)
+        if getattr(W["dw"], "shard", None) is not None and self.world_size > 1:
+            # W is column-sharded: column j is held by its owner alone ("similar_items(j) is served by the owner of
+            # column j"); every rank answers its own queries and one all-gather of [n, 2k + 1] words brings them together
+            import torch.distributed as dist
+            pack = torch.cat([ids, sc.view(torch.int32), cnt.view(n, 1)], dim=1).contiguous()
+            allp = be.empty((self.world_size * n, 2 * top_k + 1), torch.int32)
+            dist.all_gather_into_tensor(allp, pack, group=self.group)
+            bounds = np.array([shard_bounds(W["n_items"], self.world_size, r)[1] for r in range(self.world_size)])
+            owner = np.searchsorted(bounds, np.clip(q.astype(np.int64), 0, W["n_items"] - 1), side="right")
+            pick = be.to_dev(owner.astype(np.int64) * n + np.arange(n, dtype=np.int64))
+            mine = allp[pick]
+            ids, sc, cnt = mine[:, :top_k], mine[:, top_k:2 * top_k].view(torch.float32), mine[:, 2 * top_k]
         return ids.cpu().numpy(), sc.cpu().numpy(), cnt.cpu().numpy()
 
 

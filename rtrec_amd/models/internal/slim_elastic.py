@@ -68,7 +68,8 @@ class SLIMElastic:
     @property
     def item_similarity(self) -> Optional[sp.csc_matrix]:
         if self._item_similarity is None and self._w_dev is not None:
-            self._item_similarity = self._w_dev.to_csc(self.engine.be.torch)     # one download, on demand
+            # one download, on demand (a column-sharded W -- SlimEngine.shard_w -- is gathered first: a collective call)
+            self._item_similarity = self.engine.gather_weights(self._w_dev).to_csc(self.engine.be.torch)
         return self._item_similarity
 
     @item_similarity.setter

@@ -19,6 +19,7 @@ TABLE: Dict[str, tuple] = {
     "RTREC_AMD_DEVICE_INGEST": ("1", "0: bulk batches are reduced to distinct pairs by the host store, not on the device"),
     # scoring
     "RTREC_AMD_SCORE_SHARD": ("columns", "multi-GPU scoring division: item-column shards of W, or `rows` (user rows, W replicated)"),
+    "RTREC_AMD_SHARD_W": ("0", "1: multi-GPU, column-sharded scoring: every rank fits and keeps only its own column block of W (no all-gather of the coefficients)"),
     "RTREC_AMD_FORCE_EXCHANGE": (None, "run the multi-GPU exchange with one rank (test aid)"),
     "RTREC_AMD_FEATURE_ROWS": ("1", "0: no feature-row kernel"),
     "RTREC_AMD_FR_USERS": ("0", "8 / 4 / 2: force the users-per-wave form of the feature-row kernel (0: from the batch size)"),

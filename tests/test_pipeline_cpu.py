@@ -18,7 +18,7 @@ import pytest
 import scipy.sparse as sp
 
 from tests.cpu_backend import OracleBackend
-from rtrec_amd.engine import SlimEngine
+from rtrec_amd.engine import SlimEngine, shard_bounds
 from rtrec_amd.models.internal.slim_elastic import SLIMElastic
 from rtrec_amd.models.slim import SLIM
 from rtrec_amd.recommender import Recommender
@@ -189,13 +189,31 @@ def _worker(rank, world, port, q, score_shard="columns"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import torch
+        torch.set_num_threads(1)           # 8 ranks share this container's 8 cores
         z = np.load(os.path.join(G, "models.npz"))
         X = load_csc(z, "X2")
-        eng = SlimEngine(backend=OracleBackend(), rank=rank, world_size=world, score_shard=score_shard)
+        shard_w = score_shard == "columns+w"        # W stays column-sharded: no all-gather of the coefficients
+        score_shard = "columns" if shard_w else score_shard
+        eng = SlimEngine(backend=OracleBackend(), rank=rank, world_size=world, score_shard=score_shard, shard_w=shard_w)
         eng.gather_chunk_rows = 7          # several chunks -> several asynchronous all-gathers in flight
         m = SLIMElastic({"nn_feature_selection": 50}, engine=eng)
         m.partial_fit_items(X.copy(), list(range(400)))            # each rank fits its own column shard
-        ok_w = same_matrix(m.item_similarity, load_csc(z, "W2_k50"))
+        if shard_w:                        # this rank holds its own column block and nothing else ...
+            lo, hi = shard_bounds(400, world, rank)
+            own = m._w_dev
+            assert own.shard == (rank, world) and (own.nnz == 0 or (int(own.cols.min()) >= lo and int(own.cols.max()) < hi))
+            assert own.nnz < load_csc(z, "W2_k50").nnz
+            sims = m.similar_items_batch([0, 7, 399, 123], top_k=6)      # ... and item-to-item queries go to the owner
+        ok_w = same_matrix(m.item_similarity, load_csc(z, "W2_k50"))      # (sharded W: gathered on demand, a collective)
+        if shard_w:
+            solo = SLIMElastic({"nn_feature_selection": 50}, engine=SlimEngine(backend=OracleBackend()))
+            solo.item_similarity = load_csc(z, "W2_k50")
+            ok_w = ok_w and sims == solo.similar_items_batch([0, 7, 399, 123], top_k=6)
+            # a second, partial fit merges into the sharded W (old entries of the refitted columns survive / are replaced)
+            m.partial_fit_items(X.copy(), [3, 50, 51, 250, 399])
+            m._item_similarity = None
+            ok_w = ok_w and same_matrix(m.item_similarity, load_csc(z, "W2_k50"))
         zs = np.load(os.path.join(G, "scoring.npz"))
         users = zs["users"].tolist()
         out = m.recommend_batch(users, X.tocsr(), top_k=10, filter_interacted=True, dense_output=False)
@@ -204,7 +222,7 @@ def _worker(rank, world, port, q, score_shard="columns"):
         # dense (string-id) mode and a float64 W (float64 scores travel in front of the record)
         out = m.recommend_batch(users, X.tocsr(), top_k=10, filter_interacted=False, dense_output=True)
         ok = ok and out == [[x for x in row.tolist() if x >= 0] for row in zs["ids_f32_dense_nofilter"]]
-        m.item_similarity = sp.csc_matrix(load_csc(z, "W2_k50"), dtype=np.float64)
+        m.item_similarity = sp.csc_matrix(load_csc(z, "W2_k50"), dtype=np.float64)     # (an assigned W is replicated again)
         out = m.recommend_batch(users, X.tocsr(), top_k=10, filter_interacted=True, dense_output=False, ret_scores=True)
         ok = ok and [o[0] for o in out] == [[x for x in row.tolist() if x >= 0] for row in zs["ids_f64_sparse_filter"]]
         # resident X: two calls with DIFFERENT row sets of equal length must not share a cached slice / work order (ADVICE round
@@ -222,7 +240,8 @@ def _worker(rank, world, port, q, score_shard="columns"):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,score_shard", [(2, "columns"), (3, "columns"), (2, "rows"), (3, "rows")])
+@pytest.mark.parametrize("world,score_shard", [(2, "columns"), (3, "columns"), (2, "rows"), (3, "rows"), (8, "columns"), (8, "rows"),
+                                               (2, "columns+w"), (3, "columns+w"), (8, "columns+w")])
 def test_two_rank_column_sharding_gloo(world, score_shard):
     """Column-sharded fit + scoring over gloo: per-shard lists travel by all-to-all (every rank merges
     its slice of the users; 7-row chunks do not divide by 2 or 3, so padded slices are exercised) and the
@@ -235,7 +254,7 @@ def test_two_rank_column_sharding_gloo(world, score_shard):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, score_shard)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=180) for _ in procs)
+    res = sorted(q.get(timeout=420) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
