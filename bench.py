@@ -240,17 +240,24 @@ def main() -> None:
                          "followed by a 100-user recommend_batch, on a model bulk-fitted at the same workload shape (0 = skip)")
     ap.add_argument("--score-shard", default="auto", choices=["auto", "columns", "rows"],
                     help="multi-GPU scoring: item-column shards of W + list exchange (BASELINE.json's configuration), or "
-                         "user-row shards with W replicated.  auto = rows: W is ~1 MB on every BASELINE shape and a pass costs "
-                         "per user, not per column, so dividing the users is what divides the work (DESIGN.md section 6); the "
-                         "other division is timed right after and reported as `alt_sharding`")
+                         "user-row shards with W replicated.  auto = by the shape of the fitted W: at most 128 non-empty rows "
+                         "(feature-row kernel: a pass costs per user, not per column) -> rows; a general W (segment kernel: a rank "
+                         "opens only its own tiles) -> columns (DESIGN.md section 6); the other division is timed right after and "
+                         "reported as `alt_sharding`, and the line says which was chosen and why (`score_shard_choice`)")
+    ap.add_argument("--shard-w", action="store_true",
+                    help="multi-GPU, column shards: every rank fits and KEEPS only its own column block of W (no all-gather of the "
+                         "coefficients; SlimEngine.shard_w).  Implies --score-shard columns and no alt_sharding leg")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU time budget per cpu_baseline leg (4 legs)")
     ap.add_argument("--no-structured", action="store_true",
                     help="skip the `structured` leg of the default (c3) line: the same shape with item-item structure (c3s), "
                          "fit + all-users scoring through the general-W kernel")
     ap.add_argument("--no-api", action="store_true", help="skip the `api` leg (Recommender.bulk_fit / recommend_batch through the DataFrame API)")
     args = ap.parse_args()
+    shard_auto = args.score_shard == "auto" and not args.shard_w
+    if args.shard_w:
+        args.score_shard = "columns"
     if args.score_shard == "auto":
-        args.score_shard = "rows"
+        args.score_shard = "columns"        # provisional: decided from the fitted W below (the engine re-shards in place)
 
     # `python3 bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the
     # driver's own torch.distributed.run command line) as a CHILD, before this process has touched the GPU,
@@ -321,7 +328,7 @@ def main() -> None:
         log(f"[bench] workload {args.workload}: {U} x {I}, nnz={nnz} generated in {time.time() - t0:.1f}s")
 
     eng = SlimEngine(device=f"cuda:{local_rank}", rank=rank, world_size=world, tile_cols=args.tile_cols,
-                     score_shard=args.score_shard)
+                     score_shard=args.score_shard, shard_w=args.shard_w)
     eng.set_interactions(Xc, X)
 
     # ------------------------------------------------------------------ fit (each rank: its own columns)
@@ -337,7 +344,21 @@ def main() -> None:
     # W stays on the device: the write-back (and, with several ranks, the exchange of the triples) and the score
     # layouts are tensor ops there; the host copies below only feed this script's bookkeeping
     t1 = time.time()
-    eng.set_weights(eng.merge_fit(None, I, False, d_tg, d_items, d_coef, d_count))
+    dw_fit = eng.merge_fit(None, I, False, d_tg, d_items, d_coef, d_count)
+    # --score-shard auto: the division follows the layout W gets.  A W with at most 128 non-empty rows is scored by the
+    # feature-row kernel, whose cost is per USER (row setup, the heavy tiles every user needs) -- dividing the columns leaves
+    # a rank 1.38 of 1.41 ms (tools/shard_model.py) -> divide the users.  A general W is scored by the segment kernel, where a
+    # rank opens only its own shard's tiles -> the item-column shard of BASELINE.json divides the work.
+    w_rows = int(torch.unique(dw_fit.rows).numel()) if dw_fit.nnz else 0
+    shard_choice = {"mode": args.score_shard, "chosen_by": "flag", "w_rows": w_rows}
+    if shard_auto:
+        args.score_shard = "rows" if w_rows <= 128 else "columns"
+        eng.score_shard = args.score_shard
+        shard_choice = {"mode": args.score_shard, "chosen_by": "auto", "w_rows": w_rows,
+                        "why": ("W has <= 128 non-empty rows: feature-row kernel, cost per user -> user-row shards, W replicated"
+                                if w_rows <= 128 else
+                                "general W (segment kernel): a rank opens only the tiles of its own columns -> item-column shards")}
+    eng.set_weights(dw_fit)
     torch.cuda.synchronize()
     merge_s = time.time() - t1
     t1 = time.time()
@@ -364,7 +385,7 @@ def main() -> None:
         fit_s = float(t.item())
     else:
         fit_s = fit_local
-    W = eng.weights.to_csc(torch)
+    W = eng.gather_weights(eng.weights).to_csc(torch)      # (a column-sharded W is gathered for the bookkeeping below: a collective)
     if rank == 0:
         log(f"[bench] W write-back on the device {merge_s * 1e3:.1f} ms, score layouts built on the device {layout_s * 1e3:.1f} ms "
             f"(W nnz={W.nnz})")
@@ -485,7 +506,7 @@ def main() -> None:
     # the other way of dividing the scoring pass over the ranks, timed the same way (K steps, barrier + synchronize on both
     # sides, max over ranks) right after the pass of record; the answers must agree
     alt_sharding = None
-    if world > 1:
+    if world > 1 and not args.shard_w:         # (a column-sharded W has no replicated copy to divide the users against)
         other = "columns" if args.score_shard == "rows" else "rows"
         dw = eng.weights
         eng.score_shard = other
@@ -743,6 +764,7 @@ def main() -> None:
                    "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
                                    else f"user-row shard x{world}, W replicated")},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend, "alt_sharding": alt_sharding,
+        "score_shard_choice": dict(shard_choice, w_column_sharded=bool(args.shard_w)),
         "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc, "rows_rescored_by_exact_tie_pass": n_rescored,
         "fit": {"seconds": fit_s, "interactions_per_sec": nnz / fit_s, "columns_per_sec": I / fit_s,
                 "W_nnz": int(W.nnz), "mean_sweeps": float(n_iter.mean()), "mode": "exact", "tolerance_modes": fit_fast,
