@@ -901,7 +901,7 @@ class SlimEngine:
             X["sqn"] = be.empty((I,), torch.float32)
             be.column_sqnorms(I, X["cptr"], X["cval"], X["sqn"])
         n = len(targets)
-        slots = int(n_slots or min(int(settings.raw("RTREC_AMD_FIT_SLOTS", MAX_SLOTS)), max(1, n)))
+        slots = int(n_slots or min(int(settings.raw("RTREC_AMD_FIT_SLOTS", self._fit_slots_for(targets, cfg, cap, K))), max(1, n)))
         # Per-slot scratch is R (U floats) + s/touched/candidates (I each).  The X^T y step is a random
         # read-modify-write over s, i.e. bound by cache lines moved, and measured faster with FEWER
         # targets in flight once a slot is several MB (C4: 1024 slots 7.3 s, 5120 slots 9.2 s): keep
@@ -1044,6 +1044,33 @@ class SlimEngine:
                     cat("count", (0,), torch.int32), d_niter.cpu().numpy())
         return targets, items_out, coef_out, count_out, niter_out
 
+    FIT_SLOTS_SPARSE = 1024          # targets in flight when the folded columns are sparse (see _fit_slots_for)
+    FIT_SPARSE_FEATURES = 0.08       # mean density of the selected feature columns up to which FIT_SLOTS_SPARSE are used (c3s: 0.058)
+    FIT_DENSE_FEATURES = 0.25        # ... and from which the full MAX_SLOTS are (C3: 0.39; C2: 0.13 -> 2048, flat there)
+
+    def _fit_slots_for(self, targets: np.ndarray, cfg, cap: int, K: int) -> int:
+        """Targets in flight (work-queue slots) of a bulk fit with feature selection.  Every target owns a residual of U floats
+        and its waves gather from it at the rows of the columns they fold.  Where those columns are DENSE (popularity-only
+        data: the features of every target are the ~100 most popular items, 30-70 % of all users each) a fold streams its
+        residual nearly sequentially, the kernel is bound by the dependent-add chains and the fabric's streaming rate, and more
+        targets in flight are better up to 4 per SIMD (C3: 4096 slots 2.05 s, 2048 2.3 s, 1024 3.6 s).  Where they are SPARSE
+        (item clusters: ~8k-entry columns, 6 % of the users) every gather is a 64-byte sector of its own, the memory system
+        serves a fixed number of such sectors per second whatever the number of waves asking (Little's law: a wave's step
+        took ~100 us with 4096 waves in flight), and what helps is residuals that stay in L2 + Infinity Cache: c3s 4096 slots
+        1.43-1.52 s, 2048 1.30 s, 1024 0.91 s, 768 0.97-1.03 s, 512 1.03 s (tools/fit_sweep.py, profiles/r04_fit_sweep_*.jsonl;
+        W bits and sweep counts identical for every slot count -- the slots only decide who runs when).  The density comes
+        from the Gram pilot's feature selection (_gram_items); in between the count is interpolated (C2, 0.13: flat)."""
+        if K <= 0 or len(targets) <= FIT_MW_MAX_TARGETS:
+            return MAX_SLOTS
+        if "pilot_feature_density" not in self._X:
+            self._gram_items(targets, cfg, cap)            # runs the pilot when the call is large enough for one
+        d = self._X.get("pilot_feature_density")
+        if d is None:
+            return MAX_SLOTS
+        f = min(1.0, max(0.0, (d - self.FIT_SPARSE_FEATURES) / (self.FIT_DENSE_FEATURES - self.FIT_SPARSE_FEATURES)))
+        lo = self.FIT_SLOTS_SPARSE
+        return int(-(-(lo + f * (MAX_SLOTS - lo)) // 256) * 256) if f < 1.0 else MAX_SLOTS
+
     GRAM_ITEMS_MAX = 4096       # rtrec_slim_gram_matrix's limit
     GRAM_PILOT_TARGETS = 64
     GRAM_PILOT_MIN_NNZ = 8_000_000      # smaller fits take a fraction of a second: the pilot (and a larger G) would not pay
@@ -1096,6 +1123,9 @@ class SlimEngine:
                 it, cn = items.cpu().numpy(), count.cpu().numpy()
                 deepest = np.array([rank[it[k, :cn[k]]].max() if cn[k] else 0 for k in range(m)])
                 need = int(np.percentile(deepest, 90)) + 1
+                sel = np.concatenate([it[k, :cn[k]] for k in range(m)]) if cn.sum() else np.empty(0, np.int64)
+                if len(sel):          # how dense the columns a target folds are (_fit_slots_for)
+                    X["pilot_feature_density"] = float(col_nnz[sel].mean()) / max(self.n_users, 1)
                 n_top = GRAM_ITEMS if need <= GRAM_ITEMS else min(self.GRAM_ITEMS_MAX, 1 << int(need - 1).bit_length())
                 self._fit_ws.pop(key, None)
         X["gram_auto"] = min(self.n_items, n_top)

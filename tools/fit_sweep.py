@@ -49,6 +49,7 @@ def main() -> None:
             os.environ["RTREC_AMD_FIT_MODE"] = mode
         os.environ["RTREC_AMD_FIT_SLOTS"] = slots
         os.environ["RTREC_AMD_FIT_HEAVY"] = heavy
+        eng._fit_ws.clear()           # (a cached larger scratch would be reused as it is: the kernel launches min(its slots, targets))
         eng.fit_columns(np.arange(64), nn_feature_selection=K)      # workspace + warm-up
         torch.cuda.synchronize()
         t0 = time.time()
