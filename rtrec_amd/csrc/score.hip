@@ -1976,6 +1976,7 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         long long chunk = a.n_rows / (cap * kSgWaves);
         chunk = chunk < 1 ? 1 : (chunk > kSgQueueChunk ? kSgQueueChunk : chunk);
         g.chunk = static_cast<int>(chunk);
+        g.n_claims = static_cast<int>((static_cast<long long>(a.n_rows) + chunk - 1) / chunk);
         g.heavy_min = SG.heavy_min > 0 ? (SG.heavy_min - 1 < kSgCap ? SG.heavy_min - 1 : kSgCap)
                                        : sg_heavy_min_for(a.n_rows);
         const long long want = (static_cast<long long>(a.n_rows) + kSgWaves * chunk - 1) / (kSgWaves * chunk);

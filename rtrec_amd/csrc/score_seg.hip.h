@@ -43,6 +43,7 @@ struct SegArgs {
     int *flag_list; int *flag_len;
     int *queue;
     int chunk;                 // users per queue claim (1 .. kSgQueueChunk): small passes claim fewer, so that every wave gets work
+    int n_claims;              // ceil(n_rows / chunk): claim c takes the users at positions c, c + n_claims, c + 2 n_claims, ... of the order
     int heavy_min;             // users with more items than this go to score_seg_heavy_kernel (<= kSgCap; see kSgSmallPass)
     int dense_rule;            // DENSE mode through this pass: a row with fewer than top_k POSITIVE scores is flagged as well
     // long users (more items than a wave's LDS lists hold) are left to score_seg_heavy_kernel, one workgroup per user
@@ -88,7 +89,8 @@ __host__ __device__ constexpr size_t sg_wave_lds(int T, int idx_bytes) {
 }
 __host__ __device__ constexpr int sg_heavy_waves(int T) { return T <= 2048 ? SG_HEAVY_WAVES : (SG_HEAVY_WAVES < 8 ? SG_HEAVY_WAVES : 8); }
 __host__ __device__ constexpr size_t sg_heavy_lds(int T) {
-    return static_cast<size_t>(sg_heavy_waves(T)) * (static_cast<size_t>(T + 64) * 4 + 128 * 4 + 64 * 8) + 64;
+    return static_cast<size_t>(sg_heavy_waves(T)) * (static_cast<size_t>(T + 64) * 4 + 128 * 4 + 64 * 8) + 64 +
+           static_cast<size_t>(kSgCap) * 12;        // + rating | layout column | row of W of up to kSgCap items (list path)
 }
 __host__ __device__ constexpr size_t sg_heavy_scratch_bytes(int n_items, int n_tiles, int T) {
     return static_cast<size_t>(kSgHeavySlots) * (static_cast<size_t>(n_items) * 4 + static_cast<size_t>(n_tiles) * T);
@@ -323,7 +325,10 @@ __device__ __forceinline__ void sg_add_bounds(__amdgpu_buffer_rsrc_t bound, int 
     const int lane4 = lane_id() * 4;
     unsigned long long m = __ballot(r >= 0);
     while (m) {
-        constexpr int NB = 8;
+#ifndef SG_NB
+#define SG_NB 8
+#endif
+        constexpr int NB = SG_NB;
         int rq[NB];
         float aq[NB];
         uint32_t bq[NB];
@@ -401,28 +406,35 @@ __global__ __launch_bounds__(kSgWaves * 64, SG_OCC) void score_seg_kernel(SegArg
     const __amdgpu_buffer_rsrc_t bnd = sg_buffer(a.bound, static_cast<size_t>(a.R) * 256);
 
     SP_DECL
-    int w_next = 0, w_end = 0, w_base = 0;
+    int w_next = 0, w_end = 0;
     int *claimed = reinterpret_cast<int *>(rr + kSgCap);       // [3][kSgQueueChunk]: output row, first entry, length of the chunk's users
     for (;;) {
         if (w_next >= w_end) {
-            int w0 = 0;
-            if (lane == 0) w0 = atomicAdd(a.queue, a.chunk);
-            w_next = w_base = readfirst_i(w0);
-            if (w_next >= a.n_rows) break;
-            w_end = min(w_next + a.chunk, a.n_rows);
+            int c0 = 0;
+            if (lane == 0) c0 = atomicAdd(a.queue, 1);
+            const int c = readfirst_i(c0);
+            if (c >= a.n_claims) break;
+            // A claim's users are STRIDED through the work order -- positions c, c + n_claims, ...: with the order longest
+            // first, one user of every length quantile.  (Consecutive positions gave a wave four of the longest users in a
+            // row: the pass then lasted as long as those four -- 909 users of 257..512 items among 127,723 shorter ones took
+            // it from 1.11 to 1.53 ms, tools/seg_class_probe.py.)
             // the chunk's row pointers in one go: three dependent loads per chunk instead of three per user
-            if (w_next + lane < w_end) {
-                const int c_row = a.order ? a.order[w_next + lane] : w_next + lane;
+            const int pos = c + lane * a.n_claims;
+            const bool ok = lane < a.chunk && pos < a.n_rows;
+            if (ok) {
+                const int c_row = a.order ? a.order[pos] : pos;
                 const int xr = a.row_ids ? a.row_ids[c_row] : c_row;
                 int c_a0 = 0, c_na = 0;
                 if (xr >= 0 && xr < a.n_x_rows) { c_a0 = a.xb_ptr[xr]; c_na = a.xb_ptr[xr + 1] - c_a0; }      // anything else: an empty row
                 claimed[lane] = c_row; claimed[kSgQueueChunk + lane] = c_a0; claimed[2 * kSgQueueChunk + lane] = c_na;
             }
+            w_next = 0;
+            w_end = static_cast<int>(__builtin_popcountll(__ballot(ok)));      // (the valid positions are the leading lanes)
         }
         const int p = w_next++;
-        const int row = readfirst_i(claimed[p - w_base]);
-        const int a0 = readfirst_i(claimed[kSgQueueChunk + p - w_base]);
-        const int n_a = readfirst_i(claimed[2 * kSgQueueChunk + p - w_base]);
+        const int row = readfirst_i(claimed[p]);
+        const int a0 = readfirst_i(claimed[kSgQueueChunk + p]);
+        const int n_a = readfirst_i(claimed[2 * kSgQueueChunk + p]);
         const bool in_lds = n_a <= kSgCap;
         if (a.xs && n_a > a.heavy_min) continue;          // a long user: score_seg_heavy_kernel takes it, one workgroup per user
         SP_MARK(SP_CLAIM) SP_ADD(SP_JOBS, 1)
@@ -523,6 +535,15 @@ __global__ __launch_bounds__(kSgWaves * 64, SG_OCC) void score_seg_kernel(SegArg
 // user rates it -- the tiles are dealt to the workgroup's waves in descending bound order, every wave keeps a list of its
 // own (the best (k+1)-th score any wave has reached is shared through LDS and prunes for all), and wave 0 merges the
 // lists.  The user's own columns are flag bytes fl[layout column], tested when a tile is read back.
+//
+// LIST PATH (round 4): a user of up to kSgCap items keeps its items in LDS lists like the wave-per-user kernel -- no
+// scatter into xs, no flag bytes, nothing to restore -- but the workgroup's waves share them: the setup chunks (items ->
+// row of W / layout column, bound rows) are dealt to the waves and an opened tile is accumulated by ONE wave from the
+// user's side (its rows in ascending item order: scipy's order, bit-identical sums), the tiles dealt to the waves in
+// descending bound order.  Why: a full pass is as long as its longest single-wave user -- a 257..512-item user is a chain
+// of ~200 dependent L2 round trips (15 opened tiles x (segment pointers + records) per 64-row chunk), ~1.7 ms under load;
+// the 127,723 users of up to 256 items take 1.11 ms, adding 909 users of 257..512 items made it 1.53 ms, all 9,097 of
+// them 1.72 ms (tools/seg_class_probe.py).  With the workgroup the chain is the setup / 8 + two tiles.
 __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -536,6 +557,9 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
     float *lst_s = bred + nw * 128;                                                         // [nw][64] the waves' lists
     int *lst_c = reinterpret_cast<int *>(lst_s + nw * 64);
     int *shared = lst_c + nw * 64;                  // [0]: bits of the best full-list theta (> 0) any wave has reached
+    float *t_rx = reinterpret_cast<float *>(shared + 16);      // list path: rating, layout column (-1: none), row of W (-1: none)
+    int *t_lcl = reinterpret_cast<int *>(t_rx + kSgCap);       // of the user's idx-th item, shared by the waves
+    int *t_rr = t_lcl + kSgCap;
     const vf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int kk = a.kk;
     const unsigned long long kkmask = kk >= 64 ? ~0ull : ((1ull << kk) - 1ull);
@@ -559,21 +583,25 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
             continue;
         }
         if (threadIdx.x == 0) shared[0] = 0;
-        // ---- 1. scatter the ratings / flags, partial bounds per wave
+        const bool lists = n_a <= kSgCap;           // list path (uniform)
+        // ---- 1. scatter the ratings / flags (list path: fill the LDS lists), partial bounds per wave
         float B0 = 0.0f, B1 = 0.0f;
         for (int base = wave * 64; base < n_a; base += stride) {
             const int idx = base + lane;
-            int r = -1;
+            int r = -1, lc = -1;
             float x = 0.0f;
             if (idx < n_a) {
                 const int item = a.xb_col[a0 + idx];
                 x = a.xb_val[a0 + idx];
                 if (item < a.n_items) {
                     const int2 f = a.info[item];
-                    r = f.x;
-                    if (r >= 0) xs[item] = x;
-                    if (a.filter && f.y >= 0) fl[f.y] = 1;
+                    r = f.x; lc = f.y;
+                    if (!lists) {
+                        if (r >= 0) xs[item] = x;
+                        if (a.filter && f.y >= 0) fl[f.y] = 1;
+                    }
                 }
+                if (lists) { t_rx[idx] = x; t_lcl[idx] = lc; t_rr[idx] = r; }
             }
             sg_add_bounds(bnd, r, x, B0, B1);
         }
@@ -597,6 +625,29 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
             if (th > ninf && bmax * slack < th) break;
             if ((rank++ % nw) != wave) continue;
             const int t0 = t * T;
+            if (lists) {
+                // the user's side: its own columns leave the race (-inf absorbs), then its rows of W in ascending item order
+                const int ncol = min(T, a.n_cols - t0);
+                if (a.filter) {
+                    for (int idx = lane; idx < n_a; idx += 64) {
+                        const int lc = t_lcl[idx] < 0 ? -1 : t_lcl[idx] - t0;
+                        if (lc >= 0 && lc < ncol) acc[lc] = ninf;
+                    }
+                }
+                for (int idx = lane; idx - lane < n_a; idx += 64) {
+                    int s = 0, e = 0;
+                    float x = 0.0f;
+                    const int r = idx < n_a ? t_rr[idx] : -1;
+                    if (r >= 0) {
+                        x = t_rx[idx];
+                        const int *pp = a.seg_ptr + static_cast<size_t>(r) * (a.n_tiles + 1) + t;
+                        s = pp[0]; e = pp[1];
+                    }
+                    if (T == 256) sg_accumulate256(acc, went, s, e, x);
+                    else sg_accumulate<8>(acc, went, s, e, x);
+                }
+                sg_scan_tile(acc4, T, t0, L, kk, kkmask, nullptr, floor);
+            } else {
             const int i1 = a.trow_ptr[t + 1];
             for (int i0 = a.trow_ptr[t]; i0 < i1; i0 += 64) {
                 const int i = i0 + lane;
@@ -611,6 +662,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
                 else sg_accumulate<8>(acc, went, s, e, x);
             }
             sg_scan_tile(acc4, T, t0, L, kk, kkmask, a.filter ? fl + t0 : nullptr, floor);
+            }
             if (L.n >= kk && L.theta > 0.0f && lane == 0) atomicMax(shared, __float_as_int(L.theta));
         }
         // ---- 3. merge the waves' lists in wave 0, emit
@@ -630,8 +682,8 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
             }
             sg_emit(a, L, row);
         }
-        // ---- 4. restore the scratch invariants (all zero)
-        for (int base = wave * 64; base < n_a; base += stride) {
+        // ---- 4. restore the scratch invariants (all zero; the list path has touched none)
+        for (int base = wave * 64; base < n_a && !lists; base += stride) {
             const int idx = base + lane;
             if (idx < n_a) {
                 const int item = a.xb_col[a0 + idx];
