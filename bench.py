@@ -240,10 +240,10 @@ def main() -> None:
                          "followed by a 100-user recommend_batch, on a model bulk-fitted at the same workload shape (0 = skip)")
     ap.add_argument("--score-shard", default="auto", choices=["auto", "columns", "rows"],
                     help="multi-GPU scoring: item-column shards of W + list exchange (BASELINE.json's configuration), or "
-                         "user-row shards with W replicated.  auto = by the shape of the fitted W: at most 128 non-empty rows "
-                         "(feature-row kernel: a pass costs per user, not per column) -> rows; a general W (segment kernel: a rank "
-                         "opens only its own tiles) -> columns (DESIGN.md section 6); the other division is timed right after and "
-                         "reported as `alt_sharding`, and the line says which was chosen and why (`score_shard_choice`)")
+                         "user-row shards with W replicated.  auto = rows unless W is too large to replicate (the single-GPU shard "
+                         "models of round 4 favour rows for the feature-row AND the segment kernel: DESIGN.md section 6); the other "
+                         "division is timed right after and reported as `alt_sharding`, and the line says which was chosen and why "
+                         "(`score_shard_choice`)")
     ap.add_argument("--shard-w", action="store_true",
                     help="multi-GPU, column shards: every rank fits and KEEPS only its own column block of W (no all-gather of the "
                          "coefficients; SlimEngine.shard_w).  Implies --score-shard columns and no alt_sharding leg")
@@ -345,19 +345,27 @@ def main() -> None:
     # layouts are tensor ops there; the host copies below only feed this script's bookkeeping
     t1 = time.time()
     dw_fit = eng.merge_fit(None, I, False, d_tg, d_items, d_coef, d_count)
-    # --score-shard auto: the division follows the layout W gets.  A W with at most 128 non-empty rows is scored by the
-    # feature-row kernel, whose cost is per USER (row setup, the heavy tiles every user needs) -- dividing the columns leaves
-    # a rank 1.38 of 1.41 ms (tools/shard_model.py) -> divide the users.  A general W is scored by the segment kernel, where a
-    # rank opens only its own shard's tiles -> the item-column shard of BASELINE.json divides the work.
+    # --score-shard auto: by what one rank's share of the pass costs (tools/shard_model.py on one GPU, round 4,
+    # profiles/r04_shard_model_*.jsonl: local kernel time of the slowest rank at 1 / 2 / 4 / 8 ranks, before the exchange):
+    #   C3  (feature rows)  rows 1.73x / 2.62x / 6.92x   columns 1.17x / 1.39x / 1.58x
+    #   c3s (segments)      rows 1.82x / 1.75x / 2.69x   columns 1.16x / 1.20x / 1.26x
+    #   C4  (feature rows)  rows 1.90x / 2.75x / 3.54x   columns 2.13x / 2.00x / 2.00x
+    # A pass costs per USER (row setup, bound rows, the tiles every user opens) with either kernel, so dividing the users
+    # divides the work and dividing the columns mostly repeats it on every rank; W is 0.2-3 MB here, so replicating it is
+    # free.  The item-column division of BASELINE.json is the one to take when W is too large to replicate (auto: more than
+    # 2^28 stored weights, 3 GB of layouts per rank) -- then with --shard-w semantics (SlimEngine.shard_w).
     w_rows = int(torch.unique(dw_fit.rows).numel()) if dw_fit.nnz else 0
-    shard_choice = {"mode": args.score_shard, "chosen_by": "flag", "w_rows": w_rows}
+    shard_choice = {"mode": args.score_shard, "chosen_by": "flag", "w_rows": w_rows, "w_nnz": int(dw_fit.nnz)}
     if shard_auto:
-        args.score_shard = "rows" if w_rows <= 128 else "columns"
+        big_w = dw_fit.nnz > (1 << 28)
+        args.score_shard = "columns" if big_w else "rows"
         eng.score_shard = args.score_shard
-        shard_choice = {"mode": args.score_shard, "chosen_by": "auto", "w_rows": w_rows,
-                        "why": ("W has <= 128 non-empty rows: feature-row kernel, cost per user -> user-row shards, W replicated"
-                                if w_rows <= 128 else
-                                "general W (segment kernel): a rank opens only the tiles of its own columns -> item-column shards")}
+        shard_choice = {"mode": args.score_shard, "chosen_by": "auto", "w_rows": w_rows, "w_nnz": int(dw_fit.nnz),
+                        "layout": "feature rows" if w_rows <= 128 else "segments",
+                        "why": ("W too large to replicate: item-column shards" if big_w else
+                                "a pass costs per user with either kernel and W is small enough to replicate: user-row shards "
+                                "(one rank's share at 8 ranks, single-GPU model: C3 6.9x rows / 1.6x columns, c3s 2.7x / 1.3x, "
+                                "C4 3.5x / 2.0x; profiles/r04_shard_model_*.jsonl)")}
     eng.set_weights(dw_fit)
     torch.cuda.synchronize()
     merge_s = time.time() - t1

@@ -288,6 +288,154 @@ int64_t slim_oracle_fit_columns(int32_t n_users, int32_t n_items,
     return pos;
 }
 
+/* ---- optim="sgd": scikit-learn SGDRegressor as slim_elastic.py:209-222 configures it ----------------------------
+ * SGDRegressor(loss="squared_error", penalty="elasticnet", alpha, l1_ratio, fit_intercept=False, max_iter, tol,
+ * random_state, learning_rate="invscaling", eta0, average=False) with the defaults power_t=0.25, shuffle=True,
+ * early_stopping=False, n_iter_no_change=5 -> sklearn/linear_model/_stochastic_gradient.py:1664-1734 (_fit_regressor) ->
+ * sklearn/linear_model/_sgd_fast.pyx.tp:_plain_sgd32 (X is float32, so coef_ is: _stochastic_gradient.py:227,1701) with
+ * WeightVector32 (sklearn/utils/_weight_vector.pyx.tp: float weights, DOUBLE wscale, reset threshold 1e-6),
+ * CSRDataset32.shuffle (sklearn/utils/_seq_dataset.pyx.tp:137-145: Fisher-Yates with our_rand_r, the SAME seed value every
+ * epoch, applied to the order the previous epoch left) and CyHalfSquaredError (sklearn/_loss/_loss.pyx.tp:310-321).
+ * Every expression below keeps the C types the Cython source gives it (float products, double accumulators, float
+ * parameters of scale() / add()).  X: CSR rows over the K selected features, entries in ascending feature position.
+ * w[n_features] zero on entry.  Returns n_iter_ (epochs run), or -1 on a non-finite weight (sklearn raises ValueError). */
+int32_t slim_oracle_sgd(int32_t n_samples, int32_t n_features,
+                        const float *X_data, const int32_t *X_indices, const int32_t *X_indptr, const float *y,
+                        double alpha, double l1_ratio, double eta0, double power_t, double tol, int32_t max_iter,
+                        uint32_t seed, float *w)
+{
+    float *q = (float *)calloc((size_t)(n_features > 0 ? n_features : 1), sizeof(float));
+    int32_t *index = (int32_t *)malloc((size_t)(n_samples > 0 ? n_samples : 1) * sizeof(int32_t));
+    for (int32_t i = 0; i < n_samples; i++) index[i] = i;
+    double wscale = 1.0, u = 0.0, t = 1.0, best_loss = INFINITY, eta = eta0;
+    const double intercept = 0.0;
+    int no_improvement_count = 0, infinity = 0;
+    const unsigned int train_count = (unsigned int)n_samples;
+    int32_t epoch = 0;
+    for (epoch = 0; epoch < max_iter; epoch++) {
+        double sumloss = 0.0;
+        {   /* dataset.shuffle(seed): seed is passed by value */
+            uint32_t s = seed;
+            for (int32_t i = 0; i < n_samples - 1; i++) {
+                const int32_t j = i + (int32_t)(slim_oracle_rand_r(&s) % (uint32_t)(n_samples - i));
+                const int32_t tmp = index[i]; index[i] = index[j]; index[j] = tmp;
+            }
+        }
+        for (int32_t i = 0; i < n_samples; i++) {
+            const int32_t si = index[i];
+            const float *xd = X_data + X_indptr[si];
+            const int32_t *xi = X_indices + X_indptr[si];
+            const int32_t xnnz = X_indptr[si + 1] - X_indptr[si];
+            const float yv = y[si];
+            /* p = w.dot(x) + intercept: float products, double sum, the float return value of dot() */
+            double innerprod = 0.0;
+            for (int32_t j = 0; j < xnnz; j++) innerprod += w[xi[j]] * xd[j];
+            innerprod *= wscale;
+            const double p = (double)(float)innerprod + intercept;
+            eta = eta0 / pow(t, power_t);
+            sumloss += 0.5 * (p - (double)yv) * (p - (double)yv);
+            double dloss = p - (double)yv;
+            if (dloss < -1e12) dloss = -1e12; else if (dloss > 1e12) dloss = 1e12;
+            double update = -eta * dloss;
+            { const float class_weight = 1.0f, sample_weight = 1.0f; update *= class_weight * sample_weight; }
+            {   /* w.scale(max(0, 1.0 - ((1.0 - l1_ratio) * eta * alpha))): the argument becomes a float parameter */
+                const double a = 1.0 - ((1.0 - l1_ratio) * eta * alpha);
+                const float c = (float)(a > 0.0 ? a : 0.0);
+                wscale *= c;
+                if (wscale < 1e-6) {                 /* reset_wscale: sscal with a float alpha */
+                    const float ws = (float)wscale;
+                    for (int32_t f = 0; f < n_features; f++) w[f] = ws * w[f];
+                    wscale = 1.0;
+                }
+            }
+            if (update != 0.0) {                     /* w.add(x, update): c and the local wscale are floats */
+                const float c = (float)update, wsf = (float)wscale;
+                for (int32_t j = 0; j < xnnz; j++) {
+                    const double val = xd[j];
+                    w[xi[j]] = (float)((double)w[xi[j]] + val * (double)(c / wsf));
+                }
+            }
+            u += (l1_ratio * eta * alpha);
+            for (int32_t j = 0; j < xnnz; j++) {     /* l1penalty32 (truncated gradient) */
+                const int32_t idx = xi[j];
+                const double z = w[idx];
+                if (wscale * z > 0.0) {
+                    const double v = (double)w[idx] - ((u + (double)q[idx]) / wscale);
+                    w[idx] = (float)(v > 0.0 ? v : 0.0);
+                } else if (wscale * z < 0.0) {
+                    const double v = (double)w[idx] + ((u - (double)q[idx]) / wscale);
+                    w[idx] = (float)(v < 0.0 ? v : 0.0);
+                }
+                q[idx] = (float)((double)q[idx] + wscale * ((double)w[idx] - z));
+            }
+            t += 1.0;
+        }
+        for (int32_t f = 0; f < n_features; f++) if (!isfinite(w[f])) infinity = 1;
+        if (infinity) break;
+        if (tol > -INFINITY && sumloss > best_loss - tol * train_count) no_improvement_count++;
+        else no_improvement_count = 0;
+        if (sumloss < best_loss) best_loss = sumloss;
+        if (no_improvement_count >= 5) break;        /* n_iter_no_change; learning_rate is not "adaptive" */
+    }
+    {   const float ws = (float)wscale;              /* w.reset_wscale() */
+        for (int32_t f = 0; f < n_features; f++) w[f] = ws * w[f];
+    }
+    free(index); free(q);
+    if (infinity) return -1;
+    return (epoch < max_iter ? epoch : max_iter - 1) + 1;
+}
+
+/* One target column with optim="sgd" behind FeatureSelectionWrapper (slim_elastic.py:139-154): the same X^T y / top-K
+ * selection as the coordinate-descent path, X[:, sel] converted to CSR (check_array(accept_sparse="csr") on the CSC slice:
+ * a row's entries come out in ascending position of the selected features), then slim_oracle_sgd.  The zeroed target
+ * column's explicit zeros change no state (products, updates and penalties of 0) and are dropped.  Output: the K selected
+ * items ascending with their coefficients, explicit zeros kept (:153). */
+int32_t slim_oracle_fit_column_sgd(int32_t n_users, int32_t n_items,
+                                   const float *X_data, const int32_t *X_indices, const int32_t *X_indptr,
+                                   int32_t j, double alpha, double l1_ratio, double eta0, double tol,
+                                   int32_t max_iter, uint32_t seed, int32_t top_features,
+                                   int32_t *out_idx, float *out_val, int32_t *n_iter_out)
+{
+    if (top_features <= 0) return -1;     /* the reference itself fails without nn_feature_selection (no sparse_coef_) */
+    float *y = (float *)calloc((size_t)n_users, sizeof(float));
+    for (int32_t jj = X_indptr[j]; jj < X_indptr[j + 1]; jj++) y[X_indices[jj]] = X_data[jj];
+    float *scores = (float *)malloc((size_t)n_items * sizeof(float));
+    int32_t *sel = (int32_t *)malloc((size_t)n_items * sizeof(int32_t));
+    slim_oracle_feature_scores(n_items, X_data, X_indices, X_indptr, y, j, scores);
+    const int32_t K = slim_oracle_select_topk(n_items, scores, top_features, sel);
+    int32_t *Rp = (int32_t *)calloc((size_t)n_users + 1, sizeof(int32_t));
+    int64_t nnz = 0;
+    for (int32_t p = 0; p < K; p++) {
+        if (sel[p] == j) continue;
+        for (int32_t jj = X_indptr[sel[p]]; jj < X_indptr[sel[p] + 1]; jj++) { Rp[X_indices[jj] + 1]++; nnz++; }
+    }
+    for (int32_t r = 0; r < n_users; r++) Rp[r + 1] += Rp[r];
+    float *Rd = (float *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(float));
+    int32_t *Ri = (int32_t *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int32_t));
+    int32_t *fill = (int32_t *)malloc((size_t)(n_users > 0 ? n_users : 1) * sizeof(int32_t));
+    memcpy(fill, Rp, (size_t)n_users * sizeof(int32_t));
+    for (int32_t p = 0; p < K; p++) {           /* ascending feature position -> sorted rows */
+        if (sel[p] == j) continue;
+        for (int32_t jj = X_indptr[sel[p]]; jj < X_indptr[sel[p] + 1]; jj++) {
+            const int32_t r = X_indices[jj];
+            Rd[fill[r]] = X_data[jj]; Ri[fill[r]] = p; fill[r]++;
+        }
+    }
+    float *w = (float *)calloc((size_t)(K > 0 ? K : 1), sizeof(float));
+    const int32_t n_iter = slim_oracle_sgd(n_users, K, Rd, Ri, Rp, y, alpha, l1_ratio, eta0, 0.25, tol, max_iter, seed, w);
+    if (n_iter_out) *n_iter_out = n_iter;
+    fs_pair *o = (fs_pair *)malloc((size_t)(K > 0 ? K : 1) * sizeof(fs_pair));
+    for (int32_t p = 0; p < K; p++) { o[p].s = w[p]; o[p].i = sel[p]; }
+    for (int32_t a = 1; a < K; a++) {
+        fs_pair t = o[a]; int32_t b = a - 1;
+        while (b >= 0 && o[b].i > t.i) { o[b + 1] = o[b]; b--; }
+        o[b + 1] = t;
+    }
+    for (int32_t p = 0; p < K; p++) { out_idx[p] = o[p].i; out_val[p] = o[p].s; }
+    free(o); free(w); free(fill); free(Ri); free(Rd); free(Rp); free(sel); free(scores); free(y);
+    return K;
+}
+
 /* ---- scipy sparsetools csr_matmat, one row ------------------------------------------- */
 #define DEFINE_SCORE_ROW(NAME, T)                                                              \
 int32_t NAME(int32_t n_a, const int32_t *a_idx, const float *a_val,                            \

@@ -156,6 +156,20 @@ int32_t slim_oracle_recommend_batch_mt(int32_t n_rows, const int32_t *Xb_indptr,
                                        int32_t use_f64,
                                        int32_t *ids, float *scores, int32_t *counts, int32_t n_threads);
 
+/* optim="sgd" (slim_elastic.py:209-222): sklearn/linear_model/_sgd_fast.pyx.tp _plain_sgd32 as SGDRegressor(loss="squared_error",
+ * penalty="elasticnet", learning_rate="invscaling", fit_intercept=False, average=False) runs it; CSR rows over the selected
+ * features.  Returns n_iter_ (epochs), -1 on a non-finite weight. */
+int32_t slim_oracle_sgd(int32_t n_samples, int32_t n_features,
+                        const float *X_data, const int32_t *X_indices, const int32_t *X_indptr, const float *y,
+                        double alpha, double l1_ratio, double eta0, double power_t, double tol, int32_t max_iter,
+                        uint32_t seed, float *w);
+/* FeatureSelectionWrapper(SGDRegressor).fit for one target column (slim_elastic.py:139-154); -1 without feature selection */
+int32_t slim_oracle_fit_column_sgd(int32_t n_users, int32_t n_items,
+                                   const float *X_data, const int32_t *X_indices, const int32_t *X_indptr,
+                                   int32_t j, double alpha, double l1_ratio, double eta0, double tol,
+                                   int32_t max_iter, uint32_t seed, int32_t top_features,
+                                   int32_t *out_idx, float *out_val, int32_t *n_iter_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -68,6 +68,10 @@ def lib() -> C.CDLL:
         L.slim_oracle_recommend_batch.argtypes = [C.c_int32, _i32p, _i32p, _f32p, _i32p, _i32p, _f32p,
                                                   C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                   _i32p, _f32p, _i32p]
+        L.slim_oracle_fit_column_sgd.restype = C.c_int32
+        L.slim_oracle_fit_column_sgd.argtypes = [C.c_int32, C.c_int32, _f32p, _i32p, _i32p, C.c_int32, C.c_double, C.c_double,
+                                                 C.c_double, C.c_double, C.c_int32, C.c_uint32, C.c_int32, _i32p, _f32p,
+                                                 C.POINTER(C.c_int32)]
         L.slim_oracle_fit_columns_mt.restype = C.c_int32
         L.slim_oracle_fit_columns_mt.argtypes = [C.c_int32, C.c_int32, _f32p, _i32p, _i32p, C.c_int32, _i32p,
                                                  C.c_double, C.c_double, C.c_double, C.c_int32, C.c_uint32,
@@ -111,6 +115,30 @@ def cd(X_csc, y: np.ndarray, alpha=0.1, l1_ratio=0.1, tol=1e-4, max_iter=100,
     n_iter = lib().slim_oracle_cd(n_samples, n_features, d, i, p, np.ascontiguousarray(y, dtype=np.float32),
                                   C.byref(cfg), w, R, XtA, C.byref(gap))
     return w[:n_features], float(gap.value), int(n_iter)
+
+
+def fit_columns_sgd(X_csc, cols, alpha=0.1, l1_ratio=0.1, eta0=0.001, tol=1e-4, max_iter=100, random_state=43,
+                    nn_feature_selection=None):
+    """optim="sgd" behind FeatureSelectionWrapper (slim_elastic.py:139-154, 209-222): per target column the K selected items
+    (ascending) with SGDRegressor's coef_, and its n_iter_ (epochs): (ptr, idx, val, n_iter)."""
+    U, I = X_csc.shape
+    d, i, p = _csc(X_csc)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    if nn_feature_selection is None:
+        raise AttributeError("'SGDRegressor' object has no attribute 'sparse_coef_'")     # what the reference does (:273)
+    K = min(int(nn_feature_selection), I)
+    ptr = np.zeros(len(cols) + 1, dtype=np.int64)
+    idx = np.empty((len(cols), K), dtype=np.int32)
+    val = np.empty((len(cols), K), dtype=np.float32)
+    nit = np.zeros(len(cols), dtype=np.int32)
+    for t, j in enumerate(cols.tolist()):
+        it = C.c_int32(0)
+        n = lib().slim_oracle_fit_column_sgd(U, I, d, i, p, int(j), alpha, l1_ratio, eta0, tol, max_iter,
+                                             sklearn_seed(random_state), K, idx[t], val[t], C.byref(it))
+        assert n == K
+        nit[t] = it.value
+        ptr[t + 1] = ptr[t] + K
+    return ptr, idx.reshape(-1), val.reshape(-1), nit
 
 
 def fit_columns(X_csc, cols, alpha=0.1, l1_ratio=0.1, tol=1e-4, max_iter=100, random_state=43,

@@ -498,7 +498,61 @@ def gen_hybrid_calls():
     print("[golden] hybrid call sequence recorded")
 
 
+# ------------------------------------------------------------------ N4: optim="sgd" (slim_elastic.py:209-222)
+def gen_sgd():
+    """SLIMElastic({"optim": "sgd", "nn_feature_selection": K, ...}) of the real reference (scikit-learn SGDRegressor behind
+    FeatureSelectionWrapper): whole models (CSC arrays, float32 values of the float64 matrix) plus SGDRegressor.n_iter_ of every
+    column (the reference does not keep it: the column loop of slim_elastic.py:261-277 is replayed with its own wrapper), a
+    partial_fit_items on top (stale / replaced entries), and the failure without feature selection (:273).  Inputs are the
+    seeded synthetic matrices of rtrec_amd.synth (regenerated by the tests), float ratings."""
+    from sklearn.linear_model import SGDRegressor  # noqa: F401
+    out = {"cases": []}
+    cases = [dict(U=300, I=40, draws=3000, seed=3, cfg={"nn_feature_selection": 8}),
+             dict(U=1200, I=200, draws=30000, seed=3, cfg={"nn_feature_selection": 20}),
+             dict(U=2500, I=300, draws=90000, seed=5, cfg={"nn_feature_selection": 50, "alpha": 0.01, "eta0": 0.01}),
+             dict(U=800, I=120, draws=20000, seed=7, cfg={"nn_feature_selection": 10, "max_iter": 7}),
+             dict(U=900, I=150, draws=24000, seed=11, cfg={"nn_feature_selection": 64, "l1_ratio": 0.5, "tol": 1e-3, "random_state": 7})]
+    for c in cases:
+        X = interaction_matrix(c["U"], c["I"], c["draws"], seed=c["seed"]).tocsc()
+        X.sort_indices()
+        cfg = dict(c["cfg"], optim="sgd")
+        m = RefSLIMElastic(dict(cfg))
+        m.fit(X.copy())
+        W = m.item_similarity.tocsc()
+        W.sort_indices()
+        n_iter = []
+        for j in range(c["I"]):
+            model = m.get_model()
+            Xm = X.copy()
+            y = Xm.getcol(j).toarray().ravel()
+            Xm.data[Xm.indptr[j]:Xm.indptr[j + 1]] = 0
+            model.fit(Xm, y)
+            n_iter.append(int(model.model.n_iter_))
+        rec = dict(c, W_dtype=str(W.dtype), W_indptr=W.indptr.tolist(), W_indices=W.indices.tolist(),
+                   W_bits=np.ascontiguousarray(W.data, dtype=np.float32).view(np.uint32).tolist(),
+                   W_is_float32_valued=bool(np.array_equal(W.data, W.data.astype(np.float32).astype(W.dtype))), n_iter=n_iter)
+        if c["I"] == 120:        # an incremental refit on top (float32 branch of partial_fit_items, stale entries survive)
+            items = [3, 4, 50, 119]
+            m.partial_fit_items(X.copy(), items)
+            W2 = m.item_similarity.tocsc()
+            W2.sort_indices()
+            rec.update(partial_items=items, W2_dtype=str(W2.dtype), W2_indptr=W2.indptr.tolist(), W2_indices=W2.indices.tolist(),
+                       W2_bits=np.ascontiguousarray(W2.data, dtype=np.float32).view(np.uint32).tolist())
+        out["cases"].append(rec)
+        print(f"[golden] sgd {c['U']}x{c['I']} K={cfg['nn_feature_selection']}: W nnz {W.nnz} dtype {W.dtype}, epochs {min(n_iter)}..{max(n_iter)}")
+    try:
+        RefSLIMElastic({"optim": "sgd"}).fit(interaction_matrix(60, 12, 300, seed=1).tocsc())
+        out["no_feature_selection"] = None
+    except Exception as e:          # the reference itself fails here: SGDRegressor has no sparse_coef_
+        out["no_feature_selection"] = {"type": type(e).__name__, "message": str(e)}
+    json.dump(out, open(os.path.join(OUT, "sgd.json"), "w"))
+    print("[golden] sgd.json", os.path.getsize(os.path.join(OUT, "sgd.json")), out["no_feature_selection"])
+
+
 if __name__ == "__main__":
+    if "--sgd" in sys.argv:
+        gen_sgd()
+        sys.exit(0)
     if "--hybrid" in sys.argv:
         gen_hybrid_calls()
         sys.exit(0)
