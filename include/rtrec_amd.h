@@ -569,6 +569,43 @@ int rtrec_store_fold_device(const int64_t *d_order, const int64_t *d_start, int6
                             const double *d_delta, const double *d_tstamp, const double *d_old, double lo, double hi,
                             int32_t upsert, double *d_out_val, double *d_out_ts, float *d_out_val32, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * FIT with optim="sgd"  (replaces scikit-learn's SGDRegressor as slim_elastic.py:209-222 configures it, behind
+ * FeatureSelectionWrapper slim_elastic.py:139-154: sklearn/linear_model/_sgd_fast.pyx.tp _plain_sgd32, float32 weights,
+ * squared loss, elastic-net penalty with the truncated-gradient L1, invscaling learning rate, shuffle=True, n_iter_no_change=5).
+ * The feature selection is rtrec_slim_fit_columns with max_iter = 1 (its item lists, in selection order); the solver runs in
+ * blocks of epochs:
+ *
+ * rtrec_slim_sgd_schedule -- HOST routine, host pointers: everything of the solver that does not depend on the target, for
+ * the next n_epochs epochs.  sample_order[n_samples] in/out (identity before epoch 0), state[3] in/out = {wscale, u, t}
+ * ({1, 0, 1} before epoch 0).  Out: time_of[n_epochs][n_samples] = position of sample i in the epoch's shuffled order
+ * (_seq_dataset.pyx.tp:137-145, our_rand_r, the same seed value every epoch); per global step g of the block eta[g],
+ * the weight scale before / after the step's WeightVector32.scale(), the cumulative L1 penalty u after the step;
+ * reset_cnt[n_epochs * n_samples + 1] = number of reset_wscale() calls at steps < g and reset_mult[] their float factors in
+ * order (RTREC_ERR_WORKSPACE when more than reset_cap).
+ *
+ * rtrec_slim_fit_sgd_epochs -- device pointers: runs those epochs for every unfinished target.  d_ttime / d_tval
+ * [n_epochs][nnz]: per epoch, the entries of every column of X (CSC order of the columns, d_csc_ptr) sorted by time_of[row],
+ * as (time, value).  d_sel[n_targets][cap] / d_sel_count: the selected features in selection order.  State across blocks:
+ * d_w, d_q [n_targets][cap] (zero before the first block), d_best_loss (+inf), d_no_improve (0), d_n_iter (0 = running; set
+ * to n_iter_ when the target stops, -1 on a non-finite weight: scikit-learn raises ValueError there).  d_unfinished[1]
+ * receives the number of targets still running.  cap <= 64.  When a target stops, d_w holds its coef_.
+ * ------------------------------------------------------------------------------------- */
+int rtrec_slim_sgd_schedule(int32_t n_samples, int32_t n_epochs, uint32_t seed,
+                            double alpha, double l1_ratio, double eta0, double power_t,
+                            int32_t *sample_order, double *state,
+                            int32_t *time_of, double *eta, double *ws_before, double *ws_after, double *u_after,
+                            int32_t *reset_cnt, float *reset_mult, int32_t reset_cap, int32_t *n_resets);
+int rtrec_slim_fit_sgd_epochs(int32_t n_users, int32_t n_items, const int32_t *d_csc_ptr,
+                              const int32_t *d_ttime, const float *d_tval, int64_t nnz,
+                              const int32_t *d_targets, int32_t n_targets,
+                              const int32_t *d_sel, const int32_t *d_sel_count, int32_t cap,
+                              int32_t first_epoch, int32_t n_epochs, int32_t max_iter, double tol,
+                              const double *d_eta, const double *d_ws_before, const double *d_ws_after,
+                              const double *d_u_after, const int32_t *d_reset_cnt, const float *d_reset_mult,
+                              float *d_w, float *d_q, double *d_best_loss, int32_t *d_no_improve,
+                              int32_t *d_n_iter, int32_t *d_unfinished, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,6 +34,8 @@ EXPORTS = [
     "rtrec_slim_seg_fill",
     "rtrec_slim_refine_topk_f64",
     "rtrec_slim_score_candidates",
+    "rtrec_slim_sgd_schedule",
+    "rtrec_slim_fit_sgd_epochs",
 ]
 
 
@@ -163,6 +165,12 @@ def load() -> C.CDLL:
                                              vp, vp, vp, vp, vp, vp]
     L.rtrec_slim_score_candidates.restype = C.c_int
     L.rtrec_slim_score_candidates.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.rtrec_slim_sgd_schedule.restype = C.c_int
+    L.rtrec_slim_sgd_schedule.argtypes = [i32, i32, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp,
+                                          vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.rtrec_slim_fit_sgd_epochs.restype = C.c_int
+    L.rtrec_slim_fit_sgd_epochs.argtypes = [i32, i32, vp, vp, vp, C.c_int64, vp, i32, vp, vp, i32, i32, i32, i32, C.c_double,
+                                            vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtrec_store_fold_device.restype = C.c_int
     L.rtrec_store_fold_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp, vp]
     _lib = L

@@ -1044,6 +1044,92 @@ class SlimEngine:
                     cat("count", (0,), torch.int32), d_niter.cpu().numpy())
         return targets, items_out, coef_out, count_out, niter_out
 
+    SGD_EPOCH_BLOCK_BYTES = 2 << 30   # time-sorted copies of X held at once by fit_columns_sgd (8 B per stored entry and epoch)
+
+    def fit_columns_sgd(self, targets: Sequence[int], alpha: float = 0.1, l1_ratio: float = 0.1, eta0: float = 0.001,
+                        max_iter: int = 100, tol: Optional[float] = 1e-4, random_state: Optional[int] = 43,
+                        nn_feature_selection: Optional[int] = None):
+        """optim="sgd" (slim_elastic.py:209-222): scikit-learn's SGDRegressor behind FeatureSelectionWrapper, one model per
+        target column, bit-identical coef_ and n_iter_ (csrc/fit_sgd.hip; oracle: slim_oracle_sgd).  Returns device tensors
+        (targets, items [n, K] in selection order, coef [n, K], count [n]) and n_iter (numpy) like
+        fit_columns(device_out=True).  Steps: (1) the X^T y / top-K selection of the coordinate-descent kernel (one sweep,
+        coefficients dropped); (2) per block of epochs the host schedule (shuffled sample order, learning rates, weight
+        scale, cumulative L1 penalty: target-independent) and one device sort of X's entries by (column, time); (3) the
+        solver kernel, one wave per target, until every target has stopped (n_iter_no_change = 5) or max_iter is reached.
+        The solver is strictly sequential in the samples: U x epochs dependent steps per target (the reference's cost too)."""
+        if nn_feature_selection is None:
+            # the reference itself fails here (slim_elastic.py:273: SGDRegressor has no sparse_coef_)
+            raise AttributeError("'SGDRegressor' object has no attribute 'sparse_coef_'")
+        be, X = self.be, self._X
+        U, I = self.n_users, self.n_items
+        K = min(int(nn_feature_selection), I)
+        if K <= 0:
+            raise AssertionError(f"n_neighbors must be a positive integer: {K}")
+        targets = np.asarray(targets, dtype=np.int64)
+        if not isinstance(be, HipBackend):
+            return be.fit_columns_sgd(X, U, I, targets, alpha, l1_ratio, eta0, max_iter, tol, random_state, K)
+        if K > 64:
+            raise NotImplementedError("optim='sgd' on the GPU serves nn_feature_selection <= 64 (one wave lane per feature)")
+        torch = be.torch
+        # (1) feature selection: the coordinate-descent kernel's own X^T y + top-K (its item lists come in selection order)
+        d_t, d_sel, _coef, d_cnt, _ = self.fit_columns(targets, alpha=alpha, l1_ratio=l1_ratio, positive=True, max_iter=1,
+                                                      tol=1e-4, random_state=random_state, nn_feature_selection=K,
+                                                      device_out=True, mode="exact")
+        n = int(d_t.numel())
+        cap = int(d_sel.shape[1]) if n else K
+        if n == 0:
+            return d_t, d_sel, be.empty((0, cap), torch.float32), d_cnt, np.empty(0, np.int32)
+        d_sel, d_cnt = d_sel.contiguous(), d_cnt.contiguous()
+        nnz = int(X["crow"].numel())
+        tol_ = float("-inf") if tol is None else float(tol)
+        seed = sklearn_seed(random_state)
+        col_of = torch.repeat_interleave(torch.arange(I, device=X["crow"].device, dtype=torch.int64),
+                                         (X["cptr"][1:] - X["cptr"][:-1]).long())
+        crow64 = X["crow"].long()
+        block = int(max(1, min(int(max_iter), self.SGD_EPOCH_BLOCK_BYTES // max(8 * nnz, 1), 16)))
+        d_w, d_q = be.zeros((n, cap), torch.float32), be.zeros((n, cap), torch.float32)
+        d_best = torch.full((n,), float("inf"), dtype=torch.float64, device=be.device)
+        d_noimp, d_niter = be.zeros((n,), torch.int32), be.zeros((n,), torch.int32)
+        d_unf = be.zeros((1,), torch.int32)
+        order = np.arange(U, dtype=np.int32)
+        state = np.array([1.0, 0.0, 1.0], dtype=np.float64)
+        p, hp = be.ptr, (lambda a: C.c_void_p(a.ctypes.data))
+        first = 0
+        while first < max_iter:
+            ne = min(block, max_iter - first)
+            steps = ne * U
+            time_of = np.empty((ne, U), dtype=np.int32)
+            eta, wsb, wsa, ua = (np.empty(steps, dtype=np.float64) for _ in range(4))
+            rcnt = np.empty(steps + 1, dtype=np.int32)
+            rmult = np.empty(steps + 1, dtype=np.float32)
+            n_res = C.c_int32(0)
+            _native.check(be.lib.rtrec_slim_sgd_schedule(U, ne, seed, float(alpha), float(l1_ratio), float(eta0), 0.25, hp(order),
+                                                         hp(state), hp(time_of), hp(eta), hp(wsb), hp(wsa), hp(ua), hp(rcnt),
+                                                         hp(rmult), steps + 1, C.byref(n_res)), "rtrec_slim_sgd_schedule")
+            d_time_of = be.to_dev(time_of)
+            d_tt = be.empty((ne, nnz), torch.int32)
+            d_tv = be.empty((ne, nnz), torch.float32)
+            for e in range(ne):        # every column's entries by their time in this epoch (stable in the column: keys are distinct)
+                key = col_of * U + d_time_of[e].long()[crow64]
+                skey, perm = torch.sort(key)
+                d_tt[e] = (skey % U).to(torch.int32)
+                d_tv[e] = X["cval"][perm]
+            d_eta, d_wsb, d_wsa, d_ua = (be.to_dev(a) for a in (eta, wsb, wsa, ua))
+            d_rcnt, d_rmult = be.to_dev(rcnt), be.to_dev(rmult[:max(int(n_res.value), 1)].copy())
+            _native.check(be.lib.rtrec_slim_fit_sgd_epochs(U, I, p(X["cptr"]), p(d_tt), p(d_tv), nnz, p(d_t), n, p(d_sel), p(d_cnt), cap,
+                                                           first, ne, int(max_iter), tol_, p(d_eta), p(d_wsb), p(d_wsa), p(d_ua),
+                                                           p(d_rcnt), p(d_rmult), p(d_w), p(d_q), p(d_best), p(d_noimp), p(d_niter),
+                                                           p(d_unf), be.stream()), "rtrec_slim_fit_sgd_epochs")
+            first += ne
+            if int(d_unf.item()) == 0:
+                break
+        n_iter = d_niter.cpu().numpy()
+        if (n_iter < 0).any():
+            raise ValueError("Floating-point under-/overflow occurred during the SGD fit of column "
+                             f"{int(targets[np.flatnonzero(n_iter < 0)[0]])}. Scaling input data with StandardScaler or "
+                             "MinMaxScaler might help.")
+        return d_t, d_sel, d_w, d_cnt, n_iter
+
     FIT_SLOTS_SPARSE = 1024          # targets in flight when the folded columns are sparse (see _fit_slots_for)
     FIT_SPARSE_FEATURES = 0.08       # mean density of the selected feature columns up to which FIT_SLOTS_SPARSE are used (c3s: 0.058)
     FIT_DENSE_FEATURES = 0.25        # ... and from which the full MAX_SLOTS are (C3: 0.39; C2: 0.13 -> 2048, flat there)

@@ -115,12 +115,9 @@ class SLIMElastic:
         self.__dict__.setdefault("n_iter_", None)
 
     def _check_optim(self) -> None:
-        if self.optim_name == "cd":
-            return
-        if self.optim_name == "sgd":
-            raise NotImplementedError("optim='sgd' (scikit-learn SGDRegressor) is not implemented on the GPU path; "
-                                      "use optim='cd'")
-        raise ValueError(f"Invalid Optimizer name: {self.optim_name}")
+        """slim_elastic.py:195-227: "cd" -> ElasticNet, "sgd" -> SGDRegressor, anything else raises."""
+        if self.optim_name not in ("cd", "sgd"):
+            raise ValueError(f"Invalid Optimizer name: {self.optim_name}")
 
     # ---------------------------------------------------------------- fit
     def _fit_targets(self, X_csc: sp.csc_matrix, targets: np.ndarray, keep_old: bool, f64: bool) -> None:
@@ -146,6 +143,23 @@ class SLIMElastic:
                 W = self._item_similarity
                 self._w_dev = eng.upload_weights(W if isinstance(W, sp.csc_matrix) else sp.csc_matrix(W))
             old_dev = self._w_dev
+        if self.optim_name == "sgd":
+            # scikit-learn's SGDRegressor behind FeatureSelectionWrapper (slim_elastic.py:139-154, 209-222).  Without
+            # nn_feature_selection the reference fails on the first column it fits (SGDRegressor has no sparse_coef_, :273):
+            # so does this -- unless there is nothing to fit.
+            if self.nn_feature_selection is None and len(targets) == 0:
+                kw.pop("mode", None)
+            else:
+                if old_dev is not None and old_dev.lossy:
+                    raise NotImplementedError("optim='sgd' merges into a W whose values are float32 numbers")
+                d_t, d_items, d_coef, d_count, n_iter = eng.fit_columns_sgd(
+                    mine, alpha=self.alpha, l1_ratio=self.l1_ratio, eta0=self.eta0, max_iter=self.max_iter, tol=self.tol,
+                    random_state=self.random_state, nn_feature_selection=self.nn_feature_selection)
+                self.n_iter_ = n_iter
+                self._w_dev = eng.merge_fit(old_dev, n_items, f64, d_t, d_items, d_coef, d_count)
+                self._item_similarity = None
+                eng.set_weights(self._w_dev)
+                return
         if self.nn_feature_selection is not None and (old_dev is None or not old_dev.lossy):
             d_t, d_items, d_coef, d_count, n_iter = eng.fit_columns(mine, device_out=True, **kw)
             self.n_iter_ = n_iter

@@ -155,3 +155,14 @@ class OracleBackend:
             ids[q, :len(oi)] = torch.from_numpy(oi)
             sc[q, :len(oi)] = torch.from_numpy(ov)
             cnt[q] = len(oi)
+
+    def fit_columns_sgd(self, X, n_users, n_items, targets, alpha, l1_ratio, eta0, max_iter, tol, random_state, K):
+        """optim="sgd" on the stand-in backend: the oracle's restatement per column, returned in the layout of
+        SlimEngine.fit_columns_sgd (items = the K selected features, ascending here: the merge does not care)."""
+        Xc = sp.csc_matrix((X["cval"].numpy(), X["crow"].numpy(), X["cptr"].numpy()), shape=(n_users, n_items))
+        tg = np.asarray(targets, dtype=np.int64)
+        ptr, idx, val, nit = so.fit_columns_sgd(Xc, tg, alpha=alpha, l1_ratio=l1_ratio, eta0=eta0, tol=tol, max_iter=max_iter,
+                                                random_state=random_state, nn_feature_selection=K)
+        k = min(K, n_items)
+        return (torch.from_numpy(tg.astype(np.int32)), torch.from_numpy(idx.reshape(len(tg), k).copy()),
+                torch.from_numpy(val.reshape(len(tg), k).copy()), torch.full((len(tg),), k, dtype=torch.int32), nit)

@@ -646,3 +646,45 @@ def test_fit_path_randomised_parity():
     from tools.fuzz_fit import run
     messages = []
     assert run(40, seed=5, log=messages.append) == 0, messages
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_optim_sgd_on_the_gpu_matches_the_reference(case):
+    """optim="sgd" (slim_elastic.py:209-222: scikit-learn SGDRegressor behind FeatureSelectionWrapper) on the device
+    (csrc/fit_sgd.hip): W of the serial fit and SGDRegressor.n_iter_ of every column equal the real reference's
+    (tests/golden/sgd.json), K up to 64, resets of the weight scale, max_iter reached, another seed / l1_ratio / tol."""
+    import json
+    import os
+    from rtrec_amd.models.internal.slim_elastic import SLIMElastic
+    from rtrec_amd.synth import interaction_matrix
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sgd.json")))
+    c = g["cases"][case]
+    X = interaction_matrix(c["U"], c["I"], c["draws"], seed=c["seed"]).tocsc()
+    X.sort_indices()
+
+    def golden(prefix):
+        b = np.asarray(c[f"{prefix}_bits"], dtype=np.uint32)
+        return sp.csc_matrix((b.view(np.float32), np.asarray(c[f"{prefix}_indices"]), np.asarray(c[f"{prefix}_indptr"])),
+                             shape=(c["I"], c["I"]))
+    m = SLIMElastic(dict(c["cfg"], optim="sgd"), engine=SlimEngine(device="cuda:0"))
+    m.fit(X.copy())
+    W, Wg = m.item_similarity.tocsc(), golden("W")
+    W.sort_indices()
+    assert W.dtype == np.float64
+    targets = m.engine.last_fit_targets
+    assert np.array_equal(np.sort(targets), np.arange(c["I"]))
+    got_iter = np.empty(c["I"], dtype=np.int64)
+    got_iter[targets] = m.n_iter_
+    assert got_iter.tolist() == c["n_iter"], "epochs differ from SGDRegressor.n_iter_"
+    assert np.array_equal(W.indptr, Wg.indptr) and np.array_equal(W.indices, Wg.indices)
+    assert np.array_equal(W.data.astype(np.float32).view(np.uint32), Wg.data.view(np.uint32)), "coef_ bits differ"
+    if "partial_items" in c:
+        m.partial_fit_items(X.copy(), c["partial_items"])
+        W2, W2g = m.item_similarity.tocsc(), golden("W2")
+        W2.sort_indices()
+        assert np.array_equal(W2.indptr, W2g.indptr) and np.array_equal(W2.indices, W2g.indices)
+        assert np.array_equal(W2.data.astype(np.float32).view(np.uint32), W2g.data.view(np.uint32))
+    if case == 0:
+        bad = SLIMElastic({"optim": "sgd"}, engine=m.engine)
+        with pytest.raises(AttributeError, match="sparse_coef_"):
+            bad.fit(X.copy())

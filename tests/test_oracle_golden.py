@@ -181,3 +181,41 @@ def test_midsize_long_columns(oracle):
     assert np.array_equal(np.diff(ptr), np.full(len(tg), 50))
     assert np.array_equal(idx.reshape(len(tg), 50), np.asarray(ref["features"]))
     assert np.array_equal(bits(val).reshape(len(tg), 50), np.asarray(ref["coef_bits"], dtype=np.uint32))
+
+
+def _sgd_cases():
+    return json.load(open(os.path.join(G, "sgd.json")))
+
+
+def _golden_w(c, prefix="W"):
+    bits_ = np.asarray(c[f"{prefix}_bits"], dtype=np.uint32)
+    return sp.csc_matrix((bits_.view(np.float32), np.asarray(c[f"{prefix}_indices"]), np.asarray(c[f"{prefix}_indptr"])),
+                         shape=(c["I"], c["I"]))
+
+
+@pytest.mark.parametrize("case", range(5))
+def test_sgd_oracle_matches_the_reference(oracle, case):
+    """optim="sgd" (slim_elastic.py:209-222; scikit-learn SGDRegressor behind FeatureSelectionWrapper): the oracle's restatement
+    of _plain_sgd32 reproduces the real reference's W bit for bit and SGDRegressor.n_iter_ of every column
+    (tests/golden/sgd.json, tools/gen_golden.py --sgd)."""
+    from rtrec_amd.synth import interaction_matrix
+    c = _sgd_cases()["cases"][case]
+    X = interaction_matrix(c["U"], c["I"], c["draws"], seed=c["seed"]).tocsc()
+    X.sort_indices()
+    cfg = dict(c["cfg"])
+    K = cfg.pop("nn_feature_selection")
+    assert c["W_dtype"] == "float64" and c["W_is_float32_valued"]
+    ptr, idx, val, nit = oracle.fit_columns_sgd(X, np.arange(c["I"]), nn_feature_selection=K, **cfg)
+    W = merge_coefficients(None, c["I"], idx.astype(np.int64), np.repeat(np.arange(c["I"], dtype=np.int64), np.diff(ptr)), val)
+    Wg = _golden_w(c)
+    W.sort_indices()
+    assert np.array_equal(W.indptr, Wg.indptr) and np.array_equal(W.indices, Wg.indices)
+    assert np.array_equal(W.data.view(np.uint32), Wg.data.view(np.uint32))
+    assert nit.tolist() == c["n_iter"]
+
+
+def test_sgd_without_feature_selection_fails_like_the_reference(oracle):
+    g = _sgd_cases()["no_feature_selection"]
+    assert g == {"type": "AttributeError", "message": "'SGDRegressor' object has no attribute 'sparse_coef_'"}
+    with pytest.raises(AttributeError, match="sparse_coef_"):
+        oracle.fit_columns_sgd(sp.identity(4, format="csc", dtype=np.float32), [0])

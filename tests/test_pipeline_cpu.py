@@ -547,3 +547,35 @@ def test_vectorised_recommend_batch_equals_the_per_user_loop(item_kind, monkeypa
     s = cpu_slim()
     s.fit([("a", 1, 1.7e9, 3.0), ("b", 2, 1.7e9, 2.0), ("a", 2, 1.7e9, 1.0)], progress_bar=False)
     assert s._int_user_array(["a", "b"]) is None and s._int_user_array([1, 2]) is None
+
+
+def test_optim_sgd_on_the_facade_matches_the_reference():
+    """SLIMElastic({"optim": "sgd", ...}) (slim_elastic.py:209-222) through the facade on the stand-in backend: the serial fit's
+    float64 W and the incremental refit equal the reference goldens bit for bit; without nn_feature_selection the fit fails
+    like the reference's (AttributeError at slim_elastic.py:273) unless there is nothing to fit; an unknown optimiser raises
+    ValueError (slim_elastic.py:224)."""
+    from rtrec_amd.synth import interaction_matrix
+    g = json.load(open(os.path.join(G, "sgd.json")))
+    c = next(x for x in g["cases"] if "partial_items" in x)
+    X = interaction_matrix(c["U"], c["I"], c["draws"], seed=c["seed"]).tocsc()
+    X.sort_indices()
+
+    def golden(prefix):
+        b = np.asarray(c[f"{prefix}_bits"], dtype=np.uint32)
+        return sp.csc_matrix((b.view(np.float32), np.asarray(c[f"{prefix}_indices"]), np.asarray(c[f"{prefix}_indptr"])),
+                             shape=(c["I"], c["I"]))
+    m = SLIMElastic(dict(c["cfg"], optim="sgd"), engine=SlimEngine(backend=OracleBackend()))
+    m.fit(X.copy())
+    assert m.item_similarity.dtype == np.float64 == np.dtype(c["W_dtype"])
+    assert same_matrix(m.item_similarity, golden("W")) and m.n_iter_.tolist() == c["n_iter"]
+    m.partial_fit_items(X.copy(), c["partial_items"])
+    assert m.item_similarity.dtype == np.dtype(c["W2_dtype"]) and same_matrix(m.item_similarity, golden("W2"))
+    bad = SLIMElastic({"optim": "sgd"}, engine=SlimEngine(backend=OracleBackend()))
+    with pytest.raises(AttributeError, match="'SGDRegressor' object has no attribute 'sparse_coef_'"):
+        bad.fit(X.copy())
+    with pytest.raises(AttributeError, match="sparse_coef_"):
+        bad.partial_fit_items(X.copy(), [1, 2])
+    bad.partial_fit_items(X.copy(), [])                      # nothing to fit: the reference does not fail either
+    assert bad.item_similarity.nnz == 0
+    with pytest.raises(ValueError, match="Invalid Optimizer name: bogus"):
+        SLIMElastic({"optim": "bogus"}, engine=SlimEngine(backend=OracleBackend())).fit(X.copy())
