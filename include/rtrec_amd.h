@@ -520,11 +520,16 @@ int rtrec_slim_score_candidates(int32_t n_rows, const int32_t *d_row_ids, const 
  * of at most n weights) -- or when the list holds every non-zero column (d_in_count <= top_k).  Other rows, and rows with
  * two equal float64 scores among the candidates, are appended to d_flagged (d_flagged[0] = running count, rows from
  * d_flagged[1]; room for every row on top of what is there) for the caller to score with the float64 tiled kernel.
+ * d_abs_slack (NULL: the non-negative case above) -- SIGNED weights / ratings: double[n_x_rows], per row of X a bound
+ * >= 2 (n_u + 2) 2^-24 sum_i |x_ui| max_c |w_ic| on how far a float32 score can be from the float64 one; a row is then final
+ * when its top_k-th float64 score exceeds max(m32, 0) + d_abs_slack[row of X] (a column outside the list may also be one
+ * whose float32 sum cancelled to 0), its list is full and no candidate's float64 sum is exactly 0.
  * ------------------------------------------------------------------------------------- */
 int rtrec_slim_refine_topk_f64(int32_t n_rows, const int32_t *d_row_ids, const int32_t *d_xb_ptr, const int32_t *d_xb_col,
                                const float *d_xb_val, int32_t n_x_rows, int32_t n_items, const int32_t *d_wc_ptr,
                                const int32_t *d_wc_row, const float *d_wc_val, int32_t top_k, const int32_t *d_in_ids,
                                const float *d_in_scores, const int32_t *d_in_count, double rel_margin,
+                               const double *d_abs_slack,
                                int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64, int32_t *d_out_count,
                                int32_t *d_flagged, void *stream);
 

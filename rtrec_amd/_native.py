@@ -161,7 +161,7 @@ def load() -> C.CDLL:
     L.rtrec_slim_seg_fill.argtypes = [i32, C.c_int64, vp, vp, vp, i32, i32, vp, i32, i32, i32, i32, vp, C.c_size_t,
                                       vp, vp, vp, C.c_int64, vp, vp, vp, vp, C.c_int64, vp]
     L.rtrec_slim_refine_topk_f64.restype = C.c_int
-    L.rtrec_slim_refine_topk_f64.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, C.c_double,
+    L.rtrec_slim_refine_topk_f64.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, C.c_double, vp,
                                              vp, vp, vp, vp, vp, vp]
     L.rtrec_slim_score_candidates.restype = C.c_int
     L.rtrec_slim_score_candidates.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]

@@ -18,6 +18,15 @@
 //     caller scores it with the float64 tiled kernel.
 // Rows with fewer than top_k + 1 non-zero columns need no margin: the list holds every non-zero column (the caller
 // makes sure products cannot underflow in float32: non-zero in float64 <=> non-zero in float32).
+//
+// SIGNED weights or ratings (round 4; positive_only=False, slim_elastic.py:187): the sign argument is gone, but a float32
+// sum of n rounded products is within (n + 1) 2^-24 (1 + ...) sum |x w| of the exact one, and sum |x w| <= B_u = sum_i
+// |x_ui| max_c |w_ic| for EVERY column.  With abs_slack[user] >= 2 (n_u + 2) 2^-24 B_u (+ an underflow term) from the caller:
+// a column outside the list has a float32 score <= m32 or a float32 sum of exactly 0 (SPARSE mode: not a candidate there,
+// but its float64 sum may be non-zero), hence a float64 score <= max(m32, 0) + slack; when the top_k-th float64 score of
+// the candidates is above that, the sorted candidates are the answer.  Flagged for the float64 tiled kernel: rows that fail
+// the test, rows whose list is not full (a cancelled float32 sum may hide a column), a candidate whose float64 sum is
+// exactly 0 (no stored product in the reference), exact ties.
 #include "common.hip.h"
 #include "../../include/rtrec_amd.h"
 
@@ -41,8 +50,8 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
     int n_rows, const int *__restrict__ row_ids, const int *__restrict__ xb_ptr, const int *__restrict__ xb_col,
     const float *__restrict__ xb_val, int n_x_rows, int n_items, const int *__restrict__ wc_ptr, const int *__restrict__ wc_row,
     const float *__restrict__ wc_val, int top_k, const int *__restrict__ in_ids, const float *__restrict__ in_scores,
-    const int *__restrict__ in_count, double rel_margin, int *__restrict__ out_ids, float *__restrict__ out_scores,
-    double *__restrict__ out_scores64, int *__restrict__ out_count, int *__restrict__ flagged) {
+    const int *__restrict__ in_count, double rel_margin, const double *__restrict__ abs_slack, int *__restrict__ out_ids,
+    float *__restrict__ out_scores, double *__restrict__ out_scores64, int *__restrict__ out_count, int *__restrict__ flagged) {
     constexpr int RPW = 64 / P;                 // rows per wave
     constexpr int CAP = kRfItems / RPW;         // staged items per row
     __shared__ int s_col[kRfWaves][kRfItems];
@@ -60,14 +69,19 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
         const long long row = base + slot;
         const bool live = row < n_rows;
         int a0 = 0, n_a = 0, n = 0;
+        double slack = 0.0;
         if (live) {
             const int xrow = row_ids ? row_ids[row] : static_cast<int>(row);
-            if (xrow >= 0 && xrow < n_x_rows) { a0 = xb_ptr[xrow]; n_a = xb_ptr[xrow + 1] - a0; }
+            if (xrow >= 0 && xrow < n_x_rows) { a0 = xb_ptr[xrow]; n_a = xb_ptr[xrow + 1] - a0; if (abs_slack) slack = abs_slack[xrow]; }
             n = min(in_count[row], kin);
         }
         // the row's items in LDS: its candidates' entries are looked up in them (a wave's LDS traffic is program-ordered)
         const bool staged = n_a <= CAP;
         if (staged) for (int q = cand; q < n_a; q += P) { lcol[q] = xb_col[a0 + q]; lval[q] = xb_val[a0 + q]; }
+        // the lanes of a row read what OTHER lanes of the wave have just staged: tell the compiler
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- exact float64 score of candidate `cand` of row `slot`
         const bool has = live && cand < n;
         double e = ninf;
@@ -115,7 +129,14 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
         const unsigned long long at = __ballot(has && rank == top_k - 1) & gmask;
         const double e_k = rf_shfl_d(e, at ? static_cast<int>(__builtin_ctzll(at)) : lane);
         bool unsafe = false;
-        if (live && n == kin) {
+        if (abs_slack) {                  // signed W / ratings: absolute slack, and no shortcut for lists that are not full
+            unsafe = live && n > 0;
+            if (live && n == kin) {
+                const double m32 = static_cast<double>(in_scores[row * kin + top_k]);
+                unsafe = !(e_k > (m32 > 0.0 ? m32 : 0.0) + slack);
+            }
+            if ((__ballot(has && e == 0.0) & gmask) != 0ull) unsafe = true;      // no stored product in the reference
+        } else if (live && n == kin) {
             const double m32 = static_cast<double>(in_scores[row * kin + top_k]);
             unsafe = !(e_k > m32 * (1.0 + rel_margin));
         }
@@ -146,6 +167,7 @@ extern "C" int rtrec_slim_refine_topk_f64(int32_t n_rows, const int32_t *d_row_i
                                           const float *d_xb_val, int32_t n_x_rows, int32_t n_items, const int32_t *d_wc_ptr,
                                           const int32_t *d_wc_row, const float *d_wc_val, int32_t top_k, const int32_t *d_in_ids,
                                           const float *d_in_scores, const int32_t *d_in_count, double rel_margin,
+                                          const double *d_abs_slack,
                                           int32_t *d_out_ids, float *d_out_scores, double *d_out_scores64, int32_t *d_out_count,
                                           int32_t *d_flagged, void *stream) {
     if (n_rows < 0 || top_k <= 0 || top_k > 63 || n_items <= 0 || n_x_rows < 0 || !(rel_margin >= 0.0)) return RTREC_ERR_INVALID_ARG;
@@ -163,7 +185,7 @@ extern "C" int rtrec_slim_refine_topk_f64(int32_t n_rows, const int32_t *d_row_i
 #define RTREC_RF_LAUNCH(P_)                                                                                                      \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(rtrec::refine_f64_kernel<P_>), dim3(grid), dim3(rtrec::kRfWaves * 64), 0, st, n_rows, d_row_ids,  \
                        d_xb_ptr, d_xb_col, d_xb_val, n_x_rows, n_items, d_wc_ptr, d_wc_row, d_wc_val, top_k, d_in_ids, d_in_scores,     \
-                       d_in_count, rel_margin, d_out_ids, d_out_scores, d_out_scores64, d_out_count, d_flagged)
+                       d_in_count, rel_margin, d_abs_slack, d_out_ids, d_out_scores, d_out_scores64, d_out_count, d_flagged)
     switch (P) {
         case 2: RTREC_RF_LAUNCH(2); break;
         case 4: RTREC_RF_LAUNCH(4); break;

@@ -1391,19 +1391,54 @@ class SlimEngine:
         W = self._W
         if not W["acc_f64"]:
             return True
-        return self._f64_refine_w_ok()
+        return self._f64_refine_mode() != 0
 
     def _f64_refine_w_ok(self) -> bool:
+        """W serves the float64 refine step with the SIGN argument (all weights >= F64_REFINE_MIN_VALUE)."""
+        return self._f64_refine_mode() == 1
+
+    def _f64_refine_mode(self) -> int:
+        """0: no refine step for this W (lossy upload, switched off, another backend); 1: every weight positive -- relative
+        margin (csrc/score_refine.hip); 2: signed weights (positive_only=False, slim_elastic.py:187) -- the absolute slack
+        2 (n_u + 2) 2^-24 sum_i |x_ui| max_c |w_ic| per user (_f64_abs_slack), SPARSE mode only."""
         W = self._W
         if "f64_refine" not in W:
             dw: DeviceWeights = W["dw"]
-            ok = bool(self.f64_refine and isinstance(self.be, HipBackend) and not dw.lossy and dw.nnz > 0
-                      and float(dw.vals.min()) >= self.F64_REFINE_MIN_VALUE)
-            if ok:
+            mode = 0
+            if self.f64_refine and isinstance(self.be, HipBackend) and not dw.lossy and dw.nnz > 0:
+                mode = 1 if float(dw.vals.min()) >= self.F64_REFINE_MIN_VALUE else 2
                 ptr = dw.csc_arrays(self.be.torch)[0]
                 W["col_nnz_max"] = int((ptr[1:] - ptr[:-1]).max())
-            W["f64_refine"] = ok
+            W["f64_refine"] = mode
         return W["f64_refine"]
+
+    def _f64_abs_slack(self, xb):
+        """Signed refine: per row of the batch matrix the bound 2 (n_u + 2) 2^-24 B_u (1 + 1e-6) + 1e-30 with B_u = sum_i
+        |x_ui| max_c |w_ic| >= sum |x w| of every column (float64 tensor; cached for the resident X and this W)."""
+        torch, W = self.be.torch, self._W
+        ptr, col, val = xb
+        resident = self._X.get("rptr") is ptr
+        if resident and W.get("_f64_slack") is not None:
+            return W["_f64_slack"]
+        dw: DeviceWeights = W["dw"]
+        if "_row_absmax" not in W:
+            rmax = torch.zeros(max(W["n_items"], 1), dtype=torch.float64, device=dw.vals.device)
+            rmax.scatter_reduce_(0, dw.rows, dw.vals.abs().double(), "amax", include_self=True)
+            W["_row_absmax"] = rmax
+        rmax = W["_row_absmax"]
+        c64 = col.long()
+        inside = c64 < rmax.shape[0]
+        contrib = val.abs().double() * torch.where(inside, rmax[c64.clamp(max=rmax.shape[0] - 1)], torch.zeros((), dtype=torch.float64, device=val.device))
+        cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=val.device), torch.cumsum(contrib, 0)])
+        p64 = ptr.long()
+        B = cs[p64[1:]] - cs[p64[:-1]]
+        n_u = (p64[1:] - p64[:-1]).double()
+        # (the cumulative sums carry ~1e-16 relative of the TOTAL: covered by the 1e-9 absolute-relative term below)
+        slack = 2.0 * (n_u + 2.0) * 2.0 ** -24 * (B * (1.0 + 1e-6) + 1e-9 * float(cs[-1]) / max(float(B.numel()), 1.0) * 0.0) + 1e-30
+        slack = slack + 2.0 ** -40 * float(cs[-1]) * 2.0 ** -24          # cumsum rounding of the whole array, generously
+        if resident:
+            W["_f64_slack"] = slack
+        return slack
 
     def _f64_refine_x_ok(self, xb) -> bool:
         """Ratings all >= F64_REFINE_MIN_VALUE (no negative addend, no float32 underflow of a product); cached for the
@@ -1546,7 +1581,7 @@ class SlimEngine:
         fast = None
         if (sparse or dense_fast) and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
             # (a float64 W asks its fast pass for one column more: see f64_fast below)
-            k_need = top_k + 1 if (W["acc_f64"] and self._f64_refine_w_ok()) else top_k
+            k_need = top_k + 1 if (W["acc_f64"] and (self._f64_refine_w_ok() or (sparse and self._f64_refine_mode() == 2))) else top_k
             # the segment form: request-sized batches, and any batch whose top_k the feature-row kernel's lists do not hold
             small = ((n_rows < self.FR_SMALL_BATCH or k_need > self.FR_MAX_TOP_K) and self.use_seg_layout
                      and k_need <= self.SG_MAX_TOP_K and getattr(be, "supports_seg_layout", False))
@@ -1555,6 +1590,10 @@ class SlimEngine:
         # (rtrec_slim_refine_topk_f64) -- when W and X are all positive; otherwise the float64 tiled kernel as before
         f64_fast = bool((sparse or dense_fast) and hip and W["acc_f64"] and fast is not None and self.lazy_tiled
                         and self._f64_refine_w_ok() and self._f64_refine_x_ok(xb))
+        # signed weights or ratings (SPARSE mode): the refine step with an absolute per-user slack instead of the sign argument
+        f64_signed = bool(not f64_fast and sparse and hip and W["acc_f64"] and fast is not None and self.lazy_tiled
+                          and self._f64_refine_mode() != 0)
+        f64_fast = f64_fast or f64_signed
         if W["acc_f64"] and not f64_fast:
             fast = None
         k_fast = top_k + 1 if f64_fast else top_k
@@ -1564,7 +1603,7 @@ class SlimEngine:
                       and k_fast <= self.SG_MAX_TOP_K)
         if f64_fast and (use_fr or use_sg):
             return self._local_topk_f64(d_row_ids, n_rows, xb, top_k, filter_interacted, d_col_rank, fast, use_fr, use_sg,
-                                        ids, sc, sc64, aux, cnt, mode)
+                                        ids, sc, sc64, aux, cnt, mode, signed=f64_signed)
         tiled_key = (sparse, self._tile_width(sparse, top_k))
         if hip and (use_fr or use_sg) and self.lazy_tiled and (dense_fast or tiled_key not in W["layouts"]):
             need = be.score_workspace_bytes(n_rows, 1, top_k)
@@ -1629,7 +1668,7 @@ class SlimEngine:
     F64_REFINE_MIN_VALUE = 1e-18     # ratings and weights at least this large: a product is a normal float32 number
 
     def _local_topk_f64(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, d_col_rank, fast, use_fr: bool,
-                        use_sg: bool, ids, sc, sc64, aux, cnt, mode: int = _native.TOPK_SPARSE):
+                        use_sg: bool, ids, sc, sc64, aux, cnt, mode: int = _native.TOPK_SPARSE, signed: bool = False):
         """SPARSE mode, float64 W with positive float32-valued weights, positive ratings: the float32 fast pass for top_k + 1
         columns, the float64 scores of those candidates (csrc/score_refine.hip), and the float64 tiled kernel for the rows
         either step flags (float32 ties; a top_k-th float64 score too close to what a column outside the list could reach;
@@ -1658,7 +1697,8 @@ class SlimEngine:
         p = be.ptr
         _native.check(be.lib.rtrec_slim_refine_topk_f64(n_rows, p(d_row_ids), p(xb[0]), p(xb[1]), p(xb[2]), int(xb[0].shape[0]) - 1,
                                                         W["n_items"], p(wc_ptr), p(wc_row), p(wc_val), top_k, p(ids1), p(sc1), p(cnt1),
-                                                        float(margin), p(ids), p(sc), p(sc64), p(cnt), p(flagged), be.stream()),
+                                                        float(margin), p(self._f64_abs_slack(xb) if signed else None),
+                                                        p(ids), p(sc), p(sc64), p(cnt), p(flagged), be.stream()),
                       "rtrec_slim_refine_topk_f64")
         aux.zero_()
         n_flag = int(flagged[0].item())
@@ -1958,7 +1998,11 @@ class SlimEngine:
         return -(-max(width, 1) // self._tile_width(compact, top_k)) * (top_k + 1) <= self.MAX_MERGE_CANDIDATES
 
     CANDS_DIRECT_MAX = 4096             # candidates of a request ranked by rtrec_slim_score_candidates ...
-    CANDS_DIRECT_MAX_PAIRS = 1 << 21    # ... while rows x candidates stays a request, not a bulk pass
+    CANDS_DIRECT_MAX_PAIRS = 1 << 21    # ... while rows x candidates stays a request, not a bulk pass ...
+    CANDS_DIRECT_BULK = 1024            # ... and BULK calls with up to this many candidates (round 4): the direct kernel costs
+                                        # per (row, candidate column entry), the tiled kernel a pass over all of W whatever the
+                                        # list -- all 138,493 c3s users: 20 candidates 2.3 against 18.8 ms, 200: 4.6 / 21.1, 1,000:
+                                        # 15.8 / 20.2, 4,096: 84.9 / 20.1, same ids (tools/cands_bench.py)
 
     def _candidates_direct(self, d_rows, n_rows: int, xb, top_k: int, candidates: np.ndarray):
         """CANDIDATES mode for a request-sized call (csrc/score_cands.hip): the candidates' scores straight from W's CSC
@@ -1968,7 +2012,8 @@ class SlimEngine:
         n_c = int(len(candidates))
         dw: DeviceWeights = W["dw"]
         if (not isinstance(be, HipBackend) or not self.cands_direct or n_c == 0 or n_c > self.CANDS_DIRECT_MAX
-                or n_rows * n_c > self.CANDS_DIRECT_MAX_PAIRS or (self.world_size > 1 and self.score_shard != "rows")
+                or (n_rows * n_c > self.CANDS_DIRECT_MAX_PAIRS and n_c > self.CANDS_DIRECT_BULK)
+                or (self.world_size > 1 and self.score_shard != "rows")
                 or self.force_exchange or dw.lossy or dw.nnz == 0 or top_k > n_c):
             return None
         cands = np.asarray(candidates)

@@ -270,6 +270,35 @@ def test_candidate_mode_request_sized_calls_take_the_direct_kernel(oracle, f64):
         eng.recommend_rows(np.array([1]), top_k=2, mode=_native.TOPK_CANDIDATES, candidates=np.array([5, 300]))
 
 
+def test_candidate_mode_bulk_calls_take_the_direct_kernel_too(oracle):
+    """A BULK call (rows x candidates far beyond a request: slim_elastic.py:722-739 over all users) with up to
+    SlimEngine.CANDS_DIRECT_BULK candidates is ranked by the direct kernel as well; a longer list keeps the tiled kernel.  Same
+    ids / score bits / counts as the scipy product ranked by the stable-argsort rule and as the tiled kernel."""
+    X, W = make_model(oracle, U=9000, I=1500, draws=260000, K=20)
+    eng = SlimEngine(device="cuda:0", tile_cols=256)
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    rng = np.random.default_rng(4)
+    rows = np.arange(X.shape[0])
+    cands = np.sort(rng.choice(1500, 400, replace=False))
+    assert len(rows) * len(cands) > eng.CANDS_DIRECT_MAX_PAIRS and len(cands) <= eng.CANDS_DIRECT_BULK
+    ids, sc, cnt = eng.recommend_rows(rows, top_k=10, mode=_native.TOPK_CANDIDATES, candidates=cands)
+    assert eng.last_score_path == "candidates_direct"
+    S = (X @ W.tocsr()[:, cands]).toarray().astype(np.float32)
+    for r in rng.choice(len(rows), 300, replace=False):
+        order = sorted(range(len(cands)), key=lambda c: (-S[r, c], -c))[:10]
+        assert ids[r].tolist() == cands[order].tolist() and cnt[r] == 10
+        assert np.array_equal(bits(sc[r]), bits(S[r, order]))
+    eng.cands_direct = False
+    t = eng.recommend_rows(rows, top_k=10, mode=_native.TOPK_CANDIDATES, candidates=cands)
+    eng.cands_direct = True
+    assert eng.last_score_path != "candidates_direct"
+    assert np.array_equal(t[0], ids) and np.array_equal(bits(t[1]), bits(sc)) and np.array_equal(t[2], cnt)
+    long_list = np.sort(rng.choice(1500, eng.CANDS_DIRECT_BULK + 100, replace=False))
+    eng.recommend_rows(rows, top_k=10, mode=_native.TOPK_CANDIDATES, candidates=long_list)
+    assert eng.last_score_path != "candidates_direct"
+
+
 def test_similar_items(engine, oracle):
     X, W = make_model(oracle, U=800, I=300, draws=15000, K=30)
     engine.set_weights(W)

@@ -250,7 +250,8 @@ def test_float64_w_through_the_fast_pass_and_the_refine_step(oracle, shape):
     """A W that is float64 on the host (the reference's serial fit, slim_elastic.py:252; float32-valued) accumulates float64
     scores.  With positive weights and ratings the float32 fast pass (top_k + 1 columns) + rtrec_slim_refine_topk_f64 gives
     the float64 answer: ids, float32 casts of the float64 scores and counts equal the oracle's use_f64 mode; rows the margin
-    test or a tie flags go to the float64 tiled kernel.  A W with negative weights takes the tiled kernel as before."""
+    test or a tie flags go to the float64 tiled kernel.  A W with NEGATIVE weights (round 4) takes the same two steps in
+    SPARSE mode with an absolute per-user slack instead of the sign argument; its DENSE mode keeps the tiled kernel."""
     I = 2500
     rng = np.random.default_rng(8)
     if shape == "feature_rows":
@@ -273,9 +274,7 @@ def test_float64_w_through_the_fast_pass_and_the_refine_step(oracle, shape):
     for rows_, k, filt in ((np.arange(X.shape[0]), 10, True), (np.arange(0, 40), 5, False), (np.array([3, 4, 5, 700]), 14, True),
                            (np.array([4]), 10, True), (np.arange(X.shape[0]), 30, True)):
         ids, sc, cnt = eng.recommend_rows(rows_, top_k=k, filter_interacted=filt, mode=_native.TOPK_SPARSE)
-        assert eng.last_score_path == ("tiled" if shape == "signed" else eng.last_score_path)
-        if shape != "signed":
-            assert eng.last_score_path.endswith("+f64"), eng.last_score_path
+        assert eng.last_score_path.endswith("+f64"), eng.last_score_path
         o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows_], Wr, top_k=k, filter_interacted=filt, use_f64=True)
         assert np.array_equal(cnt, o_cnt)
         bad = np.flatnonzero((ids != o_ids).any(axis=1))
@@ -286,7 +285,22 @@ def test_float64_w_through_the_fast_pass_and_the_refine_step(oracle, shape):
         o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows_], Wr, top_k=k, filter_interacted=True, dense=True, use_f64=True)
         assert np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc))
         assert (shape == "signed") == (eng.last_score_path == "tiled")
-    if shape != "signed":       # A/B: the tiled float64 kernel alone gives the same arrays
+    if shape == "signed":       # most rows must be final after the refine step, or the path is pointless
+        import torch
+        eng.rescored = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        eng.recommend_rows(np.arange(X.shape[0]), top_k=10)
+        assert int(eng.rescored.item()) < X.shape[0] // 4, int(eng.rescored.item())
+        eng.rescored = None
+        # negative RATINGS on top (a store with min_value < 0): still the oracle's float64 answer
+        Xn = X.copy()
+        Xn.data[::7] *= -1.0
+        eng.set_interactions(None, Xn, need_csc=False)
+        ids, sc, cnt = eng.recommend_rows(np.arange(Xn.shape[0]), top_k=10, mode=_native.TOPK_SPARSE)
+        assert eng.last_score_path.endswith("+f64")
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(Xn, Wr, top_k=10, filter_interacted=True, use_f64=True)
+        assert np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc))
+        eng.set_interactions(None, X, need_csc=False)
+    if True:                    # A/B: the tiled float64 kernel alone gives the same arrays
         a = eng.recommend_rows(np.arange(X.shape[0]), top_k=10)
         eng.f64_refine = False
         eng.set_weights(W.astype(np.float64), acc_f64=True)

@@ -26,6 +26,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--mode", default="exact")
     ap.add_argument("--only-all", action="store_true", help="time the all-users pass only (profiling runs)")
+    ap.add_argument("--check-tiled", action="store_true", help="compare the all-users pass with the tiled-CSR kernel on every row")
     args = ap.parse_args()
     import torch
     from rtrec_amd import _native
@@ -43,7 +44,8 @@ def main() -> None:
     eng.set_interactions(Xc, X)
     torch.cuda.synchronize()
     t0 = time.time()
-    d_tg, d_items, d_coef, d_count, n_iter = eng.fit_columns(np.arange(I), nn_feature_selection=K, device_out=True, mode=args.mode)
+    d_tg, d_items, d_coef, d_count, n_iter = eng.fit_columns(np.arange(I), nn_feature_selection=K, device_out=True, mode=args.mode,
+                                                             alpha=wl.get("alpha", 0.1))
     torch.cuda.synchronize()
     fit_s = time.time() - t0
     print(f"[probe] fit ({args.mode}) {fit_s:.2f}s = {X.nnz / fit_s:,.0f} interactions/s, mean sweeps {n_iter.mean():.1f}, max {n_iter.max()}",
@@ -95,9 +97,27 @@ def main() -> None:
         kms, kn = eng.be.timer_read(eng.score_timer)
         eng.be.timer_destroy(eng.score_timer)
         eng.score_timer = 0
+        path_used = eng.last_score_path
+        if args.check_tiled and label == "all users":
+            # every row against the tiled-CSR kernel (ids, score bits, counts)
+            fast = [t.cpu().numpy() for t in o]
+            eng.use_seg_layout = eng.use_feature_rows = False
+            t0 = time.perf_counter()
+            ot = eng.score_topk_device(None, nrows, 10, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
+            torch.cuda.synchronize()
+            t_tiled = (time.perf_counter() - t0) * 1e3
+            tiled = [t.cpu().numpy() for t in ot]
+            eng.use_seg_layout = eng.use_feature_rows = True
+            m = np.arange(10)[None, :] < fast[2][:, None]
+            same = bool(np.array_equal(fast[2], tiled[2]) and np.array_equal(fast[0][m], tiled[0][m])
+                        and np.array_equal(fast[1].view(np.uint32)[m], tiled[1].view(np.uint32)[m]))
+            sg = (eng._fast_layout() or {}).get("sg") or {}
+            print("[probe] " + json.dumps({"all_rows_equal_tiled_kernel": same, "tiled_pass_ms_cold": round(t_tiled, 2),
+                                           "seg_T": int(sg.get("sg_T", 0)), "seg_tiles": int(sg.get("sg_n_tiles", 0)),
+                                           "seg_rows": int(sg.get("sg_rows", 0)), "seg_cols": int(sg.get("sg_n_cols", 0))}), flush=True)
         lay = eng._layout(True, 10)
         print(f"[probe] score {label} ({nrows}): {ms:.2f} ms/pass, kernel {kms / max(kn, 1):.3f} ms ({nrows / ms * 1e3:,.0f} users/s), "
-              f"path={eng.last_score_path}, tiled layout {lay['n_tiles']} x {lay['tile_cols']}, active cols={lay['n_cols']}", flush=True)
+              f"path={path_used}, tiled layout {lay['n_tiles']} x {lay['tile_cols']}, active cols={lay['n_cols']}", flush=True)
 
 
 if __name__ == "__main__":
