@@ -53,11 +53,26 @@ OPS_PATH = os.path.join(LIB_DIR, "librtrec_amd_ops.so")
 OPS_SOURCE = os.path.join(CSRC, "torch_ops.cpp")
 
 
+OPS_STAMP = OPS_PATH + ".stamp"      # torch version + C++ ABI flag the ops library was compiled against
+
+
+def _torch_stamp() -> str:
+    import torch
+    return f"{torch.__version__} abi={int(getattr(torch._C, '_GLIBCXX_USE_CXX11_ABI', True))}"
+
+
 def ops_stale() -> bool:
+    """The ops library is compiled against torch's headers and C++ ABI: a torch upgrade makes it stale even though no source
+    changed -- the stamp file beside it records what it was built for."""
     if not os.path.exists(OPS_PATH):
         return True
     t = os.path.getmtime(OPS_PATH)
-    return any(os.path.getmtime(d) > t for d in (OPS_SOURCE, os.path.normpath(os.path.join(CSRC, HEADERS[-1]))))
+    if any(os.path.getmtime(d) > t for d in (OPS_SOURCE, os.path.normpath(os.path.join(CSRC, HEADERS[-1])))):
+        return True
+    try:
+        return open(OPS_STAMP).read().strip() != _torch_stamp()
+    except OSError:
+        return True
 
 
 def build_ops(force: bool = False, verbose: bool = False) -> str:
@@ -77,6 +92,8 @@ def build_ops(force: bool = False, verbose: bool = False) -> str:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd, cwd=CSRC)
+    with open(OPS_STAMP, "w") as f:
+        f.write(_torch_stamp() + "\n")
     return OPS_PATH
 
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kRfWaves * 64) void refine_f64_kernel(
         const double e_k = rf_shfl_d(e, at ? static_cast<int>(__builtin_ctzll(at)) : lane);
         bool unsafe = false;
         if (abs_slack) {                  // signed W / ratings: absolute slack, and no shortcut for lists that are not full
-            unsafe = live && n > 0;
+            unsafe = live && n_a > 0;         // (an empty list too: float32 products may all have underflowed to 0)
             if (live && n == kin) {
                 const double m32 = static_cast<double>(in_scores[row * kin + top_k]);
                 unsafe = !(e_k > (m32 > 0.0 ? m32 : 0.0) + slack);

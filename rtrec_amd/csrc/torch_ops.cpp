@@ -18,6 +18,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 
 #include "../../include/rtrec_amd.h"
 
@@ -57,10 +58,51 @@ void check(int status, const char *what) {
     TORCH_CHECK(false, msg);
 }
 
+// The C-ABI takes raw device pointers: a tensor of another dtype, a strided view or a host tensor in any slot would be a
+// silent out-of-bounds access on the GPU, so every pointer handed over is checked against the element type its slot
+// declares.  ptr<void> / ptr<unsigned char> slots are byte workspaces: any dtype, still contiguous + device.
+template <typename T> struct ElemOf { static bool ok(at::ScalarType) { return true; } };
+template <> struct ElemOf<int32_t> { static bool ok(at::ScalarType s) { return s == at::kInt; } };
+template <> struct ElemOf<uint32_t> { static bool ok(at::ScalarType s) { return s == at::kInt || s == at::kUInt32; } };
+template <> struct ElemOf<int64_t> { static bool ok(at::ScalarType s) { return s == at::kLong; } };
+template <> struct ElemOf<float> { static bool ok(at::ScalarType s) { return s == at::kFloat; } };
+template <> struct ElemOf<double> { static bool ok(at::ScalarType s) { return s == at::kDouble; } };
+
+template <typename T>
+void check_tensor(const at::Tensor &t) {
+    TORCH_CHECK(t.is_contiguous(), "rtrec_amd op: tensor argument must be contiguous (got strides of a view)");
+    TORCH_CHECK(t.device().is_cuda(), "rtrec_amd op: tensor argument must live on the GPU, got ", t.device());
+    TORCH_CHECK(ElemOf<typename std::remove_const<T>::type>::ok(t.scalar_type()), "rtrec_amd op: tensor argument has dtype ",
+                t.scalar_type(), ", the slot takes ", sizeof(T) == 8 ? "a 64-bit" : "a 32-bit", " element type");
+}
+template <> void check_tensor<void>(const at::Tensor &t) {
+    TORCH_CHECK(t.is_contiguous() && t.device().is_cuda(), "rtrec_amd op: workspace tensors must be contiguous GPU tensors");
+}
+template <> void check_tensor<const void>(const at::Tensor &t) { check_tensor<void>(t); }
+
+// strided inputs (merge_topk: views of an exchanged record buffer, their strides travel as arguments): dtype + device only
+template <typename T>
+T *sptr(const at::Tensor &t) {
+    if (t.numel() == 0) return nullptr;
+    TORCH_CHECK(t.device().is_cuda(), "rtrec_amd op: tensor argument must live on the GPU, got ", t.device());
+    TORCH_CHECK(ElemOf<typename std::remove_const<T>::type>::ok(t.scalar_type()), "rtrec_amd op: tensor argument has dtype ", t.scalar_type());
+    return static_cast<T *>(t.data_ptr());
+}
+template <typename T>
+T *sptr(const c10::optional<at::Tensor> &t) { return (t.has_value() && t->defined()) ? sptr<T>(*t) : nullptr; }
+
 template <typename T = void>
-T *ptr(const at::Tensor &t) { return t.numel() > 0 ? static_cast<T *>(t.data_ptr()) : nullptr; }
+T *ptr(const at::Tensor &t) {
+    if (t.numel() == 0) return nullptr;
+    check_tensor<T>(t);
+    return static_cast<T *>(t.data_ptr());
+}
 template <typename T = void>
-T *ptr(const c10::optional<at::Tensor> &t) { return (t.has_value() && t->defined() && t->numel() > 0) ? static_cast<T *>(t->data_ptr()) : nullptr; }
+T *ptr(const c10::optional<at::Tensor> &t) {
+    if (!(t.has_value() && t->defined() && t->numel() > 0)) return nullptr;
+    check_tensor<T>(*t);
+    return static_cast<T *>(t->data_ptr());
+}
 
 void *stream_of(const at::Tensor &t) {
     return static_cast<void *>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
@@ -198,8 +240,8 @@ void merge_topk(const at::Tensor &in_ids, const at::Tensor &in_scores, const OT 
         s64_0 = in_scores64->stride(0); s64_1 = in_scores64->stride(1);
     }
     check(abi().merge_topk_strided(static_cast<int32_t>(in_ids.size(1)), static_cast<int32_t>(in_ids.size(0)), static_cast<int32_t>(top_k),
-                                   ptr<const int32_t>(in_ids), ptr<const float>(in_scores), ptr<const double>(in_scores64),
-                                   ptr<const uint32_t>(in_aux), ptr<const int32_t>(in_count), in_ids.stride(0), in_ids.stride(1), s64_0,
+                                   sptr<const int32_t>(in_ids), sptr<const float>(in_scores), sptr<const double>(in_scores64),
+                                   sptr<const uint32_t>(in_aux), sptr<const int32_t>(in_count), in_ids.stride(0), in_ids.stride(1), s64_0,
                                    s64_1, in_count.stride(0), in_count.stride(1), ptr<int32_t>(out_ids), ptr<float>(out_scores),
                                    ptr<int32_t>(out_count), stream_of(out_ids)), "rtrec_slim_merge_topk_strided");
 }

@@ -791,8 +791,13 @@ class SlimEngine:
                  torch.bincount(big % 1000), big.to(torch.int32).to(torch.float32).abs().max(), torch.cat([big, big]),
                  torch.sort(big.to(torch.float32), descending=True), torch.argsort(big % 977, stable=True))
             self.be.synchronize()
-        except Exception as e:          # a warm-up must never keep an engine from being constructed
-            logging.debug(f"rtrec_amd warm-up skipped: {e}")
+        except Exception as e:          # a warm-up must never keep an engine from being constructed -- but it must not hide a
+            # broken library either: say so, and surface / clear pending device errors now
+            logging.warning(f"rtrec_amd warm-up failed (the first real call will hit the same problem): {e!r}")
+            try:
+                self.be.synchronize()
+            except Exception as e2:
+                logging.warning(f"rtrec_amd: device error after the failed warm-up: {e2!r}")
 
     # ------------------------------------------------------------------------------ X
     def set_interactions(self, X_csc: sp.csc_matrix, X_csr: Optional[sp.csr_matrix] = None,
