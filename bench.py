@@ -597,8 +597,9 @@ def main() -> None:
 
     def feature_row_model():
             tc, R = fr["fr_tile_cols"], fr["fr_rows"]
-            # users per wave: the library's choice for this launch (csrc/score.hip: 8 from ~98k rows, 4 from ~25k, else 2)
-            uw = 8 if n_scored >= 24 * 4096 else (4 if n_scored >= 6 * 4096 else 2)
+            # users per wave: the library's choice for this launch (csrc/score.hip: streaming layout 8 from ~393k rows, resident
+            # layout from ~98k; 4 from ~25k, else 2)
+            uw = 8 if n_scored >= (24 if fr.get("fr_resident") else 96) * 4096 else (4 if n_scored >= 6 * 4096 else 2)
             kernel_name = f"score_frows_kernel<{tc // 64},{2 if R > 64 else 1},{uw}>"
             tr = fr["fr_rows_of_tile"].view(np.uint64).reshape(-1, 2)
             feat_items = np.flatnonzero(fr["fr_map"] >= 0)
@@ -616,18 +617,19 @@ def main() -> None:
             order = order.cpu().numpy().astype(np.int64) if order is not None else np.arange(n_scored, dtype=np.int64)
             if len(order) != n_scored:         # the sharded path scores in row chunks: the cached order is one chunk's
                 order = np.arange(n_scored, dtype=np.int64)
-            if fr.get("fr_resident"):          # every wave claims 8 users: positions j, j + n_wj, ... (score_frows_kernel)
-                n_wj = -(-n_scored // 8)
-                pos = np.concatenate([order, np.full(8 * n_wj - n_scored, n_scored, dtype=np.int64)])
-                own_or = own[pos.reshape(8, n_wj)].any(axis=0)                      # [wave jobs, R]
-            else:                              # jobs of 64 users: a wave takes 8 consecutive positions of the pattern-sorted
-                pos = np.concatenate([order, np.full((-n_scored) % 64, n_scored, dtype=np.int64)])      # order, else p % 8
-                own_or = own[pos.reshape(-1, 8, 8)].any(axis=2 if getattr(eng, "_order_grouped", False) else 1)      # [jobs, 8 waves, R]
+            if fr.get("fr_resident"):          # every wave claims uw users: positions j, j + n_wj, ... (score_frows_kernel)
+                n_wj = -(-n_scored // uw)
+                pos = np.concatenate([order, np.full(uw * n_wj - n_scored, n_scored, dtype=np.int64)])
+                own_or = own[pos.reshape(uw, n_wj)].any(axis=0)                     # [wave jobs, R]
+            else:                              # jobs of 8 x uw users: a wave takes uw consecutive positions of the pattern-sorted
+                pos = np.concatenate([order, np.full((-n_scored) % (8 * uw), n_scored, dtype=np.int64)])      # order, else p % 8
+                own_or = own[pos.reshape(-1, 8, uw) if getattr(eng, "_order_grouped", False) else pos.reshape(-1, uw, 8)
+                             ].any(axis=2 if getattr(eng, "_order_grouped", False) else 1)      # [jobs, 8 waves, R]
             nz_rt = np.array([[(int(tr[t, f // 64]) >> (f % 64)) & 1 for f in range(R)] for t in range(tr.shape[0])], dtype=np.int32)
             swept_rows = float((own_or.reshape(-1, R).astype(np.int32) @ nz_rt.T).sum())      # (wave, tile, row) reads of 1 slice row
             lds_bytes = swept_rows * tc * 4.0                 # upper bound: tiles pruned by the score bound are not read
-            executed_flops = 2.0 * swept_rows * 8.0 * tc
-            n_jobs = 256 if fr.get("fr_resident") else -(-n_scored // 64)     # resident: W is loaded once per workgroup
+            executed_flops = 2.0 * swept_rows * float(uw) * tc
+            n_jobs = 256 if fr.get("fr_resident") else -(-n_scored // (8 * uw))     # resident: W is loaded once per workgroup
             l2_bytes = float(n_jobs) * float(fr["fr_super_kb"][-1]) * 1024.0 + 8.0 * (nnz if n_scored == U else int(Xs.nnz))
             bounds = {"valu": {"achieved": flops / kern_s / 1e12, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": flops / kern_s / 1e12 / VALU_PEAK_TFLOPS, "flops_per_launch": flops,

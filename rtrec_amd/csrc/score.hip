@@ -1934,7 +1934,12 @@ int score_impl(const ScoreArgs &base, int top_k, int acc_bytes, int32_t *d_out_i
         const int max_grid = f.resident ? 256 : 512;
         // users per wave: 8 when that still gives every workgroup slot a few jobs, else 4, else 2 (FR.users_per_wave forces one)
         const long long slots_rows = static_cast<long long>(max_grid) * nw;            // rows per round at one user per wave
-        int uw = a.n_rows >= 24 * slots_rows ? 8 : (a.n_rows >= 6 * slots_rows ? 4 : 2);
+        // (round 4: the STREAMING layout takes 8 users per wave only from ~393k rows on -- a launch cannot be shorter than a few
+        // jobs, and a 64-user job sweeps every super-tile of W: 1M x 500k shape, 125k rows (one of 8 row shards): 0.91 -> 0.62 ms
+        // with 4 per wave, 250k rows 1.22 -> 1.02 ms; ML-20M shape, all 138k rows 1.42 -> 1.39 ms; tools/fr_uw_sweep.py,
+        // profiles/r04_fr_uw_sweep_*.json.  The resident layout's waves claim jobs on their own and keep 8 from 98k rows.)
+        const long long uw8_min = f.resident ? 24 : 96;
+        int uw = a.n_rows >= uw8_min * slots_rows ? 8 : (a.n_rows >= 6 * slots_rows ? 4 : 2);
         if (FR.users_per_wave == 8 || FR.users_per_wave == 4 || FR.users_per_wave == 2) uw = FR.users_per_wave;
         const int n_jobs = (a.n_rows + uw * nw - 1) / (uw * nw);
         const unsigned grid = static_cast<unsigned>(n_jobs < max_grid ? n_jobs : max_grid);

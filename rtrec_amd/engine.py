@@ -1434,13 +1434,18 @@ class SlimEngine:
         c64 = col.long()
         inside = c64 < rmax.shape[0]
         contrib = val.abs().double() * torch.where(inside, rmax[c64.clamp(max=rmax.shape[0] - 1)], torch.zeros((), dtype=torch.float64, device=val.device))
-        cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=val.device), torch.cumsum(contrib, 0)])
         p64 = ptr.long()
-        B = cs[p64[1:]] - cs[p64[:-1]]
-        n_u = (p64[1:] - p64[:-1]).double()
-        # (the cumulative sums carry ~1e-16 relative of the TOTAL: covered by the 1e-9 absolute-relative term below)
-        slack = 2.0 * (n_u + 2.0) * 2.0 ** -24 * (B * (1.0 + 1e-6) + 1e-9 * float(cs[-1]) / max(float(B.numel()), 1.0) * 0.0) + 1e-30
-        slack = slack + 2.0 ** -40 * float(cs[-1]) * 2.0 ** -24          # cumsum rounding of the whole array, generously
+        lengths = p64[1:] - p64[:-1]
+        n_u = lengths.double()
+        try:                # per-row float64 sums (error n_u 2^-53 B_u: far inside the 1e-6 below)
+            lo, hi = int(p64[0]), int(p64[-1])
+            B = torch.segment_reduce(contrib[lo:hi], "sum", lengths=lengths, unsafe=True)
+            err_b = 0.0
+        except Exception:   # cumulative sums instead: a difference of two prefixes carries up to 2 N 2^-53 of the TOTAL
+            cs = torch.cat([torch.zeros(1, dtype=torch.float64, device=val.device), torch.cumsum(contrib, 0)])
+            B = cs[p64[1:]] - cs[p64[:-1]]
+            err_b = 2.0 * float(contrib.numel()) * 2.0 ** -53 * float(cs[-1])
+        slack = 2.0 * (n_u + 2.0) * 2.0 ** -24 * (B * (1.0 + 1e-6) + err_b) + 1e-30
         if resident:
             W["_f64_slack"] = slack
         return slack
