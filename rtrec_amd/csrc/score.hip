@@ -2111,6 +2111,11 @@ extern "C" void rtrec_timer_destroy(void *timer) {
 }
 
 #ifdef SCORE_PROFILE
+extern "C" int rtrec_amd_seg_heavy_profile(unsigned long long *out16, int reset) {
+    if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_heavy_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_heavy_prof), z, sizeof(z)) != hipSuccess) return -4; }
+    return 0;
+}
 extern "C" int rtrec_amd_seg_profile(unsigned long long *out16, int reset) {
     if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_seg_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -4;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_seg_prof), z, sizeof(z)) != hipSuccess) return -4; }

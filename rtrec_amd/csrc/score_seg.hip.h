@@ -373,11 +373,22 @@ __device__ unsigned long long g_seg_prof[16];
 #define SP_MARK(slot) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); sp_[slot] += n_ - sp_t_; sp_t_ = n_; }
 #define SP_ADD(slot, v) { sp_[slot] += (v); }
 #define SP_FLUSH if (lane == 0) { sp_[SP_TOTAL] = __builtin_amdgcn_s_memtime() - sp_start_; for (int q_ = 0; q_ < SP_COUNT; ++q_) atomicAdd(&g_seg_prof[q_], sp_[q_]); }
+// workgroup-per-user kernel: wave-clock totals per phase, summed over all waves (rtrec_amd_seg_heavy_profile)
+enum { HP_USERS, HP_SETUP, HP_SYNC1, HP_NEXT, HP_TROW, HP_ACC, HP_SCAN, HP_SYNC2, HP_MERGE, HP_CLEAN, HP_TILES, HP_TOTAL, HP_COUNT };
+__device__ unsigned long long g_heavy_prof[16];
+#define HP_DECL unsigned long long hp_[16] = {0}; unsigned long long hp_t_ = __builtin_amdgcn_s_memtime(); const unsigned long long hp_start_ = hp_t_;
+#define HP_MARK(slot) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); hp_[slot] += n_ - hp_t_; hp_t_ = n_; }
+#define HP_ADD(slot, v) { hp_[slot] += (v); }
+#define HP_FLUSH if (lane == 0) { hp_[HP_TOTAL] = __builtin_amdgcn_s_memtime() - hp_start_; for (int q_ = 0; q_ < HP_COUNT; ++q_) atomicAdd(&g_heavy_prof[q_], hp_[q_]); }
 #else
 #define SP_DECL
 #define SP_MARK(slot)
 #define SP_ADD(slot, v)
 #define SP_FLUSH
+#define HP_DECL
+#define HP_MARK(slot)
+#define HP_ADD(slot, v)
+#define HP_FLUSH
 #endif
 
 template <typename IDX> struct SgNone;
@@ -544,6 +555,8 @@ __global__ __launch_bounds__(kSgWaves * 64, SG_OCC) void score_seg_kernel(SegArg
 // of ~200 dependent L2 round trips (15 opened tiles x (segment pointers + records) per 64-row chunk), ~1.7 ms under load;
 // the 127,723 users of up to 256 items take 1.11 ms, adding 909 users of 257..512 items made it 1.53 ms, all 9,097 of
 // them 1.72 ms (tools/seg_class_probe.py).  With the workgroup the chain is the setup / 8 + two tiles.
+// (measured, round 4: compiled for 8 waves per SIMD -- 64 VGPRs, 12 spilled, all 1024 workgroups resident -- it is no faster:
+// 0.62 -> 0.67 ms for the 1,673 long users of c3s alone)
 __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = lane_id();
@@ -569,6 +582,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
     float *xs = a.xs + static_cast<size_t>(blockIdx.x) * a.n_items;
     unsigned char *fl = a.fl + static_cast<size_t>(blockIdx.x) * a.n_tiles * T;
     const int stride = static_cast<int>(blockDim.x);
+    HP_DECL
 
     // the long users are found by their length: with a longest-first work order they are its head and a workgroup
     // leaves at the first user that is not long; without one every workgroup walks its share of the rows
@@ -583,6 +597,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
             continue;
         }
         if (threadIdx.x == 0) shared[0] = 0;
+        HP_MARK(HP_NEXT) HP_ADD(HP_USERS, wave == 0 ? 1 : 0)
         const bool lists = n_a <= kSgCap;           // list path (uniform)
         // ---- 1. scatter the ratings / flags (list path: fill the LDS lists), partial bounds per wave
         float B0 = 0.0f, B1 = 0.0f;
@@ -607,7 +622,9 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
         }
         bred[wave * 128 + 2 * lane] = B0;
         bred[wave * 128 + 2 * lane + 1] = B1;
+        HP_MARK(HP_SETUP)
         __syncthreads();            // xs / fl / bred of all waves are visible (one CU, one L1)
+        HP_MARK(HP_SYNC1)
         B0 = 0.0f; B1 = 0.0f;
         for (int w = 0; w < nw; ++w) { B0 += bred[w * 128 + 2 * lane]; B1 += bred[w * 128 + 2 * lane + 1]; }
         const float slack = 1.0f + 1e-5f + static_cast<float>(n_a) * 1.3e-7f;
@@ -625,6 +642,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
             if (th > ninf && bmax * slack < th) break;
             if ((rank++ % nw) != wave) continue;
             const int t0 = t * T;
+            HP_MARK(HP_NEXT) HP_ADD(HP_TILES, 1)
             if (lists) {
                 // the user's side: its own columns leave the race (-inf absorbs), then its rows of W in ascending item order
                 const int ncol = min(T, a.n_cols - t0);
@@ -658,17 +676,22 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
                     x = xs[rec.x];
                     if (x != 0.0f) { s = rec.y; e = rec.z; }
                 }
+                HP_MARK(HP_TROW)
                 if (T == 256) sg_accumulate256(acc, went, s, e, x);
                 else sg_accumulate<8>(acc, went, s, e, x);
+                HP_MARK(HP_ACC)
             }
             sg_scan_tile(acc4, T, t0, L, kk, kkmask, a.filter ? fl + t0 : nullptr, floor);
+            HP_MARK(HP_SCAN)
             }
             if (L.n >= kk && L.theta > 0.0f && lane == 0) atomicMax(shared, __float_as_int(L.theta));
         }
         // ---- 3. merge the waves' lists in wave 0, emit
         lst_s[wave * 64 + lane] = (lane < L.n) ? L.ls : ninf;
         lst_c[wave * 64 + lane] = L.lc;
+        HP_MARK(HP_NEXT)
         __syncthreads();
+        HP_MARK(HP_SYNC2)
         if (wave == 0) {
             for (int w = 1; w < nw; ++w) {
                 const float os = lst_s[w * 64 + lane];
@@ -682,6 +705,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
             }
             sg_emit(a, L, row);
         }
+        HP_MARK(HP_MERGE)
         // ---- 4. restore the scratch invariants (all zero; the list path has touched none)
         for (int base = wave * 64; base < n_a && !lists; base += stride) {
             const int idx = base + lane;
@@ -695,5 +719,7 @@ __global__ __launch_bounds__(1024) void score_seg_heavy_kernel(SegArgs a) {
             }
         }
         __syncthreads();
+        HP_MARK(HP_CLEAN)
     }
+    HP_FLUSH
 }

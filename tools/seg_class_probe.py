@@ -45,7 +45,20 @@ def main():
         for _ in range(5):
             eng.score_topk_device(None, n, 10, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
         torch.cuda.synchronize()
-        print(json.dumps({"set": label, "users": n, "ms_per_pass": round((time.perf_counter() - t0) / 5 * 1e3, 3), "path": eng.last_score_path}), flush=True)
+        rec = {"set": label, "users": n, "ms_per_pass": round((time.perf_counter() - t0) / 5 * 1e3, 3), "path": eng.last_score_path}
+        prof = getattr(eng.be.lib, "rtrec_amd_seg_heavy_profile", None) if os.environ.get("RTREC_AMD_LIB") else None
+        if prof is not None:          # diagnostic build (-DSCORE_PROFILE): phase clocks of the workgroup-per-user kernel, one more pass
+            import ctypes as C
+            prof(None, 1)
+            eng.score_topk_device(None, n, 10, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
+            torch.cuda.synchronize()
+            buf = (C.c_uint64 * 16)()
+            prof(buf, 0)
+            names = ["users", "setup", "sync1", "next", "trow", "acc", "scan", "sync2", "merge", "clean", "tiles", "total"]
+            v = dict(zip(names, [int(x) for x in buf]))
+            tot = max(v["total"], 1)
+            rec["heavy_profile"] = {k: (v[k] if k in ("users", "tiles", "total") else round(v[k] / tot, 4)) for k in names}
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":
