@@ -25,6 +25,11 @@ import scipy.sparse as sp
 
 from . import _native
 from . import settings
+# (round 4: the layout builders and the backend live in modules of their own; the names stay importable from here)
+from .backend import DeviceWeights, HipBackend, FIT_MW_MAX_TARGETS, XTY_SCRATCH_MAX_BYTES  # noqa: F401
+from .layouts import (TiledW, build_tiled_w, row_header_table, build_feature_rows, build_feature_rows_device,  # noqa: F401
+                      build_tiled_w_device, _heavy_tiles_first, _pack_fragments, FR_MAX_ROWS, FR_MIN_FILL,
+                      FR_TILE_HEADER_BYTES, FR_STREAM_BUF_BYTES)
 
 DEFAULT_TILE_COLS = 4096   # 16 KB of float accumulators: 8 persistent waves per CU (2 per SIMD) hide each other's latency
 DENSE_ROW_FILL = 1.0 / 3.0   # W row segments at least this full are stored dense (sparse layout)
@@ -35,9 +40,7 @@ MAX_GATHER_CHUNKS = 8
 ALLF_OUTPUT_CAP = 2048      # coefficients per target the K=None output block holds before a refit with cap = I
 GRAM_ITEMS = 512            # most popular items whose pairwise dot products the fit kernel may look up
 FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
-FIT_MW_MAX_TARGETS = 2048   # kMwMaxTargets of csrc/fit.hip: calls up to this size run the multi-wave kernel
 XTY_MIN_WALK_ENTRIES = 1e9         # ... and the per-target column walks it replaces would visit at least this many entries
-XTY_SCRATCH_MAX_BYTES = 32 << 30   # such calls get the one-pass X^T y (rtrec_fit_opts.d_xty_ws) while its scratch stays below this
 FIT_HEAVY_TARGETS = 256     # head of a bulk call sent to the multi-wave kernel (one workgroup per CU)
 FIT_HEAVY_SLOTS = 256
 FIT_HEAVY_MIN_ROWS = 2048   # ... as long as the target has at least this many users
@@ -55,639 +58,6 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     lo = min(n_items, rank * per)
     hi = min(n_items, lo + per)
     return lo, hi
-
-
-@dataclass
-class TiledW:
-    """Host-side description of one shard of W in the kernel's tiled layout."""
-    n_items: int
-    col_lo: int
-    n_cols: int           # layout columns (shard width, or number of active columns when compacted)
-    tile_cols: int
-    n_tiles: int
-    tile_ptr: np.ndarray  # int32 [n_tiles * (n_items + 1)]
-    w_col: np.ndarray     # uint16 [nnz]
-    w_val: np.ndarray     # float32 [nnz]
-    col_ids: Optional[np.ndarray] = None   # int32 [n_cols]: layout column -> global item id
-    col_map: Optional[np.ndarray] = None   # int32 [n_items]: global item id -> layout column or -1
-    dense_idx: Optional[np.ndarray] = None  # int32 [n_tiles * n_items]: dense block of (tile, row) or -1
-    dense_val: Optional[np.ndarray] = None  # float32 [n_dense * tile_cols]: zero-padded dense rows
-
-
-def build_tiled_w(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, tile_cols: int, compact: bool = False,
-                  dense_fill: Optional[float] = None) -> TiledW:
-    """Cut columns [col_lo, col_hi) of W (CSC, I x I) into tiles; per tile a CSR over all rows.
-    compact=True keeps only the columns that store at least one weight (the only ones that can
-    be recommended in SPARSE mode), in ascending id order."""
-    n_items = W_csc.shape[0]
-    indptr = np.asarray(W_csc.indptr, dtype=np.int64)
-    s, e = int(indptr[col_lo]), int(indptr[col_hi])
-    rows = np.asarray(W_csc.indices[s:e], dtype=np.int64)
-    vals = np.asarray(W_csc.data[s:e], dtype=np.float32)
-    counts = np.diff(indptr[col_lo:col_hi + 1])
-    col_ids = col_map = None
-    if compact:
-        active = np.flatnonzero(counts > 0)
-        n_cols = int(active.shape[0])
-        col_ids = (active + col_lo).astype(np.int32)
-        col_map = np.full(n_items, -1, dtype=np.int32)
-        col_map[col_ids] = np.arange(n_cols, dtype=np.int32)
-        kloc = np.repeat(np.arange(n_cols, dtype=np.int64), counts[active])
-    else:
-        n_cols = col_hi - col_lo
-        kloc = np.repeat(np.arange(n_cols, dtype=np.int64), counts)
-    tile_cols = max(256, min(int(tile_cols), -(-max(n_cols, 1) // 256) * 256))
-    n_tiles = max(1, -(-n_cols // tile_cols))
-    tile = kloc // tile_cols
-    order = np.lexsort((kloc, rows, tile))
-    key = (tile * n_items + rows)[order]
-    cnt = np.bincount(key, minlength=n_tiles * n_items)
-    # (tile, row) segments that fill at least `dense_fill` of the tile are stored as zero-padded
-    # dense vectors: the kernel then updates 4 accumulators per lane and instruction
-    dense_idx = dense_val = None
-    kl, vl = kloc[order], vals[order]
-    if dense_fill is not None:
-        dense_keys = np.flatnonzero(cnt >= max(64, int(dense_fill * tile_cols)))
-        if dense_keys.size:
-            dense_idx = np.full(n_tiles * n_items, -1, dtype=np.int32)
-            dense_idx[dense_keys] = np.arange(dense_keys.size, dtype=np.int32)
-            is_dense = dense_idx[key] >= 0
-            dense_val = np.zeros(dense_keys.size * tile_cols, dtype=np.float32)
-            dense_val[dense_idx[key[is_dense]].astype(np.int64) * tile_cols + kl[is_dense] % tile_cols] = vl[is_dense]
-            key, kl, vl = key[~is_dense], kl[~is_dense], vl[~is_dense]
-            cnt = np.bincount(key, minlength=n_tiles * n_items)
-    starts = np.zeros(n_tiles * n_items + 1, dtype=np.int64)
-    np.cumsum(cnt, out=starts[1:])
-    if starts[-1] >= 2 ** 31:
-        raise ValueError("W shard has more than 2**31 stored weights")
-    tile_ptr = np.empty(n_tiles * (n_items + 1), dtype=np.int32)
-    for t in range(n_tiles):
-        tile_ptr[t * (n_items + 1):(t + 1) * (n_items + 1)] = starts[t * n_items:t * n_items + n_items + 1]
-    w_col = (kl % tile_cols).astype(np.uint16)
-    return TiledW(n_items, col_lo, n_cols, tile_cols, n_tiles, tile_ptr, w_col, np.ascontiguousarray(vl),
-                  col_ids, col_map, dense_idx, dense_val)
-
-
-def row_header_table(T: TiledW) -> np.ndarray:
-    """[n_tiles, n_items, 4] int32 records {ptr begin, ptr end, dense block or -1, tile-local layout column
-    of the item or -1}: everything the kernel looks up per (tile, user item), in one 16-byte gather."""
-    n_items, S = T.n_items, T.tile_cols
-    tp = T.tile_ptr.reshape(T.n_tiles, n_items + 1)
-    hdr = np.empty((T.n_tiles, n_items, 4), dtype=np.int32)
-    hdr[:, :, 0] = tp[:, :-1]
-    hdr[:, :, 1] = tp[:, 1:]
-    hdr[:, :, 2] = T.dense_idx.reshape(T.n_tiles, n_items) if T.dense_idx is not None else -1
-    loc = T.col_map.astype(np.int64) if T.col_map is not None else np.arange(n_items, dtype=np.int64) - T.col_lo
-    loc = np.where((loc >= 0) & (loc < T.n_cols), loc, -1)
-    for t in range(T.n_tiles):
-        l = loc - t * S
-        hdr[t, :, 3] = np.where((loc >= 0) & (l >= 0) & (l < S), l, -1)
-    return hdr
-
-
-FR_MAX_ROWS = 128           # kFrMaxRows of csrc/score.hip
-FR_MIN_FILL = 1.0 / 64.0    # the dense R x n_cols form pays when at least this share of it is stored weights
-
-
-def build_feature_rows(W_csc: sp.csc_matrix, col_lo: int, col_hi: int, col_ids: np.ndarray, col_map: np.ndarray,
-                       tile_cols: int = 256) -> Optional[Dict[str, Any]]:
-    """"Feature-row" form of columns [col_lo, col_hi) of W for score_frows_kernel (include/rtrec_amd.h,
-    rtrec_score_opts): only items that some column selected with a non-zero weight have a row in W; when
-    those rows are few the shard is the small dense matrix of those rows over the compacted columns, cut
-    into tiles of 256 (<= 66 rows) or 128 columns so that two slices fit LDS.  None when W does not have
-    that shape (many rows, or hardly filled): the tiled-CSR kernel serves it then."""
-    n_items = W_csc.shape[0]
-    indptr = np.asarray(W_csc.indptr, dtype=np.int64)
-    s, e = int(indptr[col_lo]), int(indptr[col_hi])
-    rows = np.asarray(W_csc.indices[s:e], dtype=np.int64)
-    vals = np.asarray(W_csc.data[s:e], dtype=np.float32)
-    cols = np.repeat(np.arange(col_lo, col_hi, dtype=np.int64), np.diff(indptr[col_lo:col_hi + 1]))
-    F = np.unique(rows)
-    R, n_cols = int(len(F)), int(len(col_ids))
-    if R == 0 or R > FR_MAX_ROWS or n_cols == 0 or len(vals) < FR_MIN_FILL * R * n_cols:
-        return None
-    tc = 128 if int(tile_cols) == 128 else 256      # 256: four sums per lane and instruction; slices are cut into fragments, so
-                                                    # the tallest tile (R rows) no longer has to fit one LDS buffer
-    n_tiles = -(-n_cols // tc)
-    if n_tiles * (tc // 64) > 416:
-        return None
-    fmap = np.full(n_items, -1, dtype=np.int32)
-    fmap[F] = np.arange(R, dtype=np.int32)
-    # Column order: the kernel skips (row, tile) blocks without a weight, so columns that use the same RARE rows
-    # should share tiles.  Sort the columns lexicographically by their row pattern, rarest row first (ML-20M
-    # shape: 35 % of the blocks a pass visits are non-empty instead of 94 % in item-id order).  Any order gives
-    # the same scores: a skipped block only ever added +-0.
-    f_of, c_of = fmap[rows].astype(np.int64), col_map[cols].astype(np.int64)
-    pattern = np.zeros((R, n_cols), dtype=bool)
-    pattern[f_of, c_of] = True
-    by_rarity = np.argsort(pattern.sum(axis=1), kind="stable")          # rarest row = primary key = last lexsort key
-    # ... descending, so that the columns with the most / rarest rows -- the high scorers -- come FIRST: the
-    # kernel's running top-k then settles within the first tiles (ascending, nearly every column displaces one)
-    order = np.lexsort(tuple(pattern[r] for r in by_rarity[::-1]))[::-1]     # layout position -> compacted column
-    # ... and the TILES this order forms are visited heaviest first (sum of |w|): the columns that end up in a user's
-    # top-k are overwhelmingly in the heavy tiles, so the running k-th best score is near its final value after the
-    # first tiles and almost nothing enters the lists later (ML-20M shape: 113 -> 14 list candidates per user).
-    order = _heavy_tiles_first(order, np.bincount(c_of, weights=np.abs(vals).astype(np.float64), minlength=n_cols), tc)
-    fr_col_ids = np.asarray(col_ids, dtype=np.int32)[order]
-    fr_col_map = np.full(n_items, -1, dtype=np.int32)
-    fr_col_map[fr_col_ids] = np.arange(n_cols, dtype=np.int32)
-    lc = fr_col_map[cols].astype(np.int64)
-    t_of = lc // tc
-    present = np.zeros((n_tiles, R), dtype=bool)            # (tile, row) blocks that hold a weight
-    present[t_of, f_of] = True
-    n_rows_t = present.sum(axis=1)
-    local = np.cumsum(present, axis=1) - 1                  # row -> index inside the tile's compact slice
-    P = _pack_fragments(n_rows_t.astype(np.int64), tc)           # slices -> fragments -> super-tiles staged in LDS
-    k_of = local[t_of, f_of]                                     # rank of the weight's row among its tile's stored rows
-    g_of = P["frag_of"][t_of, k_of]                              # ... and the fragment that holds it
-    wd = np.zeros(max(int(P["super_kb"][-1]) * 256, 256), dtype=np.float32)
-    base = P["super_kb"][P["frag_super"][g_of]] * 256 + P["frag_off"][g_of] // 4
-    wd[base + (k_of - P["frag_k0"][g_of]) * tc + lc % tc] = vals
-    # tile headers: max |w| per row -- the kernel skips a tile for a wave when sum_f |x_f| max|w_f| cannot beat any of
-    # its users' current (k+1)-th best scores
-    hbase = P["super_kb"][P["frag_super"][P["first_frag"]]] * 256 + (P["frag_off"][P["first_frag"]] - FR_TILE_HEADER_BYTES) // 4
-    np.maximum.at(wd, hbase[t_of] + f_of, np.abs(vals))
-    frag_rows = np.zeros((P["n_frags"], 2), dtype=np.uint64)
-    np.bitwise_or.at(frag_rows, (g_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
-    tile_rows = np.zeros((n_tiles, 2), dtype=np.uint64)
-    np.bitwise_or.at(tile_rows, (t_of, f_of // 64), np.uint64(1) << (f_of % 64).astype(np.uint64))
-    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=frag_rows.view(np.int64),
-                fr_tile_off=P["frag_off"].astype(np.int32), fr_frag_tile=P["frag_flags"].astype(np.int32),
-                fr_super_kb=P["super_kb"].astype(np.int32), fr_super_tile=P["super_frag"].astype(np.int32), fr_rows=R,
-                fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_frags=P["n_frags"], fr_n_super=P["n_super"], fr_buf_bytes=P["buf_bytes"],
-                fr_rows_of_tile=tile_rows.view(np.int64))
-
-
-
-def _heavy_tiles_first(order: np.ndarray, col_mass: np.ndarray, tc: int) -> np.ndarray:
-    """Permute the full tiles of a column order by descending weight mass (float32-rounded, ties: earlier tile first);
-    a partial last tile stays last."""
-    n_full = len(order) // tc
-    if n_full < 2:
-        return order
-    head = order[:n_full * tc].reshape(n_full, tc)
-    tmass = col_mass[head].sum(axis=1).astype(np.float32)
-    return np.concatenate([head[np.argsort(-tmass, kind="stable")].ravel(), order[n_full * tc:]])
-
-
-FR_TILE_HEADER_BYTES = 512          # per tile, in front of its first fragment: max |w| of each of the (<= 128) rows in the tile
-FR_STREAM_BUF_BYTES = 36 * 1024     # slice buffer of the streaming layout: two 8-wave workgroups (2 buffers each) share a CU's LDS
-
-
-def _pack_fragments(n_rows_t: np.ndarray, tc: int) -> Dict[str, Any]:
-    """Lay the tiles' slices (n_rows_t[t] rows of tc floats each, rows ascending) out for LDS staging -- shared by the
-    host and device builders of the feature-row layout.
-
-    RESIDENT form: everything fits one CU's LDS next to the per-wave setup scratch -> one super-tile, one fragment
-    per tile; the kernel loads it once per workgroup.  STREAMING form: super-tiles of at most FR_STREAM_BUF_BYTES, filled
-    greedily with FRAGMENTS -- a tile's slice may continue in the next super-tile (its accumulators stay in registers
-    across the hand-over), so the buffer size is independent of the tallest tile.
-    Returns per fragment: tile, k0, k1 (ranks of the tile's stored rows it holds), first / last flags, byte offset inside
-    its super-tile; per super-tile: first fragment, KiB offset in the weight array; buf_bytes; resident."""
-    row_bytes = tc * 4
-    n_tiles = len(n_rows_t)
-    total = -(-(int(n_rows_t.sum()) * row_bytes + n_tiles * FR_TILE_HEADER_BYTES) // 1024) * 1024
-    setup = 16 * (-(-(n_tiles * (tc // 64) * 8 + 768) // 256) * 256)
-    resident = n_tiles <= 64 and total + setup + 16 * 512 + 1024 + 16 <= 160 * 1024
-    cap = max(total, 1024) if resident else FR_STREAM_BUF_BYTES
-    f_tile, f_k0, f_k1, f_off, f_super, st_frag, used = [], [], [], [], [], [0], 0
-    for t in range(n_tiles):
-        k, n = 0, int(n_rows_t[t])
-        while k < n:
-            hdr = FR_TILE_HEADER_BYTES if k == 0 else 0      # the tile's header sits in front of its first fragment
-            room = (cap - used - hdr) // row_bytes
-            # close the super-tile when it is full, holds 64 fragments (a lane per fragment), or the rest of it would
-            # take less than 8 rows of a slice that needs more
-            if used > 0 and (room < min(n - k, 8) or len(f_tile) - st_frag[-1] >= 64):
-                st_frag.append(len(f_tile))
-                used = 0
-                continue
-            take = min(n - k, room)
-            f_tile.append(t); f_k0.append(k); f_k1.append(k + take); f_off.append(used + hdr); f_super.append(len(st_frag) - 1)
-            used += hdr + take * row_bytes
-            k += take
-    st_frag.append(len(f_tile))
-    f_tile, f_k0, f_k1 = (np.asarray(a, dtype=np.int64) for a in (f_tile, f_k0, f_k1))
-    f_super, st_frag = np.asarray(f_super, dtype=np.int64), np.asarray(st_frag, dtype=np.int64)
-    n_super = len(st_frag) - 1
-    bytes_s = np.zeros(n_super, dtype=np.int64)
-    np.add.at(bytes_s, f_super, (f_k1 - f_k0) * row_bytes + np.where(f_k0 == 0, FR_TILE_HEADER_BYTES, 0))
-    super_kb = np.zeros(n_super + 1, dtype=np.int64)
-    super_kb[1:] = np.cumsum(-(-bytes_s // 1024))
-    flags = f_tile | ((f_k0 == 0).astype(np.int64) << 24) | ((f_k1 == n_rows_t[f_tile]).astype(np.int64) << 25)
-    # (tile, rank of a stored row) -> fragment
-    frag_of = np.zeros((n_tiles, max(int(n_rows_t.max()), 1)), dtype=np.int64)
-    for i in range(len(f_tile)):
-        frag_of[f_tile[i], f_k0[i]:f_k1[i]] = i
-    buf_bytes = int(cap) if resident else FR_STREAM_BUF_BYTES
-    first_frag = np.zeros(n_tiles, dtype=np.int64)
-    first_frag[f_tile[f_k0 == 0]] = np.flatnonzero(f_k0 == 0)
-    return dict(first_frag=first_frag, frag_tile=f_tile, frag_k0=f_k0, frag_flags=flags, frag_off=np.asarray(f_off, dtype=np.int64), frag_super=f_super,
-                super_frag=st_frag, super_kb=super_kb, frag_of=frag_of, buf_bytes=buf_bytes, resident=bool(resident),
-                n_frags=len(f_tile), n_super=n_super)
-
-
-def build_feature_rows_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int,
-                              tile_cols: int = 256) -> Optional[Dict[str, Any]]:
-    """build_feature_rows for a W that is resident on the device as COO triples (int64 rows / cols sorted by (col, row),
-    float32 vals): the same layout, built with tensor ops -- only the per-tile row counts (a few dozen integers) visit
-    the host for the super-tile packing.  Returns device tensors (plus the scalars and, for bench.py, small host copies)."""
-    sel = (cols >= col_lo) & (cols < col_hi)
-    r, c, v = rows[sel], cols[sel], vals[sel]
-    if r.numel() == 0:
-        return None
-    F = torch.unique(r)
-    col_ids_sorted = torch.unique(c)
-    R, n_cols = int(F.numel()), int(col_ids_sorted.numel())
-    if R > FR_MAX_ROWS or r.numel() < FR_MIN_FILL * R * n_cols:
-        return None
-    tc = 128 if int(tile_cols) == 128 else 256      # 256: four sums per lane and instruction; slices are cut into fragments, so
-                                                    # the tallest tile (R rows) no longer has to fit one LDS buffer
-    n_tiles = -(-n_cols // tc)
-    if n_tiles * (tc // 64) > 416:
-        return None
-    dev = r.device
-    i64 = torch.int64
-    fmap = torch.full((n_items,), -1, dtype=torch.int32, device=dev)
-    fmap[F] = torch.arange(R, dtype=torch.int32, device=dev)
-    f_of = fmap[r].to(i64)
-    c_of = torch.searchsorted(col_ids_sorted, c)
-    # column order: lexicographic by row pattern, rarest row most significant, descending (see build_feature_rows)
-    counts = torch.bincount(f_of, minlength=R)
-    by_rarity = torch.argsort(counts, stable=True)
-    rank = torch.empty(R, dtype=i64, device=dev)
-    rank[by_rarity] = torch.arange(R, dtype=i64, device=dev)
-    sig = (R - 1) - rank[f_of]                                  # bit significance of the entry's row: rarest = highest
-    n_words = -(-R // 60)
-    order = torch.arange(n_cols, dtype=i64, device=dev).flip(0)  # ties: descending column position, like the host builder
-    for w in range(n_words):                                     # least significant word first, stable sorts
-        inw = (sig // 60) == w
-        word = torch.zeros(n_cols, dtype=i64, device=dev)
-        word.index_add_(0, c_of[inw], torch.ones_like(sig[inw]) << (sig[inw] % 60))
-        order = order[torch.argsort(word[order], descending=True, stable=True)]
-    n_full = n_cols // tc                                        # tiles heaviest first (see build_feature_rows)
-    if n_full > 1:
-        col_mass = torch.zeros(n_cols, dtype=torch.float64, device=dev).index_add_(0, c_of, v.abs().double())
-        head = order[:n_full * tc].view(n_full, tc)
-        tmass = col_mass[head].sum(dim=1).float()
-        order = torch.cat([head[torch.argsort(tmass, descending=True, stable=True)].reshape(-1), order[n_full * tc:]])
-    fr_col_ids = col_ids_sorted[order].to(torch.int32)
-    fr_col_map = torch.full((n_items,), -1, dtype=torch.int32, device=dev)
-    fr_col_map[fr_col_ids.to(i64)] = torch.arange(n_cols, dtype=torch.int32, device=dev)
-    lc = fr_col_map[c].to(i64)
-    t_of = lc // tc
-    present = torch.zeros((n_tiles, R), dtype=torch.bool, device=dev)
-    present[t_of, f_of] = True
-    n_rows_t = present.sum(dim=1).cpu().numpy().astype(np.int64)
-    P = _pack_fragments(n_rows_t, tc)
-    local = torch.cumsum(present.to(i64), dim=1) - 1
-    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    k_of = local[t_of, f_of]
-    g_of = dv(P["frag_of"])[t_of, k_of]
-    wd = torch.zeros(max(int(P["super_kb"][-1]) * 256, 256), dtype=torch.float32, device=dev)
-    base = dv(P["super_kb"])[dv(P["frag_super"])[g_of]] * 256 + dv(P["frag_off"])[g_of] // 4
-    wd[base + (k_of - dv(P["frag_k0"])[g_of]) * tc + lc % tc] = v
-    hbase = dv(P["super_kb"][P["frag_super"][P["first_frag"]]] * 256 + (P["frag_off"][P["first_frag"]] - FR_TILE_HEADER_BYTES) // 4)
-    wd.scatter_reduce_(0, hbase[t_of] + f_of, v.abs(), reduce="amax")             # tile headers: max |w| per row
-    # one bit per (row, fragment) / (row, tile) block that holds a weight
-    blk_key = torch.unique(g_of * 128 + f_of)
-    bg, bf = blk_key // 128, blk_key % 128
-    frag_rows = torch.zeros((P["n_frags"], 2), dtype=i64, device=dev)
-    frag_rows.view(-1).index_add_(0, bg * 2 + bf // 64, torch.ones_like(bf) << (bf % 64))
-    blk = torch.zeros((n_tiles, 2), dtype=i64, device=dev)
-    pt, pf = torch.nonzero(present, as_tuple=True)
-    blk.view(-1).index_add_(0, pt * 2 + pf // 64, torch.ones_like(pf) << (pf % 64))
-    fmap_host = fmap.cpu().numpy()
-    host = dict(fr_map=fmap_host, fr_rows_of_tile=blk.cpu().numpy(), fr_super_kb=P["super_kb"].astype(np.int32), fr_rows=R,
-                fr_tile_cols=tc, fr_resident=P["resident"])
-    return dict(fr_map=fmap, fr_col_ids=fr_col_ids, fr_col_map=fr_col_map, fr_w=wd, fr_tile_rows=frag_rows,
-                fr_tile_off=dv(P["frag_off"].astype(np.int32)), fr_frag_tile=dv(P["frag_flags"].astype(np.int32)),
-                fr_super_kb=dv(P["super_kb"].astype(np.int32)), fr_super_tile=dv(P["super_frag"].astype(np.int32)),
-                fr_rows=R, fr_tile_cols=tc, fr_n_tiles=n_tiles, fr_n_frags=P["n_frags"], fr_n_super=P["n_super"],
-                fr_buf_bytes=P["buf_bytes"], fr_host=host, col_ids_sorted=col_ids_sorted)
-
-
-def build_tiled_w_device(torch, rows, cols, vals, n_items: int, col_lo: int, col_hi: int, tile_cols: int,
-                         compact: bool = False, dense_fill: Optional[float] = None) -> Optional[Dict[str, Any]]:
-    """build_tiled_w + row_header_table for a W that is resident on the device (COO triples sorted by (col, row)):
-    the same arrays, as device tensors, built with tensor ops."""
-    sel = (cols >= col_lo) & (cols < col_hi)
-    r, c, v = rows[sel], cols[sel], vals[sel]
-    dev, i64 = rows.device, torch.int64
-    col_ids = col_map = None
-    if compact:
-        col_ids = torch.unique(c)
-        n_cols = int(col_ids.numel())
-        kloc = torch.searchsorted(col_ids, c)
-        col_map = torch.full((n_items,), -1, dtype=torch.int32, device=dev)
-        col_map[col_ids] = torch.arange(n_cols, dtype=torch.int32, device=dev)
-    else:
-        n_cols = col_hi - col_lo
-        kloc = c - col_lo
-    if n_cols <= 0:
-        return None
-    S = max(256, min(int(tile_cols), -(-max(n_cols, 1) // 256) * 256))
-    n_tiles = max(1, -(-n_cols // S))
-    seg = (kloc // S) * n_items + r                                # (tile, row) segment of every weight
-    order = torch.argsort(seg * S + kloc % S)                      # by tile, row, column
-    seg, kl, vl = seg[order], kloc[order] % S, v[order]
-    cnt = torch.bincount(seg, minlength=n_tiles * n_items)
-    dense_idx = dense_val = None
-    if dense_fill is not None:
-        dense_keys = torch.nonzero(cnt >= max(64, int(dense_fill * S))).view(-1)
-        if dense_keys.numel():
-            dense_idx = torch.full((n_tiles * n_items,), -1, dtype=torch.int32, device=dev)
-            dense_idx[dense_keys] = torch.arange(dense_keys.numel(), dtype=torch.int32, device=dev)
-            is_dense = dense_idx[seg] >= 0
-            dense_val = torch.zeros(int(dense_keys.numel()) * S, dtype=torch.float32, device=dev)
-            dense_val[dense_idx[seg[is_dense]].to(i64) * S + kl[is_dense]] = vl[is_dense]
-            seg, kl, vl = seg[~is_dense], kl[~is_dense], vl[~is_dense]
-            cnt = torch.bincount(seg, minlength=n_tiles * n_items)
-    starts = torch.zeros(n_tiles * n_items + 1, dtype=i64, device=dev)
-    torch.cumsum(cnt, 0, out=starts[1:])
-    if int(starts[-1]) >= 2 ** 31:
-        raise ValueError("W shard has more than 2**31 stored weights")
-    tile_ptr = torch.empty((n_tiles, n_items + 1), dtype=torch.int32, device=dev)
-    tile_ptr[:, :-1] = starts[:-1].view(n_tiles, n_items).to(torch.int32)
-    tile_ptr[:, -1] = starts[torch.arange(1, n_tiles + 1, device=dev) * n_items].to(torch.int32)
-    hdr = torch.empty((n_tiles, n_items, 4), dtype=torch.int32, device=dev)
-    hdr[:, :, 0] = tile_ptr[:, :-1]
-    hdr[:, :, 1] = tile_ptr[:, 1:]
-    hdr[:, :, 2] = dense_idx.view(n_tiles, n_items) if dense_idx is not None else -1
-    loc = col_map.to(i64) if col_map is not None else torch.arange(n_items, dtype=i64, device=dev) - col_lo
-    loc = torch.where((loc >= 0) & (loc < n_cols), loc, torch.full_like(loc, -1))
-    for t in range(n_tiles):
-        l = loc - t * S
-        hdr[t, :, 3] = torch.where((loc >= 0) & (l >= 0) & (l < S), l, torch.full_like(l, -1)).to(torch.int32)
-    return dict(n_cols=n_cols, tile_cols=S, n_tiles=n_tiles, nnz=int(vl.numel()), dense_idx=dense_idx, dense_val=dense_val,
-                n_dense=0 if dense_idx is None else int(dense_val.numel() // S),
-                tile_ptr=tile_ptr.view(-1), w_col=kl.to(torch.int16), w_val=vl.contiguous(),
-                col_ids=None if col_ids is None else col_ids.to(torch.int32), col_map=col_map, row_hdr=hdr)
-
-
-class DeviceWeights:
-    """W (I x I) resident on the device: COO triples sorted by (column, row) -- int64 rows / cols, float32 vals, no
-    explicit zeros.  It is what a fit writes (SlimEngine.merge_fit), what the score layouts are built from
-    (SlimEngine._layout) and what `item_similarity` is materialised from when the host asks for it (to_csc); `f64`
-    records that the host-visible matrix is float64 (serial fit, slim_elastic.py:252), which selects the float64
-    accumulator of the score kernels."""
-
-    __slots__ = ("rows", "cols", "vals", "n_items", "f64", "lossy", "_host", "_csc", "shard")
-
-    def __init__(self, rows, cols, vals, n_items: int, f64: bool, host: Optional[sp.csc_matrix] = None, lossy: bool = False):
-        self.rows, self.cols, self.vals, self.n_items, self.f64 = rows, cols, vals, int(n_items), bool(f64)
-        self.shard = None              # (rank, world): only this rank's column block of W is held (SlimEngine.shard_w)
-        self.lossy = bool(lossy)       # uploaded from a float64 host matrix whose values are not float32 numbers
-        self._host = host
-        self._csc = None
-
-    @property
-    def nnz(self) -> int:
-        return int(self.vals.numel())
-
-    def csc_arrays(self, torch):
-        """(ptr, row, val) int32 / int32 / float32 device tensors: the CSC view the item-to-item kernel reads."""
-        if self._csc is None:
-            ptr = torch.searchsorted(self.cols, torch.arange(self.n_items + 1, dtype=torch.int64, device=self.cols.device))
-            self._csc = (ptr.to(torch.int32), self.rows.to(torch.int32), self.vals)
-        return self._csc
-
-    def to_csc(self, torch) -> sp.csc_matrix:
-        """The host matrix (sorted indices), downloaded once."""
-        if self._host is None:
-            ptr, row, val = self.csc_arrays(torch)
-            dt = np.float64 if self.f64 else np.float32
-            self._host = sp.csc_matrix((val.cpu().numpy().astype(dt), row.cpu().numpy(), ptr.cpu().numpy()),
-                                       shape=(self.n_items, self.n_items))
-        return self._host
-
-
-class HipBackend:
-    """Thin marshalling layer over librtrec_amd.so; all arrays are torch CUDA tensors."""
-
-    def __init__(self, device: Any = None):
-        import torch
-        if not torch.cuda.is_available():
-            raise _native.NativeLibraryError("rtrec_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
-                                             "there is no CPU fallback")
-        self.torch = torch
-        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        self.lib = _native.load()
-        from . import ops as _ops  # noqa: F401  (registers torch.ops.rtrec_amd.*)
-        self.ops = torch.ops.rtrec_amd
-        self._xty_ws = None              # scratch of the one-pass X^T y of small fit calls (grown on demand)
-        self._aux_stream = None
-        # one-time costs of a process (custom-op dispatcher set-up, loading the gfx950 code objects)
-        # belong here, next to the HIP context creation, not inside the first fit or recommend call
-        w = torch.ones(1, dtype=torch.float32, device=self.device)
-        self.ops.column_sqnorms(torch.tensor([0, 1], dtype=torch.int32, device=self.device), w, torch.empty_like(w))
-        from .utils.device_store import DeviceInteractions
-        DeviceInteractions(torch, self.device).warm_up(self.fold_pairs)
-        k = torch.arange(4, dtype=torch.int64, device=self.device)         # the tensor ops of SlimEngine.merge_fit
-        _ = (k // 2, k % 2, torch.isin(k, k[:2]), torch.argsort(k), k[k > 1], torch.cat([k, k]))
-
-    # -- helpers -------------------------------------------------------------------------
-    def to_dev(self, a: np.ndarray):
-        t = self.torch.from_numpy(np.ascontiguousarray(a))
-        return t.to(self.device, non_blocking=False)
-
-    def to_dev_small(self, a: np.ndarray):
-        """Upload of a request-sized array without a host-device round trip: staged in pinned memory (torch's caching host
-        allocator keeps the block until the copy has run) and copied asynchronously on the current stream."""
-        t = self.torch.from_numpy(np.ascontiguousarray(a))
-        if t.numel() > (1 << 16):
-            return t.to(self.device, non_blocking=False)
-        return t.pin_memory().to(self.device, non_blocking=True)
-
-    def empty(self, shape, dtype):
-        return self.torch.empty(shape, dtype=dtype, device=self.device)
-
-    def zeros(self, shape, dtype):
-        return self.torch.zeros(shape, dtype=dtype, device=self.device)
-
-    def stream(self) -> C.c_void_p:
-        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
-
-    @staticmethod
-    def ptr(t) -> C.c_void_p:
-        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-
-    def synchronize(self):
-        self.torch.cuda.synchronize(self.device)
-
-    # -- one method per entry point, each a call of the matching torch.ops.rtrec_amd custom op
-    #    (rtrec_amd/ops.py -> C-ABI); tests substitute a CPU stand-in with the same methods to
-    #    exercise the multi-process orchestration without a GPU ---------------------------------
-    def column_sqnorms(self, n_items, cptr, cval, out):
-        self.ops.column_sqnorms(cptr, cval, out)
-
-    def fit_workspace(self, n_users, n_items, slots, top_features):
-        nbytes = int(self.lib.rtrec_slim_fit_workspace_bytes(n_users, n_items, slots, top_features))
-        ws = self.empty((nbytes,), self.torch.uint8)
-        self.ops.fit_workspace_init(ws, n_users, n_items, slots, top_features)
-        return ws, self.zeros((1,), self.torch.int32)
-
-    supports_gram = True
-    supports_device_store = True     # X can stay resident as sorted COO (utils/device_store.py)
-
-    @staticmethod
-    def fit_knobs() -> Dict[str, int]:
-        """Tuning / test knobs of rtrec_fit_opts, read from the environment HERE (the library itself reads none):
-        RTREC_AMD_FIT_MODE=sw|mw, RTREC_AMD_COLWALK_MIN, RTREC_AMD_SCREEN_MIN, RTREC_AMD_LANE_MAX."""
-        mode = settings.raw("RTREC_AMD_FIT_MODE", "")
-        lane_max = settings.raw("RTREC_AMD_LANE_MAX")
-        return dict(kernel=2 if mode.startswith("m") else 1 if mode.startswith("s") else 0,
-                    colwalk_min_rows=int(settings.raw("RTREC_AMD_COLWALK_MIN", 0)),
-                    screen_min=int(settings.raw("RTREC_AMD_SCREEN_MIN", 0)),
-                    lane_max=0 if lane_max is None else (-1 if int(lane_max) == 0 else int(lane_max)))
-
-    def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
-                    ws, queue, slots, trace=None, gram=None, fast=False, one_pass_xty=True):
-        g = gram or {}
-        k = self.fit_knobs()
-        # small calls with feature selection (online partial_fit): scratch for the one-pass X^T y of all targets
-        xty = None
-        n_t, nnz = int(targets.shape[0]), int(X["rcol"].shape[0])
-        if (one_pass_xty and 0 < n_t <= FIT_MW_MAX_TARGETS and int(cfg.top_features) > 0 and int(fast) != 1 and k["kernel"] != 1 and nnz > 0
-                and settings.raw("RTREC_AMD_XTY_BATCH", "1") != "0"):
-            need = int(self.lib.rtrec_slim_xty_workspace_bytes(n_users, n_items, nnz, n_t))
-            if 0 < need <= XTY_SCRATCH_MAX_BYTES:
-                if self._xty_ws is None or self._xty_ws.numel() < need:
-                    self._xty_ws = None
-                    self._xty_ws = self.empty((int(need * 1.25),), self.torch.uint8)
-                xty = self._xty_ws
-                if "col_order" not in X:          # longest columns first (lengths from the resident CSC pointer array)
-                    X["col_order"] = self.torch.argsort(X["cptr"][1:] - X["cptr"][:-1], descending=True, stable=True).to(self.torch.int32)
-        self.ops.fit_columns(X["cptr"], X["crow"], X["cval"], X["rptr"], X["rcol"], X["rval"], X["sqn"], targets,
-                             n_users, n_items, float(cfg.l1_reg), float(cfg.l2_reg), float(cfg.tol), int(cfg.max_iter),
-                             int(cfg.seed), bool(cfg.positive), int(cfg.top_features),
-                             out_items, out_coef, out_count, out_niter, cap, ws, slots, queue, trace,
-                             g.get("G"), g.get("index"), int(g.get("n", 0)), float(g.get("rel_err", 0.0)),
-                             int(fast), k["kernel"], k["colwalk_min_rows"], k["screen_min"], k["lane_max"], xty, X.get("col_order") if xty is not None else None)
-
-    def gram_matrix(self, X, n_users, n_items, n_top):
-        """Gram matrix X_P^T X_P of the n_top most popular items in float64 for the fit kernel's Gram
-        tracking (rtrec_slim_gram_matrix: densify + tiled float64 accumulation on the device)."""
-        torch = self.torch
-        col_nnz = X["col_nnz"]
-        pop = np.argsort(-col_nnz, kind="stable")[:n_top]
-        pop = pop[col_nnz[pop] > 0]
-        P = int(len(pop))
-        if P == 0:
-            return None
-        p64 = -(-P // 64) * 64
-        gidx = np.full(n_items, -1, dtype=np.int32)
-        gidx[pop] = np.arange(P, dtype=np.int32)
-        d_gidx, d_top = self.to_dev(gidx), self.to_dev(pop.astype(np.int32))
-        nbytes = int(self.lib.rtrec_slim_gram_workspace_bytes(n_users, P))
-        ws = self.empty((nbytes,), torch.uint8)
-        G = self.empty((p64, p64), torch.float64)
-        self.ops.gram_matrix(X["cptr"], X["crow"], X["cval"], d_top, ws, G, n_users, n_items)
-        return {"G": G, "index": d_gidx, "n": p64, "rel_err": max(1e-9, 64.0 * n_users * 2.0 ** -53), "items": pop}
-
-    def score_workspace_bytes(self, n_rows, n_tiles, top_k):
-        return int(self.lib.rtrec_slim_score_workspace_bytes(n_rows, n_tiles, top_k))
-
-    supports_feature_rows = True
-    supports_seg_layout = True
-
-    def score_topk(self, n_rows, row_ids, xb, n_items, col_lo, lay, col_rank, top_k, filter_interacted, mode,
-                   acc_f64, ids, sc, sc64, aux, cnt, ws, timer=0, diagnostics=0, use_fr=True, row_order=None, rescored=None, row_order_grouped=False,
-                   use_sg=True, use_sg_heavy=True, flagged=None):
-        fr = lay if (use_fr and lay.get("fr_w") is not None) else {}
-        sg = lay.get("sg") or {} if (use_sg and not fr) else {}
-        self.ops.score_topk(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo,
-                            lay.get("col_ids"), lay.get("col_map"), int(lay.get("tile_cols", 0)), int(lay.get("n_tiles", 0)),
-                            lay.get("tile_ptr"), lay.get("w_col"), lay.get("w_val"), lay.get("dense_idx"), lay.get("dense_val"),
-                            lay.get("row_hdr"), col_rank, top_k, bool(filter_interacted), int(mode), bool(acc_f64),
-                            ids, sc, sc64, aux, cnt, ws,
-                            fr.get("fr_map"), fr.get("fr_col_ids"), fr.get("fr_col_map"), fr.get("fr_w"),
-                            fr.get("fr_tile_rows"), fr.get("fr_tile_off"), fr.get("fr_super_kb"), fr.get("fr_super_tile"),
-                            fr.get("fr_frag_tile"),
-                            int(fr.get("fr_rows", 0)), int(fr.get("fr_tile_cols", 0)), int(fr.get("fr_n_tiles", 0)),
-                            int(fr.get("fr_n_frags", 0)), int(fr.get("fr_n_super", 0)), int(fr.get("fr_buf_bytes", 0)),
-                            fr.get("fr_scratch"),
-                            row_order if (fr or sg) else None, int(timer), int(diagnostics), rescored,
-                            # bit 1: the order is by descending length (the segment kernels rely on it: _row_order(allow_grouped=False))
-                            int(bool(row_order_grouped)) | (int(bool(sg) and row_order is not None and not row_order_grouped) << 1),
-                            sg.get("sg_info"), sg.get("sg_ptr"), sg.get("sg_ent"), sg.get("sg_bound"),
-                            sg.get("sg_col_ids"), int(sg.get("sg_T", 0)), int(sg.get("sg_n_tiles", 0)), int(sg.get("sg_rows", 0)),
-                            int(sg.get("sg_n_cols", 0)), sg.get("sg_trow_ptr"), sg.get("sg_trow"),
-                            sg.get("sg_scratch") if use_sg_heavy else None, flagged,
-                            self.aux_stream_handle() if (sg and use_sg_heavy and n_rows >= self.SG_FORK_MIN_ROWS) else 0)
-
-    SG_FORK_MIN_ROWS = 8192          # = kSgForkMinRows (csrc/score_seg.hip.h)
-
-    def aux_stream_handle(self) -> int:
-        """A second stream of this backend (created on first use): the segment path's workgroup-per-long-user kernel runs on
-        it beside the main kernel (rtrec_score_opts.aux_stream).  RTREC_AMD_SG_FORK=0 turns that off (A/B)."""
-        if settings.raw("RTREC_AMD_SG_FORK", "1") == "0":
-            return 0
-        if self._aux_stream is None:
-            self._aux_stream = self.torch.cuda.Stream(device=self.device)
-        return int(self._aux_stream.cuda_stream)
-
-    def decay_f32(self, raw, ts, rate: float, now: float):
-        """float32(raw * rate ** ((now - ts) / 86400)) for resident arrays: rtrec_store_decay_device, plus the host's libm
-        for the handful of entries the kernel flags as too close to a float32 rounding boundary (csrc/store_device.hip)."""
-        torch = self.torch
-        n = int(raw.shape[0])
-        out = self.empty((n,), torch.float32)
-        if n == 0:
-            return out
-        cap = max(1024, n >> 10)
-        idx = self.empty((cap,), torch.int32)
-        cnt = self.zeros((1,), torch.int32)
-        _native.check(self.lib.rtrec_store_decay_device(self.ptr(raw), self.ptr(ts), n, float(rate), float(now), self.ptr(out),
-                                                        self.ptr(idx), self.ptr(cnt), cap, self.stream()),
-                      "rtrec_store_decay_device")
-        k = int(cnt.item())
-        sel = idx[:k].long() if k <= cap else torch.arange(n, device=raw.device)        # overflow: let the host do them all
-        if sel.numel():
-            v, t = raw[sel].cpu().numpy(), ts[sel].cpu().numpy()
-            fix = np.empty(v.shape[0], np.float32)
-            if self.lib.rtrec_store_decay(v.ctypes.data, t.ctypes.data, v.shape[0], float(rate), None, float(now), None,
-                                          fix.ctypes.data, 0) != 0:
-                raise _native.NativeLibraryError("rtrec_store_decay failed")
-            out[sel] = torch.from_numpy(fix).to(out.device)
-        return out
-
-    def fold_pairs(self, order, start, delta, tstamp, old, lo: float, hi: float, upsert: bool):
-        """(float64 values, float64 timestamps, float32 values) of a bulk batch's distinct pairs: rtrec_store_fold_device over
-        the batch sorted by (user, item, arrival) -- see DeviceInteractions.ingest."""
-        torch = self.torch
-        g = int(start.shape[0]) - 1
-        val, ts, v32 = self.empty((g,), torch.float64), self.empty((g,), torch.float64), self.empty((g,), torch.float32)
-        _native.check(self.lib.rtrec_store_fold_device(self.ptr(order), self.ptr(start), g, self.ptr(delta), self.ptr(tstamp),
-                                                       self.ptr(old) if old is not None else None, float(lo), float(hi),
-                                                       int(bool(upsert)), self.ptr(val), self.ptr(ts), self.ptr(v32), self.stream()),
-                      "rtrec_store_fold_device")
-        return val, ts, v32
-
-    def timer_create(self) -> int:
-        h = C.c_void_p()
-        _native.check(self.lib.rtrec_timer_create(C.byref(h)), "rtrec_timer_create")
-        return int(h.value)
-
-    def timer_read(self, handle: int, reset: bool = False) -> Tuple[float, int]:
-        ms, n = C.c_double(0), C.c_int64(0)
-        _native.check(self.lib.rtrec_timer_read(C.c_void_p(handle), C.byref(ms), C.byref(n), int(reset)), "rtrec_timer_read")
-        return float(ms.value), int(n.value)
-
-    def timer_destroy(self, handle: int) -> None:
-        self.lib.rtrec_timer_destroy(C.c_void_p(handle))
-
-    def score_rows(self, n_rows, row_ids, xb, n_items, col_lo, lay, acc_f64, out):
-        self.ops.score_rows(row_ids, xb[0], xb[1], xb[2], n_rows, n_items, lay["n_cols"], col_lo, lay["tile_cols"],
-                            lay["n_tiles"], lay["tile_ptr"], lay["w_col"], lay["w_val"], bool(acc_f64), out)
-
-    def merge_topk(self, n_rows, n_lists, top_k, g_ids, g_sc, g_sc64, g_aux, g_cnt, o_ids, o_sc, o_cnt):
-        """g_* are [n_lists, n_rows, top_k] tensors (g_cnt [n_lists, n_rows]); they may be strided views
-        into one packed all-gather buffer as long as the last dimension is contiguous."""
-        self.ops.merge_topk(g_ids, g_sc, g_sc64, g_aux, g_cnt, top_k, o_ids, o_sc, o_cnt)
-
-    def similar_topk(self, queries, W, top_k, ids, sc, cnt):
-        self.ops.similar_topk(queries, W["cptr"], W["crow"], W["cval"], top_k, ids, sc, cnt)
 
 
 class SlimEngine:
