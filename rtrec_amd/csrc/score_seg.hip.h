@@ -63,11 +63,19 @@ constexpr int kSgQueueChunk = 4;     // users per queue claim of a full-size pas
 constexpr int kSgMaxKk = 64;         // top_k + 1 list entries: one per lane
 // A pass with fewer users than the chip has wave slots (~7k) leaves most of it idle, and its latency is its longest
 // user's: there a user of more than n_rows / 16 items (at least 32) gets a whole workgroup (score_seg_heavy_kernel: eight
-// waves share the user's tiles) instead of one wave.  From 8192 rows on only users beyond a wave's LDS lists do.
+// waves share the user's tiles) instead of one wave.  The threshold rises with the pass size (sg_heavy_min_for); from ~49k rows
+// on only users beyond a wave's LDS lists get a workgroup.
 constexpr int kSgSmallHeavyMin = 32;
 constexpr int kSgForkMinRows = 8192;      // passes from this size on run the heavy pass on the caller's auxiliary stream
+// Round 4 (tools/seg_shard_probe.py, the strided user slices of 2 .. 32 row shards of c3s): a pass of 8k-50k users is still
+// short of waves, and its long single-wave users set its length -- 17,312 users: threshold 512 0.64 ms, 384 0.51 ms, 256
+// 0.57 ms; 8,656 users: 512 0.63 ms, 384 0.50 ms, 256 0.38 ms; 34,624: 0.74 / 0.72 / 0.96 ms; 69k and more: 512 is best
+// (the workgroup kernel costs more slot time than it saves latency once the chip is full).
 __host__ __device__ constexpr int sg_heavy_min_for(int n_rows) {
-    return n_rows / 16 < kSgSmallHeavyMin ? kSgSmallHeavyMin : (n_rows / 16 > kSgCap ? kSgCap : n_rows / 16);
+    return n_rows >= 49152 ? kSgCap
+         : n_rows >= 12288 ? (kSgCap < 384 ? kSgCap : 384)
+         : n_rows >= 6144 ? (kSgCap < 256 ? kSgCap : 256)
+         : (n_rows / 16 < kSgSmallHeavyMin ? kSgSmallHeavyMin : (n_rows / 16 > kSgCap ? kSgCap : n_rows / 16));
 }
 #ifndef SG_OCC
 #define SG_OCC 7          // waves per SIMD the main kernel is compiled for (72 VGPRs)
