@@ -436,3 +436,59 @@ def test_midsize_long_columns_on_gpu(c3):
         assert c3["n_iter"][k] == ref["n_iter"][n], f"column {j}: sweeps"
         assert np.array_equal(c3["items"][k, :c][o], ref["features"][n]), f"column {j}: features"
         assert np.array_equal(bits(c3["coef"][k, :c][o]), np.asarray(ref["coef_bits"][n], dtype=np.uint32)), f"column {j}: coefficients"
+
+
+# ------------------------------------------------------------------------------------------ C4S: wide tiles at full size
+def test_c4s_wide_tile_segment_path_at_full_size(oracle):
+    """The 500k-item shape WITH item clusters and alpha = 0.005 (bench.py WORKLOADS["c4s"]: with the default alpha the L1
+    threshold leaves a degenerate W at a million users): W gets tens of thousands of rows and ~100k active columns, so the
+    segment layout takes tiles wider than 256 columns and the GENERIC accumulate loop -- the path that had no full-size
+    workload.  All 1M users: segment kernels == tiled-CSR kernel on every row; oracle on a sample; the
+    exact fit of sampled columns equals the oracle's."""
+    import torch
+    from bench import WORKLOADS
+    from rtrec_amd.synth import workload_matrix
+    wl = WORKLOADS["c4s"]
+    U, I, K, alpha = wl["U"], wl["I"], wl["K"], wl["alpha"]
+    X = workload_matrix(wl)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(Xc, X)
+    d_t, d_items, d_coef, d_count, n_iter = eng.fit_columns(np.arange(I), nn_feature_selection=K, device_out=True, alpha=alpha)
+    eng.set_weights(eng.merge_fit(None, I, False, d_t, d_items, d_coef, d_count))
+    W = eng.weights.to_csc(torch)
+    assert np.count_nonzero(np.diff(W.tocsr().indptr)) > 10_000, "the workload must give W tens of thousands of rows"
+    # the exact fit of sampled columns (popular, middle, tail) against the oracle with the same alpha
+    tg = d_t.cpu().numpy().astype(np.int64)
+    lens = np.diff(Xc.indptr)
+    sample = np.unique(np.concatenate([np.argsort(-lens)[:4], np.random.default_rng(5).choice(np.flatnonzero(lens > 50), 40, replace=False)]))
+    pos = {int(t): k for k, t in enumerate(tg)}
+    ptr, idx, val, nit = oracle.fit_columns(Xc, sample, nn_feature_selection=K, alpha=alpha, n_threads=CPU_THREADS)
+    items, coef, count = d_items.cpu().numpy(), d_coef.cpu().numpy(), d_count.cpu().numpy()
+    for n, j in enumerate(sample):
+        k = pos[int(j)]
+        c = count[k]
+        o = np.argsort(items[k, :c], kind="stable")
+        assert n_iter[k] == nit[n] and np.array_equal(items[k, :c][o], idx[ptr[n]:ptr[n + 1]])
+        assert np.array_equal(bits(coef[k, :c][o]), bits(val[ptr[n]:ptr[n + 1]])), f"column {j}"
+    rows = np.arange(U)
+    ids, sc, cnt = eng.recommend_rows(rows, top_k=10)
+    assert eng.last_score_path == "segments"
+    sg = eng._fast_layout()["sg"]
+    assert int(sg["sg_T"]) > 256, "the catalogue must need tiles wider than 256 columns"
+    eng.use_seg_layout = False
+    try:
+        ids3, sc3, cnt3 = eng.recommend_rows(rows, top_k=10)
+        assert eng.last_score_path == "tiled"
+    finally:
+        eng.use_seg_layout = True
+    assert np.array_equal(cnt, cnt3)
+    m = np.arange(10)[None, :] < cnt[:, None]
+    assert np.array_equal(ids[m], ids3[m]) and np.array_equal(bits(sc)[m], bits(sc3)[m])
+    ulen = np.diff(X.indptr)
+    smp = np.unique(np.concatenate([np.random.default_rng(9).choice(U, 1500, replace=False), np.argsort(-ulen)[:100]]))
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[smp], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
+    assert np.array_equal(ids[smp], o_ids) and np.array_equal(cnt[smp], o_cnt) and np.array_equal(bits(sc[smp]), bits(o_sc))
+    del eng
+    torch.cuda.empty_cache()
