@@ -235,6 +235,14 @@ def _worker(rank, world, port, q, score_shard="columns"):
         for rows in ([5, 17, 40, 41, 300], [9, 3, 77, 78, 1100], [5, 17, 40, 41, 300], [1, 2, 3, 4, 6]):
             got, ref = eng.recommend_rows(rows, top_k=5), solo.recommend_rows(rows, top_k=5)
             ok = ok and all(np.array_equal(a, b) for a, b in zip(got, ref))
+        if world == 2 and score_shard == "columns" and not shard_w:
+            # optim="sgd" shards like the coordinate-descent fit: every rank fits its own targets, the triples are all-gathered
+            sgd = SLIMElastic({"optim": "sgd", "nn_feature_selection": 6, "max_iter": 12},
+                              engine=SlimEngine(backend=OracleBackend(), rank=rank, world_size=world))
+            sgd.partial_fit_items(X.copy(), list(range(0, 400, 5)))
+            ref = SLIMElastic({"optim": "sgd", "nn_feature_selection": 6, "max_iter": 12}, engine=SlimEngine(backend=OracleBackend()))
+            ref.partial_fit_items(X.copy(), list(range(0, 400, 5)))
+            ok_w = ok_w and same_matrix(sgd.item_similarity, ref.item_similarity)
         q.put((rank, ok_w, ok, eng._layout(True)["n_cols"]))
     finally:
         dist.destroy_process_group()
