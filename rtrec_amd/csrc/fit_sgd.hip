@@ -49,10 +49,19 @@ struct SgdArgs {
     int *unfinished;
 };
 
+// uniform minimum of the 64 lane values: four row_shr steps + two row broadcasts in the DPP path (no LDS crossbar round
+// trips: this reduction runs once per solver step)
+template <int CTRL> __device__ __forceinline__ int sgd_dpp(int v, int fill) {
+    return __builtin_amdgcn_update_dpp(fill, v, CTRL, 0xf, 0xf, false);
+}
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const int o = shfl_xor_t(v, m); v = o < v ? o : v; }
-    return v;
+    v = min(v, sgd_dpp<0x111>(v, kSgdInf));
+    v = min(v, sgd_dpp<0x112>(v, kSgdInf));
+    v = min(v, sgd_dpp<0x114>(v, kSgdInf));
+    v = min(v, sgd_dpp<0x118>(v, kSgdInf));
+    v = min(v, sgd_dpp<0x142>(v, kSgdInf));      // row_bcast:15
+    v = min(v, sgd_dpp<0x143>(v, kSgdInf));      // row_bcast:31
+    return readlane_i(v, 63);
 }
 
 __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
@@ -85,11 +94,24 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
             float y_v = yc < ye ? tv[yc] : 0.0f;
             double sumloss = 0.0;
             int ri = a.reset_cnt[g0];
+            // the schedule of 64 consecutive steps in registers (lane l: step gw + l): a target whose samples are dense in time
+            // reads its tables once per 64 steps instead of six dependent broadcast loads per step
+            long long gw = -(1ll << 40);
+            double w_eta = 0.0, w_wsb = 0.0, w_wsa = 0.0, w_ua = 0.0;
+            int w_rc0 = 0, w_rc1 = 0;
+            const long long g_last = static_cast<long long>(a.n_epochs) * U - 1;
             for (;;) {
                 const int tmin = min(wave_min_i(my_t), y_t);
                 if (tmin == kSgdInf) break;
                 const long long g = g0 + tmin;
-                const int rc = a.reset_cnt[g];
+                if (g - gw >= 64) {
+                    gw = g;
+                    const long long gl = min(gw + lane, g_last);
+                    w_eta = a.eta[gl]; w_wsb = a.ws_before[gl]; w_wsa = a.ws_after[gl]; w_ua = a.u_after[gl];
+                    w_rc0 = a.reset_cnt[gl]; w_rc1 = a.reset_cnt[gl + 1];
+                }
+                const int wl = static_cast<int>(g - gw);
+                const int rc = readlane_i(w_rc0, wl);
                 while (ri < rc) { w = __fmul_rn(a.reset_mult[ri], w); ++ri; }       // reset_wscale() of the skipped steps
                 const bool part = my_t == tmin;
                 unsigned long long m = __ballot(part);
@@ -97,24 +119,24 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
                 double innerprod = 0.0;
                 for (unsigned long long mm = m; mm; mm &= mm - 1)
                     innerprod = __dadd_rn(innerprod, static_cast<double>(readlane_f(prod, static_cast<int>(__builtin_ctzll(mm)))));
-                innerprod = __dmul_rn(innerprod, a.ws_before[g]);
+                innerprod = __dmul_rn(innerprod, readlane_d(w_wsb, wl));
                 const double p = static_cast<double>(static_cast<float>(innerprod));
                 const double yv = (y_t == tmin) ? static_cast<double>(y_v) : 0.0;
-                const double eta = a.eta[g];
+                const double eta = readlane_d(w_eta, wl);
                 const double d = __dsub_rn(p, yv);
                 sumloss = __dadd_rn(sumloss, __dmul_rn(__dmul_rn(0.5, d), d));
                 double dloss = d;
                 if (dloss < -1e12) dloss = -1e12; else if (dloss > 1e12) dloss = 1e12;
                 const double update = __dmul_rn(-eta, dloss);        // (x class_weight x sample_weight = 1.0f: exact)
-                if (a.reset_cnt[g + 1] > rc) { w = __fmul_rn(a.reset_mult[ri], w); ++ri; }   // this step's w.scale() reset
-                const double wsd = a.ws_after[g];
+                if (readlane_i(w_rc1, wl) > rc) { w = __fmul_rn(a.reset_mult[ri], w); ++ri; }   // this step's w.scale() reset
+                const double wsd = readlane_d(w_wsa, wl);
                 if (update != 0.0 && part) {
                     const float c = static_cast<float>(update), wsf = static_cast<float>(wsd);
                     w = static_cast<float>(__dadd_rn(static_cast<double>(w),
                                                      __dmul_rn(static_cast<double>(my_x), static_cast<double>(__fdiv_rn(c, wsf)))));
                 }
                 if (part) {                                          // l1penalty32
-                    const double u = a.u_after[g];
+                    const double u = readlane_d(w_ua, wl);
                     const double z = static_cast<double>(w);
                     const double sz = __dmul_rn(wsd, z);
                     if (sz > 0.0) {
