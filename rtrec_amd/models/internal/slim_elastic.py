@@ -378,7 +378,9 @@ class SLIMElastic:
             return rows                                    # every list is full (the usual case): nothing to cut
         cnt = counts.tolist()
         if not ret_scores:
-            return [row[:c] for row, c in zip(rows, cnt)]
+            for p in np.flatnonzero(counts < ids.shape[1]).tolist():      # cut only the short rows (no B new lists)
+                rows[p] = rows[p][:cnt[p]]
+            return rows
         return [(row[:c], scores[r, :c].copy()) for r, (row, c) in enumerate(zip(rows, cnt))]
 
     # ---------------------------------------------------------------- predict (dense / sparse score rows)
