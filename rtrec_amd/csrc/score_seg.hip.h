@@ -96,8 +96,8 @@ __host__ __device__ constexpr size_t sg_wave_lds(int T, int idx_bytes) {
     return static_cast<size_t>(T + 64) * 4 + static_cast<size_t>(kSgCap) * (4 + 2 * idx_bytes) + 64;   // + 64 junk slots, + claimed chunk
 }
 __host__ __device__ constexpr int sg_heavy_waves(int T) { return T <= 2048 ? SG_HEAVY_WAVES : (SG_HEAVY_WAVES < 8 ? SG_HEAVY_WAVES : 8); }
-__host__ __device__ constexpr size_t sg_heavy_lds(int T) {
-    return static_cast<size_t>(sg_heavy_waves(T)) * (static_cast<size_t>(T + 64) * 4 + 128 * 4 + 64 * 8) + 64 +
+__host__ __device__ constexpr size_t sg_heavy_lds(int T, int waves = 0) {
+    return static_cast<size_t>(waves > 0 ? waves : sg_heavy_waves(T)) * (static_cast<size_t>(T + 64) * 4 + 128 * 4 + 64 * 8) + 64 +
            static_cast<size_t>(kSgCap) * 12;        // + rating | layout column | row of W of up to kSgCap items (list path)
 }
 __host__ __device__ constexpr size_t sg_heavy_scratch_bytes(int n_items, int n_tiles, int T) {
