@@ -594,7 +594,7 @@ int rtrec_store_fold_device(const int64_t *d_order, const int64_t *d_start, int6
  * as (time, value).  d_sel[n_targets][cap] / d_sel_count: the selected features in selection order.  State across blocks:
  * d_w, d_q [n_targets][cap] (zero before the first block), d_best_loss (+inf), d_no_improve (0), d_n_iter (0 = running; set
  * to n_iter_ when the target stops, -1 on a non-finite weight: scikit-learn raises ValueError there).  d_unfinished[1]
- * receives the number of targets still running.  cap <= 64.  When a target stops, d_w holds its coef_.
+ * receives the number of targets still running.  cap <= 256 (up to 64: one feature per wave lane, else two or four).  When a target stops, d_w holds its coef_.
  * ------------------------------------------------------------------------------------- */
 int rtrec_slim_sgd_schedule(int32_t n_samples, int32_t n_epochs, uint32_t seed,
                             double alpha, double l1_ratio, double eta0, double power_t,

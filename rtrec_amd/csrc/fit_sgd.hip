@@ -18,7 +18,8 @@
 //   * per epoch the CSC copy of X is sorted by time inside every column (shared by all targets: the caller builds it with
 //     one device sort), so a target's samples come out of a K-way merge: lane f holds a cursor into feature f's column.
 // One wave per target: lane = position of the feature in the selection (= X[:, selected]'s column order, hence the order of a
-// row's entries and of the double-precision dot product), y is a uniform cursor.  All arithmetic keeps the C types of the
+// row's entries and of the double-precision dot product; K <= 64: one position per lane, up to K = 256 two or four), y is a
+// uniform cursor.  All arithmetic keeps the C types of the
 // Cython source: float products, double sums, the float parameters of WeightVector.scale() / add().
 #include "common.hip.h"
 #include "../../include/rtrec_amd.h"
@@ -31,6 +32,7 @@
 namespace rtrec {
 
 constexpr int kSgdInf = 0x7fffffff;
+constexpr int kSgdMaxFeatures = 256;       // selected features per target: up to four per wave lane
 
 struct SgdArgs {
     int U, I;
@@ -64,6 +66,9 @@ __device__ __forceinline__ int wave_min_i(int v) {
     return readlane_i(v, 63);
 }
 
+// F features per lane (K <= 64 F): the feature at position f * 64 + lane of the selection is lane's f-th.  A row's entries
+// are summed position by position, i.e. f outer, lanes inner.
+template <int F>
 __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
     const int lane = lane_id();
     const int U = a.U;
@@ -71,12 +76,18 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
         if (a.n_iter[t] != 0) continue;                      // finished in an earlier block of epochs
         const int j = a.targets[t];
         const int Kc = a.sel_count[t];
-        const int col = lane < Kc ? a.sel[static_cast<size_t>(t) * a.cap + lane] : -1;
-        const bool live = col >= 0 && col != j;              // (the zeroed target column's explicit zeros change nothing)
-        const int cb = live ? a.cptr[col] : 0, ce = live ? a.cptr[col + 1] : 0;
+        int cb[F], ce[F];
+        float w[F], q[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int pos = f * 64 + lane;
+            const int col = pos < Kc ? a.sel[static_cast<size_t>(t) * a.cap + pos] : -1;
+            const bool live = col >= 0 && col != j;          // (the zeroed target column's explicit zeros change nothing)
+            cb[f] = live ? a.cptr[col] : 0; ce[f] = live ? a.cptr[col + 1] : 0;
+            w[f] = pos < a.cap ? a.w[static_cast<size_t>(t) * a.cap + pos] : 0.0f;
+            q[f] = pos < a.cap ? a.q[static_cast<size_t>(t) * a.cap + pos] : 0.0f;
+        }
         const int yb = a.cptr[j], ye = a.cptr[j + 1];
-        float w = lane < a.cap ? a.w[static_cast<size_t>(t) * a.cap + lane] : 0.0f;
-        float q = lane < a.cap ? a.q[static_cast<size_t>(t) * a.cap + lane] : 0.0f;
         double best_loss = a.best_loss[t];
         int no_imp = a.no_improve[t];
         int done = 0;
@@ -84,11 +95,16 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
             const int *tt = a.ttime + static_cast<size_t>(ep) * a.nnz;
             const float *tv = a.tval + static_cast<size_t>(ep) * a.nnz;
             const long long g0 = static_cast<long long>(ep) * U;
-            int cur = cb;
-            int my_t = cur < ce ? tt[cur] : kSgdInf;
-            float my_x = cur < ce ? tv[cur] : 0.0f;
-            int nx_t = cur + 1 < ce ? tt[cur + 1] : kSgdInf;   // one entry ahead: an advance does not wait for memory
-            float nx_x = cur + 1 < ce ? tv[cur + 1] : 0.0f;
+            int cur[F], my_t[F], nx_t[F];
+            float my_x[F], nx_x[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                cur[f] = cb[f];
+                my_t[f] = cur[f] < ce[f] ? tt[cur[f]] : kSgdInf;
+                my_x[f] = cur[f] < ce[f] ? tv[cur[f]] : 0.0f;
+                nx_t[f] = cur[f] + 1 < ce[f] ? tt[cur[f] + 1] : kSgdInf;   // one entry ahead: an advance does not wait for memory
+                nx_x[f] = cur[f] + 1 < ce[f] ? tv[cur[f] + 1] : 0.0f;
+            }
             int yc = yb;
             int y_t = yc < ye ? tt[yc] : kSgdInf;
             float y_v = yc < ye ? tv[yc] : 0.0f;
@@ -101,7 +117,10 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
             int w_rc0 = 0, w_rc1 = 0;
             const long long g_last = static_cast<long long>(a.n_epochs) * U - 1;
             for (;;) {
-                const int tmin = min(wave_min_i(my_t), y_t);
+                int lmin = my_t[0];
+#pragma unroll
+                for (int f = 1; f < F; ++f) lmin = min(lmin, my_t[f]);
+                const int tmin = min(wave_min_i(lmin), y_t);
                 if (tmin == kSgdInf) break;
                 const long long g = g0 + tmin;
                 if (g - gw >= 64) {
@@ -112,13 +131,21 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
                 }
                 const int wl = static_cast<int>(g - gw);
                 const int rc = readlane_i(w_rc0, wl);
-                while (ri < rc) { w = __fmul_rn(a.reset_mult[ri], w); ++ri; }       // reset_wscale() of the skipped steps
-                const bool part = my_t == tmin;
-                unsigned long long m = __ballot(part);
-                const float prod = part ? __fmul_rn(w, my_x) : 0.0f;
+                while (ri < rc) {                                   // reset_wscale() of the skipped steps
+                    const float rm = a.reset_mult[ri];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) w[f] = __fmul_rn(rm, w[f]);
+                    ++ri;
+                }
+                bool part[F];
                 double innerprod = 0.0;
-                for (unsigned long long mm = m; mm; mm &= mm - 1)
-                    innerprod = __dadd_rn(innerprod, static_cast<double>(readlane_f(prod, static_cast<int>(__builtin_ctzll(mm)))));
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    part[f] = my_t[f] == tmin;
+                    const float prod = part[f] ? __fmul_rn(w[f], my_x[f]) : 0.0f;
+                    for (unsigned long long mm = __ballot(part[f]); mm; mm &= mm - 1)
+                        innerprod = __dadd_rn(innerprod, static_cast<double>(readlane_f(prod, static_cast<int>(__builtin_ctzll(mm)))));
+                }
                 innerprod = __dmul_rn(innerprod, readlane_d(w_wsb, wl));
                 const double p = static_cast<double>(static_cast<float>(innerprod));
                 const double yv = (y_t == tmin) ? static_cast<double>(y_v) : 0.0;
@@ -128,30 +155,38 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
                 double dloss = d;
                 if (dloss < -1e12) dloss = -1e12; else if (dloss > 1e12) dloss = 1e12;
                 const double update = __dmul_rn(-eta, dloss);        // (x class_weight x sample_weight = 1.0f: exact)
-                if (readlane_i(w_rc1, wl) > rc) { w = __fmul_rn(a.reset_mult[ri], w); ++ri; }   // this step's w.scale() reset
-                const double wsd = readlane_d(w_wsa, wl);
-                if (update != 0.0 && part) {
-                    const float c = static_cast<float>(update), wsf = static_cast<float>(wsd);
-                    w = static_cast<float>(__dadd_rn(static_cast<double>(w),
-                                                     __dmul_rn(static_cast<double>(my_x), static_cast<double>(__fdiv_rn(c, wsf)))));
+                if (readlane_i(w_rc1, wl) > rc) {                    // this step's w.scale() reset
+                    const float rm = a.reset_mult[ri];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) w[f] = __fmul_rn(rm, w[f]);
+                    ++ri;
                 }
-                if (part) {                                          // l1penalty32
-                    const double u = readlane_d(w_ua, wl);
-                    const double z = static_cast<double>(w);
-                    const double sz = __dmul_rn(wsd, z);
-                    if (sz > 0.0) {
-                        const double v = __dsub_rn(static_cast<double>(w), __ddiv_rn(__dadd_rn(u, static_cast<double>(q)), wsd));
-                        w = static_cast<float>(v > 0.0 ? v : 0.0);
-                    } else if (sz < 0.0) {
-                        const double v = __dadd_rn(static_cast<double>(w), __ddiv_rn(__dsub_rn(u, static_cast<double>(q)), wsd));
-                        w = static_cast<float>(v < 0.0 ? v : 0.0);
+                const double wsd = readlane_d(w_wsa, wl);
+                const double u = readlane_d(w_ua, wl);
+#pragma unroll
+                for (int f = 0; f < F; ++f) {
+                    if (update != 0.0 && part[f]) {
+                        const float c = static_cast<float>(update), wsf = static_cast<float>(wsd);
+                        w[f] = static_cast<float>(__dadd_rn(static_cast<double>(w[f]),
+                                                            __dmul_rn(static_cast<double>(my_x[f]), static_cast<double>(__fdiv_rn(c, wsf)))));
                     }
-                    q = static_cast<float>(__dadd_rn(static_cast<double>(q), __dmul_rn(wsd, __dsub_rn(static_cast<double>(w), z))));
-                    // advance this lane's cursor
-                    ++cur;
-                    my_t = nx_t; my_x = nx_x;
-                    nx_t = cur + 1 < ce ? tt[cur + 1] : kSgdInf;
-                    nx_x = cur + 1 < ce ? tv[cur + 1] : 0.0f;
+                    if (part[f]) {                                       // l1penalty32
+                        const double z = static_cast<double>(w[f]);
+                        const double sz = __dmul_rn(wsd, z);
+                        if (sz > 0.0) {
+                            const double v = __dsub_rn(static_cast<double>(w[f]), __ddiv_rn(__dadd_rn(u, static_cast<double>(q[f])), wsd));
+                            w[f] = static_cast<float>(v > 0.0 ? v : 0.0);
+                        } else if (sz < 0.0) {
+                            const double v = __dadd_rn(static_cast<double>(w[f]), __ddiv_rn(__dsub_rn(u, static_cast<double>(q[f])), wsd));
+                            w[f] = static_cast<float>(v < 0.0 ? v : 0.0);
+                        }
+                        q[f] = static_cast<float>(__dadd_rn(static_cast<double>(q[f]), __dmul_rn(wsd, __dsub_rn(static_cast<double>(w[f]), z))));
+                        // advance this lane's cursor
+                        ++cur[f];
+                        my_t[f] = nx_t[f]; my_x[f] = nx_x[f];
+                        nx_t[f] = cur[f] + 1 < ce[f] ? tt[cur[f] + 1] : kSgdInf;
+                        nx_x[f] = cur[f] + 1 < ce[f] ? tv[cur[f] + 1] : 0.0f;
+                    }
                 }
                 if (y_t == tmin) {
                     ++yc;
@@ -161,19 +196,33 @@ __global__ __launch_bounds__(64) void fit_sgd_kernel(SgdArgs a) {
             }
             {   // the epoch's remaining (skipped) steps
                 const int rc = a.reset_cnt[g0 + U];
-                while (ri < rc) { w = __fmul_rn(a.reset_mult[ri], w); ++ri; }
+                while (ri < rc) {
+                    const float rm = a.reset_mult[ri];
+#pragma unroll
+                    for (int f = 0; f < F; ++f) w[f] = __fmul_rn(rm, w[f]);
+                    ++ri;
+                }
             }
             const int epoch = a.first_epoch + ep;
-            if (__ballot(lane < Kc && !isfinite(w))) { done = -1; break; }      // any_nonfinite(weights): sklearn raises ValueError
+            bool bad = false;
+#pragma unroll
+            for (int f = 0; f < F; ++f) bad = bad || (f * 64 + lane < Kc && !isfinite(w[f]));
+            if (__ballot(bad)) { done = -1; break; }      // any_nonfinite(weights): sklearn raises ValueError
             if (sumloss > __dsub_rn(best_loss, __dmul_rn(a.tol, static_cast<double>(static_cast<unsigned int>(U))))) ++no_imp;
             else no_imp = 0;
             if (sumloss < best_loss) best_loss = sumloss;
             if (no_imp >= 5 || epoch == a.max_iter - 1) {
-                w = __fmul_rn(static_cast<float>(a.ws_after[g0 + U - 1]), w);    // w.reset_wscale()
+                const float rm = static_cast<float>(a.ws_after[g0 + U - 1]);     // w.reset_wscale()
+#pragma unroll
+                for (int f = 0; f < F; ++f) w[f] = __fmul_rn(rm, w[f]);
                 done = epoch + 1;
             }
         }
-        if (lane < a.cap) { a.w[static_cast<size_t>(t) * a.cap + lane] = w; a.q[static_cast<size_t>(t) * a.cap + lane] = q; }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const int pos = f * 64 + lane;
+            if (pos < a.cap) { a.w[static_cast<size_t>(t) * a.cap + pos] = w[f]; a.q[static_cast<size_t>(t) * a.cap + pos] = q[f]; }
+        }
         if (lane == 0) {
             a.best_loss[t] = best_loss; a.no_improve[t] = no_imp;
             if (done) a.n_iter[t] = done; else atomicAdd(a.unfinished, 1);
@@ -251,8 +300,8 @@ extern "C" int rtrec_slim_fit_sgd_epochs(int32_t n_users, int32_t n_items, const
                                          const double *d_u_after, const int32_t *d_reset_cnt, const float *d_reset_mult,
                                          float *d_w, float *d_q, double *d_best_loss, int32_t *d_no_improve,
                                          int32_t *d_n_iter, int32_t *d_unfinished, void *stream) {
-    if (n_users <= 0 || n_items <= 0 || n_targets < 0 || n_epochs <= 0 || max_iter <= 0 || cap <= 0 || cap > 64)
-        return cap > 64 ? RTREC_ERR_UNSUPPORTED : RTREC_ERR_INVALID_ARG;
+    if (n_users <= 0 || n_items <= 0 || n_targets < 0 || n_epochs <= 0 || max_iter <= 0 || cap <= 0 || cap > kSgdMaxFeatures)
+        return cap > kSgdMaxFeatures ? RTREC_ERR_UNSUPPORTED : RTREC_ERR_INVALID_ARG;
     if (n_targets == 0) return RTREC_OK;
     if (!d_csc_ptr || !d_ttime || !d_tval || !d_targets || !d_sel || !d_sel_count || !d_eta || !d_ws_before || !d_ws_after ||
         !d_u_after || !d_reset_cnt || !d_reset_mult || !d_w || !d_q || !d_best_loss || !d_no_improve || !d_n_iter || !d_unfinished)
@@ -268,6 +317,8 @@ extern "C" int rtrec_slim_fit_sgd_epochs(int32_t n_users, int32_t n_items, const
     (void)hipGetLastError();
     if (hipMemsetAsync(d_unfinished, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const int grid = n_targets < 16384 ? n_targets : 16384;
-    hipLaunchKernelGGL(fit_sgd_kernel, dim3(grid), dim3(64), 0, st, a);
+    if (cap <= 64) hipLaunchKernelGGL(fit_sgd_kernel<1>, dim3(grid), dim3(64), 0, st, a);
+    else if (cap <= 128) hipLaunchKernelGGL(fit_sgd_kernel<2>, dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(fit_sgd_kernel<4>, dim3(grid), dim3(64), 0, st, a);
     return rtrec::launch_status();
 }

@@ -443,8 +443,9 @@ class SlimEngine:
         targets = np.asarray(targets, dtype=np.int64)
         if not isinstance(be, HipBackend):
             return be.fit_columns_sgd(X, U, I, targets, alpha, l1_ratio, eta0, max_iter, tol, random_state, K)
-        if K > 64:
-            raise NotImplementedError("optim='sgd' on the GPU serves nn_feature_selection <= 64 (one wave lane per feature)")
+        if K > self.SGD_MAX_FEATURES:
+            raise NotImplementedError(f"optim='sgd' on the GPU serves nn_feature_selection <= {self.SGD_MAX_FEATURES} "
+                                      "(up to four features per wave lane)")
         torch = be.torch
         # (1) feature selection: the coordinate-descent kernel's own X^T y + top-K (its item lists come in selection order)
         d_t, d_sel, _coef, d_cnt, _ = self.fit_columns(targets, alpha=alpha, l1_ratio=l1_ratio, positive=True, max_iter=1,
@@ -504,6 +505,8 @@ class SlimEngine:
                              f"{int(targets[np.flatnonzero(n_iter < 0)[0]])}. Scaling input data with StandardScaler or "
                              "MinMaxScaler might help.")
         return d_t, d_sel, d_w, d_cnt, n_iter
+
+    SGD_MAX_FEATURES = 256           # csrc/fit_sgd.hip: kSgdMaxFeatures
 
     FIT_SLOTS_SPARSE = 1024          # targets in flight when the folded columns are sparse (see _fit_slots_for)
     FIT_SPARSE_FEATURES = 0.08       # mean density of the selected feature columns up to which FIT_SLOTS_SPARSE are used (c3s: 0.058)

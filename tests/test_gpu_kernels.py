@@ -677,11 +677,12 @@ def test_fit_path_randomised_parity():
     assert run(40, seed=5, log=messages.append) == 0, messages
 
 
-@pytest.mark.parametrize("case", range(5))
+@pytest.mark.parametrize("case", range(7))
 def test_optim_sgd_on_the_gpu_matches_the_reference(case):
     """optim="sgd" (slim_elastic.py:209-222: scikit-learn SGDRegressor behind FeatureSelectionWrapper) on the device
     (csrc/fit_sgd.hip): W of the serial fit and SGDRegressor.n_iter_ of every column equal the real reference's
-    (tests/golden/sgd.json), K up to 64, resets of the weight scale, max_iter reached, another seed / l1_ratio / tol."""
+    (tests/golden/sgd.json), K up to 130 (one, two and four features per wave lane), resets of the weight scale, max_iter
+    reached, another seed / l1_ratio / tol."""
     import json
     import os
     from rtrec_amd.models.internal.slim_elastic import SLIMElastic

@@ -193,7 +193,7 @@ def _golden_w(c, prefix="W"):
                          shape=(c["I"], c["I"]))
 
 
-@pytest.mark.parametrize("case", range(5))
+@pytest.mark.parametrize("case", range(7))
 def test_sgd_oracle_matches_the_reference(oracle, case):
     """optim="sgd" (slim_elastic.py:209-222; scikit-learn SGDRegressor behind FeatureSelectionWrapper): the oracle's restatement
     of _plain_sgd32 reproduces the real reference's W bit for bit and SGDRegressor.n_iter_ of every column

@@ -62,7 +62,7 @@ def run(iters: int, seed: int, log=print) -> int:
 
 
 def run_sgd(iters: int, seed: int, log=print) -> int:
-    """optim="sgd": csrc/fit_sgd.hip against slim_oracle_sgd -- random shapes, K 1..64, penalties, learning rates (large ones
+    """optim="sgd": csrc/fit_sgd.hip against slim_oracle_sgd -- random shapes, K 1..256 (one, two, four features per lane), penalties, learning rates (large ones
     drive the weight scale through its resets), epochs, tol (None: no early stop), seeds, signed ratings."""
     from oracle import slim_oracle as so
     from rtrec_amd.engine import SlimEngine
@@ -74,7 +74,7 @@ def run_sgd(iters: int, seed: int, log=print) -> int:
         U = int(rng.choice([40, 150, 600, 2500]))
         I = int(rng.choice([8, 20, 90, 300]))
         draws = int(U * rng.choice([2, 6, 20]))
-        K = int(rng.choice([1, 2, 5, 20, 50, 64]))
+        K = int(rng.choice([1, 2, 5, 20, 50, 64, 65, 100, 128, 129, 200, 256]))
         alpha = float(rng.choice([1e-4, 0.01, 0.1, 1.0]))
         l1_ratio = float(rng.choice([0.0, 0.1, 0.5, 1.0]))
         eta0 = float(rng.choice([1e-3, 0.01, 0.05, 0.3]))

@@ -511,7 +511,10 @@ def gen_sgd():
              dict(U=1200, I=200, draws=30000, seed=3, cfg={"nn_feature_selection": 20}),
              dict(U=2500, I=300, draws=90000, seed=5, cfg={"nn_feature_selection": 50, "alpha": 0.01, "eta0": 0.01}),
              dict(U=800, I=120, draws=20000, seed=7, cfg={"nn_feature_selection": 10, "max_iter": 7}),
-             dict(U=900, I=150, draws=24000, seed=11, cfg={"nn_feature_selection": 64, "l1_ratio": 0.5, "tol": 1e-3, "random_state": 7})]
+             dict(U=900, I=150, draws=24000, seed=11, cfg={"nn_feature_selection": 64, "l1_ratio": 0.5, "tol": 1e-3, "random_state": 7}),
+             # more than one feature per wave lane on the device (two up to K = 128, four up to 256)
+             dict(U=700, I=130, draws=16000, seed=13, cfg={"nn_feature_selection": 100}),
+             dict(U=500, I=140, draws=40000, seed=17, cfg={"nn_feature_selection": 130, "max_iter": 12, "eta0": 0.01})]      # (no X^T y tie at the K-th place: D1)
     for c in cases:
         X = interaction_matrix(c["U"], c["I"], c["draws"], seed=c["seed"]).tocsc()
         X.sort_indices()
