@@ -534,6 +534,23 @@ int rtrec_slim_refine_topk_f64(int32_t n_rows, const int32_t *d_row_ids, const i
                                int32_t *d_flagged, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * DENSE MODE: ZERO-SCORE COLUMNS BEHIND A SHORT FAST-PASS LIST  (the tail of _dense_topk_indicies, slim_elastic.py:745-778:
+ * argsort over ALL columns -- after a user's positive scores come the zero-score columns, the higher column id first
+ * (DESIGN.md D1), interacted items excluded).  For a shard [col_lo, col_hi) whose weights, like the ratings, are all positive
+ * and normal (the CALLER checks both: then a list that is not full holds every column the user's row touches, and every other
+ * column scores exactly +0.0).
+ * d_flagged_in: the rows rtrec_slim_score_topk_opt flagged in DENSE mode without a tiled layout ([0] = count, rows from [1]).
+ * A flagged row whose list (d_out_* [n_rows][top_k], d_out_count) is shorter than top_k, all positive and free of equal
+ * neighbours is completed in place -- ids = the highest column ids of the shard that are neither listed nor (filter_interacted)
+ * rated by the user, scores +0.0, d_out_count raised -- every other flagged row is copied to d_flagged_out (same form; must
+ * not alias d_flagged_in) for the tiled DENSE kernel.  top_k <= 64.
+ * ------------------------------------------------------------------------------------- */
+int rtrec_slim_dense_fill(int32_t n_rows, const int32_t *d_row_ids, const int32_t *d_xb_ptr, const int32_t *d_xb_col,
+                          int32_t n_x_rows, int32_t col_lo, int32_t col_hi, int32_t top_k, int32_t filter_interacted,
+                          int32_t *d_out_ids, float *d_out_scores, uint32_t *d_out_aux, int32_t *d_out_count,
+                          const int32_t *d_flagged_in, int32_t *d_flagged_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * SEGMENT LAYOUT BUILDER  (the d_sg_* arrays of rtrec_score_opts from a W resident on the device; what has to happen
  * between a mini-batch refit -- rtrec/models/slim.py:29-43 writes W's columns, slim_elastic.py:371-374 -- and the next
  * recommend -- slim_elastic.py:707-708).  Specification: rtrec_amd/seg_layout.py::build_seg_layout.

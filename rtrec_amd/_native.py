@@ -36,6 +36,7 @@ EXPORTS = [
     "rtrec_slim_score_candidates",
     "rtrec_slim_sgd_schedule",
     "rtrec_slim_fit_sgd_epochs",
+    "rtrec_slim_dense_fill",
 ]
 
 
@@ -163,6 +164,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_refine_topk_f64.restype = C.c_int
     L.rtrec_slim_refine_topk_f64.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, C.c_double, vp,
                                              vp, vp, vp, vp, vp, vp]
+    L.rtrec_slim_dense_fill.restype = C.c_int
+    L.rtrec_slim_dense_fill.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.rtrec_slim_score_candidates.restype = C.c_int
     L.rtrec_slim_score_candidates.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp]
     L.rtrec_slim_sgd_schedule.restype = C.c_int

@@ -110,6 +110,7 @@ class SlimEngine:
         self.f64_refine = settings.raw("RTREC_AMD_F64_REFINE", "1") != "0"      # float64 W: float32 fast pass + float64 refine
         self.cands_direct = settings.raw("RTREC_AMD_CANDS_DIRECT", "1") != "0"   # request-sized CANDIDATES calls: csrc/score_cands.hip
         self.dense_fast = settings.raw("RTREC_AMD_DENSE_FAST", "1") != "0"    # DENSE mode through the fast SPARSE-style pass
+        self.dense_fill = settings.raw("RTREC_AMD_DENSE_FILL", "1") != "0"    # ... its short lists completed in place (and so column shards)
         self._sg_scratch = None           # zeroed scratch of the segment path's workgroup-per-user kernel
         self._order_grouped = False       # the work order _row_order handed out last is the pattern-grouped one
         self.sg_heavy_min = int(settings.raw("RTREC_AMD_SG_HEAVY_MIN", "0"))   # v > 0: segment path, users of more than v - 1 items get a workgroup
@@ -835,6 +836,15 @@ class SlimEngine:
             return self._X["rval_min_ok"]
         return bool(float(val.min()) >= self.F64_REFINE_MIN_VALUE)
 
+    def _dense_fill_ok(self, xb) -> bool:
+        """rtrec_slim_dense_fill's precondition: weights and ratings all >= F64_REFINE_MIN_VALUE -- every product is a positive
+        normal float32 number, so a column the user's row touches has a positive score and every other one exactly +0.0."""
+        W = self._W
+        if "w_min_ok" not in W:
+            dw: DeviceWeights = W["dw"]
+            W["w_min_ok"] = bool(not dw.lossy and (dw.nnz == 0 or float(dw.vals.min()) >= self.F64_REFINE_MIN_VALUE))
+        return W["w_min_ok"] and self._f64_refine_x_ok(xb)
+
     def _seg_form(self) -> Optional[Dict[str, Any]]:
         """The segment layout of this rank's shard as a layout dict ({"sg": ..., "n_cols": ...}), or None."""
         W, be = self._W, self.be
@@ -958,9 +968,14 @@ class SlimEngine:
         # all of W's columns: a row whose leading top_k scores are all positive is final (positives outrank every zero-score
         # column, zeros outrank negatives); the kernel flags the others, and every tie (DENSE orders ties by item id), for the
         # tiled DENSE kernel below.
+        # (a COLUMN SHARD flags nearly every row -- a user's positive scores sit in a few shards -- so it takes the fast pass
+        # only when the flagged rows can be completed in place: rtrec_slim_dense_fill, positive weights and ratings)
+        full_range = W.get("col_lo", 0) == 0 and W.get("col_hi", 0) == W["n_items"]
+        dense_fill = bool(mode == _native.TOPK_DENSE and hip and self.dense_fast and self.dense_fill and self.lazy_tiled
+                          and not W["acc_f64"] and top_k <= 63 and self._dense_fill_ok(xb))
         dense_fast = bool(mode == _native.TOPK_DENSE and hip and self.dense_fast and self.lazy_tiled
                           and (not W["acc_f64"] or self._f64_refine_w_ok())
-                          and W.get("col_lo", 0) == 0 and W.get("col_hi", 0) == W["n_items"])
+                          and (full_range or dense_fill))
         fast = None
         if (sparse or dense_fast) and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
             # (a float64 W asks its fast pass for one column more: see f64_fast below)
@@ -995,11 +1010,19 @@ class SlimEngine:
             order = self._row_order(d_row_ids, n_rows, xb, fast, allow_grouped=use_fr)
             self.last_score_path = "feature_rows" if use_fr else "segments"
             flagged = pack[2 * nk + cap:] if flag_words else be.empty((n_rows + 1,), torch.int32)
+            fill = dense_fast and dense_fill
+            flagged_fast = be.empty((n_rows + 1,), torch.int32) if fill else flagged
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, top_k, filter_interacted,
                           mode, False, ids, sc, None, aux, cnt, self._score_ws, timer=self.score_timer,
                           diagnostics=self.diagnostics | ((self.fr_users_per_wave & 0xf) << 8) | ((self.sg_heavy_min & 0xfff) << 12), use_fr=use_fr, row_order=order,
                           rescored=None, row_order_grouped=(order is not None and use_fr and self._order_grouped),
-                          use_sg=use_sg, use_sg_heavy=self.use_seg_heavy, flagged=flagged)
+                          use_sg=use_sg, use_sg_heavy=self.use_seg_heavy, flagged=flagged_fast)
+            if fill:          # DENSE mode: short all-positive lists are completed with the zero-score columns, the rest stays flagged
+                p = be.ptr
+                _native.check(be.lib.rtrec_slim_dense_fill(n_rows, p(d_row_ids), p(xb[0]), p(xb[1]), int(xb[0].shape[0]) - 1,
+                                                           int(W["col_lo"]), int(W["col_hi"]), top_k, int(bool(filter_interacted)),
+                                                           p(ids), p(sc), p(aux), p(cnt), p(flagged_fast), p(flagged), be.stream()),
+                              "rtrec_slim_dense_fill")
             if flag_words:                # one download: the lists and the counter
                 h = pack.cpu().numpy()
                 n_flag = int(h[2 * nk + cap])

@@ -33,6 +33,7 @@ TABLE: Dict[str, tuple] = {
     "RTREC_AMD_NATIVE_SEG_BUILD": ("1", "0: build the segment layout with tensor ops instead of csrc/seg_build.hip"),
     "RTREC_AMD_F64_REFINE": ("1", "0: a float64 W is scored by the float64 tiled kernel only, not by the float32 fast pass + float64 refine step"),
     "RTREC_AMD_CANDS_DIRECT": ("1", "0: request-sized CANDIDATES calls go through the tiled kernel like bulk ones"),
+    "RTREC_AMD_DENSE_FILL": ("1", "0: DENSE mode's short fast-pass lists go to the tiled kernel instead of being completed in place (and column shards keep the tiled kernel)"),
     "RTREC_AMD_DENSE_FAST": ("1", "0: DENSE mode (string ids) is scored by the tiled kernel only, not by the fast pass + flagged rows"),
     "RTREC_AMD_LAZY_TILED": ("1", "0: build the tiled layout with every W instead of only when a call flags exact score ties"),
     "RTREC_AMD_ABLATE": ("0", "ablation bits forwarded as rtrec_score_opts.diagnostics (diagnostic builds only)"),

@@ -245,6 +245,76 @@ def test_dense_mode_through_the_fast_pass(oracle, shape, filt):
     assert np.array_equal(ids2, o_ids) and np.array_equal(bits(sc2), bits(o_sc)) and np.array_equal(cnt2, o_cnt)
 
 
+@pytest.mark.parametrize("filt", [True, False])
+@pytest.mark.parametrize("shape", ["general", "feature_rows"])
+def test_dense_mode_short_lists_are_completed_in_place_and_column_shards_take_the_fast_pass(oracle, shape, filt):
+    """DENSE mode (slim_elastic.py:745-778), positive W and ratings: a user with fewer than top_k positive scores gets the
+    zero-score columns behind them, the higher id first, interacted items excluded (rtrec_slim_dense_fill) -- without the tiled
+    kernel -- and a COLUMN SHARD (where that is nearly every user) therefore takes the fast pass too.  Full W and three column
+    shards merged, against the oracle's dense mode, bit for bit; users with no items, one item, equal ratings (exact ties:
+    those rows stay flagged), and one who rated the whole top of the id range."""
+    import torch
+    I = 2500
+    rng = np.random.default_rng(14)
+    if shape == "general":
+        W = random_w(I, 0.002, seed=23, n_blocks=10)
+    else:
+        rows = np.sort(rng.choice(I, 90, replace=False))
+        nnz = 30_000
+        W = sp.csc_matrix(((rng.random(nnz) + 0.01).astype(np.float32), (rng.choice(rows, nnz), rng.integers(0, I, nnz))), shape=(I, I))
+        W.sum_duplicates(); W.setdiag(0); W.eliminate_zeros(); W.sort_indices()
+    X = interaction_matrix(1500, I, 9000, seed=6).tolil()        # ~6 items per user: few positive scores, fewer per shard
+    X[3, :] = 0
+    X[4, :] = 0; X[4, 17] = 2.0
+    X[5, :] = 0; X[5, [100, 200]] = [1.0, 1.0]
+    X[6, :] = 0; X[6, np.arange(I - 40, I)] = 1.5            # rated the 40 highest ids: the zero fill has to skip them
+    X[7, :] = 0; X[7, np.arange(0, I, 2)] = 0.5              # rated every other item
+    X = X.tocsr().astype(np.float32)
+    X.eliminate_zeros(); X.sort_indices()
+    eng = SlimEngine(device="cuda:0")
+    eng.set_interactions(None, X, need_csc=False)
+    eng.set_weights(W)
+    eng.rescored = eng.be.zeros((1,), torch.int32)
+    for rows, k in ((np.arange(X.shape[0]), 10), (np.arange(0, 40), 5), (np.array([3, 4, 5, 6, 7, 700]), 15), (np.array([6]), 63)):
+        ids, sc, cnt = eng.recommend_rows(rows, top_k=k, filter_interacted=filt, mode=_native.TOPK_DENSE)
+        assert eng.last_score_path in ("segments", "feature_rows")
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], W.tocsr(), top_k=k, filter_interacted=filt, dense=True)
+        assert np.array_equal(cnt, o_cnt)
+        bad = np.flatnonzero((ids != o_ids).any(axis=1))
+        assert bad.size == 0, f"ids differ for rows {rows[bad][:8]}: {ids[bad[0]]} vs {o_ids[bad[0]]}"
+        assert np.array_equal(bits(sc), bits(o_sc))
+        if len(rows) == X.shape[0]:
+            assert int(eng.rescored.item()) < len(rows) // 10, "most short lists should have been completed in place"
+    # three column shards on one GPU, merged like the exchange does
+    rows, k = np.arange(X.shape[0]), 10
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[rows], W.tocsr(), top_k=k, filter_interacted=filt, dense=True)
+    parts = []
+    for r in range(3):
+        e = SlimEngine(device="cuda:0", rank=r, world_size=3)
+        e.world_size_for_merge = 3
+        e.set_interactions(None, X, need_csc=False)
+        e.set_weights(W)
+        e.rescored = e.be.zeros((1,), torch.int32)
+        d_rows = e.be.to_dev(rows.astype(np.int32))
+        xb = (e._X["rptr"], e._X["rcol"], e._X["rval"])
+        parts.append(e._local_topk(d_rows, len(rows), xb, k, filt, _native.TOPK_DENSE, None))
+        assert e.last_score_path in ("segments", "feature_rows"), e.last_score_path
+        assert int(e.rescored.item()) < len(rows) // 10
+    be = eng.be
+    g = [torch.stack([p[j] for p in parts]).contiguous() for j in (0, 1, 3, 4)]
+    m_ids, m_sc, m_cnt = be.empty((len(rows), k), torch.int32), be.empty((len(rows), k), torch.float32), be.empty((len(rows),), torch.int32)
+    _native.check(be.lib.rtrec_slim_merge_topk(len(rows), 3, k, be.ptr(g[0]), be.ptr(g[1]), None, be.ptr(g[2]), be.ptr(g[3]),
+                                               be.ptr(m_ids), be.ptr(m_sc), be.ptr(m_cnt), be.stream()), "merge")
+    assert np.array_equal(m_cnt.cpu().numpy(), o_cnt)
+    bad = np.flatnonzero((m_ids.cpu().numpy() != o_ids).any(axis=1))
+    assert bad.size == 0, f"sharded ids differ for rows {bad[:8]}: {m_ids.cpu().numpy()[bad[0]]} vs {o_ids[bad[0]]}"
+    assert np.array_equal(bits(m_sc.cpu().numpy()), bits(o_sc))
+    # the switch: without the fill a shard keeps the tiled kernel
+    e.dense_fill = False
+    e._local_topk(d_rows, len(rows), xb, k, filt, _native.TOPK_DENSE, None)
+    assert e.last_score_path == "tiled"
+
+
 @pytest.mark.parametrize("shape", ["general", "feature_rows", "signed"])
 def test_float64_w_through_the_fast_pass_and_the_refine_step(oracle, shape):
     """A W that is float64 on the host (the reference's serial fit, slim_elastic.py:252; float32-valued) accumulates float64
