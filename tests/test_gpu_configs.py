@@ -80,17 +80,10 @@ def c3():
     torch.cuda.empty_cache()
 
 
-def test_c3_fit_sampled_columns_match_oracle(c3, oracle):
-    rng = np.random.default_rng(11)
-    I, K = C3["I"], C3["K"]
-    nnz = np.diff(c3["Xc"].indptr)
-    # the targets with the most coordinate-descent work are NOT the longest columns: take both ends
-    work = np.argsort(-c3["n_iter"] * 1.0)[:6]
-    heavy = np.argsort(-nnz)[:8]
-    active = np.flatnonzero(np.diff(c3["W"].indptr) > 0)
-    sample = np.unique(np.concatenate([c3["tg"][work], heavy, rng.choice(active, 40, replace=False),
-                                       rng.choice(I, 60, replace=False)]))
-    check_fit_sample(oracle, c3["Xc"], sample, c3["tg"], c3["items"], c3["coef"], c3["count"], c3["n_iter"], K)
+def test_c3_fit_all_columns_match_oracle(c3, oracle):
+    """The exact fit of ALL 26,744 columns against the oracle (round 4: the 16-thread oracle takes ~1.5 min for them; rounds
+    1-3 compared ~110 sampled columns): feature sets, coefficient bits and sweep counts."""
+    check_fit_sample(oracle, c3["Xc"], np.arange(C3["I"]), c3["tg"], c3["items"], c3["coef"], c3["count"], c3["n_iter"], C3["K"])
 
 
 def test_c3_fit_is_idempotent(c3):
@@ -119,10 +112,11 @@ def test_c3_recommend_all_users_properties_samples_and_both_kernels(c3, oracle):
     finally:
         eng.use_feature_rows = True
     assert np.array_equal(ids, ids3) and np.array_equal(bits(sc), bits(sc3)) and np.array_equal(cnt, cnt3)
+    # the oracle over ALL 138,493 users (round 4: not a sample -- a defect common to both kernels would show here)
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X, W.tocsr(), top_k=10, n_threads=CPU_THREADS)
+    bad = np.flatnonzero((ids != o_ids).any(axis=1) | (cnt != o_cnt) | (bits(sc) != bits(o_sc)).any(axis=1))
+    assert bad.size == 0, f"{bad.size} users differ from the oracle, first {bad[:5]}"
     sample = np.sort(np.random.default_rng(3).choice(U, 4000, replace=False))
-    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
-    assert np.array_equal(ids[sample], o_ids) and np.array_equal(cnt[sample], o_cnt)
-    assert np.array_equal(bits(sc[sample]), bits(o_sc))
     ids4, _, cnt4 = eng.recommend_rows(sample[:500], top_k=10, filter_interacted=False)
     o4, _, c4 = oracle.recommend_batch(X[sample[:500]], W.tocsr(), top_k=10, filter_interacted=False)
     assert np.array_equal(ids4, o4) and np.array_equal(cnt4, c4)
@@ -196,10 +190,10 @@ def test_c4_bulk_fit_and_score_at_full_size(c4, oracle):
     e_ids, e_sc, e_cnt = m.model.engine.recommend_rows(users, top_k=10)
     assert np.array_equal(e_ids, ids) and np.array_equal(e_cnt, cnt)
     check_topk_properties(e_ids, e_sc, e_cnt, X, W, users, 10)
-    sample = users[rng.choice(len(users), 600, replace=False)]
-    pos = np.searchsorted(users, sample)
-    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
-    assert np.array_equal(e_ids[pos], o_ids) and np.array_equal(e_cnt[pos], o_cnt) and np.array_equal(bits(e_sc[pos]), bits(o_sc))
+    # the oracle over ALL 200,000 scored users (round 4: not a sample of 600)
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[users], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
+    bad = np.flatnonzero((e_ids != o_ids).any(axis=1) | (e_cnt != o_cnt) | (bits(e_sc) != bits(o_sc)).any(axis=1))
+    assert bad.size == 0, f"{bad.size} users differ from the oracle, first {users[bad[:5]]}"
     # fitted columns: the heaviest targets and random ones against the oracle on the exported matrix
     Xc = m.interactions.to_csc()
     nnz = np.diff(Xc.indptr)
@@ -325,16 +319,10 @@ def c3s():
     torch.cuda.empty_cache()
 
 
-def test_c3s_fit_sampled_columns_match_oracle(c3s, oracle):
-    rng = np.random.default_rng(12)
-    I, K = C3S["I"], C3S["K"]
-    nnz = np.diff(c3s["Xc"].indptr)
-    work = np.argsort(-c3s["n_iter"] * 1.0)[:6]
-    heavy = np.argsort(-nnz)[:8]
-    active = np.flatnonzero(np.diff(c3s["W"].indptr) > 0)
-    sample = np.unique(np.concatenate([c3s["tg"][work], heavy, rng.choice(active, 40, replace=False),
-                                       rng.choice(I, 60, replace=False)]))
-    check_fit_sample(oracle, c3s["Xc"], sample, c3s["tg"], c3s["items"], c3s["coef"], c3s["count"], c3s["n_iter"], K)
+def test_c3s_fit_all_columns_match_oracle(c3s, oracle):
+    """Like test_c3_fit_all_columns_match_oracle, on the structured workload: every column."""
+    check_fit_sample(oracle, c3s["Xc"], np.arange(C3S["I"]), c3s["tg"], c3s["items"], c3s["coef"], c3s["count"], c3s["n_iter"],
+                     C3S["K"])
 
 
 def test_c3s_recommend_all_users_segment_kernel(c3s, oracle):
@@ -359,9 +347,10 @@ def test_c3s_recommend_all_users_segment_kernel(c3s, oracle):
     by_len = np.argsort(-lens)
     sample = np.unique(np.concatenate([np.random.default_rng(3).choice(U, 3000, replace=False), by_len[:300],
                                        np.flatnonzero((lens > 400) & (lens <= 512))[:300]]))
-    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
-    assert np.array_equal(ids[sample], o_ids) and np.array_equal(cnt[sample], o_cnt)
-    assert np.array_equal(bits(sc[sample]), bits(o_sc))
+    # the oracle over ALL users at top-10 (round 4: not a sample), then the sample at other k / filter settings
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X, W.tocsr(), top_k=10, n_threads=CPU_THREADS)
+    bad = np.flatnonzero((ids != o_ids).any(axis=1) | (cnt != o_cnt) | (bits(sc) != bits(o_sc)).any(axis=1))
+    assert bad.size == 0, f"{bad.size} users differ from the oracle, first {bad[:5]}"
     for k, filt in ((25, True), (10, False), (1, True)):
         ids4, sc4, cnt4 = eng.recommend_rows(sample[:600], top_k=k, filter_interacted=filt)
         assert eng.last_score_path == "segments"
@@ -372,12 +361,9 @@ def test_c3s_recommend_all_users_segment_kernel(c3s, oracle):
 def test_c3s_dense_mode_and_float64_w_at_full_size(c3s, oracle):
     """The other two forms the reference scores in, at full size: DENSE mode (string item ids, slim_elastic.py:745-778) and a
     float64 W (the serial fit, :252).  Both run the fast pass plus the rows it flags; ALL rows must equal the tiled kernel
-    of the same mode, and samples (random users, the longest, the shortest) the oracle."""
+    of the same mode and the oracle's (all 138,493 users)."""
     eng, X, W, U = c3s["eng"], c3s["X"], c3s["W"], C3S["U"]
     rows = np.arange(U)
-    lens = np.diff(X.indptr)
-    sample = np.unique(np.concatenate([np.random.default_rng(4).choice(U, 1500, replace=False), np.argsort(-lens)[:150],
-                                       np.argsort(lens)[:300]]))
     Wr = W.tocsr()
     # DENSE
     d = eng.recommend_rows(rows, top_k=10, mode=_native.TOPK_DENSE)
@@ -389,8 +375,8 @@ def test_c3s_dense_mode_and_float64_w_at_full_size(c3s, oracle):
     finally:
         eng.dense_fast = True
     assert all(np.array_equal(a.view(np.int32), b.view(np.int32)) for a, b in zip(d, t))
-    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], Wr, top_k=10, dense=True, n_threads=CPU_THREADS)
-    assert np.array_equal(d[0][sample], o_ids) and np.array_equal(bits(d[1][sample]), bits(o_sc)) and np.array_equal(d[2][sample], o_cnt)
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X, Wr, top_k=10, dense=True, n_threads=CPU_THREADS)          # ALL users (round 4)
+    assert np.array_equal(d[0], o_ids) and np.array_equal(bits(d[1]), bits(o_sc)) and np.array_equal(d[2], o_cnt)
     # float64 W
     try:
         eng.set_weights(W.astype(np.float64), acc_f64=True)
@@ -401,8 +387,8 @@ def test_c3s_dense_mode_and_float64_w_at_full_size(c3s, oracle):
         t = eng.recommend_rows(rows, top_k=10)
         assert eng.last_score_path == "tiled"
         assert all(np.array_equal(a.view(np.int32), b.view(np.int32)) for a, b in zip(f, t))
-        o_ids, o_sc, o_cnt = oracle.recommend_batch(X[sample], Wr, top_k=10, use_f64=True, n_threads=CPU_THREADS)
-        assert np.array_equal(f[0][sample], o_ids) and np.array_equal(bits(f[1][sample]), bits(o_sc)) and np.array_equal(f[2][sample], o_cnt)
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(X, Wr, top_k=10, use_f64=True, n_threads=CPU_THREADS)    # ALL users (round 4)
+        assert np.array_equal(f[0], o_ids) and np.array_equal(bits(f[1]), bits(o_sc)) and np.array_equal(f[2], o_cnt)
     finally:
         eng.f64_refine = True
         eng.set_weights(W)
@@ -443,7 +429,7 @@ def test_c4s_wide_tile_segment_path_at_full_size(oracle):
     """The 500k-item shape WITH item clusters and alpha = 0.005 (bench.py WORKLOADS["c4s"]: with the default alpha the L1
     threshold leaves a degenerate W at a million users): W gets tens of thousands of rows and ~100k active columns, so the
     segment layout takes tiles wider than 256 columns and the GENERIC accumulate loop -- the path that had no full-size
-    workload.  All 1M users: segment kernels == tiled-CSR kernel on every row; oracle on a sample; the
+    workload.  All 1M users: segment kernels == tiled-CSR kernel == oracle on every row; the
     exact fit of sampled columns equals the oracle's."""
     import torch
     from bench import WORKLOADS
@@ -486,9 +472,8 @@ def test_c4s_wide_tile_segment_path_at_full_size(oracle):
     assert np.array_equal(cnt, cnt3)
     m = np.arange(10)[None, :] < cnt[:, None]
     assert np.array_equal(ids[m], ids3[m]) and np.array_equal(bits(sc)[m], bits(sc3)[m])
-    ulen = np.diff(X.indptr)
-    smp = np.unique(np.concatenate([np.random.default_rng(9).choice(U, 1500, replace=False), np.argsort(-ulen)[:100]]))
-    o_ids, o_sc, o_cnt = oracle.recommend_batch(X[smp], W.tocsr(), top_k=10, n_threads=CPU_THREADS)
-    assert np.array_equal(ids[smp], o_ids) and np.array_equal(cnt[smp], o_cnt) and np.array_equal(bits(sc[smp]), bits(o_sc))
+    o_ids, o_sc, o_cnt = oracle.recommend_batch(X, W.tocsr(), top_k=10, n_threads=CPU_THREADS)          # ALL 1M users (round 4)
+    bad = np.flatnonzero((ids != o_ids).any(axis=1) | (cnt != o_cnt) | (bits(sc) != bits(o_sc)).any(axis=1))
+    assert bad.size == 0, f"{bad.size} users differ from the oracle, first {bad[:5]}"
     del eng
     torch.cuda.empty_cache()
