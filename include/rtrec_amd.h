@@ -534,6 +534,20 @@ int rtrec_slim_refine_topk_f64(int32_t n_rows, const int32_t *d_row_ids, const i
                                int32_t *d_flagged, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * SPARSE MODE OVER COLUMN SHARDS: THE TIE KEY OF EVERY LIST ENTRY  (the order _sparse_topk_indicies, slim_elastic.py:782-818,
+ * gives columns with equal scores: a stable sort over scipy's reverse-first-touch product order).
+ * d_ids / d_count: the lists of rtrec_slim_score_topk(_opt) for this rank's columns ([n_rows][top_k], item ids).  d_aux
+ * [n_rows][top_k] receives, per valid entry, the position in the user's row of X (rows sorted by item id) of the first item
+ * whose row of W stores a weight in the entry's column (W in CSC form: d_wc_ptr[n_items + 1], d_wc_row ascending per column;
+ * a rank may hold only its own columns' entries), 0 for the others -- the key rtrec_slim_merge_topk orders equal scores by.
+ * On one shard the score call computes it only for rows whose own list holds a tie; two columns of DIFFERENT shards can tie
+ * without either shard seeing one, so a rank that holds part of the columns calls this before the exchange.
+ * ------------------------------------------------------------------------------------- */
+int rtrec_slim_first_touch_aux(int32_t n_rows, const int32_t *d_row_ids, const int32_t *d_xb_ptr, const int32_t *d_xb_col,
+                               int32_t n_x_rows, int32_t n_items, const int32_t *d_wc_ptr, const int32_t *d_wc_row,
+                               int32_t top_k, const int32_t *d_ids, const int32_t *d_count, uint32_t *d_aux, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * DENSE MODE: ZERO-SCORE COLUMNS BEHIND A SHORT FAST-PASS LIST  (the tail of _dense_topk_indicies, slim_elastic.py:745-778:
  * argsort over ALL columns -- after a user's positive scores come the zero-score columns, the higher column id first
  * (DESIGN.md D1), interacted items excluded).  For a shard [col_lo, col_hi) whose weights, like the ratings, are all positive

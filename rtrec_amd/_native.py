@@ -37,6 +37,7 @@ EXPORTS = [
     "rtrec_slim_sgd_schedule",
     "rtrec_slim_fit_sgd_epochs",
     "rtrec_slim_dense_fill",
+    "rtrec_slim_first_touch_aux",
 ]
 
 
@@ -164,6 +165,8 @@ def load() -> C.CDLL:
     L.rtrec_slim_refine_topk_f64.restype = C.c_int
     L.rtrec_slim_refine_topk_f64.argtypes = [i32, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, C.c_double, vp,
                                              vp, vp, vp, vp, vp, vp]
+    L.rtrec_slim_first_touch_aux.restype = C.c_int
+    L.rtrec_slim_first_touch_aux.argtypes = [i32, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp]
     L.rtrec_slim_dense_fill.restype = C.c_int
     L.rtrec_slim_dense_fill.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     L.rtrec_slim_score_candidates.restype = C.c_int

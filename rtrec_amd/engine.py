@@ -941,6 +941,24 @@ class SlimEngine:
     # ------------------------------------------------------------------------------ score
     def _local_topk(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
                     d_col_rank, pad_rows: int = 0, host: bool = False):
+        """This rank's lists (ids, scores, float64 scores or None, tie keys, counts) for its columns of W.  A rank that holds
+        only PART of the columns (column shards) completes the SPARSE-mode tie key of every entry before the lists travel: two
+        columns of different shards can have equal scores without either shard seeing a tie (csrc/score_first_touch.hip)."""
+        out = self._local_topk_impl(d_row_ids, n_rows, xb, top_k, filter_interacted, mode, d_col_rank, pad_rows, host)
+        be, W = self.be, self._W
+        lo, hi = W.get("col_lo", 0), W.get("col_hi", 0)
+        if (mode == _native.TOPK_SPARSE and n_rows > 0 and isinstance(be, HipBackend) and hi > lo
+                and not (lo == 0 and hi == W["n_items"])):
+            ids, _sc, _sc64, aux, cnt = out
+            wc_ptr, wc_row, _ = W["dw"].csc_arrays(be.torch)
+            p = be.ptr
+            _native.check(be.lib.rtrec_slim_first_touch_aux(n_rows, p(d_row_ids), p(xb[0]), p(xb[1]), int(xb[0].shape[0]) - 1,
+                                                            W["n_items"], p(wc_ptr), p(wc_row), top_k, p(ids), p(cnt), p(aux),
+                                                            be.stream()), "rtrec_slim_first_touch_aux")
+        return out
+
+    def _local_topk_impl(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
+                         d_col_rank, pad_rows: int = 0, host: bool = False):
         be, W = self.be, self._W
         torch = be.torch
         # ids | scores | counts are views of ONE buffer: a caller that wants them on the host downloads it in one copy

@@ -343,6 +343,49 @@ def test_merge_topk_equals_unsharded(oracle):
     assert np.array_equal(o_cnt.cpu().numpy(), cnt)
 
 
+@pytest.mark.parametrize("shape", ["feature_rows", "general"])
+def test_column_shards_order_cross_shard_ties_like_the_reference(oracle, shape):
+    """Columns of DIFFERENT shards with bit-equal scores (here: every column of the second half of W is a copy of one in the
+    first half, integer ratings): neither shard sees a tie, so neither would compute the reference's tie key (position of the
+    first touching item in the user's row, slim_elastic.py:782-818 over scipy's product order) -- a rank that holds part of
+    the columns completes it for every entry (rtrec_slim_first_touch_aux) and the merged lists equal the oracle's."""
+    import torch
+    rng = np.random.default_rng(12)
+    I, U, half = 800, 900, 400
+    R = 60 if shape == "feature_rows" else 300
+    rows_w = np.sort(rng.choice(I, R, replace=False))
+    nnz = 4000 if shape == "feature_rows" else 2500
+    r, c = rng.choice(rows_w, nnz), rng.integers(0, half, nnz)
+    v = rng.integers(1, 4, nnz).astype(np.float32)
+    A = sp.csc_matrix((v, (r, c)), shape=(I, half), dtype=np.float32)
+    A.sum_duplicates()
+    W = sp.hstack([A, A], format="csc").astype(np.float32)          # column j + 400 == column j
+    W.sort_indices()
+    ur = np.repeat(np.arange(U), rng.integers(1, 40, U))
+    ui = np.where(rng.random(len(ur)) < 0.6, rng.choice(rows_w, len(ur)), rng.integers(0, I, len(ur)))
+    X = sp.csr_matrix((rng.integers(1, 6, len(ur)).astype(np.float32), (ur, ui)), shape=(U, I), dtype=np.float32)
+    X.sum_duplicates(); X.sort_indices()
+    rows = np.arange(U, dtype=np.int32)
+    for k, filt in ((10, True), (3, False)):
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(X, W.tocsr(), top_k=k, filter_interacted=filt)
+        parts = []
+        for rank in range(2):
+            e = SlimEngine(device="cuda:0", rank=rank, world_size=2)
+            e.set_interactions(None, X, need_csc=False)
+            e.set_weights(W)
+            xb = (e._X["rptr"], e._X["rcol"], e._X["rval"])
+            parts.append(e._local_topk(e.be.to_dev(rows), U, xb, k, filt, _native.TOPK_SPARSE, None))
+        be = e.be
+        g = [torch.stack([p[j] for p in parts]).contiguous() for j in (0, 1, 3, 4)]
+        m_ids, m_sc, m_cnt = be.empty((U, k), torch.int32), be.empty((U, k), torch.float32), be.empty((U,), torch.int32)
+        _native.check(be.lib.rtrec_slim_merge_topk(U, 2, k, be.ptr(g[0]), be.ptr(g[1]), None, be.ptr(g[2]), be.ptr(g[3]),
+                                                   be.ptr(m_ids), be.ptr(m_sc), be.ptr(m_cnt), be.stream()), "merge")
+        assert np.array_equal(m_cnt.cpu().numpy(), o_cnt)
+        bad = np.flatnonzero((m_ids.cpu().numpy() != o_ids).any(axis=1))
+        assert bad.size == 0, f"{bad.size} rows differ, first {bad[:5]}: {m_ids.cpu().numpy()[bad[0]]} vs {o_ids[bad[0]]}"
+        assert np.array_equal(bits(m_sc.cpu().numpy()), bits(o_sc))
+
+
 @pytest.mark.parametrize("tile_cols", [256, 1024, 4096])     # 256: the engine widens the tiles for large k
 @pytest.mark.parametrize("top_k", [1, 10, 50, 64, 200])    # > 63: the successive-scan selection
 def test_score_wide_catalogue_heavy_users(oracle, tile_cols, top_k):
