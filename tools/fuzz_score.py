@@ -78,7 +78,7 @@ def run(iters: int, seed: int, log=print, shards: bool = True) -> int:
                 log(f"MISMATCH it={it} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} dense={dense} f64={f64} n_rows={len(rows)} path={eng.last_score_path} "
                     f"heavy_min={eng.sg_heavy_min} integer={integer} tc={eng.FR_TILE_COLS} "
                     f"fr={lay.get('fr_w') is not None} rows_wrong={len(wrong)} first={wrong[:5].tolist()}")
-        if shards and not f64 and it % 3 == 0:
+        if shards and it % 3 == 0:
             # the same W as 2 .. 4 COLUMN SHARDS on this GPU (the engines of N ranks, scored one after another), their lists merged
             # like the exchange merges them: SPARSE and DENSE mode against the oracle on the full W
             import torch
@@ -94,22 +94,23 @@ def run(iters: int, seed: int, log=print, shards: bool = True) -> int:
                 e.world_size_for_merge = N
                 e.FR_TILE_COLS, e.FR_MIN_ROWS = eng.FR_TILE_COLS, eng.FR_MIN_ROWS
                 e.set_interactions(None, X, need_csc=False)
-                e.set_weights(W)
+                e.set_weights(W.astype(np.float64) if f64 else W, acc_f64=f64)
                 xb = (e._X["rptr"], e._X["rcol"], e._X["rval"])
                 parts.append(e._local_topk(e.be.to_dev(rows), len(rows), xb, top_k, filt, mode, None))
                 paths.append(e.last_score_path)
             be = eng.be
             g = [torch.stack([p[j] for p in parts]).contiguous() for j in (0, 1, 3, 4)]
+            g64 = torch.stack([p[2] for p in parts]).contiguous() if f64 else None
             m_ids, m_sc = be.empty((len(rows), top_k), torch.int32), be.empty((len(rows), top_k), torch.float32)
             m_cnt = be.empty((len(rows),), torch.int32)
-            _native.check(be.lib.rtrec_slim_merge_topk(len(rows), N, top_k, be.ptr(g[0]), be.ptr(g[1]), None, be.ptr(g[2]), be.ptr(g[3]),
+            _native.check(be.lib.rtrec_slim_merge_topk(len(rows), N, top_k, be.ptr(g[0]), be.ptr(g[1]), be.ptr(g64), be.ptr(g[2]), be.ptr(g[3]),
                                                        be.ptr(m_ids), be.ptr(m_sc), be.ptr(m_cnt), be.stream()), "merge")
-            o_ids, o_sc, o_cnt = so.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt, dense=dense)
+            o_ids, o_sc, o_cnt = so.recommend_batch(X[rows], Wr, top_k=top_k, filter_interacted=filt, dense=dense, use_f64=f64)
             ids, sc, cnt = m_ids.cpu().numpy(), m_sc.cpu().numpy(), m_cnt.cpu().numpy()
             if not (np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(sc.view(np.uint32), o_sc.view(np.uint32))):
                 bad += 1
                 wrong = np.flatnonzero((ids != o_ids).any(axis=1) | (cnt != o_cnt))
-                log(f"MISMATCH (column shards) it={it} N={N} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} dense={dense} "
+                log(f"MISMATCH (column shards) it={it} f64={f64} N={N} R={R} n_cols={n_cols} U={U} top_k={top_k} filt={filt} dense={dense} "
                     f"n_rows={len(rows)} paths={paths} integer={integer} rows_wrong={len(wrong)} first={wrong[:5].tolist()}")
         if it % 50 == 49:
             log(f"[fuzz] {it + 1} configurations, {bad} mismatches, {time.time() - t0:.0f}s")
