@@ -124,6 +124,20 @@ class OracleBackend:
                                                 dense=(mode == 1), use_f64=bool(acc_f64))
         ids.copy_(torch.from_numpy(o_ids)); sc.copy_(torch.from_numpy(o_sc)); cnt.copy_(torch.from_numpy(o_cnt))
         aux.zero_()
+        if mode == 0:
+            # the reference's tie key (csrc/score_first_touch.hip): position, in the user's row, of the first item whose row of
+            # W stores a weight in the column -- lists of different column shards are merged by (score, key, id)
+            Wc, Xs = Wr.tocsc(), Xall[rsel].tocsr()
+            Wc.sort_indices(); Xs.sort_indices()
+            o_aux = np.zeros((n_rows, top_k), np.int32)
+            for r in range(n_rows):
+                items = Xs.indices[Xs.indptr[r]:Xs.indptr[r + 1]]
+                for k in range(int(o_cnt[r])):
+                    rows_c = Wc.indices[Wc.indptr[o_ids[r, k]]:Wc.indptr[o_ids[r, k] + 1]]
+                    pos = np.searchsorted(items, rows_c)
+                    hit = (pos < len(items)) & (items[np.minimum(pos, max(len(items) - 1, 0))] == rows_c) if len(items) else np.zeros(len(rows_c), bool)
+                    o_aux[r, k] = int(pos[hit].min()) if hit.any() else 0
+            aux.copy_(torch.from_numpy(o_aux))
         if sc64 is not None:
             sc64.copy_(torch.from_numpy(o_sc.astype(np.float64)))
 

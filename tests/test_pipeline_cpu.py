@@ -235,6 +235,26 @@ def _worker(rank, world, port, q, score_shard="columns"):
         for rows in ([5, 17, 40, 41, 300], [9, 3, 77, 78, 1100], [5, 17, 40, 41, 300], [1, 2, 3, 4, 6]):
             got, ref = eng.recommend_rows(rows, top_k=5), solo.recommend_rows(rows, top_k=5)
             ok = ok and all(np.array_equal(a, b) for a, b in zip(got, ref))
+        if world <= 3 and score_shard == "columns":
+            # exact score ties ACROSS column shards (the second half of W's columns are copies of the first, integer ratings):
+            # neither shard sees a tie, the reference's tie key has to travel with every entry (round 4)
+            rng = np.random.default_rng(3)
+            half = 200
+            rows_w = np.sort(rng.choice(400, 60, replace=False))
+            A = sp.csc_matrix((rng.integers(1, 4, 1500).astype(np.float32), (rng.choice(rows_w, 1500), rng.integers(0, half, 1500))),
+                              shape=(400, half), dtype=np.float32)
+            A.sum_duplicates()
+            Wt = sp.hstack([A, A], format="csc").astype(np.float32)
+            Wt.sort_indices()
+            ur = np.repeat(np.arange(150), rng.integers(1, 30, 150))
+            Xt = sp.csr_matrix((rng.integers(1, 6, len(ur)).astype(np.float32), (ur, rng.choice(rows_w, len(ur)))), shape=(150, 400),
+                               dtype=np.float32)
+            Xt.sum_duplicates(); Xt.sort_indices()
+            for e in (eng, solo):
+                e.set_interactions(None, Xt, need_csc=False)
+                e.set_weights(Wt)
+            got, ref = eng.recommend_rows(np.arange(150), top_k=7), solo.recommend_rows(np.arange(150), top_k=7)
+            ok = ok and all(np.array_equal(a, b) for a, b in zip(got, ref))
         if world == 2 and score_shard == "columns" and not shard_w:
             # optim="sgd" shards like the coordinate-descent fit: every rank fits its own targets, the triples are all-gathered
             sgd = SLIMElastic({"optim": "sgd", "nn_feature_selection": 6, "max_iter": 12},
