@@ -48,6 +48,11 @@ def run(iters: int, seed: int, log=print) -> int:
             kw["decay_in_days"] = int(rng.choice([7, 30, 365]))
         if rng.random() < 0.3:
             kw["min_value"], kw["max_value"] = -5, 10
+        if K is not None and rng.random() < 0.15:        # scikit-learn's SGDRegressor behind the feature selection (csrc/fit_sgd.hip)
+            kw["optim"] = "sgd"
+            kw["max_iter"] = int(rng.choice([3, 12, 30]))
+            if rng.random() < 0.5:
+                kw["eta0"] = float(rng.choice([1e-4, 1e-3, 1e-2]))
         strings = rng.random() < 0.3
         uid = (lambda x: f"u{int(x)}") if strings else int
         iid = (lambda x: f"i{int(x)}") if strings else int
@@ -64,12 +69,13 @@ def run(iters: int, seed: int, log=print) -> int:
             ts = float(tss[-1])
             batch = [(uid(a), iid(b), float(t), float(r)) for a, b, t, r in zip(us, its, tss, rs)]
             upsert = bool(rng.integers(0, 2))
-            if step == 0:
-                for m in (g, c):
-                    m.fit(batch, update_interaction=upsert, progress_bar=False)
-            else:
-                for m in (g, c):
-                    m.fit(batch, update_interaction=upsert, progress_bar=False)
+            fg = outcome(lambda: g.fit(batch, update_interaction=upsert, progress_bar=False))
+            fc = outcome(lambda: c.fit(batch, update_interaction=upsert, progress_bar=False))
+            if isinstance(fg, tuple) or isinstance(fc, tuple):      # a fit that raises (a diverging SGD fit: ValueError) must raise on both sides
+                if fg != fc:
+                    ok = False
+                    log(f"MISMATCH it={it} step={step} kw={kw}: fit outcomes {fg} vs {fc}")
+                break
             users = [uid(x) for x in rng.integers(0, U + 5, 25)]
             k = int(rng.integers(1, 13)) if rng.random() < 0.85 else int(rng.choice([40, 64, 90]))
             filt = bool(rng.integers(0, 2))
@@ -82,6 +88,15 @@ def run(iters: int, seed: int, log=print) -> int:
             # W: a candidate list holding it raises IndexError, in the reference inside scipy; both sides must raise alike)
             rg = outcome(lambda: g.recommend_batch(users, candidate_items=cands, top_k=k, filter_interacted=filt))
             rc = outcome(lambda: c.recommend_batch(users, candidate_items=cands, top_k=k, filter_interacted=filt))
+            if not isinstance(rg, tuple) and rng.random() < 0.4:      # the array form of the same call: ids [n, k] (-1 padded) + counts
+                ag = outcome(lambda: g.recommend_batch(users, candidate_items=cands, top_k=k, filter_interacted=filt, as_arrays=True))
+                if isinstance(ag, tuple) and len(ag) == 2 and isinstance(ag[0], str):
+                    rg = ag
+                else:
+                    a_ids, a_cnt = ag
+                    back = [a_ids[n, :a_cnt[n]].tolist() for n in range(len(users))]
+                    if back != [list(x) for x in rg] or not all(x is None or x == -1 for n in range(len(users)) for x in a_ids[n, a_cnt[n]:].tolist()):
+                        rg = ("arrays differ from lists",)
             one = users[0]
             og = outcome(lambda: g.recommend(one, candidate_items=cands, top_k=k, filter_interacted=filt))
             oc = outcome(lambda: c.recommend(one, candidate_items=cands, top_k=k, filter_interacted=filt))
