@@ -1067,6 +1067,7 @@ constexpr int kFrCandCap = 64;               // candidates a wave buffers per me
 __host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
 constexpr int kFrStep = 2;                   // rows of W per sweep step
 constexpr int kFrSetupChunks = 4;            // 64-entry chunks of a long user row whose loads are issued together
+constexpr int kFrSetupChunksLong = 8;        // ... for rows of 1,152+ entries in the 2- and 4-user forms of the kernel
 constexpr int kFrTileHeaderBytes = 512;      // per tile, in front of its first fragment: max |w| of each row (FR_TILE_HEADER_BYTES)
 constexpr int kFrZeroRowBytes = 1024;        // one slice row of +0.0 (the widest tile: 256 columns)
 // per-wave LDS setup scratch actually needed: the interacted-column mask words, a pad, 128 ratings
@@ -1343,17 +1344,22 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             if (cm0[u] >= 0) mark(cm0[u]);
             if (fm1[u] >= 0) xl[fm1[u]] = xv1[u];
             if (cm1[u] >= 0) mark(cm1[u]);
-            for (int b = 128; b < n_a; b += 64 * kFrSetupChunks) {          // rows beyond 128 entries, four chunks per round:
-                int item[kFrSetupChunks], f[kFrSetupChunks], c[kFrSetupChunks];   // their entries, then what they map to, are
-                float xv[kFrSetupChunks];                                   // requested together (two round trips per round)
+            // rows beyond 128 entries, four chunks per round: their entries, then what they map to, are requested together
+            // (two round trips per round).  The 2- and 4-user forms (smaller passes: row shards, API batches -- their length is
+            // their longest user's setup) first take a very long row eight chunks at a time (sixteen spill): a 78k-item user of the
+            // 1M x 500k shape is 305 rounds of four chunks, ~0.6 ms, in a 125k-user pass of 0.6 ms
+            auto setup_round = [&](auto CHc, int b) {
+                constexpr int CH = decltype(CHc)::value;
+                int item[CH], f[CH], c[CH];
+                float xv[CH];
 #pragma unroll
-                for (int j = 0; j < kFrSetupChunks; ++j) {
+                for (int j = 0; j < CH; ++j) {
                     const int q = b + 64 * j + lane;
                     item[j] = -1; xv[j] = 0.0f;
                     if (q < n_a) { item[j] = a.xb_col[a0 + q]; xv[j] = a.xb_val[a0 + q]; }
                 }
 #pragma unroll
-                for (int j = 0; j < kFrSetupChunks; ++j) {
+                for (int j = 0; j < CH; ++j) {
                     f[j] = -1; c[j] = -1;
                     if (item[j] >= 0 && item[j] < a.n_items) {
                         f[j] = a.fmap[item[j]];
@@ -1361,11 +1367,17 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < kFrSetupChunks; ++j) {
+                for (int j = 0; j < CH; ++j) {
                     if (f[j] >= 0) xl[f[j]] = xv[j];
                     if (c[j] >= 0) mark(c[j]);
                 }
+            };
+            int b = 128;
+            if constexpr (UW < 8) {
+                for (; b + 64 * kFrSetupChunksLong <= n_a; b += 64 * kFrSetupChunksLong)
+                    setup_round(std::integral_constant<int, kFrSetupChunksLong>{}, b);
             }
+            for (; b < n_a; b += 64 * kFrSetupChunks) setup_round(std::integral_constant<int, kFrSetupChunks>{}, b);
             uint32_t *xu = xs_wave + u * kFrUserWords;
             fr_static_for<2>([&](auto H) { xu[H() * 64 + lane] = __float_as_uint(xl[H() * 64 + lane]); });
             for (int w = lane; w < mwords; w += 64) ms_wave[static_cast<size_t>(u) * mwords + w] = Ml[w];

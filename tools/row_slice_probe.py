@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Why is a STRIDED 1/8 row shard of C4 slower than a contiguous slice of the same size?  Times SlimEngine._local_topk for
+different 125k-user row sets of one fitted model (contiguous head / middle / tail, strided, random), with the work order the
+engine picks and with none.   python tools/row_slice_probe.py --workload c4"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    from bench import WORKLOADS
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--parts", type=int, default=8)
+    args = ap.parse_args()
+    import torch
+    from rtrec_amd import _native
+    from rtrec_amd.engine import SlimEngine
+    from rtrec_amd.synth import workload_matrix
+    wl = WORKLOADS[args.workload]
+    U, I, K = wl["U"], wl["I"], wl["K"]
+    X = workload_matrix(wl, seed=20251003, float_ratings=True)
+    Xc = X.tocsc(); Xc.sort_indices()
+    eng = SlimEngine(device="cuda:0", score_shard="rows")
+    eng.set_interactions(Xc, X)
+    out = eng.fit_columns(np.arange(I), nn_feature_selection=K, device_out=True, mode="gram")
+    eng.set_weights(eng.merge_fit(None, I, False, *out[:4]))
+    xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
+    lens = np.diff(X.indptr)
+    n = U // args.parts
+    rng = np.random.default_rng(1)
+    sets = {"contiguous_head": np.arange(n), "contiguous_middle": np.arange(U // 2, U // 2 + n), "contiguous_tail": np.arange(U - n, U),
+            "strided": np.arange(0, U, args.parts)[:n], "random_sorted": np.sort(rng.choice(U, n, replace=False)),
+            "random_unsorted": rng.choice(U, n, replace=False)}
+    for name, rows in sets.items():
+        d = eng.be.to_dev(rows.astype(np.int32))
+        m = len(rows)
+        rec = {"set": name, "rows": m, "items_mean": float(lens[rows].mean()), "items_max": int(lens[rows].max())}
+        for _ in range(3):
+            eng._local_topk(d, m, xb, 10, True, _native.TOPK_SPARSE, None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            eng._local_topk(d, m, xb, 10, True, _native.TOPK_SPARSE, None)
+        torch.cuda.synchronize()
+        rec["ms"] = (time.perf_counter() - t0) / 5 * 1e3
+        rec["path"] = eng.last_score_path
+        rec["grouped"] = bool(getattr(eng, "_order_grouped", False))
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()
