@@ -309,6 +309,18 @@ def test_dense_mode_short_lists_are_completed_in_place_and_column_shards_take_th
     bad = np.flatnonzero((m_ids.cpu().numpy() != o_ids).any(axis=1))
     assert bad.size == 0, f"sharded ids differ for rows {bad[:8]}: {m_ids.cpu().numpy()[bad[0]]} vs {o_ids[bad[0]]}"
     assert np.array_equal(bits(m_sc.cpu().numpy()), bits(o_sc))
+    # a catalogue smaller than top_k leaves after the filter: the fill runs out of columns and the count says so
+    It = 14
+    Wt = sp.csc_matrix((np.array([0.5, 0.25, 1.0], np.float32), ([1, 2, 3], [5, 6, 7])), shape=(It, It))
+    Xt = sp.csr_matrix((np.ones(9, np.float32), ([0, 0, 0, 0, 0, 1, 1, 2, 2], [1, 2, 9, 12, 13, 3, 0, 4, 11])), shape=(4, It))
+    Xt.sort_indices()
+    et = SlimEngine(device="cuda:0")
+    et.set_interactions(None, Xt, need_csc=False)
+    et.set_weights(Wt)
+    for kk in (10, 13, 3):
+        t_ids, t_sc, t_cnt = et.recommend_rows(np.arange(4), top_k=kk, filter_interacted=filt, mode=_native.TOPK_DENSE)
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(Xt, Wt.tocsr(), top_k=kk, filter_interacted=filt, dense=True)
+        assert np.array_equal(t_cnt, o_cnt) and np.array_equal(t_ids, o_ids) and np.array_equal(bits(t_sc), bits(o_sc)), (kk, t_ids, o_ids)
     # the switch: without the fill a shard keeps the tiled kernel
     e.dense_fill = False
     e._local_topk(d_rows, len(rows), xb, k, filt, _native.TOPK_DENSE, None)
