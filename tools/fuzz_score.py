@@ -46,7 +46,7 @@ def run(iters: int, seed: int, log=print, shards: bool = True) -> int:
             vals[vals == 0] = 1.0
         W = sp.csc_matrix((vals, (rr, cc)), shape=(I, I), dtype=np.float32)
         W.sum_duplicates(); W.eliminate_zeros(); W.sort_indices()
-        n_it = rng.integers(0, int(rng.choice([5, 60, 400])), U)
+        n_it = rng.integers(0, int(rng.choice([5, 60, 400, 400, 3000])), U)      # (3000: rows of 640+ entries take the long setup rounds)
         ur = np.repeat(np.arange(U), n_it)
         ui = np.where(rng.random(len(ur)) < rng.uniform(0.1, 0.9), rng.choice(feat, len(ur)), rng.integers(0, I, len(ur)))
         xv = rng.integers(1, 6, len(ur)).astype(np.float32) if integer else (rng.random(len(ur)).astype(np.float32) * 5 - rng.choice([0.0, 0.5]))
