@@ -356,7 +356,7 @@ def main() -> None:
     # profiles/r04_shard_model_*.jsonl: local kernel time of the slowest rank at 1 / 2 / 4 / 8 ranks, before the exchange):
     #   C3  (feature rows)  rows 1.79x / 2.94x / 4.00x   columns 1.21x / 1.69x / 2.10x
     #   c3s (segments)      rows 1.83x / 2.57x / 3.53x   columns 1.17x / 1.14x / 1.23x
-    #   C4  (feature rows)  rows 1.89x / 3.50x / 4.08x (4.65x with the long-row setup)   columns 1.19x / 1.12x / 1.11x
+    #   C4  (feature rows)  rows 1.89x / 3.50x / 4.08x (6.4x at 8 with the long-row setup and the giant rows spread over the waves)   columns 1.19x / 1.12x / 1.11x
     # A pass costs per USER (row setup, bound rows, the tiles every user opens) with either kernel, so dividing the users
     # divides the work and dividing the columns mostly repeats it on every rank; W is 0.2-3 MB here, so replicating it is
     # free.  The item-column division of BASELINE.json is the one to take when W is too large to replicate (auto: more than
@@ -372,7 +372,7 @@ def main() -> None:
                         "why": ("W too large to replicate: item-column shards" if big_w else
                                 "a pass costs per user with either kernel and W is small enough to replicate: user-row shards "
                                 "(one rank's share at 8 ranks, single-GPU model: C3 4.0x rows / 2.1x columns, c3s 3.5x / 1.2x, "
-                                "C4 4.6x / 1.1x; profiles/r04_shard_model_*.jsonl)")}
+                                "C4 6.4x / 1.1x; profiles/r04_shard_model_*.jsonl)")}
     eng.set_weights(dw_fit)
     torch.cuda.synchronize()
     merge_s = time.time() - t1

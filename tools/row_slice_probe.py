@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--parts", type=int, default=8)
+    ap.add_argument("--giants", type=int, default=-1, help="SlimEngine.ROW_ORDER_GIANTS override (0: giant rows are not spread)")
     args = ap.parse_args()
     import torch
     from rtrec_amd import _native
@@ -29,6 +30,8 @@ def main():
     X = workload_matrix(wl, seed=20251003, float_ratings=True)
     Xc = X.tocsc(); Xc.sort_indices()
     eng = SlimEngine(device="cuda:0", score_shard="rows")
+    if args.giants >= 0:
+        eng.ROW_ORDER_GIANTS = args.giants
     eng.set_interactions(Xc, X)
     out = eng.fit_columns(np.arange(I), nn_feature_selection=K, device_out=True, mode="gram")
     eng.set_weights(eng.merge_fit(None, I, False, *out[:4]))
@@ -39,10 +42,13 @@ def main():
     sets = {"contiguous_head": np.arange(n), "contiguous_middle": np.arange(U // 2, U // 2 + n), "contiguous_tail": np.arange(U - n, U),
             "strided": np.arange(0, U, args.parts)[:n], "random_sorted": np.sort(rng.choice(U, n, replace=False)),
             "random_unsorted": rng.choice(U, n, replace=False)}
+    for r in range(args.parts):                      # every strided shard of an N-rank pass (tools/shard_model.py takes their maximum)
+        sets[f"strided_{r}"] = np.arange(r, U, args.parts)
     for name, rows in sets.items():
         d = eng.be.to_dev(rows.astype(np.int32))
         m = len(rows)
-        rec = {"set": name, "rows": m, "items_mean": float(lens[rows].mean()), "items_max": int(lens[rows].max())}
+        top = np.sort(lens[rows])[::-1][:4]
+        rec = {"set": name, "rows": m, "items_mean": float(lens[rows].mean()), "items_max": int(lens[rows].max()), "longest_4": top.tolist()}
         for _ in range(3):
             eng._local_topk(d, m, xb, 10, True, _native.TOPK_SPARSE, None)
         torch.cuda.synchronize()
