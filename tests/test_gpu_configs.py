@@ -157,6 +157,21 @@ def test_c3_row_sets_scored_again_get_the_grouped_order(c3):
             o = eng.score_topk_device(None, 40_000, 10, True, _native.TOPK_SPARSE, d_rows=d)
             assert eng.last_score_path == "feature_rows"
             assert all(np.array_equal(a.cpu().numpy().view(np.int32), b.view(np.int32)) for a, b in zip(o, f))
+    # the grouped order is a permutation, and its giant rows (more than ROW_ORDER_GIANT_LEN entries) sit at every 8th position
+    # of the head, longest first: a wave takes consecutive positions, and giants must not share one (round 4)
+    X = c3["X"]
+    lens = np.diff(X.indptr)
+    for d in sets:
+        rows = d.cpu().numpy()
+        ent = next(e for e in eng._X["_orders"] if e[0] is d)
+        assert ent[5], "the cached order of a row set scored three times is the grouped one"
+        order = ent[4].cpu().numpy()
+        assert np.array_equal(np.sort(order), np.arange(len(rows)))
+        giants = np.flatnonzero(lens[rows] > eng.ROW_ORDER_GIANT_LEN)
+        giants = giants[np.argsort(-lens[rows][giants], kind="stable")][:eng.ROW_ORDER_GIANTS]
+        assert len(giants) > 0, "the ML-20M shape has users of more than 4,096 items in every 40k-user slice"
+        assert np.array_equal(lens[rows][order[0:8 * len(giants):8]], lens[rows][giants])
+        assert (lens[rows][order[1:8]] <= eng.ROW_ORDER_GIANT_LEN).all()
 
 
 @pytest.fixture(scope="module")
