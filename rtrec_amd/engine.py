@@ -60,6 +60,35 @@ def shard_bounds(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def spread_giant_rows(torch, order, lens, max_giants: int, giant_len: int):
+    """The pattern-grouped work order with its giant rows spread out (SlimEngine._row_order).  A wave of the feature-row kernel
+    takes CONSECUTIVE positions of that order (2, 4 or 8) and sets its users up one after the other; the few giant rows (tens of
+    thousands of entries: they rate every feature item, so their patterns are neighbours at the head) must not share a wave --
+    four of them in one wave made one of eight C4 row shards 0.81 ms instead of 0.59 (tools/row_slice_probe.py).  Up to
+    `max_giants` rows of more than `giant_len` entries (`lens`: entries per row, indexed like the values of `order`) go to
+    positions 0, 8, 16, ... of the head, longest first; the gaps are filled from the tail of the order (its lightest patterns);
+    everything else keeps its place.  Returns a permutation of the same rows."""
+    n_rows = int(order.numel())
+    n_g = min(int(max_giants), n_rows // 64)
+    if n_g <= 0:
+        return order
+    g_len, g_idx = torch.topk(lens, n_g)
+    g_idx = g_idx[g_len > giant_len]
+    n_g = int(g_idx.numel())
+    if n_g == 0:
+        return order
+    is_g = torch.zeros(n_rows, dtype=torch.bool, device=order.device)
+    is_g[g_idx] = True
+    rest = order[~is_g[order]]
+    n_fill = 7 * n_g
+    head = torch.empty(8 * n_g, dtype=order.dtype, device=order.device)
+    gap = torch.ones(8 * n_g, dtype=torch.bool, device=order.device)
+    gap[0::8] = False
+    head[0::8] = g_idx.to(order.dtype)
+    head[gap] = rest[rest.numel() - n_fill:]
+    return torch.cat([head, rest[:rest.numel() - n_fill]])
+
+
 class SlimEngine:
     """Fit / score / similar-items on one GPU (one shard of W)."""
 
@@ -1240,26 +1269,7 @@ class SlimEngine:
             order = torch.arange(n_rows, device=col.device)
             for w in range(n_words):                                  # least significant word first, stable sorts
                 order = order[torch.argsort(words[order, w], descending=True, stable=True)]
-            # A wave takes CONSECUTIVE positions of this order (2, 4 or 8), and sets its users up one after the other: the few
-            # giant rows (tens of thousands of entries: they rate every feature item, so their patterns are neighbours at the
-            # head) must not share a wave -- four of them in one wave made one of eight C4 row shards 0.81 ms instead of
-            # 0.59 (tools/row_slice_probe.py).  They go to every 8th position of the head, the gaps are filled from the tail.
-            n_g = min(self.ROW_ORDER_GIANTS, n_rows // 64)
-            if n_g > 0:
-                g_len, g_idx = torch.topk(lens64, n_g)
-                g_idx = g_idx[g_len > self.ROW_ORDER_GIANT_LEN]
-                n_g = int(g_idx.numel())
-            if n_g > 0:
-                is_g = torch.zeros(n_rows, dtype=torch.bool, device=col.device)
-                is_g[g_idx] = True
-                rest = order[~is_g[order]]
-                n_fill = 7 * n_g
-                head = torch.empty(8 * n_g, dtype=order.dtype, device=col.device)
-                gap = torch.ones(8 * n_g, dtype=torch.bool, device=col.device)
-                gap[0::8] = False
-                head[0::8] = g_idx
-                head[gap] = rest[rest.numel() - n_fill:]
-                order = torch.cat([head, rest[:rest.numel() - n_fill]])
+            order = spread_giant_rows(torch, order, lens64, self.ROW_ORDER_GIANTS, self.ROW_ORDER_GIANT_LEN)
             order = order.to(torch.int32)
         if cache is not None:
             if seen is not None:

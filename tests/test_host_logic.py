@@ -950,3 +950,28 @@ def test_every_environment_switch_is_in_the_settings_table():
     with pytest.raises(KeyError):
         settings.raw("RTREC_AMD_NO_SUCH_SWITCH")
     assert "RTREC_AMD_SG_FORK" in settings.describe()
+
+
+def test_grouped_work_order_spreads_giant_rows_over_the_head():
+    """engine.spread_giant_rows (the feature-row kernel's pattern-grouped order): rows of more than `giant_len` entries, at most
+    `max_giants` of them, longest first, at positions 0, 8, 16, ... -- a wave takes consecutive positions and sets its users up
+    one after the other -- the gaps filled from the tail, everything else in place; always a permutation."""
+    import torch
+    from rtrec_amd.engine import spread_giant_rows
+    rng = np.random.default_rng(1)
+    n = 5000
+    lens = torch.from_numpy(rng.integers(1, 300, n))
+    giants = [7, 4000, 123, 4999]
+    lens[giants] = torch.tensor([90_000, 50_000, 7_000, 4_097])
+    order = torch.from_numpy(rng.permutation(n))
+    out = spread_giant_rows(torch, order, lens, 32, 4096)
+    assert sorted(out.tolist()) == list(range(n))
+    assert out[0:32:8].tolist() == giants                                   # longest first, one per 8 positions
+    rest = [x for x in order.tolist() if x not in giants]
+    assert out[32:].tolist() == rest[:len(rest) - 28]                         # the body keeps its order ...
+    assert sorted(out[:32].tolist()) == sorted(giants + rest[len(rest) - 28:])   # ... the gaps hold the tail
+    # at most max_giants; none above the threshold: unchanged; tiny row sets: unchanged
+    assert spread_giant_rows(torch, order, lens, 2, 4096)[0:16:8].tolist() == giants[:2]
+    assert torch.equal(spread_giant_rows(torch, order, lens, 32, 100_000), order)
+    assert torch.equal(spread_giant_rows(torch, order[:40], lens, 32, 4096), order[:40])
+    assert torch.equal(spread_giant_rows(torch, order, lens, 0, 4096), order)
