@@ -1483,7 +1483,11 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                     wmm = fmaxf(wmm, fr_dpp_f<0x142>(wmm, 0.0f));
                     wmm = fmaxf(wmm, fr_dpp_f<0x143>(wmm, 0.0f));
                     const float wtop = __fmul_rn(readlane_f(wmm, 63), 1.0001f);
-                    const unsigned long long open1 = __ballot(lane < UW && !(thrv >= 0.0f && __fmul_rn(l1v, wtop) <= thrv));
+                    // (a user with NO rating on a row of W -- an empty row, a position past the end of the batch in the last job --
+                    // has bound 0: every sum is +0, no candidate; it must not hold the tile open while its list is empty.  Such a
+                    // slot used to keep its wave sweeping EVERY tile: a batch whose size is no multiple of the job size paid one
+                    // unpruned wave at its end, 0.06-0.09 ms whatever its size -- tools/row_slice_probe.py, round 4)
+                    const unsigned long long open1 = __ballot(lane < UW && l1v > 0.0f && !(thrv >= 0.0f && __fmul_rn(l1v, wtop) <= thrv));
                     bool all_skip = true;
                     if (open1) fr_static_for<UW>([&](auto Uc) {
                         constexpr int u = decltype(Uc)::value;
@@ -1497,7 +1501,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                         b = __fadd_rn(b, fr_dpp_f<0x143>(b, 0.0f));      // row_bcast:31: lane 63 holds the wave's sum
                         const float bound = __fmul_rn(readlane_f(b, 63), 1.0001f);
                         const float thr_u = readlane_f(ls4[u >> 2], (u & 3) * 16 + kk - 1);
-                        if (!(thr_u >= 0.0f && bound <= thr_u)) all_skip = false;
+                        if (bound > 0.0f && !(thr_u >= 0.0f && bound <= thr_u)) all_skip = false;
                     });
                     tile_skip = all_skip;
                     if (!tile_skip) fr_static_for<UW>([&](auto Uc) { acc[decltype(Uc)::value] = vec(0.0f); });
