@@ -69,6 +69,15 @@ const char *rtrec_amd_last_error(void);
 int rtrec_slim_column_sqnorms(int32_t n_items, const int32_t *d_csc_ptr, const float *d_csc_val,
                               float *d_sqnorm, void *stream);
 
+/* Left-to-right float32 sums of n_sums segments of d_values: d_out[s] = (...((0 + v[o_s]) + v[o_s + 1]) + ...),
+ * o = d_offsets[n_sums + 1] -- the accumulation order of the reference's dot products (_cd_fast.pyx:464-466
+ * `tmp += R[X_indices[jj]] * X_data[jj]`, :506-509 XtA; scipy csr_matvec).  mode 0: the binade-speculative fold the
+ * fit kernels use (csrc/fold_spec.hip.h: integer prefix sums inside a binade, bit-identical to the chain), one
+ * 256-entry group per step; mode 2 / 3: the same with 2 / 4 groups per step (the running value stays an integer
+ * from group to group); mode 1: the literal chain of dependent float additions.  One wave per segment. */
+int rtrec_slim_ordered_sums(const float *d_values, const int64_t *d_offsets, int32_t n_sums, int32_t mode,
+                            float *d_out, void *stream);
+
 /* Bytes of scratch rtrec_slim_fit_columns needs for `n_slots` concurrently fitted targets. */
 size_t rtrec_slim_fit_workspace_bytes(int32_t n_users, int32_t n_items, int32_t n_slots,
                                       int32_t top_features);
@@ -170,6 +179,14 @@ typedef struct {
     int64_t        nnz;
     const int32_t *d_col_order;   /* optional int32[n_items]: item ids by descending column length (the one-pass X^T y
                                      starts its longest columns first); any permutation gives the same results */
+    /* How the ordered dot products are evaluated (results are bit-identical either way; A/B runs and tests):
+     *   0, 1  the literal chain of dependent float additions (the default: measured faster inside both fit kernels,
+     *         DESIGN.md section 3.4 "the binade-speculative fold")
+     *   2     the binade-speculative fold (csrc/fold_spec.hip.h: integer prefix sums inside a binade, one real float
+     *         addition where the running sum changes binade) for every column of at least 64 entries (tests: small
+     *         matrices exercise it)
+     *   3     the speculative fold for columns of at least 512 entries */
+    int32_t        fold;
 } rtrec_fit_opts;
 
 size_t rtrec_slim_xty_workspace_bytes(int32_t n_users, int32_t n_items, int64_t nnz, int32_t n_targets);

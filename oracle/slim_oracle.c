@@ -44,6 +44,31 @@ static float seq_asum(int32_t n, const float *a)
     return s;
 }
 
+/* Test switch: evaluate the coordinate-descent dot products (tmp, XtA) with the CPU model of the device's
+ * binade-speculative fold (fold_model.c) instead of the literal loop.  Off by default; tests turn it on to show
+ * that the speculative fold leaves every coefficient bit and sweep count of the goldens unchanged, and to count
+ * how many entries of real sums take the integer path.  Per thread. */
+typedef struct { int64_t entries, spec_entries, serial_entries, passes; } fold_model_stats;
+float fold_model_fold(float acc, const float *p, int64_t n, fold_model_stats *st);
+static __thread int g_fold_model = 0;
+static __thread fold_model_stats g_fold_stats;
+void slim_oracle_set_fold_model(int on) { g_fold_model = on; memset(&g_fold_stats, 0, sizeof g_fold_stats); }
+void slim_oracle_fold_model_stats(int64_t out[4])
+{
+    out[0] = g_fold_stats.entries; out[1] = g_fold_stats.spec_entries;
+    out[2] = g_fold_stats.serial_entries; out[3] = g_fold_stats.passes;
+}
+/* sum_{jj} a(jj) * b(jj) through the fold model: products rounded exactly like the literal loop's */
+static float model_dot(const float *R, const float *X_data, const int32_t *X_indices, int32_t b, int32_t e, int r_first)
+{
+    float *p = (float *)malloc(sizeof(float) * (size_t)(e > b ? e - b : 1));
+    for (int32_t jj = b; jj < e; jj++)
+        p[jj - b] = r_first ? R[X_indices[jj]] * X_data[jj] : X_data[jj] * R[X_indices[jj]];
+    const float v = fold_model_fold(0.0f, p, e - b, &g_fold_stats);
+    free(p);
+    return v;
+}
+
 /* ---- _cd_fast.pyx:327-561, float32, no sample weights, X_mean == 0 -------------------- */
 int32_t slim_oracle_cd(int32_t n_samples, int32_t n_features,
                        const float *X_data, const int32_t *X_indices, const int32_t *X_indptr,
@@ -86,6 +111,8 @@ int32_t slim_oracle_cd(int32_t n_samples, int32_t n_features,
                     R[X_indices[jj]] += X_data[jj] * w_ii;
 
             float tmp = 0.0f;                                                    /* :464 */
+            if (g_fold_model) tmp = model_dot(R, X_data, X_indices, startptr, endptr, 1);
+            else
             for (int32_t jj = startptr; jj < endptr; jj++)
                 tmp += R[X_indices[jj]] * X_data[jj];
 
@@ -115,6 +142,8 @@ int32_t slim_oracle_cd(int32_t n_samples, int32_t n_features,
         if (w_max == 0.0f || d_w_max / w_max < d_w_tol || n_iter == cfg->max_iter - 1) { /* :499 */
             for (int32_t ii = 0; ii < n_features; ii++) {                        /* :506 */
                 float s = 0.0f;
+                if (g_fold_model) s = model_dot(R, X_data, X_indices, X_indptr[ii], X_indptr[ii + 1], 0);
+                else
                 for (int32_t kk = X_indptr[ii]; kk < X_indptr[ii + 1]; kk++)
                     s += X_data[kk] * R[X_indices[kk]];
                 s -= beta * w[ii];

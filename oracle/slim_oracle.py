@@ -32,8 +32,9 @@ def build(force: bool = False) -> str:
     """Compile the oracle with gcc if the .so is missing or stale."""
     src = os.path.join(_HERE, "slim_oracle.c")
     hdr = os.path.join(_HERE, "slim_oracle.h")
+    fold = os.path.join(_HERE, "fold_model.c")
     stale = (not os.path.exists(_LIB_PATH)
-             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+             or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(fold)))
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB_PATH
@@ -204,3 +205,58 @@ def similar_items(W_csc, item: int, top_k=10):
                                         np.ascontiguousarray(W_csc.data, dtype=np.float32),
                                         int(item), int(k), oi, ov)
     return oi[:n], ov[:n]
+
+
+# ---- CPU model of the device's binade-speculative ordered fold (oracle/fold_model.c) ---------------------------
+class FoldStats(C.Structure):
+    _fields_ = [("entries", C.c_int64), ("spec_entries", C.c_int64), ("serial_entries", C.c_int64), ("passes", C.c_int64)]
+
+
+def _fold_lib():
+    L = lib()
+    if not getattr(L, "_fold_ready", False):
+        L.fold_model_fold.restype = C.c_float
+        L.fold_model_fold.argtypes = [C.c_float, _f32p, C.c_int64, C.POINTER(FoldStats)]
+        L.fold_model_sequential.restype = C.c_float
+        L.fold_model_sequential.argtypes = [C.c_float, _f32p, C.c_int64]
+        L.fold_model_fuzz.restype = C.c_int64
+        L.fold_model_fuzz.argtypes = [C.c_uint32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(FoldStats)]
+        L._fold_ready = True
+    return L
+
+
+def fold_speculative(products: np.ndarray, acc0: float = 0.0):
+    """(sum, FoldStats) of the speculative fold model over float32 `products`, starting from acc0."""
+    p = np.ascontiguousarray(products, dtype=np.float32)
+    st = FoldStats()
+    v = _fold_lib().fold_model_fold(np.float32(acc0), p, p.size, C.byref(st))
+    return np.float32(v), st
+
+
+def fold_sequential(products: np.ndarray, acc0: float = 0.0) -> np.float32:
+    """The reference's left-to-right float32 accumulation (_cd_fast.pyx:464-466)."""
+    p = np.ascontiguousarray(products, dtype=np.float32)
+    return np.float32(_fold_lib().fold_model_sequential(np.float32(acc0), p, p.size))
+
+
+def fold_fuzz(seed: int, n_folds: int, max_len: int, kind: int = -1):
+    """(mismatches, FoldStats) over n_folds generated sums; kind -1 mixes all generators."""
+    st = FoldStats()
+    bad = _fold_lib().fold_model_fuzz(seed, n_folds, max_len, kind, C.byref(st))
+    return int(bad), st
+
+
+def set_fold_model(on: bool) -> None:
+    """Route the coordinate-descent dot products of THIS thread's oracle calls through the fold model (tests only)."""
+    L = _fold_lib()
+    L.slim_oracle_set_fold_model.restype = None
+    L.slim_oracle_set_fold_model.argtypes = [C.c_int]
+    L.slim_oracle_set_fold_model(1 if on else 0)
+
+
+def fold_model_stats() -> FoldStats:
+    L = _fold_lib()
+    out = (C.c_int64 * 4)()
+    L.slim_oracle_fold_model_stats.restype = None
+    L.slim_oracle_fold_model_stats(out)
+    return FoldStats(out[0], out[1], out[2], out[3])

@@ -38,6 +38,7 @@ EXPORTS = [
     "rtrec_slim_fit_sgd_epochs",
     "rtrec_slim_dense_fill",
     "rtrec_slim_first_touch_aux",
+    "rtrec_slim_ordered_sums",
 ]
 
 
@@ -50,7 +51,8 @@ class FitOpts(C.Structure):
     _fields_ = [("d_trace", C.c_void_p), ("d_gram", C.c_void_p), ("d_gram_index", C.c_void_p),
                 ("gram_n", C.c_int32), ("gram_rel_err", C.c_double), ("fast", C.c_int32), ("kernel", C.c_int32),
                 ("colwalk_min_rows", C.c_int32), ("screen_min", C.c_int32), ("lane_max", C.c_int32),
-                ("d_xty_ws", C.c_void_p), ("xty_ws_bytes", C.c_size_t), ("nnz", C.c_int64), ("d_col_order", C.c_void_p)]
+                ("d_xty_ws", C.c_void_p), ("xty_ws_bytes", C.c_size_t), ("nnz", C.c_int64), ("d_col_order", C.c_void_p),
+                ("fold", C.c_int32)]
 
 
 class ScoreOpts(C.Structure):
@@ -179,6 +181,8 @@ def load() -> C.CDLL:
                                             vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.rtrec_store_fold_device.restype = C.c_int
     L.rtrec_store_fold_device.argtypes = [vp, vp, C.c_int64, vp, vp, vp, C.c_double, C.c_double, i32, vp, vp, vp, vp]
+    L.rtrec_slim_ordered_sums.restype = C.c_int
+    L.rtrec_slim_ordered_sums.argtypes = [vp, vp, i32, i32, vp, vp]
     _lib = L
     return L
 

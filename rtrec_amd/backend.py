@@ -127,13 +127,15 @@ class HipBackend:
     @staticmethod
     def fit_knobs() -> Dict[str, int]:
         """Tuning / test knobs of rtrec_fit_opts, read from the environment HERE (the library itself reads none):
-        RTREC_AMD_FIT_MODE=sw|mw, RTREC_AMD_COLWALK_MIN, RTREC_AMD_SCREEN_MIN, RTREC_AMD_LANE_MAX."""
+        RTREC_AMD_FIT_MODE=sw|mw, RTREC_AMD_COLWALK_MIN, RTREC_AMD_SCREEN_MIN, RTREC_AMD_LANE_MAX,
+        RTREC_AMD_FOLD=chain|spec|spec-all (how ordered dot products are evaluated; bit-identical results)."""
         mode = settings.raw("RTREC_AMD_FIT_MODE", "")
         lane_max = settings.raw("RTREC_AMD_LANE_MAX")
         return dict(kernel=2 if mode.startswith("m") else 1 if mode.startswith("s") else 0,
                     colwalk_min_rows=int(settings.raw("RTREC_AMD_COLWALK_MIN", 0)),
                     screen_min=int(settings.raw("RTREC_AMD_SCREEN_MIN", 0)),
-                    lane_max=0 if lane_max is None else (-1 if int(lane_max) == 0 else int(lane_max)))
+                    lane_max=0 if lane_max is None else (-1 if int(lane_max) == 0 else int(lane_max)),
+                    fold={"": 0, "chain": 1, "spec-all": 2, "spec": 3}[settings.raw("RTREC_AMD_FOLD", "")])
 
     def fit_columns(self, n_users, n_items, X, targets, cfg, out_items, out_coef, out_count, out_niter, cap,
                     ws, queue, slots, trace=None, gram=None, fast=False, one_pass_xty=True):
@@ -157,7 +159,7 @@ class HipBackend:
                              int(cfg.seed), bool(cfg.positive), int(cfg.top_features),
                              out_items, out_coef, out_count, out_niter, cap, ws, slots, queue, trace,
                              g.get("G"), g.get("index"), int(g.get("n", 0)), float(g.get("rel_err", 0.0)),
-                             int(fast), k["kernel"], k["colwalk_min_rows"], k["screen_min"], k["lane_max"], xty, X.get("col_order") if xty is not None else None)
+                             int(fast), k["kernel"], k["colwalk_min_rows"], k["screen_min"], k["lane_max"], xty, X.get("col_order") if xty is not None else None, k["fold"])
 
     def gram_matrix(self, X, n_users, n_items, n_top):
         """Gram matrix X_P^T X_P of the n_top most popular items in float64 for the fit kernel's Gram

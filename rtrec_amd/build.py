@@ -14,8 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_DIR = os.path.join(_HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "librtrec_amd.so")
-SOURCES = ["score.hip", "fit.hip", "store_host.hip", "store_device.hip", "seg_build.hip", "score_refine.hip", "score_cands.hip", "fit_sgd.hip", "score_dense_fill.hip", "score_first_touch.hip"]
-HEADERS = ["common.hip.h", "score_seg.hip.h", os.path.join("..", "..", "include", "rtrec_amd.h")]
+SOURCES = ["score.hip", "fit.hip", "store_host.hip", "store_device.hip", "seg_build.hip", "score_refine.hip", "score_cands.hip", "fit_sgd.hip", "score_dense_fill.hip", "score_first_touch.hip", "ordered_fold.hip"]
+HEADERS = ["common.hip.h", "score_seg.hip.h", "fold_spec.hip.h", os.path.join("..", "..", "include", "rtrec_amd.h")]
 # -ffp-contract=off: the kernels reproduce the reference's float32 rounding sequence, so a
 # multiply must never be fused into the following add.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]

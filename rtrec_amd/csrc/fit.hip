@@ -22,6 +22,7 @@
 // Scratch invariants between targets (set by rtrec_slim_fit_workspace_init): R == 0, s ==
 // kUntouched, w_all == 0, ever_flag == 0.
 #include "common.hip.h"
+#include "fold_spec.hip.h"
 #include "../../include/rtrec_amd.h"
 
 namespace rtrec {
@@ -65,6 +66,7 @@ struct FitArgs {
     // optional, latency mode: the non-zero entries of X^T y of every target of the call, computed beforehand by
     // xty_batch_kernel (one pass over X for the whole call); target t owns [t * I, t * I + pre_cnt[t])
     const int *pre_cnt; const int *pre_i; const float *pre_s;
+    int spec_min;             // columns of at least this many entries are folded by fold256_spec (csrc/fold_spec.hip.h); INT_MAX: never
 };
 
 __device__ __forceinline__ float cd_update(float tmp, float alpha, float beta, float nrm, int positive) {
@@ -165,6 +167,80 @@ __device__ float dot_pass(const int *__restrict__ crow, const float *__restrict_
     return tmp;
 }
 
+// The same sum by integer prefix sums inside a binade (csrc/fold_spec.hip.h) -- bit-identical to dot_pass, without the
+// chain of dependent additions.  Lane L takes entries 4L .. 4L+3 of a 256-entry group (one 16-byte load of the row ids
+// and one of the values, 4-byte aligned), so the products arrive in the layout fold256_spec scans; same software
+// pipeline as dot_pass (gathers of group k+1 and the index loads of group k+2 in flight while group k is folded).
+struct __attribute__((packed, aligned(4))) PackedI4 { int x, y, z, w; };
+struct __attribute__((packed, aligned(4))) PackedF4 { float x, y, z, w; };
+
+__device__ float dot_pass_spec(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
+                               int b, int e, float w_old) {
+    const int lane = lane_id();
+    const bool add_back = (w_old != 0.0f);
+    float tmp = 0.0f;
+    const int n_full = (e - b) >> 8;
+    int o = b;
+    auto prods = [&](const PackedF4 &v, const PackedF4 &x, float (&p)[4]) {
+        const float vv[4] = {v.x, v.y, v.z, v.w}, xx[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float t = vv[u];
+            if (add_back) t = __fadd_rn(t, __fmul_rn(xx[u], w_old));
+            p[u] = __fmul_rn(t, xx[u]);
+        }
+    };
+    if (n_full > 0) {
+        PackedI4 ra, rb{0, 0, 0, 0};
+        PackedF4 xa, xb{0.0f, 0.0f, 0.0f, 0.0f}, va;
+        ra = *reinterpret_cast<const PackedI4 *>(crow + o + 4 * lane);
+        xa = *reinterpret_cast<const PackedF4 *>(cval + o + 4 * lane);
+        va.x = R[ra.x]; va.y = R[ra.y]; va.z = R[ra.z]; va.w = R[ra.w];
+        if (n_full > 1) {
+            rb = *reinterpret_cast<const PackedI4 *>(crow + o + 256 + 4 * lane);
+            xb = *reinterpret_cast<const PackedF4 *>(cval + o + 256 + 4 * lane);
+        }
+        for (int k = 0; k < n_full; ++k) {
+            PackedF4 vn{0.0f, 0.0f, 0.0f, 0.0f}, xc{0.0f, 0.0f, 0.0f, 0.0f};
+            PackedI4 rc{0, 0, 0, 0};
+            if (k + 1 < n_full) { vn.x = R[rb.x]; vn.y = R[rb.y]; vn.z = R[rb.z]; vn.w = R[rb.w]; }
+            if (k + 2 < n_full) {
+                rc = *reinterpret_cast<const PackedI4 *>(crow + o + 512 + 4 * lane);
+                xc = *reinterpret_cast<const PackedF4 *>(cval + o + 512 + 4 * lane);
+            }
+            float p[4];
+            prods(va, xa, p);
+            tmp = fold256_spec(tmp, p[0], p[1], p[2], p[3]);
+            va = vn; xa = xb; rb = rc; xb = xc;
+            o += 256;
+        }
+    }
+    if (o < e) {
+        const int n = e - o;
+        float p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int oo = 4 * lane + u;
+            p[u] = 0.0f;
+            if (oo < n) {
+                const float x = cval[o + oo];
+                float t = R[crow[o + oo]];
+                if (add_back) t = __fadd_rn(t, __fmul_rn(x, w_old));
+                p[u] = __fmul_rn(t, x);
+            }
+        }
+        tmp = fold256_spec(tmp, p[0], p[1], p[2], p[3], n);
+    }
+    return tmp;
+}
+
+template <bool SPEC>
+__device__ __forceinline__ float dot_pass_any(const int *__restrict__ crow, const float *__restrict__ cval, const float *R,
+                                              int b, int e, float w_old, float *fold_buf, int spec_min) {
+    if (SPEC && e - b >= spec_min) return dot_pass_spec(crow, cval, R, b, e, w_old);
+    return dot_pass(crow, cval, R, b, e, w_old, fold_buf);
+}
+
 // R[r] <- (R[r] + x*w_old) - x*w_new over the column (element-wise, order free; 4 x 64 entries
 // per step so that four gathers are in flight per lane).
 __device__ void update_pass(const int *__restrict__ crow, const float *__restrict__ cval, float *R,
@@ -196,9 +272,10 @@ __device__ void update_pass(const int *__restrict__ crow, const float *__restric
 }
 
 // sum over [b, e) of x * R[r], left to right (XtA of _cd_fast.pyx:506-509).
+template <bool SPEC>
 __device__ float xta_pass(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, int b, int e,
-                          float *fold_buf) {
-    return dot_pass(crow, cval, R, b, e, 0.0f, fold_buf);   // R[r]*x == x*R[r] (one rounding, commutative)
+                          float *fold_buf, int spec_min) {
+    return dot_pass_any<SPEC>(crow, cval, R, b, e, 0.0f, fold_buf, spec_min);   // R[r]*x == x*R[r] (one rounding, commutative)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -223,6 +300,7 @@ __device__ float xta_pass(const int *__restrict__ crow, const float *__restrict_
 // The result of a screened decision is therefore bit-identical to the reference's.
 // ---------------------------------------------------------------------------------------------
 constexpr int kScreenMaxLen = 1 << 20;
+constexpr int kSpecMinDefault = 512;     // rtrec_fit_opts.fold = 3: shorter columns keep the chain (the first entries of a fold are serial anyway)
 constexpr int kScreenMinDefault = 192;
 
 struct Screen { double lo, hi; };   // the ordered sum lies in [lo, hi]
@@ -728,7 +806,7 @@ __device__ __forceinline__ Prep prep_target(const FitArgs &a, int j, int K, floa
     return P;
 }
 
-template <bool ALLF>
+template <bool ALLF, bool SPEC>
 __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) {
     const int lane = lane_id();
     const int U = a.U, I = a.I;
@@ -878,7 +956,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                 }
                 if (!screened && !a.fast) {
                     FIT_PH_T0
-                    tmp = dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf); tr_folded += e - b;
+                    tmp = dot_pass_any<SPEC>(a.crow, a.cval, R, b, e, w_old, fold_buf, a.spec_min); tr_folded += e - b;
                     FIT_PH_ADD(ph_fold)
                 }
             }
@@ -934,7 +1012,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                         float xta = 0.0f;
                         const int b = a.cptr[p], e = a.cptr[p + 1];
                         if (p != j && b != e) {
-                            xta = xta_pass(a.crow, a.cval, R, b, e, fold_buf);
+                            xta = xta_pass<SPEC>(a.crow, a.cval, R, b, e, fold_buf, a.spec_min);
                             xta = __fsub_rn(xta, __fmul_rn(beta, w_all[p]));
                         }
                         dn_take(xta);
@@ -963,7 +1041,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                             screen_pass(a.crow, a.cval, R, b, e, ps, pa);
                             screen_xta_interval(screen_interval(ps, pa, e - b), bw, positive, lo, hi);
                         } else {
-                            const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, b, e, fold_buf), bw);
+                            const float xta = __fsub_rn(xta_pass<SPEC>(a.crow, a.cval, R, b, e, fold_buf, a.spec_min), bw);
                             tr_folded += e - b;
                             lo = hi = positive ? xta : fabsf(xta);
                         }
@@ -976,7 +1054,7 @@ __device__ void fit_one(const FitArgs &a, int t, int slot, unsigned char *smem) 
                     if (!(hi >= best_lo)) continue;
                     float v = lo;
                     if (lo != hi) {
-                        const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, f_b[p], f_e[p], fold_buf), __fmul_rn(beta, f_w[p]));
+                        const float xta = __fsub_rn(xta_pass<SPEC>(a.crow, a.cval, R, f_b[p], f_e[p], fold_buf, a.spec_min), __fmul_rn(beta, f_w[p]));
                         tr_folded += f_e[p] - f_b[p];
                         v = positive ? xta : fabsf(xta);
                     }
@@ -1161,6 +1239,7 @@ __device__ __forceinline__ float lane_dot(const int *__restrict__ crow, const fl
     return tmp;
 }
 
+template <bool SPEC>
 __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *smem) {
     const int lane = lane_id();
     const int U = a.U, I = a.I;
@@ -1216,7 +1295,7 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
             if (screened) return 0.0f;
         }
         tr_folded += e - b;
-        return dot_pass(a.crow, a.cval, R, b, e, w_old, fold_buf);
+        return dot_pass_any<SPEC>(a.crow, a.cval, R, b, e, w_old, fold_buf, a.spec_min);
     };
 
     long long ph_rng = 0, ph_dots = 0, ph_loop = 0, ph_gap = 0;      // phase clocks (trace only)
@@ -1340,7 +1419,7 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
                         if (!(hi >= best_lo)) continue;
                         float v = lo;
                         if (lo != hi) {
-                            const float xta = __fsub_rn(xta_pass(a.crow, a.cval, R, b, e, fold_buf), bw);
+                            const float xta = __fsub_rn(xta_pass<SPEC>(a.crow, a.cval, R, b, e, fold_buf, a.spec_min), bw);
                             tr_folded += e - b;
                             v = positive ? xta : fabsf(xta);
                         }
@@ -1429,7 +1508,8 @@ __device__ void fit_one_allf(const FitArgs &a, int t, int slot, unsigned char *s
     }
 }
 
-template <bool ALLF>
+// SPEC: long columns may fold by integer prefix sums (csrc/fold_spec.hip.h); the chain-only form is a kernel of its own
+template <bool ALLF, bool SPEC>
 __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(FitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int slot = blockIdx.x;
@@ -1438,8 +1518,8 @@ __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(Fit
         if (lane_id() == 0) t = atomicAdd(a.queue, 1);
         t = readfirst_i(t);
         if (t >= a.n_targets) return;
-        if (ALLF) fit_one_allf(a, t, slot, smem);
-        else fit_one<false>(a, t, slot, smem);
+        if (ALLF) fit_one_allf<SPEC>(a, t, slot, smem);
+        else fit_one<false, SPEC>(a, t, slot, smem);
     }
 }
 
@@ -1465,6 +1545,10 @@ constexpr int kProdDepth = 8;    // chunks a producer wave keeps in flight
 constexpr int kMwMaxTargets = 2048;  // calls with at most this many targets use the multi-wave kernel
 constexpr int kColWalkMinRows = 1024;  // targets with at least this many users take the column-walk X^T y
 constexpr int kRing = 128;       // ring slots of 64 products (>= kProducers * kProdDepth, power of 2)
+#ifndef MW_SPEC_GROUPS
+#define MW_SPEC_GROUPS 4
+#endif
+constexpr int kSpecGroups = MW_SPEC_GROUPS;   // 256-entry groups the speculative consumer folds per turn
 
 struct MwLds {
     float *ring;   // [kRing][64]
@@ -1496,92 +1580,14 @@ __device__ __forceinline__ void lds_store_release(int *p, int v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// Ordered fold of one 64-product chunk held as one float4 per lane in lanes 0..15 (product i = component
-// i%4 of lane i/4): lane 0 adds them left to right, fetching lane n's components with the DPP modifier
-// row_shl:n on the product operand.  That operand is written by an LDS read, not by a VALU instruction, so
-// no DPP wait states apply; the accumulator is the plain second source.  64 instructions per 64 products
-// and nothing else on the chain: no broadcast reads, no v_readlane, no SGPR traffic.  Lanes 0..15 must be
-// enabled in EXEC (DPP does not read disabled lanes); only lane 0's result is meaningful.
-__device__ __forceinline__ float chain64_dpp(float acc, const float4 &p) {
-    asm volatile(
-        "v_add_f32 %0, %1, %0\n\t"
-        "v_add_f32 %0, %2, %0\n\t"
-        "v_add_f32 %0, %3, %0\n\t"
-        "v_add_f32 %0, %4, %0\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:1 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:2 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:3 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:4 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:5 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:6 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:7 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:9 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:10 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:11 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:12 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:13 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:14 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %1, %0 row_shl:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %0 row_shl:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %3, %0 row_shl:15 row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %4, %0 row_shl:15 row_mask:0xf bank_mask:0xf"
-        : "+v"(acc)
-        : "v"(p.x), "v"(p.y), "v"(p.z), "v"(p.w)
-        : "memory");
-    return acc;
-}
-
 // Ordered fold of one stream of 64-element chunks.
 //   MODE 0: sum over column entries [b, e) of (R[row] (+ x*w_old)) * x      (dot / XtA)
 //   MODE 1: sum over r in [b, e) of R[r]*R[r]                                (R . R)
 // Chunks are padded with +0.0 products, which never change the sum.  `seq` is the workgroup-wide
 // running chunk number (identical in every wave).  Returns the sum in wave 0, 0 elsewhere.
-template <int MODE>
+template <int MODE, bool SPEC>
 __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, const MwLds &M,
-                         int b, int e, float w_old, int wave, int lane, int &seq) {
+                         int b, int e, float w_old, int wave, int lane, int &seq, int spec_min, long long *wait_ticks = nullptr) {
     // padded to whole groups of kFoldGroup chunks: the extra products are +0.0 and never change the sum
     const int n_chunks = (((e - b + 63) >> 6) + kFoldGroup - 1) & ~(kFoldGroup - 1);
     float tmp = 0.0f;
@@ -1596,7 +1602,59 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
         // multiple of four with +0.0 products) -- the ring reads of group g+1 and the ready flags of group
         // g+2 are requested before the 256 adds of group g, and `done` is published once per group.
         __builtin_amdgcn_s_setprio(3);
-        if (n_chunks > 0 && lane < 16) {
+        if (SPEC && n_chunks > 0 && e - b >= spec_min) {
+            // Binade-speculative consumer (csrc/fold_spec.hip.h): four chunks are 256 consecutive products in the ring (groups
+            // are aligned: seq and n_chunks are multiples of four); lane L reads products 4L .. 4L+3 of a group with one
+            // ds_read_b128 and the wave folds kSpecGroups groups per turn -- one integer scan per group instead of 256 dependent
+            // additions, the running value in an SGPR from group to group.  A stream whose chunk count is not a multiple of
+            // 4 * kSpecGroups ends with groups the producers never fill: those are not waited for and fold as +0.0.
+            static_assert(kFoldGroup == 4, "fold_groups_spec consumes groups of 4 x 64 products");
+            constexpr int SG = kSpecGroups, Cp = 4 * SG;                       // chunks per turn
+            const float4 *ring4 = reinterpret_cast<const float4 *>(M.ring);
+            auto slot_of = [&](int c) { return (seq + c) & (kRing - 1); };
+            auto wait_chunks = [&](int c0) {                                   // chunks [c0, c0 + Cp) below n_chunks are ready
+                for (;;) {
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < Cp; ++k)
+                        if (c0 + k < n_chunks)
+                            bad |= (__hip_atomic_load(&M.ready[slot_of(c0 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + c0 + k + 1);
+                    if (!bad) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            };
+            auto read_groups = [&](int c0, float (&P)[SG][4]) {
+#pragma unroll
+                for (int g = 0; g < SG; ++g) {
+                    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (c0 + 4 * g < n_chunks) v = ring4[slot_of(c0 + 4 * g) * 16 + lane];
+                    P[g][0] = v.x; P[g][1] = v.y; P[g][2] = v.z; P[g][3] = v.w;
+                }
+            };
+            float A[SG][4], B[SG][4];
+            wait_chunks(0);
+            read_groups(0, A);
+            for (int c = 0; c < n_chunks; c += Cp) {
+                const bool more = c + Cp < n_chunks;
+                if (more) {
+                    if (wait_ticks) {
+                        const long long w0 = static_cast<long long>(wall_clock64());
+                        wait_chunks(c + Cp);
+                        *wait_ticks += static_cast<long long>(wall_clock64()) - w0;
+                    } else {
+                        wait_chunks(c + Cp);
+                    }
+                    read_groups(c + Cp, B);                                    // in flight while this turn's groups are folded
+                }
+                tmp = fold_groups_spec<SG>(tmp, A);
+                if (more) {
+#pragma unroll
+                    for (int g = 0; g < SG; ++g) { A[g][0] = B[g][0]; A[g][1] = B[g][1]; A[g][2] = B[g][2]; A[g][3] = B[g][3]; }
+                }
+                if (lane == 0) lds_store_release(M.done, seq + min(c + Cp, n_chunks));
+            }
+        } else if (n_chunks > 0 && lane < 16) {
             constexpr int Gp = kFoldGroup;
             const float4 *ring4 = reinterpret_cast<const float4 *>(M.ring);
             auto slot_of = [&](int c) { return (seq + c) & (kRing - 1); };
@@ -1611,16 +1669,26 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
             for (int k = 0; k < Gp; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             for (int c = 0; c < n_chunks; c += Gp) {
                 if (c + Gp < n_chunks) {
+#ifdef MW_TRACE_WAIT      // diagnostic build: ticks the chain consumer waits for its producers (tr[7] of the trace)
+                    bool waited = false;
+                    long long w0 = 0;
+#endif
                     for (;;) {
                         bool bad = false;
 #pragma unroll
                         for (int k = 0; k < Gp; ++k) bad |= (f[k] != seq + c + Gp + k + 1);
                         if (!bad) break;
+#ifdef MW_TRACE_WAIT
+                        if (wait_ticks && !waited) { waited = true; w0 = static_cast<long long>(wall_clock64()); }
+#endif
                         __builtin_amdgcn_s_sleep(1);
 #pragma unroll
                         for (int k = 0; k < Gp; ++k)
                             f[k] = __hip_atomic_load(&M.ready[slot_of(c + Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
+#ifdef MW_TRACE_WAIT
+                    if (waited) *wait_ticks += static_cast<long long>(wall_clock64()) - w0;
+#endif
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
@@ -1955,6 +2023,7 @@ __device__ int xty_colwalk_mw(const FitArgs &a, int j, float *R, float *s, int *
     return *lds_tc;
 }
 
+template <bool SPEC>
 __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *smem) {
     const int tid = static_cast<int>(threadIdx.x), wave = tid >> 6, lane = tid & 63;
     const int U = a.U, I = a.I;
@@ -1976,7 +2045,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     const int ny = ye - yb;
 
     const long long tr0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
-    long long tr_folded = 0, ph_fold = 0, ph_upd = 0, ph_gap = 0, ph_cyc = 0;
+    long long tr_folded = 0, ph_fold = 0, ph_upd = 0, ph_gap = 0, ph_cyc = 0, ph_wait = 0;
     if (tid < kRing) M.ready[tid] = 0;
     if (tid == 0) *M.done = 0;
     int seq = 0;
@@ -2044,7 +2113,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                 if (!screened) {
                     const long long c0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
                     const long long k0 = a.trace ? static_cast<long long>(__builtin_amdgcn_s_memtime()) : 0;
-                    const float tmp = mw_fold<0>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq);
+                    const float tmp = mw_fold<0, SPEC>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq, a.spec_min, a.trace ? &ph_wait : nullptr);
                     if (a.trace) { ph_fold += static_cast<long long>(wall_clock64()) - c0; ph_cyc += static_cast<long long>(__builtin_amdgcn_s_memtime()) - k0; }
                     tr_folded += e - b;
                     upd ^= 1;
@@ -2111,14 +2180,14 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                     if (!(hi >= best_lo)) continue;
                     float v = lo;
                     if (lo != hi) {
-                        const float xta = __fsub_rn(mw_fold<0>(a.crow, a.cval, R, M, f_b[p], f_e[p], 0.0f, wave, lane, seq),
+                        const float xta = __fsub_rn(mw_fold<0, SPEC>(a.crow, a.cval, R, M, f_b[p], f_e[p], 0.0f, wave, lane, seq, a.spec_min),
                                                     __fmul_rn(beta, f_w[p]));
                         tr_folded += f_e[p] - f_b[p];
                         v = positive ? xta : fabsf(xta);
                     }
                     dn_take(v);
                 }
-                R_norm2 = mw_fold<1>(a.crow, a.cval, R, M, 0, U, 0.0f, wave, lane, seq);
+                R_norm2 = mw_fold<1, SPEC>(a.crow, a.cval, R, M, 0, U, 0.0f, wave, lane, seq, a.spec_min);
                 Ry = 0.0f;
                 if (wave == 0) {   // short folds stay on the consumer wave
                     for (int o = yb; o < ye; o += 64) {
@@ -2181,10 +2250,18 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     if (a.trace && tid == 0) {
         long long *tr = a.trace + static_cast<size_t>(t) * 8;
         tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
-        tr[4] = ph_fold; tr[5] = ph_upd; tr[6] = ph_gap; tr[7] = ph_cyc;
+        tr[4] = ph_fold; tr[5] = ph_upd; tr[6] = ph_gap;
+#ifdef MW_TRACE_WAIT
+        tr[7] = ph_wait;
+#else
+        tr[7] = SPEC && a.spec_min < 0x7fffffff ? ph_wait : ph_cyc;   // speculative fold: ticks the consumer waited for its producers
+#endif
     }
 }
 
+// SPEC: the consumer wave may fold by integer prefix sums (csrc/fold_spec.hip.h); the chain-only form is a kernel of its
+// own so that its register allocation is the one the literal chain was tuned with
+template <bool SPEC>
 __global__ __launch_bounds__(kMwThreads, 4) void fit_columns_mw_kernel(FitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int slot = blockIdx.x;
@@ -2196,7 +2273,7 @@ __global__ __launch_bounds__(kMwThreads, 4) void fit_columns_mw_kernel(FitArgs a
         const int t = M.bc_i[3];
         __syncthreads();
         if (t >= a.n_targets) return;
-        fit_one_mw(a, t, slot, smem);
+        fit_one_mw<SPEC>(a, t, slot, smem);
     }
 }
 
@@ -2459,11 +2536,16 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
     a.colwalk_min_rows = (opts && opts->colwalk_min_rows > 0) ? opts->colwalk_min_rows : kColWalkMinRows;
     a.screen_min = (opts && opts->screen_min > 0) ? opts->screen_min : kScreenMinDefault;
     a.lane_max = (opts && opts->lane_max != 0) ? (opts->lane_max < 0 ? 0 : opts->lane_max) : kLaneMaxDefault;
+    {   // how the ordered dot products are evaluated (rtrec_fit_opts.fold); results are bit-identical either way
+        const int fold = opts ? opts->fold : 0;
+        a.spec_min = fold == 2 ? 64 : (fold == 3 ? kSpecMinDefault : 0x7fffffff);
+    }
     (void)hipGetLastError();
     if (hipMemsetAsync(d_queue, 0, 4, st) != hipSuccess) return RTREC_ERR_LAUNCH;
     const int grid = n_slots < n_targets ? n_slots : n_targets;
     if (allf) {
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true>), dim3(grid), dim3(64), kFoldBufBytes + 16, st, a);
+        if (a.spec_min < 0x7fffffff) hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true, true>), dim3(grid), dim3(64), kFoldBufBytes + 16, st, a);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<true, false>), dim3(grid), dim3(64), kFoldBufBytes + 16, st, a);
     } else {
         // few targets (online partial_fit): the heaviest target is the critical path -> latency mode (multi-wave
         // kernel); opts->kernel forces one of the two (A/B runs, tests).  The tolerance mode has no ordered fold to
@@ -2496,12 +2578,19 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
         }
         if (latency_mode) {
             size_t mw_lds = mw_lds_bytes(K);
+#ifdef MW_LDS_PAD       // diagnostic build: extra dynamic LDS so that only one workgroup fits a CU
+            mw_lds += MW_LDS_PAD;
+#endif
             if (a.fast >= 2 && a.gram && K <= 64) mw_lds = ((mw_lds + 15) / 16) * 16 + static_cast<size_t>(K) * 64 * 4;
-            hipLaunchKernelGGL(fit_columns_mw_kernel, dim3(grid), dim3(kMwThreads), mw_lds, st, a);
+            if (a.spec_min < 0x7fffffff)
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_mw_kernel<true>), dim3(grid), dim3(kMwThreads), mw_lds, st, a);
+            else
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_mw_kernel<false>), dim3(grid), dim3(kMwThreads), mw_lds, st, a);
         } else {
             size_t lds = kFoldBufBytes + feat_lds_bytes(K);
             if (a.fast >= 2 && a.gram && K <= 64) lds = kFoldBufBytes + ((feat_lds_bytes(K) + 15) / 16) * 16 + static_cast<size_t>(K) * 64 * 4;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false>), dim3(grid), dim3(64), lds, st, a);
+            if (a.spec_min < 0x7fffffff) hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false, true>), dim3(grid), dim3(64), lds, st, a);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(fit_columns_kernel<false, false>), dim3(grid), dim3(64), lds, st, a);
         }
     }
     return rtrec::launch_status();

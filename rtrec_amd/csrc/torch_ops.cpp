@@ -133,7 +133,7 @@ void fit_columns(const at::Tensor &cptr, const at::Tensor &crow, const at::Tenso
                  at::Tensor out_items, at::Tensor out_coef, at::Tensor out_count, at::Tensor out_n_iter, int64_t cap, at::Tensor ws,
                  int64_t n_slots, at::Tensor queue, OT trace, const OT &gram, const OT &gram_index, int64_t gram_n, double gram_rel_err,
                  int64_t fast, int64_t kernel, int64_t colwalk_min_rows, int64_t screen_min, int64_t lane_max, OT xty_ws,
-                 const OT &col_order) {
+                 const OT &col_order, int64_t fold) {
     rtrec_fit_cfg cfg{static_cast<float>(l1_reg), static_cast<float>(l2_reg), static_cast<float>(tol), static_cast<int32_t>(max_iter),
                       static_cast<uint32_t>(seed), positive ? 1 : 0, static_cast<int32_t>(top_features)};
     rtrec_fit_opts o{};
@@ -151,6 +151,7 @@ void fit_columns(const at::Tensor &cptr, const at::Tensor &crow, const at::Tenso
     o.xty_ws_bytes = (xty_ws.has_value() && xty_ws->defined()) ? static_cast<size_t>(xty_ws->numel()) : 0;
     o.nnz = rcol.size(0);
     o.d_col_order = ptr<const int32_t>(col_order);
+    o.fold = static_cast<int32_t>(fold);
     check(abi().fit_columns_opt(n_users, n_items, ptr<const int32_t>(cptr), ptr<const int32_t>(crow), ptr<const float>(cval),
                                 ptr<const int32_t>(rptr), ptr<const int32_t>(rcol), ptr<const float>(rval), ptr<const float>(sqn),
                                 ptr<const int32_t>(targets), static_cast<int32_t>(targets.size(0)), &cfg, ptr<int32_t>(out_items),
@@ -286,7 +287,7 @@ TORCH_LIBRARY(rtrec_amd, m) {
           "int n_users, int n_items, float l1_reg, float l2_reg, float tol, int max_iter, int seed, bool positive, int top_features, "
           "Tensor(a!) out_items, Tensor(b!) out_coef, Tensor(c!) out_count, Tensor(d!) out_n_iter, int cap, Tensor(e!) ws, int n_slots, "
           "Tensor(f!) queue, Tensor(g!)? trace, Tensor? gram, Tensor? gram_index, int gram_n, float gram_rel_err, int fast, int kernel, "
-          "int colwalk_min_rows, int screen_min, int lane_max, Tensor(h!)? xty_ws, Tensor? col_order) -> ()");
+          "int colwalk_min_rows, int screen_min, int lane_max, Tensor(h!)? xty_ws, Tensor? col_order, int fold) -> ()");
     m.def("score_topk(Tensor? row_ids, Tensor xb_ptr, Tensor xb_col, Tensor xb_val, int n_rows, int n_items, int n_cols, int col_offset, "
           "Tensor? col_ids, Tensor? col_map, int tile_cols, int n_tiles, Tensor? tile_ptr, Tensor? w_col, Tensor? w_val, Tensor? dense_idx, "
           "Tensor? dense_val, Tensor? row_hdr, Tensor? col_rank, int top_k, bool filter_interacted, int mode, bool acc_f64, "

@@ -50,6 +50,7 @@ TABLE: Dict[str, tuple] = {
     "RTREC_AMD_LANE_MAX": (None, "fit kernel: longest column handled one entry per lane"),
     "RTREC_AMD_COLWALK_MIN": ("0", "fit kernel: column-walk threshold"),
     "RTREC_AMD_SCREEN_MIN": ("0", "fit kernel: screening threshold"),
+    "RTREC_AMD_FOLD": ("", "chain | spec | spec-all: ordered dot products by the literal add chain (default), or by the binade-speculative fold for columns >= 512 / >= 64 entries (bit-identical results, A/B and tests)"),
     "RTREC_AMD_XTY_BATCH": ("1", "0: no one-pass X^T y for small fit calls"),
     "RTREC_AMD_DEBUG_XTY": (None, "print the one-pass X^T y decision"),
     # serving

@@ -761,3 +761,90 @@ def test_optim_sgd_on_the_gpu_matches_the_reference(case):
         bad = SLIMElastic({"optim": "sgd"}, engine=m.engine)
         with pytest.raises(AttributeError, match="sparse_coef_"):
             bad.fit(X.copy())
+
+
+
+# ---- the ordered fold itself (csrc/fold_spec.hip.h): integer prefix sums inside a binade == the chain of float additions ----
+def _fold_streams(rng):
+    """Entry streams that exercise every branch of fold256_spec: drifting and zero-mean sums, integers, exact ties against a
+    large running sum (half-integers of its ulp), cancellations to +0, wide dynamic range, infinities, tiny values, and short
+    / ragged lengths around the 256-entry group."""
+    out = []
+    for n in (1, 3, 4, 63, 64, 65, 255, 256, 257, 511, 1000, 4099, 20011):
+        out.append((rng.random(n, dtype=np.float32) * 3).astype(np.float32))
+        out.append(((rng.random(n, dtype=np.float32) - 0.5) * 3).astype(np.float32))
+        out.append(rng.integers(-10, 30, n).astype(np.float32))
+        p = (0.5 * rng.integers(-2, 7, n)).astype(np.float32); p[0] = np.float32(2.0 ** 24 * (1 + rng.random())); out.append(p)
+        p = (0.5 * rng.integers(-6, 3, n)).astype(np.float32); p[0] = np.float32(-2.0 ** 25 * (1 + rng.random())); out.append(p)
+        x = (rng.random(n, dtype=np.float32) * 10).astype(np.float32); p = np.empty(n, np.float32); p[0::2] = x[0::2]; p[1::2] = -x[0::2][: len(p[1::2])]; out.append(p)
+        e = rng.integers(100, 160, n).astype(np.uint32); m = rng.integers(0, 1 << 23, n).astype(np.uint32); sg = rng.integers(0, 2, n).astype(np.uint32)
+        out.append(((sg << 31) | (e << 23) | m).view(np.float32))
+        p = (rng.random(n, dtype=np.float32) * 1e30).astype(np.float32); p[n // 2] = np.inf; out.append(p)
+        out.append((rng.random(n, dtype=np.float32) * 1e-40).astype(np.float32))              # subnormal sums
+        p = (rng.random(n, dtype=np.float32)).astype(np.float32); p[: n // 3] = 0.0; out.append(p)   # leading zeros
+        # multiples of the running sum's half ulp: ties on most entries
+        run = np.float32(1000.0 * (1 + rng.random())); p = np.empty(n, np.float32); p[0] = run
+        for i in range(1, n):
+            hu = np.float32(2.0 ** (int(np.floor(np.log2(abs(float(run))))) - 24)) if run != 0 else np.float32(1.0)
+            p[i] = hu * np.float32(rng.integers(-2, 5)); run = np.float32(run + p[i])
+        out.append(p)
+    return out
+
+
+def test_ordered_sums_speculative_fold_equals_the_chain(oracle):
+    import torch
+    lib = _native.load()
+    rng = np.random.default_rng(2025)
+    streams = _fold_streams(rng)
+    off = np.zeros(len(streams) + 1, np.int64)
+    off[1:] = np.cumsum([len(s) for s in streams])
+    vals = torch.from_numpy(np.concatenate(streams)).cuda()
+    d_off = torch.from_numpy(off).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for mode in (0, 1, 2, 3):
+        o = torch.empty(len(streams), dtype=torch.float32, device="cuda")
+        _native.check(lib.rtrec_slim_ordered_sums(vals.data_ptr(), d_off.data_ptr(), len(streams), mode, o.data_ptr(), st), "ordered_sums")
+        outs.append(o.cpu().numpy())
+    ref = np.array([oracle.fold_sequential(s) for s in streams], dtype=np.float32)
+    model = np.array([oracle.fold_speculative(s)[0] for s in streams], dtype=np.float32)
+    nan = np.isnan(ref)
+    for name, got in (("device chain", outs[1]), ("device speculative", outs[0]), ("device speculative, 2 groups per step", outs[2]),
+                      ("device speculative, 4 groups per step", outs[3]), ("cpu model", model)):
+        assert np.array_equal(np.isnan(got), nan), name
+        bad = np.flatnonzero((bits(got) != bits(ref)) & ~nan)
+        assert bad.size == 0, f"{name}: streams {bad[:10]} differ (lengths {[len(streams[b]) for b in bad[:10]]})"
+
+
+@pytest.mark.parametrize("U,I,draws,K,positive,float_ratings", [
+    (3000, 800, 90000, 50, True, True),
+    (3000, 800, 90000, 50, True, False),
+    (3000, 800, 90000, 50, False, True),
+    (600, 200, 12000, None, True, True),
+    (20000, 300, 700000, 20, True, True),      # long columns (2-10k entries): many 256-entry groups per fold, binade changes mid-column
+])
+@pytest.mark.parametrize("fit_mode", ["sw", "mw"])
+@pytest.mark.parametrize("fold", ["spec-all", "chain"])
+def test_fit_columns_fold_forms_bit_exact(engine, oracle, U, I, draws, K, positive, float_ratings, fit_mode, fold, monkeypatch):
+    """rtrec_fit_opts.fold: the binade-speculative fold forced on every column of >= 64 entries, and the literal chain (the
+    default of every other fit test), give the oracle's coefficient bits and sweep counts in both kernels."""
+    monkeypatch.setenv("RTREC_AMD_FIT_MODE", fit_mode)
+    monkeypatch.setenv("RTREC_AMD_FOLD", fold)
+    monkeypatch.setenv("RTREC_AMD_XTY_BATCH", "0")
+    X = interaction_matrix(U, I, draws, seed=23, float_ratings=float_ratings)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    engine.set_interactions(Xc, X)
+    cols = np.arange(I) if U < 20000 else np.argsort(-np.diff(Xc.indptr))[:48]
+    tg, items, coef, count, n_iter = engine.fit_columns(cols, positive=positive, nn_feature_selection=K)
+    ptr, idx, val, nit = oracle.fit_columns(Xc, tg, positive=positive, nn_feature_selection=K)
+    assert np.array_equal(n_iter, nit), f"n_iter differs on {np.flatnonzero(n_iter != nit)[:10]}"
+    assert np.array_equal(count, np.diff(ptr))
+    for t in range(len(tg)):
+        c = count[t]
+        o_i, o_v = idx[ptr[t]:ptr[t + 1]], val[ptr[t]:ptr[t + 1]]
+        if K is None:
+            assert np.array_equal(items[t, :c], o_i) and np.array_equal(bits(coef[t, :c]), bits(o_v)), f"target {tg[t]}"
+        else:
+            a = np.argsort(items[t, :c], kind="stable"); b = np.argsort(o_i, kind="stable")
+            assert np.array_equal(items[t, :c][a], o_i[b]) and np.array_equal(bits(coef[t, :c][a]), bits(o_v[b])), f"target {tg[t]}"

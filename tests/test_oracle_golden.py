@@ -219,3 +219,33 @@ def test_sgd_without_feature_selection_fails_like_the_reference(oracle):
     assert g == {"type": "AttributeError", "message": "'SGDRegressor' object has no attribute 'sparse_coef_'"}
     with pytest.raises(AttributeError, match="sparse_coef_"):
         oracle.fit_columns_sgd(sp.identity(4, format="csc", dtype=np.float32), [0])
+
+
+
+# ---- the CPU model of the device's binade-speculative fold (oracle/fold_model.c) ----
+@pytest.mark.parametrize("kind", [-1, 0, 1, 2, 3, 4, 5, 6, 7])
+def test_fold_model_equals_the_sequential_sum_on_generated_streams(oracle, kind):
+    bad, st = oracle.fold_fuzz(4242 + kind, 120_000, 3000, kind)     # 1.08e6 sums over the nine generators
+    assert bad == 0
+    assert st.entries > 1e8 and st.spec_entries + st.serial_entries == st.entries
+
+
+def test_fold_model_inside_the_oracle_cd_keeps_every_golden_bit(oracle):
+    """The oracle's coordinate descent with its dot products routed through the fold model: coefficients and sweep counts
+    of the reference-generated goldens are unchanged (and most entries take the integer path)."""
+    z = np.load(os.path.join(G, "cd_columns.npz"))
+    X = load_csc(z, "X")
+    oracle.set_fold_model(True)
+    try:
+        for name, kw in [("default", {}), ("nonpositive", {"positive": False})]:
+            for j in range(X.shape[1]):
+                Xj = X.copy()
+                y = Xj[:, j].toarray().ravel()
+                Xj.data[Xj.indptr[j]:Xj.indptr[j + 1]] = 0
+                w, _, n_iter = oracle.cd(Xj, y, **kw)
+                assert n_iter == z[f"{name}_n_iter"][j], f"column {j}"
+                assert np.array_equal(bits(w), bits(z[f"{name}_coef"][j])), f"column {j}"
+        st = oracle.fold_model_stats()
+        assert st.entries > 0 and st.spec_entries + st.serial_entries == st.entries
+    finally:
+        oracle.set_fold_model(False)

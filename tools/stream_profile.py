@@ -111,7 +111,7 @@ def main():
                "targets": int(len(dur)), "kernel_span_ms": span * 1e3, "sum_target_s": float(dur.sum()),
                "dur_ms_quantiles": [float(np.quantile(dur, q) * 1e3) for q in (0.5, 0.9, 0.99, 1.0)],
                "prep_ms_quantiles": [float(np.quantile(prep, q) * 1e3) for q in (0.5, 0.9, 0.99, 1.0)], "sum_prep_s": float(prep.sum()),
-               "top": [dict(ny=(int(ny[j]) if ny is not None else None), dur_ms=float(dur[j] * 1e3), prep_ms=float(prep[j] * 1e3), folded=float(tr[j, 3]), fold_ms=float(tr[j, 4] * 1e-5), upd_ms=float(tr[j, 5] * 1e-5), gap_ms=float(tr[j, 6] * 1e-5), fold_cycles_per_entry=float(tr[j, 7] / max(tr[j, 3], 1))) for j in top[:3]]}
+               "top": [dict(ny=(int(ny[j]) if ny is not None else None), dur_ms=float(dur[j] * 1e3), prep_ms=float(prep[j] * 1e3), folded=float(tr[j, 3]), fold_ms=float(tr[j, 4] * 1e-5), upd_ms=float(tr[j, 5] * 1e-5), gap_ms=float(tr[j, 6] * 1e-5), fold_cycles_per_entry=float(tr[j, 7] / max(tr[j, 3], 1)), wait_ms=float(tr[j, 7] * 1e-5), folded_entries=float(tr[j, 3])) for j in top[:3]]}
         reports.append(rep)
         print(json.dumps(rep), flush=True)
     if args.out:
