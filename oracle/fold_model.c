@@ -13,10 +13,10 @@
  *   or whose quotient is an exact tie (its rounding depends on the parity of the prefix), ends the run: it
  *   is added with one real float addition and the run restarts in the new binade.
  *
- * fold_model_group() below is the same control flow as the device function, entry for entry (256-entry
- * groups, the same pass / serial-stretch policy, wrapping 32-bit integer prefixes, the saturating float->int
- * conversion of v_cvt_i32_f32); fold_model_fuzz() compares it with the plain sequential loop on generated
- * sums.  Nothing here is part of the product path.  Build: see oracle/Makefile (-ffp-contract=off).
+ * group_finish / group_loop / fold_model_window below are the device's fold_group_finish / fold_group_loop /
+ * fold_groups_spec<G>, entry for entry (256-entry groups, windows of G groups, the same pass / serial-stretch policy,
+ * wrapping 32-bit integer prefixes, the saturating float->int conversion of v_cvt_i32_f32); fold_model_fuzz() compares
+ * them with the plain sequential loop on generated sums.  Nothing here is part of the product path.  Build: see oracle/Makefile (-ffp-contract=off).
  */
 #include <math.h>
 #include <stdint.h>
@@ -35,20 +35,18 @@ static inline int32_t cvt_i32_sat(float q)
     return (int32_t)q;
 }
 
-long long g_dbg[8]; int g_dbg_on = 0;
 typedef struct {
     int64_t entries;        /* entries folded */
     int64_t spec_entries;   /* entries absorbed by integer prefix sums */
     int64_t serial_entries; /* entries added with a real float addition */
-    int64_t passes;         /* speculative passes */
+    int64_t passes;         /* speculative passes (quantisations of a group) */
 } fold_model_stats;
 
 enum { kGroup = 256 };
-int kMinAdvance = 32, kSerialLead = 16;   /* policy constants (the device's kFoldMinAdvance / kFoldSerialLead); variables only so that tools can explore */
+int kMinAdvance = 32, kSerialLead = 16;   /* the device's kFoldMinAdvance / kFoldSerialLead (variables so that tools can explore) */
 /* a serial stretch from pos runs to the end of the 64-entry row that holds entry pos + kSerialLead (the device adds whole
  * rows with its DPP chain) */
 static inline int stretch_end(int pos, int n) { const int to = ((pos + kSerialLead) | 63) + 1; return to < n ? to : n; }
-long long g_fail_passes = 0;
 
 static float serial_add(float acc, const float *p, int from, int to, fold_model_stats *st)
 {
@@ -57,77 +55,96 @@ static float serial_add(float acc, const float *p, int from, int to, fold_model_
     return acc;
 }
 
-/* One group of up to 256 products (the device pads a short group with +0.0 products; +0.0 never changes a
- * sum that started at +0, and the model simply stops at n).
- *
- * One speculative pass over entries [pos, n) from acc = +-M0 u:
- *   s_i = p_i / (+-u) (exact), r_i = rndne(s_i), d_i = s_i - r_i, A_i = M0 + sum_{k<=i} r_k  (plain integer prefixes).
- *   Non-tie entries add r_i.  A tie (|d_i| == 1/2: the exact sum lies half way between two grid points) rounds to
- *   the EVEN grid point: M -> M + r_i if M is even (r_i is the even neighbour of s_i), M + r_i + 2 d_i if M is odd;
- *   either way the value after a tie is even.  So the true running value is M_i = A_i + C_i with C_i the sum of the
- *   tie corrections c_t = 2 d_t ((A_{t-1} + C_{t-1}) & 1) of the ties t <= i: a walk over the TIE entries only.
- *   Range: every running value must stay strictly inside (2^23, 2^24) (same binade, grid u).  |C_i| <= the number of
- *   ties <= 256, so the test is made on A_i with a margin of 256 on both sides (conservative: an entry that fails
- *   it is simply added with a real float addition).  Entries whose quotient is not finite fail it too.
- *   The first failing entry j ends the pass: acc = +-(A_{j-1} + C_{j-1}) u, then acc += p_j in float. */
-float fold_model_group(float acc, const float *p, int n, fold_model_stats *st)
+/* fold_group_finish of the device: one group (entries [pos, n) of p; the device pads to 256 with +0.0) against the
+ * running value M u.  Returns 1 when the group is absorbed (*acc = the new sum); otherwise *acc is the sum through the
+ * first failing entry j (added with a real float addition), *pos = j + 1, *adv = entries absorbed before j.
+ *   s_i = p_i / (+-u) (exact), r_i = rndne(s_i), d_i = s_i - r_i, A_i = M + sum_{k<=i} r_k  (plain, wrapping prefixes).
+ *   A tie (|d_i| == 1/2) rounds to the EVEN grid point: the running value takes r_i when it is even, r_i + 2 d_i when it is
+ *   odd; with C_i the sum of those corrections the true running value is A_i + C_i.  Range: A_i strictly inside
+ *   (2^23 + 256, 2^24 - 256) -- |C_i| <= 256 -- ; an entry that fails it, or whose quotient is not finite, ends the pass. */
+static int group_finish(float *acc, uint32_t bits, const float *p, int n, int *pos, int *adv, fold_model_stats *st)
 {
-    int pos = 0;
-    while (pos < n) {
-        const uint32_t bits = f2u(acc);
-        const uint32_t ex = (bits >> 23) & 255u;
-        if (ex < 24u || ex == 255u) {           /* zero, subnormal, tiny, inf, nan: no integer image */
-            const int to = stretch_end(pos, n);
-            acc = serial_add(acc, p, pos, to, st);
-            pos = to;
-            continue;
-        }
-        const uint32_t sign = bits & 0x80000000u;
-        const float scale = u2f(((277u - ex) << 23) | sign);      /* +-2^(150-ex) = +-1/u */
-        const float ulp = u2f(((ex - 23u) << 23) | sign);          /* +-u */
-        const uint32_t M0 = (bits & 0x7fffffu) | 0x800000u;
-        uint32_t A = M0;            /* plain prefix (wrapping, like the device's integer scan) */
-        int32_t C = 0;              /* tie corrections so far */
-        int j = -1;
-        if (st) st->passes++;
-        for (int i = pos; i < n; i++) {
-            const float s = p[i] * scale;                          /* exact (power of two) unless it overflows */
-            const float r = rintf(s);                              /* v_rndne_f32 */
-            const float d = s - r;
-            const int odd = !(fabsf(d) < 0.5f);                    /* exact tie, or inf / nan */
-            const int tie = odd && (fabsf(d) == 0.5f);
-            const uint32_t An = A + (uint32_t)cvt_i32_sat(r);
-            const int ok = (uint32_t)(An - 0x800101u) < 0x7ffdffu; /* 2^23 + 256 < An < 2^24 - 256 */
-            if (!ok || (odd && !tie)) { j = i; if (g_dbg_on) { g_dbg[An - 0x800101u >= 0x80000000u ? 0 : (An <= 0x800101u ? 1 : 2)]++; int a = i - pos; g_dbg[3 + (a < 4 ? 0 : a < 16 ? 1 : a < 64 ? 2 : 3)]++; g_dbg[7] += (i < 256 && pos == 0); } break; }
-            if (tie && ((A + (uint32_t)C) & 1u)) C += d > 0.0f ? 1 : -1;
-            A = An;
-        }
-        acc = (float)(int32_t)(A + (uint32_t)C) * ulp;            /* exact: 2^23 < A + C < 2^24 */
-        if (j < 0) { if (st) st->spec_entries += n - pos; break; }
-        if (st) { st->spec_entries += j - pos; st->serial_entries += 1; }
-        acc = acc + p[j];                                          /* the one real addition */
-        g_fail_passes++;
-        const int adv = j - pos;
-        pos = j + 1;
+    const uint32_t ex = (bits >> 23) & 255u, sign = bits & 0x80000000u;
+    const float scale = u2f(((277u - ex) << 23) | sign);      /* +-2^(150-ex) = +-1/u */
+    const float ulp = u2f(((ex - 23u) << 23) | sign);          /* +-u */
+    uint32_t A = (bits & 0x7fffffu) | 0x800000u;
+    int32_t C = 0;
+    int j = -1;
+    if (st) st->passes++;
+    for (int i = *pos; i < n; i++) {
+        const float s = p[i] * scale;                          /* exact (power of two) unless it overflows */
+        const float r = rintf(s);                              /* v_rndne_f32 */
+        const float d = s - r;
+        const int odd = !(fabsf(d) < 0.5f);                    /* exact tie, or inf / nan */
+        const int tie = odd && (fabsf(d) == 0.5f);
+        const uint32_t An = A + (uint32_t)cvt_i32_sat(r);
+        const int ok = (uint32_t)(An - 0x800101u) < 0x7ffdffu; /* 2^23 + 256 < An < 2^24 - 256 */
+        if (!ok || (odd && !tie)) { j = i; break; }
+        if (tie && ((A + (uint32_t)C) & 1u)) C += d > 0.0f ? 1 : -1;
+        A = An;
+    }
+    *acc = (float)(int32_t)(A + (uint32_t)C) * ulp;           /* exact: 2^23 < A + C < 2^24 */
+    if (j < 0) { if (st) st->spec_entries += n - *pos; return 1; }
+    if (st) { st->spec_entries += j - *pos; st->serial_entries += 1; }
+    *acc = *acc + p[j];                                        /* the one real addition */
+    *adv = j - *pos;
+    *pos = j + 1;
+    return 0;
+}
+
+/* fold_group_loop of the device: one group from entry pos on, a speculative pass per turn */
+static float group_loop(float acc, const float *p, int n, int pos, int adv, fold_model_stats *st)
+{
+    for (;;) {
         if ((adv < kMinAdvance || n - pos <= 24) && pos < n) {
             const int to = stretch_end(pos, n);
             acc = serial_add(acc, p, pos, to, st);
             pos = to;
         }
+        if (pos >= n) return acc;
+        const uint32_t bits = f2u(acc);
+        const uint32_t ex = (bits >> 23) & 255u;
+        if (ex < 24u || ex == 255u) { adv = 0; continue; }      /* zero, subnormal, tiny, inf, nan: no integer image */
+        if (group_finish(&acc, bits, p, n, &pos, &adv, st)) return acc;
+    }
+}
+
+/* fold_groups_spec<G> of the device: a window of up to G groups.  While the groups are clean in the binade of the sum the
+ * device keeps the running value an integer from group to group; the first group that is not is finished from its
+ * quantisation at hand, the groups after it go through the loop from their start. */
+float fold_model_window(float acc, const float *p, int n, int G, fold_model_stats *st)
+{
+    int g = 0, pos = 0, adv = kGroup;
+    const uint32_t bits0 = f2u(acc);
+    const uint32_t ex0 = (bits0 >> 23) & 255u;
+    if (ex0 >= 24u && ex0 != 255u) {
+        for (; g < G && g * kGroup < n; g++) {
+            const int n_g = n - g * kGroup < kGroup ? n - g * kGroup : kGroup;
+            int ps = 0, ad = kGroup;
+            const uint32_t bits = f2u(acc);                      /* same binade as bits0 while the groups are clean */
+            if (((bits >> 23) & 255u) != ex0 || ((bits ^ bits0) & 0x80000000u)) break;   /* (cannot happen after a clean group) */
+            if (!group_finish(&acc, bits, p + g * kGroup, n_g, &ps, &ad, st)) { pos = ps; adv = ad; break; }
+        }
+    } else {
+        adv = 0;
+    }
+    for (; g < G && g * kGroup < n; g++) {
+        const int n_g = n - g * kGroup < kGroup ? n - g * kGroup : kGroup;
+        acc = group_loop(acc, p + g * kGroup, n_g, pos, adv, st);
+        pos = 0; adv = kGroup;
     }
     if (st) st->entries += n;
     return acc;
 }
 
-long long g_pos_hist[8]; long long g_fold_count;
+int fold_model_groups_per_window = 4;     /* the multi-wave kernel's consumer; the single-wave kernel and rtrec_slim_ordered_sums mode 0 use 1 */
+
 float fold_model_fold(float acc, const float *p, int64_t n, fold_model_stats *st)
 {
-    g_fold_count++;
-    for (int64_t o = 0; o < n; o += kGroup) {
-        const long long f0 = g_fail_passes;
-        const int m = (int)(n - o < kGroup ? n - o : kGroup);
-        acc = fold_model_group(acc, p + o, m, st);
-        g_pos_hist[o < 256 ? 0 : o < 1024 ? 1 : o < 4096 ? 2 : o < 16384 ? 3 : 4] += g_fail_passes - f0;
+    const int G = fold_model_groups_per_window, W = G * kGroup;
+    for (int64_t o = 0; o < n; o += W) {
+        const int m = (int)(n - o < W ? n - o : W);
+        acc = fold_model_window(acc, p + o, m, G, st);
     }
     return acc;
 }

@@ -239,8 +239,10 @@ def fold_sequential(products: np.ndarray, acc0: float = 0.0) -> np.float32:
     return np.float32(_fold_lib().fold_model_sequential(np.float32(acc0), p, p.size))
 
 
-def fold_fuzz(seed: int, n_folds: int, max_len: int, kind: int = -1):
-    """(mismatches, FoldStats) over n_folds generated sums; kind -1 mixes all generators."""
+def fold_fuzz(seed: int, n_folds: int, max_len: int, kind: int = -1, groups_per_window: int = 4):
+    """(mismatches, FoldStats) over n_folds generated sums; kind -1 mixes all generators.  groups_per_window: the G of the
+    device's fold_groups_spec<G> being modelled (1: single-wave kernel, 4: the multi-wave kernel's consumer)."""
+    C.c_int.in_dll(_fold_lib(), "fold_model_groups_per_window").value = int(groups_per_window)
     st = FoldStats()
     bad = _fold_lib().fold_model_fuzz(seed, n_folds, max_len, kind, C.byref(st))
     return int(bad), st

@@ -225,9 +225,10 @@ def test_sgd_without_feature_selection_fails_like_the_reference(oracle):
 # ---- the CPU model of the device's binade-speculative fold (oracle/fold_model.c) ----
 @pytest.mark.parametrize("kind", [-1, 0, 1, 2, 3, 4, 5, 6, 7])
 def test_fold_model_equals_the_sequential_sum_on_generated_streams(oracle, kind):
-    bad, st = oracle.fold_fuzz(4242 + kind, 120_000, 3000, kind)     # 1.08e6 sums over the nine generators
-    assert bad == 0
-    assert st.entries > 1e8 and st.spec_entries + st.serial_entries == st.entries
+    for G in (1, 2, 4):                                                  # 1.08e6 sums over the nine generators, per window size
+        bad, st = oracle.fold_fuzz(4242 + kind + 100 * G, 40_000, 3000, kind, groups_per_window=G)
+        assert bad == 0, f"G={G}"
+        assert st.entries > 3e7 and st.spec_entries + st.serial_entries == st.entries
 
 
 def test_fold_model_inside_the_oracle_cd_keeps_every_golden_bit(oracle):
