@@ -826,8 +826,11 @@ class SlimEngine:
         torch, W = self.be.torch, self._W
         ptr, col, val = xb
         resident = self._X.get("rptr") is ptr
-        if resident and W.get("_f64_slack") is not None:
-            return W["_f64_slack"]
+        # keyed by the identity of the resident row-pointer tensor: set_interactions() replaces X without touching W, and a
+        # slack computed for the previous X is too short (new users) or too small (changed ratings) -- ADVICE round 4
+        ent = W.get("_f64_slack")
+        if resident and ent is not None and ent[0] is ptr:
+            return ent[1]
         dw: DeviceWeights = W["dw"]
         if "_row_absmax" not in W:
             rmax = torch.zeros(max(W["n_items"], 1), dtype=torch.float64, device=dw.vals.device)
@@ -850,7 +853,7 @@ class SlimEngine:
             err_b = 2.0 * float(contrib.numel()) * 2.0 ** -53 * float(cs[-1])
         slack = 2.0 * (n_u + 2.0) * 2.0 ** -24 * (B * (1.0 + 1e-6) + err_b) + 1e-30
         if resident:
-            W["_f64_slack"] = slack
+            W["_f64_slack"] = (ptr, slack)
         return slack
 
     def _f64_refine_x_ok(self, xb) -> bool:

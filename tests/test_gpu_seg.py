@@ -381,6 +381,15 @@ def test_float64_w_through_the_fast_pass_and_the_refine_step(oracle, shape):
         assert eng.last_score_path.endswith("+f64")
         o_ids, o_sc, o_cnt = oracle.recommend_batch(Xn, Wr, top_k=10, filter_interacted=True, use_f64=True)
         assert np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc))
+        # X replaced (more users, larger ratings) while W -- and the per-user slack cached with it -- stays:
+        # the slack must follow the new X (it used to be read past its end / be too small for the new ratings)
+        Xg = sp.vstack([X * 3.0, X[:200] * 5.0]).tocsr().astype(np.float32)
+        Xg.sort_indices()
+        eng.set_interactions(None, Xg, need_csc=False)
+        ids, sc, cnt = eng.recommend_rows(np.arange(Xg.shape[0]), top_k=10, mode=_native.TOPK_SPARSE)
+        assert eng.last_score_path.endswith("+f64")
+        o_ids, o_sc, o_cnt = oracle.recommend_batch(Xg, Wr, top_k=10, filter_interacted=True, use_f64=True)
+        assert np.array_equal(cnt, o_cnt) and np.array_equal(ids, o_ids) and np.array_equal(bits(sc), bits(o_sc))
         eng.set_interactions(None, X, need_csc=False)
     if True:                    # A/B: the tiled float64 kernel alone gives the same arrays
         a = eng.recommend_rows(np.arange(X.shape[0]), top_k=10)
