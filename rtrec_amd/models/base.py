@@ -296,6 +296,8 @@ class BaseModel(ABC):
                                    filter_interacted: bool, as_arrays: bool) -> Any:
         candidate_item_ids = self._candidate_ids(candidate_items)
         B = int(uid.shape[0])
+        if B == 0:                                       # an empty batch: nothing to score
+            return (np.empty((0, top_k), dtype=np.int64), np.zeros(0, dtype=np.int32)) if as_arrays else []
         cold = uid > self.interactions.max_user_id       # an integer id the store has never seen is a cold-start user
         n_cold = int(np.count_nonzero(cold))
         mapped = not self.item_ids.pass_through          # string item ids: internal -> raw through id_to_obj
@@ -308,7 +310,7 @@ class BaseModel(ABC):
                                                          filter_interacted)
         if not as_arrays:
             # lists: the hot users' rows in one tolist() (int32 as it comes off the device), cut only where a list is short;
-            # cold users all get the hot-items list (the same object for each, like the reference's `[hot for _ in users]`)
+            # cold users all get the hot-items list
             hot_lists: List[List[Any]] = []
             if h_ids is not None:
                 hot_lists = self._rows_as_lists(h_ids)
@@ -323,7 +325,7 @@ class BaseModel(ABC):
             if n_cold == 0:
                 return hot_lists
             cold_row = [self.item_ids.get(i) for i in hot_rows_list] if mapped else hot_rows_list
-            rows: List[List[Any]] = [cold_row] * B
+            rows: List[List[Any]] = [list(cold_row) for _ in range(B)]      # a list of its own per user, like the reference's
             for p_, r_ in zip(np.flatnonzero(~cold).tolist(), hot_lists):
                 rows[p_] = r_
             return rows

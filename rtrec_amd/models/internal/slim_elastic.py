@@ -72,6 +72,13 @@ class SLIMElastic:
             self._item_similarity = self.engine.gather_weights(self._w_dev).to_csc(self.engine.be.torch)
         return self._item_similarity
 
+    def gather_item_similarity(self) -> Optional[sp.csc_matrix]:
+        """The host copy of W, explicitly.  With a column-sharded W (SlimEngine.shard_w, several ranks) this is a COLLECTIVE:
+        every rank must call it at the same point -- reading `item_similarity`, `save()` and pickling go through it, so a
+        model whose W is sharded is saved by calling this on ALL ranks first and pickling on one of them afterwards (the
+        host copy is then cached and no further exchange happens).  A call on one rank only blocks in all_gather."""
+        return self.item_similarity
+
     @item_similarity.setter
     def item_similarity(self, W: Optional[sp.csc_matrix]) -> None:
         self._item_similarity = W

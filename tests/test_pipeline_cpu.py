@@ -568,6 +568,10 @@ def test_vectorised_recommend_batch_equals_the_per_user_loop(item_kind, monkeypa
     with pytest.raises(IndexError):
         m.recommend_batch([0, -n_users - 1], top_k=5)
     assert m.recommend_batch([], top_k=5) == [] and m.recommend_batch(np.empty(0, np.int64), top_k=5) == []
+    e_ids, e_counts = m.recommend_batch(np.empty(0, np.int64), top_k=5, as_arrays=True)        # no (None, None)
+    assert e_ids.shape == (0, 5) and e_counts.shape == (0,)
+    cold_rows = m.recommend_batch([900, 901, 5], top_k=5)                                      # every cold user a list of its own
+    assert cold_rows[0] == cold_rows[1] and cold_rows[0] is not cold_rows[1]
     rec = Recommender(m)
     assert rec.recommend_batch([1, 2], top_k=3) == m.recommend_batch([1, 2], top_k=3)
     assert rec.recommend_batch([1, 2], top_k=3, as_arrays=True)[1].tolist() == [3, 3]
