@@ -234,9 +234,7 @@ class HipBackend:
         cap = max(1024, n >> 10)
         idx = self.empty((cap,), torch.int32)
         cnt = self.zeros((1,), torch.int32)
-        _native.check(self.lib.rtrec_store_decay_device(self.ptr(raw), self.ptr(ts), n, float(rate), float(now), self.ptr(out),
-                                                        self.ptr(idx), self.ptr(cnt), cap, self.stream()),
-                      "rtrec_store_decay_device")
+        self.ops.store_decay_device(raw, ts, float(rate), float(now), out, idx, cnt)
         k = int(cnt.item())
         sel = idx[:k].long() if k <= cap else torch.arange(n, device=raw.device)        # overflow: let the host do them all
         if sel.numel():
@@ -254,10 +252,7 @@ class HipBackend:
         torch = self.torch
         g = int(start.shape[0]) - 1
         val, ts, v32 = self.empty((g,), torch.float64), self.empty((g,), torch.float64), self.empty((g,), torch.float32)
-        _native.check(self.lib.rtrec_store_fold_device(self.ptr(order), self.ptr(start), g, self.ptr(delta), self.ptr(tstamp),
-                                                       self.ptr(old) if old is not None else None, float(lo), float(hi),
-                                                       int(bool(upsert)), self.ptr(val), self.ptr(ts), self.ptr(v32), self.stream()),
-                      "rtrec_store_fold_device")
+        self.ops.store_fold_device(order, start, delta, tstamp, old, float(lo), float(hi), bool(upsert), val, ts, v32)
         return val, ts, v32
 
     def timer_create(self) -> int:

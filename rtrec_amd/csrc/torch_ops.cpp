@@ -18,6 +18,7 @@
 
 #include <stdexcept>
 #include <string>
+#include <vector>
 #include <type_traits>
 
 #include "../../include/rtrec_amd.h"
@@ -35,6 +36,16 @@ struct Abi {
     decltype(&rtrec_slim_score_rows) score_rows = nullptr;
     decltype(&rtrec_slim_merge_topk_strided) merge_topk_strided = nullptr;
     decltype(&rtrec_slim_similar_topk) similar_topk = nullptr;
+    decltype(&rtrec_store_decay_device) store_decay_device = nullptr;
+    decltype(&rtrec_store_fold_device) store_fold_device = nullptr;
+    decltype(&rtrec_slim_fit_sgd_epochs) fit_sgd_epochs = nullptr;
+    decltype(&rtrec_slim_first_touch_aux) first_touch_aux = nullptr;
+    decltype(&rtrec_slim_dense_fill) dense_fill = nullptr;
+    decltype(&rtrec_slim_refine_topk_f64) refine_topk_f64 = nullptr;
+    decltype(&rtrec_slim_score_candidates) score_candidates = nullptr;
+    decltype(&rtrec_slim_seg_plan) seg_plan = nullptr;
+    decltype(&rtrec_slim_seg_fill) seg_fill = nullptr;
+    decltype(&rtrec_slim_ordered_sums) ordered_sums = nullptr;
 };
 Abi g_abi;
 
@@ -254,6 +265,111 @@ void similar_topk(const at::Tensor &queries, const at::Tensor &wc_ptr, const at:
                              ptr<float>(scores), ptr<int32_t>(count), stream_of(ids)), "rtrec_slim_similar_topk");
 }
 
+// ---- round 5: the device entry points that used to be called by raw ctypes, same typed checks ----
+void store_decay_device(const at::Tensor &raw, const at::Tensor &ts, double rate, double now, at::Tensor out, at::Tensor unsafe_idx,
+                        at::Tensor unsafe_count) {
+    TORCH_CHECK(ts.numel() == raw.numel() && out.numel() == raw.numel(), "store_decay_device: raw, ts and out must have one length");
+    check(abi().store_decay_device(ptr<const double>(raw), ptr<const double>(ts), raw.numel(), rate, now, ptr<float>(out),
+                                   ptr<int32_t>(unsafe_idx), ptr<int32_t>(unsafe_count), static_cast<int32_t>(unsafe_idx.numel()),
+                                   stream_of(out)), "rtrec_store_decay_device");
+}
+
+void store_fold_device(const at::Tensor &order, const at::Tensor &start, const at::Tensor &delta, const at::Tensor &tstamp, const OT &old,
+                       double lo, double hi, bool upsert, at::Tensor out_val, at::Tensor out_ts, at::Tensor out_val32) {
+    const int64_t g = start.numel() - 1;
+    TORCH_CHECK(g >= 0 && out_val.numel() == g && out_ts.numel() == g && out_val32.numel() == g, "store_fold_device: outputs must hold one entry per group");
+    TORCH_CHECK(delta.numel() == order.numel() && tstamp.numel() == order.numel(), "store_fold_device: order, delta and tstamp must have one length");
+    check(abi().store_fold_device(ptr<const int64_t>(order), ptr<const int64_t>(start), g, ptr<const double>(delta), ptr<const double>(tstamp),
+                                  ptr<const double>(old), lo, hi, upsert ? 1 : 0, ptr<double>(out_val), ptr<double>(out_ts),
+                                  ptr<float>(out_val32), stream_of(out_val)), "rtrec_store_fold_device");
+}
+
+void fit_sgd_epochs(const at::Tensor &cptr, const at::Tensor &ttime, const at::Tensor &tval, const at::Tensor &targets, const at::Tensor &sel,
+                    const at::Tensor &sel_count, int64_t n_users, int64_t n_items, int64_t nnz, int64_t cap, int64_t first_epoch,
+                    int64_t n_epochs, int64_t max_iter, double tol, const at::Tensor &eta, const at::Tensor &ws_before,
+                    const at::Tensor &ws_after, const at::Tensor &u_after, const at::Tensor &reset_cnt, const at::Tensor &reset_mult,
+                    at::Tensor w, at::Tensor q, at::Tensor best_loss, at::Tensor no_improve, at::Tensor n_iter, at::Tensor unfinished) {
+    check(abi().fit_sgd_epochs(static_cast<int32_t>(n_users), static_cast<int32_t>(n_items), ptr<const int32_t>(cptr), ptr<const int32_t>(ttime),
+                               ptr<const float>(tval), nnz, ptr<const int32_t>(targets), static_cast<int32_t>(targets.numel()),
+                               ptr<const int32_t>(sel), ptr<const int32_t>(sel_count), static_cast<int32_t>(cap),
+                               static_cast<int32_t>(first_epoch), static_cast<int32_t>(n_epochs), static_cast<int32_t>(max_iter), tol,
+                               ptr<const double>(eta), ptr<const double>(ws_before), ptr<const double>(ws_after), ptr<const double>(u_after),
+                               ptr<const int32_t>(reset_cnt), ptr<const float>(reset_mult), ptr<float>(w), ptr<float>(q),
+                               ptr<double>(best_loss), ptr<int32_t>(no_improve), ptr<int32_t>(n_iter), ptr<int32_t>(unfinished),
+                               stream_of(w)), "rtrec_slim_fit_sgd_epochs");
+}
+
+void first_touch_aux(const OT &row_ids, const at::Tensor &xb_ptr, const at::Tensor &xb_col, int64_t n_rows, int64_t n_items,
+                     const at::Tensor &wc_ptr, const at::Tensor &wc_row, int64_t top_k, const at::Tensor &ids, const at::Tensor &count,
+                     at::Tensor aux) {
+    check(abi().first_touch_aux(static_cast<int32_t>(n_rows), ptr<const int32_t>(row_ids), ptr<const int32_t>(xb_ptr), ptr<const int32_t>(xb_col),
+                                static_cast<int32_t>(xb_ptr.size(0)) - 1, static_cast<int32_t>(n_items), ptr<const int32_t>(wc_ptr),
+                                ptr<const int32_t>(wc_row), static_cast<int32_t>(top_k), ptr<const int32_t>(ids), ptr<const int32_t>(count),
+                                ptr<uint32_t>(aux), stream_of(aux)), "rtrec_slim_first_touch_aux");
+}
+
+void dense_fill(const OT &row_ids, const at::Tensor &xb_ptr, const at::Tensor &xb_col, int64_t n_rows, int64_t col_lo, int64_t col_hi,
+                int64_t top_k, bool filter_interacted, at::Tensor ids, at::Tensor scores, at::Tensor aux, at::Tensor count,
+                const at::Tensor &flagged_in, at::Tensor flagged_out) {
+    check(abi().dense_fill(static_cast<int32_t>(n_rows), ptr<const int32_t>(row_ids), ptr<const int32_t>(xb_ptr), ptr<const int32_t>(xb_col),
+                           static_cast<int32_t>(xb_ptr.size(0)) - 1, static_cast<int32_t>(col_lo), static_cast<int32_t>(col_hi),
+                           static_cast<int32_t>(top_k), filter_interacted ? 1 : 0, ptr<int32_t>(ids), ptr<float>(scores), ptr<uint32_t>(aux),
+                           ptr<int32_t>(count), ptr<const int32_t>(flagged_in), ptr<int32_t>(flagged_out), stream_of(ids)),
+          "rtrec_slim_dense_fill");
+}
+
+void refine_topk_f64(const OT &row_ids, const at::Tensor &xb_ptr, const at::Tensor &xb_col, const at::Tensor &xb_val, int64_t n_rows,
+                     int64_t n_items, const at::Tensor &wc_ptr, const at::Tensor &wc_row, const at::Tensor &wc_val, int64_t top_k,
+                     const at::Tensor &in_ids, const at::Tensor &in_scores, const at::Tensor &in_count, double rel_margin,
+                     const OT &abs_slack, at::Tensor out_ids, at::Tensor out_scores, at::Tensor out_scores64, at::Tensor out_count,
+                     at::Tensor flagged) {
+    check(abi().refine_topk_f64(static_cast<int32_t>(n_rows), ptr<const int32_t>(row_ids), ptr<const int32_t>(xb_ptr), ptr<const int32_t>(xb_col),
+                                ptr<const float>(xb_val), static_cast<int32_t>(xb_ptr.size(0)) - 1, static_cast<int32_t>(n_items),
+                                ptr<const int32_t>(wc_ptr), ptr<const int32_t>(wc_row), ptr<const float>(wc_val), static_cast<int32_t>(top_k),
+                                ptr<const int32_t>(in_ids), ptr<const float>(in_scores), ptr<const int32_t>(in_count), rel_margin,
+                                ptr<const double>(abs_slack), ptr<int32_t>(out_ids), ptr<float>(out_scores), ptr<double>(out_scores64),
+                                ptr<int32_t>(out_count), ptr<int32_t>(flagged), stream_of(out_ids)), "rtrec_slim_refine_topk_f64");
+}
+
+void score_candidates(const OT &row_ids, const at::Tensor &xb_ptr, const at::Tensor &xb_col, const at::Tensor &xb_val, int64_t n_rows,
+                      int64_t n_items, const at::Tensor &wc_ptr, const at::Tensor &wc_row, const at::Tensor &wc_val, const at::Tensor &cands,
+                      int64_t top_k, bool acc_f64, at::Tensor ids, at::Tensor scores, OT scores64, at::Tensor count) {
+    check(abi().score_candidates(static_cast<int32_t>(n_rows), ptr<const int32_t>(row_ids), ptr<const int32_t>(xb_ptr), ptr<const int32_t>(xb_col),
+                                 ptr<const float>(xb_val), static_cast<int32_t>(xb_ptr.size(0)) - 1, static_cast<int32_t>(n_items),
+                                 ptr<const int32_t>(wc_ptr), ptr<const int32_t>(wc_row), ptr<const float>(wc_val), ptr<const int32_t>(cands),
+                                 static_cast<int32_t>(cands.numel()), static_cast<int32_t>(top_k), acc_f64 ? 1 : 0, ptr<int32_t>(ids),
+                                 ptr<float>(scores), ptr<double>(scores64), ptr<int32_t>(count), stream_of(ids)), "rtrec_slim_score_candidates");
+}
+
+// returns {n_cols, n_rows, tile_cols, n_tiles} of the segment layout (the C-ABI writes them to host memory after its own sync)
+std::vector<int64_t> seg_plan(const at::Tensor &rows, const at::Tensor &cols, int64_t n_items, int64_t col_lo, int64_t col_hi,
+                              const at::Tensor &labels, at::Tensor ws) {
+    TORCH_CHECK(cols.numel() == rows.numel(), "seg_plan: rows and cols must have one length");
+    int32_t out[4] = {0, 0, 0, 0};
+    check(abi().seg_plan(static_cast<int32_t>(n_items), rows.numel(), ptr<const int64_t>(rows), ptr<const int64_t>(cols),
+                         static_cast<int32_t>(col_lo), static_cast<int32_t>(col_hi), ptr<const int64_t>(labels), ptr(ws),
+                         static_cast<size_t>(ws.numel()), out, stream_of(ws)), "rtrec_slim_seg_plan");
+    return {out[0], out[1], out[2], out[3]};
+}
+
+void seg_fill(const at::Tensor &rows, const at::Tensor &cols, const at::Tensor &vals, int64_t n_items, int64_t col_lo, int64_t col_hi,
+              const at::Tensor &plan_ws, int64_t n_cols, int64_t n_rows, int64_t tile_cols, int64_t n_tiles, at::Tensor ws, at::Tensor info,
+              at::Tensor seg_ptr, at::Tensor ent, at::Tensor bound, at::Tensor col_ids, at::Tensor trow_ptr, at::Tensor trow) {
+    TORCH_CHECK(cols.numel() == rows.numel() && vals.numel() == rows.numel(), "seg_fill: rows, cols and vals must have one length");
+    check(abi().seg_fill(static_cast<int32_t>(n_items), rows.numel(), ptr<const int64_t>(rows), ptr<const int64_t>(cols), ptr<const float>(vals),
+                         static_cast<int32_t>(col_lo), static_cast<int32_t>(col_hi), ptr<const void>(plan_ws), static_cast<int32_t>(n_cols),
+                         static_cast<int32_t>(n_rows), static_cast<int32_t>(tile_cols), static_cast<int32_t>(n_tiles), ptr(ws),
+                         static_cast<size_t>(ws.numel()), ptr<int32_t>(info), ptr<int32_t>(seg_ptr), ptr<int32_t>(ent), ent.size(0),
+                         ptr<uint32_t>(bound), ptr<int32_t>(col_ids), ptr<int32_t>(trow_ptr), ptr<int32_t>(trow), trow.size(0),
+                         stream_of(info)), "rtrec_slim_seg_fill");
+}
+
+void ordered_sums(const at::Tensor &values, const at::Tensor &offsets, int64_t mode, at::Tensor out) {
+    TORCH_CHECK(offsets.numel() == out.numel() + 1, "ordered_sums: offsets must hold one more entry than out");
+    check(abi().ordered_sums(ptr<const float>(values), ptr<const int64_t>(offsets), static_cast<int32_t>(out.numel()),
+                             static_cast<int32_t>(mode), ptr<float>(out), stream_of(out)), "rtrec_slim_ordered_sums");
+}
+
 }  // namespace
 
 // Bind the ops to a build of the C-ABI library (called once by rtrec_amd.ops with _native.lib_path()).
@@ -272,6 +388,16 @@ extern "C" int rtrec_ops_bind(const char *path) {
         bind_one(h, a.score_rows, "rtrec_slim_score_rows");
         bind_one(h, a.merge_topk_strided, "rtrec_slim_merge_topk_strided");
         bind_one(h, a.similar_topk, "rtrec_slim_similar_topk");
+        bind_one(h, a.store_decay_device, "rtrec_store_decay_device");
+        bind_one(h, a.store_fold_device, "rtrec_store_fold_device");
+        bind_one(h, a.fit_sgd_epochs, "rtrec_slim_fit_sgd_epochs");
+        bind_one(h, a.first_touch_aux, "rtrec_slim_first_touch_aux");
+        bind_one(h, a.dense_fill, "rtrec_slim_dense_fill");
+        bind_one(h, a.refine_topk_f64, "rtrec_slim_refine_topk_f64");
+        bind_one(h, a.score_candidates, "rtrec_slim_score_candidates");
+        bind_one(h, a.seg_plan, "rtrec_slim_seg_plan");
+        bind_one(h, a.seg_fill, "rtrec_slim_seg_fill");
+        bind_one(h, a.ordered_sums, "rtrec_slim_ordered_sums");
         g_abi = a;
         return 0;
     } catch (const std::exception &) {
@@ -304,6 +430,28 @@ TORCH_LIBRARY(rtrec_amd, m) {
           "Tensor(a!) out_ids, Tensor(b!) out_scores, Tensor(c!) out_count) -> ()");
     m.def("similar_topk(Tensor queries, Tensor wc_ptr, Tensor wc_row, Tensor wc_val, int top_k, Tensor(a!) ids, Tensor(b!) scores, "
           "Tensor(c!) count) -> ()");
+    m.def("store_decay_device(Tensor raw, Tensor ts, float rate, float now, Tensor(a!) out, Tensor(b!) unsafe_idx, Tensor(c!) unsafe_count) -> ()");
+    m.def("store_fold_device(Tensor order, Tensor start, Tensor delta, Tensor tstamp, Tensor? old, float lo, float hi, bool upsert, "
+          "Tensor(a!) out_val, Tensor(b!) out_ts, Tensor(c!) out_val32) -> ()");
+    m.def("fit_sgd_epochs(Tensor cptr, Tensor ttime, Tensor tval, Tensor targets, Tensor sel, Tensor sel_count, int n_users, int n_items, "
+          "int nnz, int cap, int first_epoch, int n_epochs, int max_iter, float tol, Tensor eta, Tensor ws_before, Tensor ws_after, "
+          "Tensor u_after, Tensor reset_cnt, Tensor reset_mult, Tensor(a!) w, Tensor(b!) q, Tensor(c!) best_loss, Tensor(d!) no_improve, "
+          "Tensor(e!) n_iter, Tensor(f!) unfinished) -> ()");
+    m.def("first_touch_aux(Tensor? row_ids, Tensor xb_ptr, Tensor xb_col, int n_rows, int n_items, Tensor wc_ptr, Tensor wc_row, int top_k, "
+          "Tensor ids, Tensor count, Tensor(a!) aux) -> ()");
+    m.def("dense_fill(Tensor? row_ids, Tensor xb_ptr, Tensor xb_col, int n_rows, int col_lo, int col_hi, int top_k, bool filter_interacted, "
+          "Tensor(a!) ids, Tensor(b!) scores, Tensor(c!) aux, Tensor(d!) count, Tensor flagged_in, Tensor(e!) flagged_out) -> ()");
+    m.def("refine_topk_f64(Tensor? row_ids, Tensor xb_ptr, Tensor xb_col, Tensor xb_val, int n_rows, int n_items, Tensor wc_ptr, "
+          "Tensor wc_row, Tensor wc_val, int top_k, Tensor in_ids, Tensor in_scores, Tensor in_count, float rel_margin, Tensor? abs_slack, "
+          "Tensor(a!) out_ids, Tensor(b!) out_scores, Tensor(c!) out_scores64, Tensor(d!) out_count, Tensor(e!) flagged) -> ()");
+    m.def("score_candidates(Tensor? row_ids, Tensor xb_ptr, Tensor xb_col, Tensor xb_val, int n_rows, int n_items, Tensor wc_ptr, "
+          "Tensor wc_row, Tensor wc_val, Tensor cands, int top_k, bool acc_f64, Tensor(a!) ids, Tensor(b!) scores, Tensor(c!)? scores64, "
+          "Tensor(d!) count) -> ()");
+    m.def("seg_plan(Tensor rows, Tensor cols, int n_items, int col_lo, int col_hi, Tensor labels, Tensor(a!) ws) -> int[]");
+    m.def("seg_fill(Tensor rows, Tensor cols, Tensor vals, int n_items, int col_lo, int col_hi, Tensor plan_ws, int n_cols, int n_rows, "
+          "int tile_cols, int n_tiles, Tensor(a!) ws, Tensor(b!) info, Tensor(c!) seg_ptr, Tensor(d!) ent, Tensor(e!) bound, "
+          "Tensor(f!) col_ids, Tensor(g!) trow_ptr, Tensor(h!) trow) -> ()");
+    m.def("ordered_sums(Tensor values, Tensor offsets, int mode, Tensor(a!) out) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(rtrec_amd, CUDA, m) {
@@ -315,4 +463,14 @@ TORCH_LIBRARY_IMPL(rtrec_amd, CUDA, m) {
     m.impl("score_rows", &score_rows);
     m.impl("merge_topk", &merge_topk);
     m.impl("similar_topk", &similar_topk);
+    m.impl("store_decay_device", &store_decay_device);
+    m.impl("store_fold_device", &store_fold_device);
+    m.impl("fit_sgd_epochs", &fit_sgd_epochs);
+    m.impl("first_touch_aux", &first_touch_aux);
+    m.impl("dense_fill", &dense_fill);
+    m.impl("refine_topk_f64", &refine_topk_f64);
+    m.impl("score_candidates", &score_candidates);
+    m.impl("seg_plan", &seg_plan);
+    m.impl("seg_fill", &seg_fill);
+    m.impl("ordered_sums", &ordered_sums);
 }

@@ -522,10 +522,8 @@ class SlimEngine:
                 d_tv[e] = X["cval"][perm]
             d_eta, d_wsb, d_wsa, d_ua = (be.to_dev(a) for a in (eta, wsb, wsa, ua))
             d_rcnt, d_rmult = be.to_dev(rcnt), be.to_dev(rmult[:max(int(n_res.value), 1)].copy())
-            _native.check(be.lib.rtrec_slim_fit_sgd_epochs(U, I, p(X["cptr"]), p(d_tt), p(d_tv), nnz, p(d_t), n, p(d_sel), p(d_cnt), cap,
-                                                           first, ne, int(max_iter), tol_, p(d_eta), p(d_wsb), p(d_wsa), p(d_ua),
-                                                           p(d_rcnt), p(d_rmult), p(d_w), p(d_q), p(d_best), p(d_noimp), p(d_niter),
-                                                           p(d_unf), be.stream()), "rtrec_slim_fit_sgd_epochs")
+            be.ops.fit_sgd_epochs(X["cptr"], d_tt, d_tv, d_t, d_sel, d_cnt, U, I, nnz, cap, first, ne, int(max_iter), tol_, d_eta, d_wsb,
+                                  d_wsa, d_ua, d_rcnt, d_rmult, d_w, d_q, d_best, d_noimp, d_niter, d_unf)
             first += ne
             if int(d_unf.item()) == 0:
                 break
@@ -983,10 +981,7 @@ class SlimEngine:
                 and not (lo == 0 and hi == W["n_items"])):
             ids, _sc, _sc64, aux, cnt = out
             wc_ptr, wc_row, _ = W["dw"].csc_arrays(be.torch)
-            p = be.ptr
-            _native.check(be.lib.rtrec_slim_first_touch_aux(n_rows, p(d_row_ids), p(xb[0]), p(xb[1]), int(xb[0].shape[0]) - 1,
-                                                            W["n_items"], p(wc_ptr), p(wc_row), top_k, p(ids), p(cnt), p(aux),
-                                                            be.stream()), "rtrec_slim_first_touch_aux")
+            be.ops.first_touch_aux(d_row_ids, xb[0], xb[1], n_rows, W["n_items"], wc_ptr, wc_row, top_k, ids, cnt, aux)
         return out
 
     def _local_topk_impl(self, d_row_ids, n_rows: int, xb, top_k: int, filter_interacted: bool, mode: int,
@@ -1068,11 +1063,8 @@ class SlimEngine:
                           rescored=None, row_order_grouped=(order is not None and use_fr and self._order_grouped),
                           use_sg=use_sg, use_sg_heavy=self.use_seg_heavy, flagged=flagged_fast)
             if fill:          # DENSE mode: short all-positive lists are completed with the zero-score columns, the rest stays flagged
-                p = be.ptr
-                _native.check(be.lib.rtrec_slim_dense_fill(n_rows, p(d_row_ids), p(xb[0]), p(xb[1]), int(xb[0].shape[0]) - 1,
-                                                           int(W["col_lo"]), int(W["col_hi"]), top_k, int(bool(filter_interacted)),
-                                                           p(ids), p(sc), p(aux), p(cnt), p(flagged_fast), p(flagged), be.stream()),
-                              "rtrec_slim_dense_fill")
+                be.ops.dense_fill(d_row_ids, xb[0], xb[1], n_rows, int(W["col_lo"]), int(W["col_hi"]), top_k, bool(filter_interacted),
+                                  ids, sc, aux, cnt, flagged_fast, flagged)
             if flag_words:                # one download: the lists and the counter
                 h = pack.cpu().numpy()
                 n_flag = int(h[2 * nk + cap])
@@ -1150,12 +1142,8 @@ class SlimEngine:
                       use_sg=use_sg, use_sg_heavy=self.use_seg_heavy, flagged=flagged)
         wc_ptr, wc_row, wc_val = W["dw"].csc_arrays(torch)
         margin = 2.0 * (W["col_nnz_max"] + 2) * 2.0 ** -24
-        p = be.ptr
-        _native.check(be.lib.rtrec_slim_refine_topk_f64(n_rows, p(d_row_ids), p(xb[0]), p(xb[1]), p(xb[2]), int(xb[0].shape[0]) - 1,
-                                                        W["n_items"], p(wc_ptr), p(wc_row), p(wc_val), top_k, p(ids1), p(sc1), p(cnt1),
-                                                        float(margin), p(self._f64_abs_slack(xb) if signed else None),
-                                                        p(ids), p(sc), p(sc64), p(cnt), p(flagged), be.stream()),
-                      "rtrec_slim_refine_topk_f64")
+        be.ops.refine_topk_f64(d_row_ids, xb[0], xb[1], xb[2], n_rows, W["n_items"], wc_ptr, wc_row, wc_val, top_k, ids1, sc1, cnt1,
+                               float(margin), self._f64_abs_slack(xb) if signed else None, ids, sc, sc64, cnt, flagged)
         aux.zero_()
         n_flag = int(flagged[0].item())
         if self.rescored is not None:
@@ -1490,11 +1478,8 @@ class SlimEngine:
         cnt = pack[2 * nk:]
         ids._rtrec_pack = pack
         sc64 = be.empty((n_rows, top_k), torch.float64) if f64 else None
-        p = be.ptr
-        _native.check(be.lib.rtrec_slim_score_candidates(n_rows, p(d_rows), p(xb[0]), p(xb[1]), p(xb[2]), int(xb[0].shape[0]) - 1,
-                                                         W["n_items"], p(wc_ptr), p(wc_row), p(wc_val), p(d_c), n_c, top_k, int(f64),
-                                                         p(ids), p(sc), p(sc64), p(cnt), be.stream()),
-                      "rtrec_slim_score_candidates")
+        be.ops.score_candidates(d_rows, xb[0], xb[1], xb[2], n_rows, W["n_items"], wc_ptr, wc_row, wc_val, d_c, top_k, bool(f64),
+                                ids, sc, sc64, cnt)
         self.last_score_path = "candidates_direct"
         return ids, sc, cnt
 

@@ -14,6 +14,11 @@ is written on top of them; they are also the interface for callers that already 
     torch.ops.rtrec_amd.score_rows          score vectors (predict*)
     torch.ops.rtrec_amd.merge_topk          per-tile / per-GPU top-k lists -> top-k
     torch.ops.rtrec_amd.similar_topk        similar_items
+    torch.ops.rtrec_amd.store_decay_device  time decay of a resident store      .store_fold_device   bulk ingest: fold per (user, item)
+    torch.ops.rtrec_amd.fit_sgd_epochs      optim="sgd" epochs                  .first_touch_aux     cross-shard tie key
+    torch.ops.rtrec_amd.dense_fill          DENSE lists completed in place      .refine_topk_f64     float64 refine of a fast pass
+    torch.ops.rtrec_amd.score_candidates    request-sized CANDIDATES calls      .seg_plan / .seg_fill  segment layout of a general W
+    torch.ops.rtrec_amd.ordered_sums        left-to-right float32 sums (the fit kernels' fold, for tests and tools)
 
 The registration lives in csrc/torch_ops.cpp (TORCH_LIBRARY / TORCH_LIBRARY_IMPL: librtrec_amd_ops.so, built by
 rtrec_amd/build.py with the host compiler); importing this module loads it and binds it to the C-ABI library
@@ -32,7 +37,19 @@ from . import _native
 from . import build as _build
 
 OPS = ["column_sqnorms", "fit_workspace_init", "gram_matrix", "fit_columns", "score_topk", "score_rows", "merge_topk",
-       "similar_topk"]
+       "similar_topk", "store_decay_device", "store_fold_device", "fit_sgd_epochs", "first_touch_aux", "dense_fill",
+       "refine_topk_f64", "score_candidates", "seg_plan", "seg_fill", "ordered_sums"]
+
+# C-ABI export each op launches (tests: every kernel-launching export of include/rtrec_amd.h is behind an op)
+EXPORT_OF = {"column_sqnorms": "rtrec_slim_column_sqnorms", "fit_workspace_init": "rtrec_slim_fit_workspace_init",
+             "gram_matrix": "rtrec_slim_gram_matrix", "fit_columns": "rtrec_slim_fit_columns_opt",
+             "score_topk": "rtrec_slim_score_topk_opt", "score_rows": "rtrec_slim_score_rows",
+             "merge_topk": "rtrec_slim_merge_topk_strided", "similar_topk": "rtrec_slim_similar_topk",
+             "store_decay_device": "rtrec_store_decay_device", "store_fold_device": "rtrec_store_fold_device",
+             "fit_sgd_epochs": "rtrec_slim_fit_sgd_epochs", "first_touch_aux": "rtrec_slim_first_touch_aux",
+             "dense_fill": "rtrec_slim_dense_fill", "refine_topk_f64": "rtrec_slim_refine_topk_f64",
+             "score_candidates": "rtrec_slim_score_candidates", "seg_plan": "rtrec_slim_seg_plan", "seg_fill": "rtrec_slim_seg_fill",
+             "ordered_sums": "rtrec_slim_ordered_sums"}
 
 
 def _load() -> None:

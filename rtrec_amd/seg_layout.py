@@ -287,10 +287,7 @@ def build_seg_layout_native(be, rows, cols, vals, n_items: int, col_lo: int, col
     labels = labels.contiguous()
     p = be.ptr
     pws = be.empty((int(lib.rtrec_slim_seg_plan_workspace_bytes(n_items)),), torch.uint8)
-    out = (C.c_int32 * 4)()
-    _native.check(lib.rtrec_slim_seg_plan(n_items, nnz, p(rows), p(cols), int(col_lo), int(col_hi), p(labels), p(pws), pws.numel(),
-                                          C.cast(out, C.c_void_p), be.stream()), "rtrec_slim_seg_plan")
-    n_cols, R, T, n_tiles = (int(x) for x in out)
+    n_cols, R, T, n_tiles = (int(x) for x in be.ops.seg_plan(rows, cols, n_items, int(col_lo), int(col_hi), labels, pws))
     if n_cols == 0 or R == 0 or T == 0:
         return None
     i32 = torch.int32
@@ -299,9 +296,8 @@ def build_seg_layout_native(be, rows, cols, vals, n_items: int, col_lo: int, col
     ent, bound = be.empty((2 * nnz, 2), i32), be.empty((R, 64), i32)
     col_ids, trow_ptr = be.empty((n_cols,), i32), be.empty((n_tiles + 1,), i32)
     trow = be.empty((min(nnz, R * n_tiles), 4), i32)
-    _native.check(lib.rtrec_slim_seg_fill(n_items, nnz, p(rows), p(cols), p(vals), int(col_lo), int(col_hi), p(pws), n_cols, R, T, n_tiles,
-                                          p(fws), fws.numel(), p(info), p(seg_ptr), p(ent), ent.shape[0], p(bound), p(col_ids),
-                                          p(trow_ptr), p(trow), trow.shape[0], be.stream()), "rtrec_slim_seg_fill")
+    be.ops.seg_fill(rows, cols, vals, n_items, int(col_lo), int(col_hi), pws, n_cols, R, T, n_tiles, fws, info, seg_ptr, ent, bound,
+                    col_ids, trow_ptr, trow)
     return dict(sg_trow=trow, sg_trow_ptr=trow_ptr, sg_T=T, sg_n_tiles=n_tiles, sg_rows=R, sg_n_cols=n_cols, sg_info=info,
                 sg_ptr=seg_ptr, sg_ent=ent, sg_bound=bound, sg_col_ids=col_ids, sg_nnz=nnz, sg_labels=labels,
                 _workspaces=(pws, fws))        # the fill is only enqueued: its workspaces live as long as the layout

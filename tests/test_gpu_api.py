@@ -449,3 +449,38 @@ def test_hybrid_slimfm_call_sequence_on_the_gpu():
     from tests.hybrid_replay import replay
     replay(lambda cfg: SLIMElastic(cfg))
 
+
+
+def test_custom_ops_refuse_mistyped_tensors():
+    """csrc/torch_ops.cpp checks every pointer it hands to the C-ABI: a tensor of another dtype, a strided view or a host
+    tensor raises instead of becoming an out-of-bounds access on the GPU -- for the ops added in round 5 as for the old ones."""
+    import torch
+    from rtrec_amd import ops as _registered        # noqa: F401  (importing it loads and binds the ops library)
+    ops = torch.ops.rtrec_amd
+    dev = "cuda:0"
+    i32 = lambda *s: torch.zeros(*s, dtype=torch.int32, device=dev)
+    i64 = lambda *s: torch.zeros(*s, dtype=torch.int64, device=dev)
+    f32 = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+    f64 = lambda *s: torch.zeros(*s, dtype=torch.float64, device=dev)
+    ptr2 = torch.tensor([0, 0], dtype=torch.int32, device=dev)
+    bad_calls = [
+        lambda: ops.store_decay_device(f32(4), f64(4), 0.9, 1.0, f32(4), i32(8), i32(1)),                        # raw must be float64
+        lambda: ops.store_fold_device(i32(4), i64(2), f64(4), f64(4), None, 0.0, 5.0, False, f64(1), f64(1), f32(1)),   # order int64
+        lambda: ops.first_touch_aux(None, ptr2, i64(1), 1, 4, ptr2, i32(1), 2, i32(1, 2), i32(1), i32(1, 2)),    # xb_col int32
+        lambda: ops.dense_fill(None, ptr2, i32(1), 1, 0, 4, 2, True, i64(1, 2), f32(1, 2), i32(1, 2), i32(1), i32(2), i32(2)),
+        lambda: ops.refine_topk_f64(None, ptr2, i32(1), f64(1), 1, 4, ptr2, i32(1), f32(1), 2, i32(1, 3), f32(1, 3), i32(1), 1e-6, None,
+                                    i32(1, 2), f32(1, 2), f64(1, 2), i32(1), i32(2)),                               # xb_val float32
+        lambda: ops.score_candidates(None, ptr2, i32(1), f32(1), 1, 4, ptr2, i32(1), f32(1), i64(2), 2, False, i32(1, 2), f32(1, 2), None, i32(1)),
+        lambda: ops.seg_plan(i32(4), i64(4), 8, 0, 8, i64(8), torch.zeros(64, dtype=torch.uint8, device=dev)),     # rows int64
+        lambda: ops.ordered_sums(f64(8), i64(2), 0, f32(1)),                                                      # values float32
+        lambda: ops.ordered_sums(f32(8).cpu(), i64(2), 0, f32(1)),                                                # host tensor
+        lambda: ops.ordered_sums(f32(16)[::2], i64(2), 0, f32(1)),                                                # strided view
+    ]
+    for k, call in enumerate(bad_calls):
+        with pytest.raises((RuntimeError, NotImplementedError)):
+            call()
+    # and a well-typed call goes through
+    vals = torch.arange(8, dtype=torch.float32, device=dev)
+    out = f32(1)
+    ops.ordered_sums(vals, torch.tensor([0, 8], dtype=torch.int64, device=dev), 0, out)
+    assert float(out.item()) == 28.0
