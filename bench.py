@@ -67,6 +67,27 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def attach_profile(path, kernel_name, fingerprint, root=None):
+    """A committed rocprofv3 summary (profiles/r*_<workload>_*.json) may ride on the bench line only when it describes (a) the
+    kernel the line names as dominant and (b) THE BUILD BEING TIMED: its "build".lib_sha256 equals the sha256 of the
+    librtrec_amd.so this process loaded (a summary of another round's kernels used to be attached by name
+    alone).  Returns (summary or None, relative path of a summary that was refused as stale or None)."""
+    root = root or ROOT
+    if not path:
+        return None, None
+    rel = os.path.relpath(path, root)
+    try:
+        j = json.load(open(path))
+    except Exception:
+        return None, None
+    if kernel_name is not None and j.get("kernel", "").split("<")[0] != kernel_name.split("<")[0]:
+        return None, None                      # another kernel's counters: not this line's business
+    have = (j.get("build") or {}).get("lib_sha256")
+    if not have or have != (fingerprint or {}).get("lib_sha256"):
+        return None, rel
+    return dict(j, source=rel), None
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -201,6 +222,24 @@ def structured_leg(args, top_k):
            "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_GBps": algo_bytes / (kms / max(kn, 1) * 1e-3) / 1e9,
            "algorithmic_frac_of_hbm_peak": algo_bytes / (kms / max(kn, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "topk_ids_crc32": zlib.crc32(out[0].cpu().numpy().tobytes())}
+    # roofline of the general-W (segment) kernel in the driver's own line: kernel time by HIP
+    # events over the timed steps (main kernel + the workgroup-per-long-user pass it forks), the bytes that MUST cross HBM
+    # (user rows in, lists out, W once), and the counter traffic of the same kernel of the SAME build when a profile exists
+    import glob
+    from rtrec_amd import build as _build
+    kern_s = kms / max(kn, 1) * 1e-3
+    compulsory = 8.0 * X.nnz + 4.0 * (U + 1) + 12.0 * top_k * U + 4.0 * U + 8.0 * float(W.nnz)
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_c3s_pmc_traffic.json")))
+    tj, stale = attach_profile(paths[-1] if paths else None, eng.last_score_path and "score_seg_kernel", _build.fingerprint())
+    traffic = tj["hbm_bytes_per_launch_corrected"] if tj else None
+    res["roofline"] = {"kernel": "score_seg_kernel (+ score_seg_heavy_kernel)", "bound": "hbm", "kernel_ms_avg": kern_s * 1e3,
+                       "achieved": compulsory / kern_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": compulsory / kern_s / 1e9 / HBM_PEAK_GBS, "compulsory_bytes_per_launch": compulsory,
+                       "traffic": traffic, "traffic_vs_compulsory": (traffic / compulsory if traffic else None),
+                       "traffic_source": (tj or {}).get("source"), "traffic_stale": stale, "traffic_measured_in_run": False,
+                       "l2_hit_rate": (tj or {}).get("l2_hit_rate"),
+                       "note": "W (2.9 MB of records) is L2-resident: the SURVEY 8d figure (algorithmic_*) prices gathered W entries "
+                               "that never reach DRAM; `frac` is on the compulsory bytes, `traffic` is what the fabric counters saw"}
     # the other forms the reference scores in: DENSE mode (string item ids: every column competes, slim_elastic.py:745-778)
     # and a float64 W (its serial fit, :252) -- both through the fast pass plus the rows it flags
     other = {}
@@ -740,32 +779,20 @@ def main() -> None:
         paths = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
         return paths[-1] if paths else None
 
-    traffic, traffic_src, counters = None, None, None
-    tpath = latest(f"r*_{args.workload}_pmc_traffic.json")
-    if world == 1 and tpath:
-        try:
-            tj = json.load(open(tpath))
-            if tj.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
-                traffic, traffic_src = tj["hbm_bytes_per_launch_corrected"], os.path.relpath(tpath, ROOT)
-        except Exception:
-            traffic = None
-    cpath = latest(f"r*_{args.workload}_score_counters.json")
-    if world == 1 and cpath:
-        try:
-            cj = json.load(open(cpath))       # only a summary of THIS line's dominant kernel may be attached
-            if cj.get("kernel", "").split("<")[0] == kernel_name.split("<")[0]:
-                counters = dict(cj, source=os.path.relpath(cpath, ROOT))
-            else:
-                log(f"[bench] {os.path.relpath(cpath, ROOT)} describes {cj.get('kernel')!r}, not {kernel_name.split('<')[0]}: not attached")
-        except Exception:
-            counters = None
-    fpath = latest(f"r*_{args.workload}_fit_pmc.json")
-    fit_traffic = None
-    if world == 1 and fpath:
-        try:
-            fit_traffic = dict(json.load(open(fpath)), source=os.path.relpath(fpath, ROOT))
-        except Exception:
-            fit_traffic = None
+    from rtrec_amd import build as _build
+    fp = _build.fingerprint()
+    traffic, traffic_src, counters, fit_traffic, stale = None, None, None, None, []
+    if world == 1:
+        tj, st_ = attach_profile(latest(f"r*_{args.workload}_pmc_traffic.json"), kernel_name, fp)
+        if tj:
+            traffic, traffic_src = tj["hbm_bytes_per_launch_corrected"], tj["source"]
+        stale += [st_] if st_ else []
+        counters, st_ = attach_profile(latest(f"r*_{args.workload}_score_counters.json"), kernel_name, fp)
+        stale += [st_] if st_ else []
+        fit_traffic, st_ = attach_profile(latest(f"r*_{args.workload}_fit_pmc.json"), None, fp)
+        stale += [st_] if st_ else []
+        for st_ in stale:
+            log(f"[bench] {st_} was measured on another build of librtrec_amd.so: not attached")
 
     best = bounds[bound]
     line = {
@@ -797,6 +824,7 @@ def main() -> None:
                                      "`traffic` (PMC, profiles/) measures"}},
         "roofline": {"kernel": kernel_name, "bound": ("hbm" if bound.startswith("hbm") else bound), "achieved": best["achieved"], "peak": best["peak"],
                      "unit": best["unit"], "frac": best["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_measured_in_run": False, "traffic_stale": (stale or None), "build": fp,
                      "traffic_vs_compulsory": (traffic / compulsory_hbm if traffic else None),
                      "kernel_ms_avg": kern_ms, "launches": int(n_launch.value), "bounds": bounds,
                      "algorithmic": algorithmic, "counters": counters, "score_path": score_path},

@@ -28,6 +28,52 @@ def _hipcc() -> str:
     return exe
 
 
+BUILD_INFO = os.path.join(LIB_DIR, "build_info.json")
+
+
+def _sha256(path: str) -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def fingerprint() -> dict:
+    """Identity of the kernel library a measurement was taken with: sha256 of librtrec_amd.so (what actually ran) plus the
+    git commit it was built at (recorded at build time -- the GPU box has no .git).  Profile summaries carry it
+    (tools/pmc_round_summary.py) and bench.py attaches a summary to its line only when it matches the running build."""
+    import json
+    info = {}
+    try:
+        info = json.load(open(BUILD_INFO))
+    except Exception:
+        pass
+    lib = os.environ.get("RTREC_AMD_LIB") or LIB_PATH
+    sha = _sha256(lib) if os.path.exists(lib) else None
+    if info.get("lib_sha256") != sha:           # an A/B library or a rebuild without the record: only the hash is known
+        info = {"git_head": None, "git_dirty": None}
+    return {"lib_sha256": sha, "git_head": info.get("git_head"), "git_dirty": info.get("git_dirty")}
+
+
+def _write_build_info() -> None:
+    import json
+    head, dirty = None, None
+    try:
+        root = os.path.dirname(_HERE)
+        head = subprocess.check_output(["git", "rev-parse", "HEAD"], cwd=root, stderr=subprocess.DEVNULL).decode().strip()
+        dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--", "rtrec_amd/csrc", "include"], cwd=root,
+                                             stderr=subprocess.DEVNULL).decode().strip())
+    except Exception:
+        pass
+    try:
+        with open(BUILD_INFO, "w") as f:
+            json.dump({"lib_sha256": _sha256(LIB_PATH), "git_head": head, "git_dirty": dirty}, f)
+    except OSError:
+        pass
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB_PATH):
         return True
@@ -43,6 +89,9 @@ def build_native(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd, cwd=CSRC)
+        _write_build_info()
+    elif not os.path.exists(BUILD_INFO):
+        _write_build_info()
     build_ops(force=force, verbose=verbose)
     return LIB_PATH
 

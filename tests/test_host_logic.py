@@ -975,3 +975,32 @@ def test_grouped_work_order_spreads_giant_rows_over_the_head():
     assert torch.equal(spread_giant_rows(torch, order, lens, 32, 100_000), order)
     assert torch.equal(spread_giant_rows(torch, order[:40], lens, 32, 4096), order[:40])
     assert torch.equal(spread_giant_rows(torch, order, lens, 0, 4096), order)
+
+
+def test_bench_attaches_a_profile_summary_only_for_the_build_it_times(tmp_path):
+    """a rocprofv3 summary rides on the bench line only when its "build".lib_sha256 equals the
+    library being timed; a summary of another build is reported as stale, one of another kernel is ignored."""
+    import json
+    import bench
+    fp = {"lib_sha256": "a" * 64, "git_head": "deadbeef"}
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    fresh = prof / "r05_c3_pmc_traffic.json"
+    fresh.write_text(json.dumps({"build": fp, "kernel": "score_frows_kernel<4,2,4>", "hbm_bytes_per_launch_corrected": 123}))
+    stale = prof / "r04_c3_pmc_traffic.json"
+    stale.write_text(json.dumps({"build": {"lib_sha256": "b" * 64}, "kernel": "score_frows_kernel<4,2,4>", "hbm_bytes_per_launch_corrected": 9}))
+    unstamped = prof / "r03_c3_pmc_traffic.json"
+    unstamped.write_text(json.dumps({"kernel": "score_frows_kernel<4,2,4>", "hbm_bytes_per_launch_corrected": 9}))
+    other = prof / "r05_c3_score_counters.json"
+    other.write_text(json.dumps({"build": fp, "kernel": "score_seg_kernel<8,unsigned short,true>", "per_launch": {}}))
+    j, st = bench.attach_profile(str(fresh), "score_frows_kernel<4,2,4>", fp, root=str(tmp_path))
+    assert j["hbm_bytes_per_launch_corrected"] == 123 and j["source"] == os.path.join("profiles", "r05_c3_pmc_traffic.json") and st is None
+    for path in (stale, unstamped):
+        j, st = bench.attach_profile(str(path), "score_frows_kernel<4,2,4>", fp, root=str(tmp_path))
+        assert j is None and st == os.path.join("profiles", path.name)
+    assert bench.attach_profile(str(other), "score_frows_kernel<4,2,4>", fp, root=str(tmp_path)) == (None, None)     # another kernel
+    assert bench.attach_profile(None, "k", fp) == (None, None) and bench.attach_profile(str(prof / "missing.json"), "k", fp) == (None, None)
+    # the running build's own fingerprint names the library file that is loaded
+    from rtrec_amd import build
+    f = build.fingerprint()
+    assert f["lib_sha256"] == build._sha256(build.LIB_PATH)

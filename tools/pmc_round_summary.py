@@ -39,9 +39,21 @@ def load(d, wl):
     return {k: {c: (v[0] / max(len(v[1]), 1), len(v[1])) for c, v in cs.items()} for k, cs in acc.items()}
 
 
+def build_stamp():
+    """Which library build the counters describe (rtrec_amd.build.fingerprint: sha256 of librtrec_amd.so + the git commit it
+    was built at); bench.py attaches a summary to its line only when this matches the build it is timing."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        from rtrec_amd import build
+        return build.fingerprint()
+    except Exception as exc:
+        return {"lib_sha256": None, "git_head": None, "error": repr(exc)}
+
+
 def main():
     d, tag, wl = sys.argv[1], sys.argv[2], sys.argv[3]
     per = load(d, wl)
+    stamp = build_stamp()
     stats = glob.glob(os.path.join(d, f"stats_{wl}_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(d, f"{tag}_{wl}_kernel_stats.csv"))
@@ -69,7 +81,7 @@ def main():
         launches = max(v[1] for v in per[k].values())
         fetch_kb, write_kb = c.get("FETCH_SIZE", 0.0), c.get("WRITE_SIZE", 0.0)
         hit, miss = c.get("TCC_HIT_sum", 0.0), c.get("TCC_MISS_sum", 0.0)
-        json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, "
+        json.dump({"build": stamp, "source": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, "
                              f"tools/profile_round.sh {tag} {wl}) -- python3 bench.py --steps 3 --no-cpu-baseline",
                    "kernel": k.replace("void rtrec::", "").replace("void ", "").replace(" ", ""), "launches_averaged": launches,
                    "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
@@ -79,7 +91,7 @@ def main():
                            "Infinity-Cache hits are counted, so this is an upper bound of DRAM traffic"},
                   open(os.path.join(d, f"{tag}_{wl}_pmc_traffic.json"), "w"), indent=1)
         wave_cyc = c.get("SQ_WAVE_CYCLES", 0.0)
-        json.dump({"kernel": k.replace("void rtrec::", "").replace("void ", "").replace(" ", ""), "launches_averaged": launches,
+        json.dump({"build": stamp, "kernel": k.replace("void rtrec::", "").replace("void ", "").replace(" ", ""), "launches_averaged": launches,
                    "per_launch": c,
                    "derived": {"valu_busy_frac_of_wave_cycles": c.get("SQ_ACTIVE_INST_VALU", 0.0) / wave_cyc if wave_cyc else None,
                                "wait_any_frac": c.get("SQ_WAIT_ANY", 0.0) / wave_cyc if wave_cyc else None,
@@ -100,7 +112,7 @@ def main():
                 "launches_averaged": max(v[1] for v in cs.values()), "per_launch": c,
                 "hbm_bytes_per_launch_corrected": int(fetch_kb * 1024 * 2 + write_kb * 1024),
                 "l2_hit_rate": hit / (hit + miss) if hit + miss else None}
-        json.dump(dict(out, note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); the fit's "
+        json.dump(dict(out, build=stamp, note="FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); the fit's "
                                  "residual gathers are 4-byte accesses, for which the counter is uncalibrated (+-2x on the read side)"),
                   open(os.path.join(d, f"{tag}_{wl}_fit_pmc.json"), "w"), indent=1)
     print("summaries:", sorted(f for f in os.listdir(d) if f.startswith(tag)))
