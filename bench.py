@@ -271,6 +271,71 @@ def structured_leg(args, top_k):
     return res
 
 
+def scale_leg(name, args, rank, world, local_rank, shard_auto):
+    """The same measurement as the main line on another BASELINE config, on ALL ranks: sharded exact fit, W merged on the
+    device, K timed all-users scoring steps between barriers (MAX over ranks).  bench.py --gpus N carries it for c4 -- the
+    1 M x 500k config `north_star` quotes its >= 6x at 8 GPUs on -- so that a scaling run records that shape next to the
+    ML-20M-shape headline."""
+    import torch
+    import torch.distributed as dist
+    from rtrec_amd import _native
+    from rtrec_amd.engine import SlimEngine
+    from rtrec_amd.synth import workload_matrix
+    wl = WORKLOADS[name]
+    U, I, K, top_k = wl["U"], wl["I"], wl["K"], args.top_k
+    t0 = time.time()
+    X = workload_matrix(wl, seed=20251003, float_ratings=True)
+    Xc = X.tocsc()
+    Xc.sort_indices()
+    gen_s = time.time() - t0
+    eng = SlimEngine(device=f"cuda:{local_rank}", rank=rank, world_size=world, tile_cols=args.tile_cols,
+                     score_shard=args.score_shard, shard_w=args.shard_w)
+    eng.set_interactions(Xc, X)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    mine = eng.owned_columns(np.arange(I))
+    d_tg, d_items, d_coef, d_count, n_iter = eng.fit_columns(mine, nn_feature_selection=K, device_out=True)
+    torch.cuda.synchronize()
+    fit_s = time.time() - t0
+    dw = eng.merge_fit(None, I, False, d_tg, d_items, d_coef, d_count)
+    if shard_auto:
+        eng.score_shard = "columns" if dw.nnz > (1 << 28) else "rows"
+    eng.set_weights(dw)
+    d_rows = eng.be.to_dev(np.arange(U, dtype=np.int32))
+    xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
+    step = lambda: eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
+    out = step()
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, fit_s], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt, fit_s = float(t[0].item()), float(t[1].item())
+    res = {"workload": f"{name}: {wl['desc']}", "n_users": U, "n_items": I, "nnz": int(X.nnz), "value": U * args.steps / dt, "unit": "users/s",
+           "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "fit_seconds": fit_s, "fit_interactions_per_sec": X.nnz / fit_s,
+           "score_shard": eng.score_shard if world > 1 else "single GPU", "score_path": eng.last_score_path, "W_nnz": int(dw.nnz),
+           "topk_ids_crc32": zlib.crc32(out[0].cpu().numpy().tobytes()), "generate_seconds": gen_s,
+           "note": "same protocol as the main line: barrier + synchronize on both sides of the K steps, MAX over ranks; ids CRC is the "
+                   "same for every --gpus N (the sharded pass returns the unsharded answer)"}
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,6 +363,9 @@ def main() -> None:
                     help="skip the `structured` leg of the default (c3) line: the same shape with item-item structure (c3s), "
                          "fit + all-users scoring through the general-W kernel")
     ap.add_argument("--no-api", action="store_true", help="skip the `api` leg (Recommender.bulk_fit / recommend_batch through the DataFrame API)")
+    ap.add_argument("--no-c4", action="store_true",
+                    help="skip the `c4` leg of the default (c3) line: BASELINE config 4's shape (1 M x 500k, 100 M interactions), "
+                         "sharded fit + all-users scoring at this --gpus N (about 45 s)")
     args = ap.parse_args()
     shard_auto = args.score_shard == "auto" and not args.shard_w
     if args.shard_w:
@@ -764,6 +832,18 @@ def main() -> None:
                    "note": "SURVEY 8d figure (8 B per gathered W entry); it prices W entries that never reach DRAM (W stays in L2 / LDS "
                            "and most of it is pruned), so where it exceeds the peak it is NOT a physical fraction of any hardware limit"}
 
+    # the config the multi-GPU target is quoted on, at this N, on every rank (before the ranks other than 0 leave)
+    c4_leg = None
+    if args.workload == "c3" and not args.no_c4:
+        try:
+            c4_leg = scale_leg("c4", args, rank, world, local_rank, shard_auto)
+            if rank == 0:
+                log(f"[bench] c4 leg: fit {c4_leg['fit_seconds']:.2f}s, score {c4_leg['ms_per_step']:.2f} ms/step "
+                    f"({c4_leg['value']:,.0f} users/s) over {c4_leg['score_shard']}")
+        except Exception as exc:          # (every rank fails or none: the leg has no rank-dependent branch before its first collective)
+            log(f"[bench] c4 leg failed on rank {rank}: {exc!r}")
+            c4_leg = {"error": repr(exc)}
+
     # same value for every --gpus N: the sharded path returns the unsharded answer
     topk_crc = zlib.crc32(out[0].cpu().numpy().tobytes()) if rank == 0 else 0
     if rank != 0:
@@ -828,6 +908,7 @@ def main() -> None:
                      "traffic_vs_compulsory": (traffic / compulsory_hbm if traffic else None),
                      "kernel_ms_avg": kern_ms, "launches": int(n_launch.value), "bounds": bounds,
                      "algorithmic": algorithmic, "counters": counters, "score_path": score_path},
+        "c4": c4_leg,
         "step_accounting": {"cold_step_ms": cold_step_ms, "row_order_ms": row_order_ms, "warm_ms_per_step": ms_per_step,
                             "note": "cold = the first pass after a new X / W: it builds the work order of the rows (an index of X for the "
                                     "layout in use: argsort by row length, or by feature-row pattern for the feature-row kernel), which the "

@@ -37,6 +37,8 @@ MAX_SLOTS = 4096   # 4 single-wave workgroups per SIMD; with Gram tracking the s
 GATHER_CHUNK_ROWS = 131072  # rows per exchange chunk of a column-sharded scoring call: a launch of the score kernel needs this
                             # many users to fill the chip a few times over (32k-row chunks: 6.4 ms per ML-20M pass against 2.6)
 MAX_GATHER_CHUNKS = 8
+ROW_CHUNK_ROWS = 49152     # least slots per exchange chunk of a row-sharded scoring call (each rank's launch per chunk): C4 at 8
+                           # ranks (125k slots per rank) runs as two chunks, the gather of the first beside the kernel of the second
 ALLF_OUTPUT_CAP = 2048      # coefficients per target the K=None output block holds before a refit with cap = I
 GRAM_ITEMS = 512            # most popular items whose pairwise dot products the fit kernel may look up
 FIT_SCRATCH_GIB = 16.0      # total per-slot scratch of a bulk fit is kept near this (see fit_columns)
@@ -128,6 +130,7 @@ class SlimEngine:
         self._fit_ws: Dict[Tuple[int, int, int, int], Any] = {}
         self._score_ws = None
         self.gather_chunk_rows = GATHER_CHUNK_ROWS
+        self.row_chunk_rows = ROW_CHUNK_ROWS
         self.last_fit_stats: Dict[str, Any] = {}
         self.score_timer = 0          # rtrec_timer handle (HipBackend.timer_create) bracketing the dominant score kernel
         self.use_feature_rows = settings.raw("RTREC_AMD_FEATURE_ROWS", "1") != "0"     # A/B switch of the score kernel
@@ -1400,22 +1403,54 @@ class SlimEngine:
                 slices.clear()
             slices.append((d_rows, d_rows._version, (n_rows, self.rank, G), mine))
         m = int(mine.shape[0])
-        # every rank's (ids | scores | counts) buffer, laid out for q rows, is gathered as it is; rows a short slice does
-        # not have (global row index >= n_rows) are cut off below, so their slots may hold anything
-        width = (2 * k + 1) * q
-        if m > 0:
-            ids, sc, sc64, aux, cnt = self._local_topk(mine, m, xb, k, filter_interacted, mode, d_rank, pad_rows=q)
-            fin = ids._base if ids._base is not None else ids          # the flat buffer the three are views of
-            fin = fin.reshape(-1)
+        # Slots (rows of a rank's slice) are cut into chunks so that the all-gather of chunk c (RCCL, asynchronous) runs
+        # beside the kernel of chunk c + 1 -- the same overlap the column path has; one blocking gather after the whole
+        # local pass used to stand behind the kernel (C4 at 8 ranks: 73.5 MB received per rank after a 0.6 ms kernel,
+        # VERDICT round 4).  A chunk keeps at least row_chunk_rows slots: a launch must still fill the chip.
+        per = max(1, int(self.row_chunk_rows))
+        n_chunks = max(1, min(MAX_GATHER_CHUNKS, q // per))
+        bounds = [q * c // n_chunks for c in range(n_chunks + 1)]
+        chunk_rows = None                    # this rank's row tensors per chunk: kept with the slice (their work orders are cached by identity)
+        for ent in slices:
+            if ent[3] is mine and len(ent) > 4 and ent[4][0] == bounds:
+                chunk_rows = ent[4][1]
+        if chunk_rows is None:
+            chunk_rows = [mine[min(bounds[c], m):min(bounds[c + 1], m)] if n_chunks > 1 else mine for c in range(n_chunks)]
+            for i_, ent in enumerate(slices):
+                if ent[3] is mine:
+                    slices[i_] = ent[:4] + ((bounds, chunk_rows),)
+        pending = []
+        for c in range(n_chunks):
+            qc = bounds[c + 1] - bounds[c]
+            rows_c = chunk_rows[c]
+            mc = int(rows_c.shape[0])
+            # every rank's (ids | scores | counts) buffer, laid out for qc slots, is gathered as it is; slots a short slice does
+            # not have (global row index >= n_rows) are cut off below, so they may hold anything
+            width = (2 * k + 1) * qc
+            if mc > 0:
+                ids, sc, sc64, aux, cnt = self._local_topk(rows_c, mc, xb, k, filter_interacted, mode, d_rank, pad_rows=qc)
+                fin = ids._base if ids._base is not None else ids          # the flat buffer the three are views of
+                fin = fin.reshape(-1)
+            else:
+                fin = be.empty((width,), torch.int32)
+            out = be.empty((G * width,), torch.int32)
+            work = dist.all_gather_into_tensor(out, fin, group=self.group, async_op=(n_chunks > 1))
+            pending.append((qc, out, fin, work))
+        o_ids_p, o_sc_p, o_cnt_p = [], [], []
+        for qc, out, fin, work in pending:
+            if work is not None:
+                work.wait()
+            out = out.view(G, (2 * k + 1) * qc)
+            # slot i of rank p <- row i*G + p of the batch: [slot, rank] order is the batch order
+            o_ids_p.append(out[:, :qc * k].view(G, qc, k).transpose(0, 1).reshape(G * qc, k))
+            o_sc_p.append(out[:, qc * k:2 * qc * k].view(G, qc, k).transpose(0, 1).reshape(G * qc, k))
+            o_cnt_p.append(out[:, 2 * qc * k:].t().reshape(G * qc))
+        if n_chunks == 1:
+            o_ids, o_sc, o_cnt = o_ids_p[0][:n_rows], o_sc_p[0][:n_rows].view(torch.float32), o_cnt_p[0][:n_rows]
         else:
-            fin = be.empty((width,), torch.int32)
-        out = be.empty((G * width,), torch.int32)
-        dist.all_gather_into_tensor(out, fin, group=self.group)
-        out = out.view(G, width)
-        # row i*G + p of the batch <- rank p, slot i
-        o_ids = out[:, :q * k].view(G, q, k).transpose(0, 1).reshape(G * q, k)[:n_rows]
-        o_sc = out[:, q * k:2 * q * k].view(G, q, k).transpose(0, 1).reshape(G * q, k)[:n_rows].view(torch.float32)
-        o_cnt = out[:, 2 * q * k:].t().reshape(G * q)[:n_rows]
+            o_ids = torch.cat(o_ids_p)[:n_rows]
+            o_sc = torch.cat(o_sc_p)[:n_rows].view(torch.float32)
+            o_cnt = torch.cat(o_cnt_p)[:n_rows]
         return o_ids, o_sc, o_cnt
 
     MAX_TOP_K = 1023            # kMaxTopK of csrc/score.hip

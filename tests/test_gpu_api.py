@@ -328,7 +328,7 @@ X, users = load("X2").tocsr(), zs["users"].tolist()
 for mode in ("columns", "rows"):
     eng = SlimEngine(device="cuda:0", rank=0, world_size=1, score_shard=mode)
     eng.force_exchange = True
-    eng.gather_chunk_rows = 7                       # several chunks: several asynchronous exchanges in flight
+    eng.row_chunk_rows = eng.gather_chunk_rows = 7                       # several chunks: several asynchronous exchanges in flight
     m = SLIMElastic({"nn_feature_selection": 50}, engine=eng)
     for dtype, tag in ((np.float32, "f32"), (np.float64, "f64")):
         m.item_similarity = sp.csc_matrix(load("W2_k50"), dtype=dtype)

@@ -196,7 +196,8 @@ def _worker(rank, world, port, q, score_shard="columns"):
         shard_w = score_shard == "columns+w"        # W stays column-sharded: no all-gather of the coefficients
         score_shard = "columns" if shard_w else score_shard
         eng = SlimEngine(backend=OracleBackend(), rank=rank, world_size=world, score_shard=score_shard, shard_w=shard_w)
-        eng.gather_chunk_rows = 7          # several chunks -> several asynchronous all-gathers in flight
+        eng.gather_chunk_rows = 7          # several chunks -> several asynchronous exchanges in flight (column path) ...
+        eng.row_chunk_rows = 3             # ... and several overlapped all-gathers of a rank's row slice (row path), also at world 8
         m = SLIMElastic({"nn_feature_selection": 50}, engine=eng)
         m.partial_fit_items(X.copy(), list(range(400)))            # each rank fits its own column shard
         if shard_w:                        # this rank holds its own column block and nothing else ...

@@ -12,7 +12,7 @@ mkdir -p $O
 cd $R
 python3 bench.py --workload $WL > $O/bench_$WL.json 2> $O/bench_$WL.log
 echo "bench rc=$?"
-rocprofv3 --kernel-trace --stats -d $O -o stats_$WL --output-format csv -- python3 bench.py --workload $WL --no-cpu-baseline --no-api --no-structured --stream-batches 0 > $O/bench_${WL}_under_rocprof.json 2> $O/rocprof_stats.log
+rocprofv3 --kernel-trace --stats -d $O -o stats_$WL --output-format csv -- python3 bench.py --workload $WL --no-cpu-baseline --no-api --no-structured --no-c4 --stream-batches 0 > $O/bench_${WL}_under_rocprof.json 2> $O/rocprof_stats.log
 echo "stats rc=$?"
 i=0
 for C in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
@@ -21,7 +21,7 @@ for C in "FETCH_SIZE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD" \
          "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_REQ_sum TCC_READ_sum"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O -o pmc${i}_$WL --output-format csv -- python3 bench.py --workload $WL --steps 3 --no-cpu-baseline --no-fast-fit --stream-batches 0 --no-api --no-structured > /dev/null 2> $O/rocprof_pmc$i.log
+  timeout 600 rocprofv3 --pmc $C --kernel-trace -d $O -o pmc${i}_$WL --output-format csv -- python3 bench.py --workload $WL --steps 3 --no-cpu-baseline --no-fast-fit --stream-batches 0 --no-api --no-structured --no-c4 > /dev/null 2> $O/rocprof_pmc$i.log
   echo "pmc pass $i rc=$?"
 done
 python3 tools/pmc_round_summary.py $O $TAG $WL
