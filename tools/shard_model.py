@@ -95,13 +95,36 @@ def main() -> None:
                 e._local_topk(d_slice, m, xb, k, True, _native.TOPK_SPARSE, None)
             torch.cuda.synchronize()
             rows_ms.append((time.perf_counter() - t0) / args.steps * 1e3)
-        print(json.dumps({"world": N, "column_shards": {"local_ms_max": worst, "local_ms_min": min(per_rank),
-                                                         "speedup_vs_1": base / worst, "bytes_received_per_rank": exch_bytes},
-                          "row_shards": {"local_ms_max": max(rows_ms), "speedup_vs_1": base / max(rows_ms),
-                                         "bytes_received_per_rank": (N - 1) * q * (k * 8 + 4)},
-                          "users_per_s_compute_only": {"columns": U / (worst * 1e-3), "rows": U / (max(rows_ms) * 1e-3)}}),
-              flush=True)
+        # The exchange, priced for a stated range of achieved all-gather / all-to-all rates (bytes RECEIVED per rank per second
+        # over xGMI: 7 links x ~153 GB/s peak per GPU; RCCL's ring forms are per-link bound, so 100-400 GB/s brackets what
+        # messages of this size reach) plus a fixed cost per collective.  `serial`: the whole exchange after the whole local pass
+        # (round 4's row path); `overlapped`: the pass cut into C chunks whose exchanges run beside the next chunk's kernel
+        # (both paths now): max(local, exchange) + min(local, exchange) / C.
+        from rtrec_amd.engine import GATHER_CHUNK_ROWS, MAX_GATHER_CHUNKS, ROW_CHUNK_ROWS
+        row_bytes = (N - 1) * q * (k * 8 + 4)
+        c_rows = max(1, min(MAX_GATHER_CHUNKS, q // ROW_CHUNK_ROWS))
+        c_cols = max(1, min(MAX_GATHER_CHUNKS, (U + GATHER_CHUNK_ROWS // 2) // GATHER_CHUNK_ROWS))
+        lat_ms = 0.04                                  # launch + handshake of one collective
 
+        def priced(local_ms, nbytes, n_coll, chunks):
+            out = {}
+            for bw in (100.0, 200.0, 400.0):
+                ex = 0.0 if N == 1 else nbytes / (bw * 1e9) * 1e3 + lat_ms * n_coll * chunks
+                serial = local_ms + ex
+                over = max(local_ms, ex) + min(local_ms, ex) / chunks
+                out[f"{int(bw)}GBps"] = {"exchange_ms": ex, "step_ms_serial": serial, "speedup_serial": base / serial,
+                                         "step_ms_overlapped": over, "speedup_overlapped": base / over}
+            return out
+        print(json.dumps({"world": N, "column_shards": {"local_ms_max": worst, "local_ms_min": min(per_rank),
+                                                         "speedup_vs_1": base / worst, "bytes_received_per_rank": exch_bytes,
+                                                         "chunks": c_cols, "with_exchange": priced(worst, exch_bytes, 2, c_cols)},
+                          "row_shards": {"local_ms_max": max(rows_ms), "speedup_vs_1": base / max(rows_ms),
+                                         "bytes_received_per_rank": row_bytes, "chunks": c_rows,
+                                         "with_exchange": priced(max(rows_ms), row_bytes, 1, c_rows)},
+                          "users_per_s_compute_only": {"columns": U / (worst * 1e-3), "rows": U / (max(rows_ms) * 1e-3)},
+                          "note": "speedup_vs_1 is compute only (slowest rank's kernel); with_exchange adds the collective at an ASSUMED "
+                                  "rate -- no multi-GPU hardware run exists for this repository"}),
+              flush=True)
 
 if __name__ == "__main__":
     main()
