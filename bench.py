@@ -305,7 +305,8 @@ def scale_leg(name, args, rank, world, local_rank, shard_auto):
     eng.set_weights(dw)
     d_rows = eng.be.to_dev(np.arange(U, dtype=np.int32))
     xb = (eng._X["rptr"], eng._X["rcol"], eng._X["rval"])
-    step = lambda: eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
+    step = lambda: eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb,
+                                         with_scores=(world == 1 or args.exchange_scores))
     out = step()
     for _ in range(max(args.warmup, 1)):
         out = step()
@@ -363,6 +364,8 @@ def main() -> None:
                     help="skip the `structured` leg of the default (c3) line: the same shape with item-item structure (c3s), "
                          "fit + all-users scoring through the general-W kernel")
     ap.add_argument("--no-api", action="store_true", help="skip the `api` leg (Recommender.bulk_fit / recommend_batch through the DataFrame API)")
+    ap.add_argument("--exchange-scores", action="store_true",
+                    help="several ranks, user-row shards: all-gather the float32 scores with the ids (84 instead of 44 bytes per user)")
     ap.add_argument("--no-c4", action="store_true",
                     help="skip the `c4` leg of the default (c3) line: BASELINE config 4's shape (1 M x 500k, 100 M interactions), "
                          "sharded fit + all-users scoring at this --gpus N (about 45 s)")
@@ -557,7 +560,10 @@ def main() -> None:
         # -- local top-k per column shard in row chunks, an all-to-all of the per-shard lists per chunk
         # overlapped with the next chunk's kernel, strided merge of this rank's slice, all-gather of the
         # final lists; or, with --score-shard rows, this rank's slice of the users against all of W.
-        return eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb)
+        # (several ranks, user-row shards: ids + counts travel, 44 B per user -- recommend_batch hands out item ids; with
+        # --exchange-scores the float32 scores travel too, 84 B per user)
+        return eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb,
+                                     with_scores=(world == 1 or args.exchange_scores))
 
     # Honest step accounting: the first pass after a new X / W pays for the work order of the rows
     # (SlimEngine._row_order: an index of X for the layout in use, cached afterwards) -- timed here on its own and as
@@ -624,6 +630,8 @@ def main() -> None:
     ms_per_step = dt / args.steps * 1e3
     value = U * args.steps / dt
     crc_main = zlib.crc32(out[0].cpu().numpy().tobytes())
+    if out[1] is None:          # the timed exchange carried ids + counts only: the bookkeeping below reads the scores too
+        out = eng.score_topk_device(None, U, top_k, True, _native.TOPK_SPARSE, d_rows=d_rows, xb=xb, with_scores=True)
 
     # the other way of dividing the scoring pass over the ranks, timed the same way (K steps, barrier + synchronize on both
     # sides, max over ranks) right after the pass of record; the answers must agree
@@ -886,7 +894,10 @@ def main() -> None:
                    "w_rows": (fr["fr_rows"] if fr is not None else (int(lay["sg"]["sg_rows"]) if lay.get("sg") else None)),
                    "score_layout": ("feature rows" if fr is not None else "segments" if lay.get("sg") else "tiled CSR"),
                    "parallelism": ("single GPU" if world == 1 else f"item-column shard x{world}" if args.score_shard == "columns"
-                                   else f"user-row shard x{world}, W replicated")},
+                                   else f"user-row shard x{world}, W replicated"),
+                   "exchange": (None if world == 1 else "per-shard records, all-to-all + all-gather of the final lists" if args.score_shard == "columns"
+                                else ("ids + scores + counts, 84 B per user" if args.exchange_scores else "ids + counts, 44 B per user") +
+                                f", all-gather in chunks of >= {eng.row_chunk_rows} slots per rank overlapped with the next chunk's kernel")},
         "ranks_seen": ranks_seen, "rank_devices": rank_devices, "backend": backend, "alt_sharding": alt_sharding,
         "score_shard_choice": dict(shard_choice, w_column_sharded=bool(args.shard_w)),
         "pcie_inclusive_users_per_sec": pcie_users_per_s, "topk_ids_crc32": topk_crc, "rows_rescored_by_exact_tie_pass": n_rescored,

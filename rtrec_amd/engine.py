@@ -1277,7 +1277,7 @@ class SlimEngine:
 
     def score_topk_device(self, row_ids: Optional[np.ndarray], n_rows: int, top_k: int, filter_interacted: bool,
                           mode: int, col_rank: Optional[np.ndarray] = None, xb=None, d_rows=None, host: bool = False,
-                          candidates: Optional[np.ndarray] = None):
+                          candidates: Optional[np.ndarray] = None, with_scores: bool = True):
         """Device tensors (ids, scores, counts) of the GLOBAL top-k for the given rows of X
         (or of the CSR batch `xb` = (ptr, col, val) device tensors).  `d_rows` may pass the row ids
         as a device tensor that is already resident (bench.py reuses it across steps).
@@ -1289,7 +1289,9 @@ class SlimEngine:
         (B/G * 124 B from each peer instead of all B * 124 B of an all-gather), merge_topk_kernel merges
         that slice in place through strides, and only the final k-lists (84 B per user) are all-gathered.
         Rows are processed in chunks whose exchanges (RCCL, asynchronous on its own stream) overlap the
-        scoring kernel of the next chunk."""
+        scoring kernel of the next chunk.
+        with_scores=False (row shards): only ids and counts travel -- what `recommend_batch` returns (the reference hands out
+        item ids, base.py:188-269) -- 44 instead of 84 bytes per user at k = 10; the score tensor is then None."""
         be = self.be
         if not self._W:
             raise RuntimeError("Model must be fitted before calling batch_recommend.")
@@ -1316,7 +1318,7 @@ class SlimEngine:
         if d_rows is None:
             d_rows = torch.arange(n_rows, dtype=torch.int32, device=xb[0].device)
         if self.score_shard == "rows":
-            return self._score_row_sharded(d_rows, n_rows, xb, k, filter_interacted, mode, d_rank)
+            return self._score_row_sharded(d_rows, n_rows, xb, k, filter_interacted, mode, d_rank, with_scores)
         # chunks exist so that one chunk's exchange overlaps the next chunk's kernel; a chunk must still be large enough to
         # fill the chip (GATHER_CHUNK_ROWS), so passes of up to ~200k rows are one chunk
         per = max(1, int(self.gather_chunk_rows))
@@ -1379,7 +1381,8 @@ class SlimEngine:
             o_cnt[a:b] = out[:m, 2 * k]
         return o_ids, o_scs, o_cnt
 
-    def _score_row_sharded(self, d_rows, n_rows: int, xb, k: int, filter_interacted: bool, mode: int, d_rank):
+    def _score_row_sharded(self, d_rows, n_rows: int, xb, k: int, filter_interacted: bool, mode: int, d_rank,
+                           with_scores: bool = True):
         """score_shard == "rows": this rank scores rows r, r+G, r+2G, ... of the batch (strided, so that
         every rank gets the same mix of heavy and light users whatever their order) against the whole W
         -- no merge step: its lists are final -- and the final records [k scores | k ids | count] of all
@@ -1433,24 +1436,34 @@ class SlimEngine:
                 fin = fin.reshape(-1)
             else:
                 fin = be.empty((width,), torch.int32)
-            out = be.empty((G * width,), torch.int32)
-            work = dist.all_gather_into_tensor(out, fin, group=self.group, async_op=(n_chunks > 1))
-            pending.append((qc, out, fin, work))
+            if with_scores:
+                out = be.empty((G * width,), torch.int32)
+                work = dist.all_gather_into_tensor(out, fin, group=self.group, async_op=(n_chunks > 1))
+                pending.append((qc, out, None, fin, (work,)))
+            else:           # ids and counts only: two contiguous pieces of the same buffer, two collectives
+                out_i, out_c = be.empty((G * qc * k,), torch.int32), be.empty((G * qc,), torch.int32)
+                w1 = dist.all_gather_into_tensor(out_i, fin[:qc * k], group=self.group, async_op=(n_chunks > 1))
+                w2 = dist.all_gather_into_tensor(out_c, fin[2 * qc * k:2 * qc * k + qc], group=self.group, async_op=(n_chunks > 1))
+                pending.append((qc, out_i, out_c, fin, (w1, w2)))
         o_ids_p, o_sc_p, o_cnt_p = [], [], []
-        for qc, out, fin, work in pending:
-            if work is not None:
-                work.wait()
-            out = out.view(G, (2 * k + 1) * qc)
+        for qc, out, out_c, fin, works in pending:
+            for work in works:
+                if work is not None:
+                    work.wait()
             # slot i of rank p <- row i*G + p of the batch: [slot, rank] order is the batch order
-            o_ids_p.append(out[:, :qc * k].view(G, qc, k).transpose(0, 1).reshape(G * qc, k))
-            o_sc_p.append(out[:, qc * k:2 * qc * k].view(G, qc, k).transpose(0, 1).reshape(G * qc, k))
-            o_cnt_p.append(out[:, 2 * qc * k:].t().reshape(G * qc))
-        if n_chunks == 1:
-            o_ids, o_sc, o_cnt = o_ids_p[0][:n_rows], o_sc_p[0][:n_rows].view(torch.float32), o_cnt_p[0][:n_rows]
-        else:
-            o_ids = torch.cat(o_ids_p)[:n_rows]
-            o_sc = torch.cat(o_sc_p)[:n_rows].view(torch.float32)
-            o_cnt = torch.cat(o_cnt_p)[:n_rows]
+            if with_scores:
+                out = out.view(G, (2 * k + 1) * qc)
+                o_ids_p.append(out[:, :qc * k].view(G, qc, k).transpose(0, 1).reshape(G * qc, k))
+                o_sc_p.append(out[:, qc * k:2 * qc * k].view(G, qc, k).transpose(0, 1).reshape(G * qc, k))
+                o_cnt_p.append(out[:, 2 * qc * k:].t().reshape(G * qc))
+            else:
+                o_ids_p.append(out.view(G, qc, k).transpose(0, 1).reshape(G * qc, k))
+                o_cnt_p.append(out_c.view(G, qc).t().reshape(G * qc))
+        o_ids = (o_ids_p[0] if n_chunks == 1 else torch.cat(o_ids_p))[:n_rows]
+        o_cnt = (o_cnt_p[0] if n_chunks == 1 else torch.cat(o_cnt_p))[:n_rows]
+        o_sc = None
+        if with_scores:
+            o_sc = (o_sc_p[0] if n_chunks == 1 else torch.cat(o_sc_p))[:n_rows].view(torch.float32)
         return o_ids, o_sc, o_cnt
 
     MAX_TOP_K = 1023            # kMaxTopK of csrc/score.hip

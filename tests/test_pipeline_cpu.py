@@ -236,6 +236,13 @@ def _worker(rank, world, port, q, score_shard="columns"):
         for rows in ([5, 17, 40, 41, 300], [9, 3, 77, 78, 1100], [5, 17, 40, 41, 300], [1, 2, 3, 4, 6]):
             got, ref = eng.recommend_rows(rows, top_k=5), solo.recommend_rows(rows, top_k=5)
             ok = ok and all(np.array_equal(a, b) for a, b in zip(got, ref))
+        if score_shard == "rows":
+            # ids and counts only (what recommend_batch hands out): two collectives per chunk, no score tensor
+            from rtrec_amd import _native as nat
+            rows_ = np.arange(0, 1200, 7, dtype=np.int32)
+            got = eng.score_topk_device(rows_, len(rows_), 5, True, nat.TOPK_SPARSE, with_scores=False)
+            ref = solo.recommend_rows(rows_, top_k=5)
+            ok = ok and got[1] is None and np.array_equal(np.asarray(got[0]), ref[0]) and np.array_equal(np.asarray(got[2]), ref[2])
         if world <= 3 and score_shard == "columns":
             # exact score ties ACROSS column shards (the second half of W's columns are copies of the first, integer ratings):
             # neither shard sees a tie, the reference's tie key has to travel with every entry (round 4)
