@@ -27,6 +27,7 @@ from . import _native
 from . import settings
 # (round 4: the layout builders and the backend live in modules of their own; the names stay importable from here)
 from .backend import DeviceWeights, HipBackend, FIT_MW_MAX_TARGETS, XTY_SCRATCH_MAX_BYTES  # noqa: F401
+from . import score_plan
 from .layouts import (TiledW, build_tiled_w, row_header_table, build_feature_rows, build_feature_rows_device,  # noqa: F401
                       build_tiled_w_device, _heavy_tiles_first, _pack_fragments, FR_MAX_ROWS, FR_MIN_FILL,
                       FR_TILE_HEADER_BYTES, FR_STREAM_BUF_BYTES)
@@ -1008,57 +1009,50 @@ class SlimEngine:
         sc64 = be.empty((n_rows, top_k), torch.float64) if W["acc_f64"] else None
         sparse = mode == _native.TOPK_SPARSE
         hip = isinstance(be, HipBackend)
-        # SPARSE mode, float32 W: the fast form of the shard (feature rows / segments).  The tiled layout is then needed only
-        # for the rows whose fast-pass list holds an exact score tie (the exact-tie pass orders those like the reference):
-        # with lazy_tiled it is built when a call first flags such a row -- after a mini-batch the first recommend builds one
-        # layout, not two -- at the price of reading one counter back per call while it does not exist.
-        # DENSE mode (string ids: every column competes, slim_elastic.py:745-778) takes the same fast pass when this rank holds
-        # all of W's columns: a row whose leading top_k scores are all positive is final (positives outrank every zero-score
-        # column, zeros outrank negatives); the kernel flags the others, and every tie (DENSE orders ties by item id), for the
-        # tiled DENSE kernel below.
-        # (a COLUMN SHARD flags nearly every row -- a user's positive scores sit in a few shards -- so it takes the fast pass
-        # only when the flagged rows can be completed in place: rtrec_slim_dense_fill, positive weights and ratings)
-        full_range = W.get("col_lo", 0) == 0 and W.get("col_hi", 0) == W["n_items"]
-        dense_fill = bool(mode == _native.TOPK_DENSE and hip and self.dense_fast and self.dense_fill and self.lazy_tiled
-                          and not W["acc_f64"] and top_k <= 63 and self._dense_fill_ok(xb))
-        dense_fast = bool(mode == _native.TOPK_DENSE and hip and self.dense_fast and self.lazy_tiled
-                          and (not W["acc_f64"] or self._f64_refine_w_ok())
-                          and (full_range or dense_fill))
+        # Which kernels serve this call is decided by two pure functions (rtrec_amd/score_plan.py; table-tested on the CPU):
+        #   SPARSE mode, float32 W: the fast form of the shard (feature rows / segments).  The tiled layout is then needed only
+        #   for the rows whose fast-pass list holds an exact score tie (the exact-tie pass orders those like the reference): with
+        #   lazy_tiled it is built when a call first flags such a row -- after a mini-batch the first recommend builds one
+        #   layout, not two -- at the price of reading one counter back per call while it does not exist.
+        #   DENSE mode (string ids: every column competes, slim_elastic.py:745-778) takes the same fast pass when this rank holds
+        #   all of W's columns: a row whose leading top_k scores are all positive is final (positives outrank every zero-score
+        #   column, zeros outrank negatives); the kernel flags the others, and every tie (DENSE orders ties by item id), for the
+        #   tiled DENSE kernel below.  (A COLUMN SHARD flags nearly every row -- a user's positive scores sit in a few shards --
+        #   so it takes the fast pass only when the flagged rows can be completed in place: rtrec_slim_dense_fill.)
+        #   float64 W (serial fit): the float32 fast pass for top_k + 1 columns, then the candidates' float64 scores
+        #   (rtrec_slim_refine_topk_f64) -- W and X all positive, or (SPARSE) signed with an absolute per-user slack; otherwise
+        #   the float64 tiled kernel.
+        facts = score_plan.ScoreFacts(
+            mode=mode, hip=hip, acc_f64=bool(W["acc_f64"]), top_k=top_k, n_rows=n_rows,
+            full_range=(W.get("col_lo", 0) == 0 and W.get("col_hi", 0) == W["n_items"]),
+            nonempty_shard=(W.get("col_hi", 0) > W.get("col_lo", 0)),
+            dense_fast_on=bool(self.dense_fast), dense_fill_on=bool(self.dense_fill), lazy_tiled=bool(self.lazy_tiled),
+            feature_rows_on=bool(self.use_feature_rows), seg_layout_on=bool(self.use_seg_layout),
+            seg_supported=bool(getattr(be, "supports_seg_layout", False)),
+            dense_fill_ok=lambda: self._dense_fill_ok(xb), f64_w_ok=self._f64_refine_w_ok,
+            f64_x_ok=lambda: self._f64_refine_x_ok(xb), f64_refine_mode=self._f64_refine_mode,
+            limits=score_plan.Limits(self.FR_SMALL_BATCH, self.FR_MIN_ROWS, self.FR_MAX_TOP_K, self.SG_MAX_TOP_K))
+        req = score_plan.plan_fast_layout(facts)
         fast = None
-        if (sparse or dense_fast) and hip and self._W.get("col_hi", 0) > self._W.get("col_lo", 0):
-            # (a float64 W asks its fast pass for one column more: see f64_fast below)
-            k_need = top_k + 1 if (W["acc_f64"] and (self._f64_refine_w_ok() or (sparse and self._f64_refine_mode() == 2))) else top_k
+        if req.want:
             # the segment form: request-sized batches, and any batch whose top_k the feature-row kernel's lists do not hold
-            small = ((n_rows < self.FR_SMALL_BATCH or k_need > self.FR_MAX_TOP_K) and self.use_seg_layout
-                     and k_need <= self.SG_MAX_TOP_K and getattr(be, "supports_seg_layout", False))
-            fast = self._small_batch_layout() if small else self._fast_layout()
-        # float64 W (serial fit): the float32 fast pass for top_k + 1 columns, then the candidates' float64 scores
-        # (rtrec_slim_refine_topk_f64) -- when W and X are all positive; otherwise the float64 tiled kernel as before
-        f64_fast = bool((sparse or dense_fast) and hip and W["acc_f64"] and fast is not None and self.lazy_tiled
-                        and self._f64_refine_w_ok() and self._f64_refine_x_ok(xb))
-        # signed weights or ratings (SPARSE mode): the refine step with an absolute per-user slack instead of the sign argument
-        f64_signed = bool(not f64_fast and sparse and hip and W["acc_f64"] and fast is not None and self.lazy_tiled
-                          and self._f64_refine_mode() != 0)
-        f64_fast = f64_fast or f64_signed
-        if W["acc_f64"] and not f64_fast:
-            fast = None
-        k_fast = top_k + 1 if f64_fast else top_k
-        use_fr = bool(fast is not None and self.use_feature_rows and fast.get("fr_w") is not None and n_rows >= self.FR_MIN_ROWS
-                      and k_fast <= self.FR_MAX_TOP_K)
-        use_sg = bool(fast is not None and not use_fr and self.use_seg_layout and fast.get("sg") is not None
-                      and k_fast <= self.SG_MAX_TOP_K)
-        if f64_fast and (use_fr or use_sg):
-            return self._local_topk_f64(d_row_ids, n_rows, xb, top_k, filter_interacted, d_col_rank, fast, use_fr, use_sg,
-                                        ids, sc, sc64, aux, cnt, mode, signed=f64_signed)
+            fast = self._small_batch_layout() if req.small else self._fast_layout()
         tiled_key = (sparse, self._tile_width(sparse, top_k))
-        if hip and (use_fr or use_sg) and self.lazy_tiled and (dense_fast or tiled_key not in W["layouts"]):
+        plan = score_plan.choose_path(facts, req, has_fr=bool(fast is not None and fast.get("fr_w") is not None),
+                                      has_sg=bool(fast is not None and fast.get("sg") is not None),
+                                      tiled_exists=tiled_key in W["layouts"])
+        use_fr, use_sg, dense_fast = plan.use_fr, plan.use_sg, req.dense_fast
+        if plan.path is score_plan.Path.FAST_F64:
+            return self._local_topk_f64(d_row_ids, n_rows, xb, top_k, filter_interacted, d_col_rank, fast, use_fr, use_sg,
+                                        ids, sc, sc64, aux, cnt, mode, signed=plan.f64_signed)
+        if plan.path is score_plan.Path.FAST and plan.lazy:
             need = be.score_workspace_bytes(n_rows, 1, top_k)
             if self._score_ws is None or self._score_ws.numel() < need:
                 self._score_ws = be.empty((need,), torch.uint8)
             order = self._row_order(d_row_ids, n_rows, xb, fast, allow_grouped=use_fr)
             self.last_score_path = "feature_rows" if use_fr else "segments"
             flagged = pack[2 * nk + cap:] if flag_words else be.empty((n_rows + 1,), torch.int32)
-            fill = dense_fast and dense_fill
+            fill = plan.fill
             flagged_fast = be.empty((n_rows + 1,), torch.int32) if fill else flagged
             be.score_topk(n_rows, d_row_ids, xb, W["n_items"], W["col_lo"], fast, d_col_rank, top_k, filter_interacted,
                           mode, False, ids, sc, None, aux, cnt, self._score_ws, timer=self.score_timer,

@@ -1004,3 +1004,127 @@ def test_bench_attaches_a_profile_summary_only_for_the_build_it_times(tmp_path):
     from rtrec_amd import build
     f = build.fingerprint()
     assert f["lib_sha256"] == build._sha256(build.LIB_PATH)
+
+
+# ---- the scoring dispatch as pure functions (rtrec_amd/score_plan.py): explicit table + invariants over the cross product ----
+def _facts(**kw):
+    from rtrec_amd import score_plan as sp_
+    d = dict(mode=sp_.TOPK_SPARSE, hip=True, acc_f64=False, top_k=10, n_rows=100_000, full_range=True, nonempty_shard=True,
+             dense_fast_on=True, dense_fill_on=True, lazy_tiled=True, feature_rows_on=True, seg_layout_on=True, seg_supported=True,
+             dense_fill_ok=lambda: True, f64_w_ok=lambda: True, f64_x_ok=lambda: True, f64_refine_mode=lambda: 1)
+    for k in ("dense_fill_ok", "f64_w_ok", "f64_x_ok", "f64_refine_mode"):
+        if k in kw and not callable(kw[k]):
+            v = kw[k]
+            kw[k] = (lambda v=v: v)
+    d.update(kw)
+    return sp_.ScoreFacts(**d)
+
+
+def _plan(has_fr=True, has_sg=False, tiled=False, **kw):
+    from rtrec_amd import score_plan as sp_
+    f = _facts(**kw)
+    req = sp_.plan_fast_layout(f)
+    got_fr, got_sg = (has_fr, has_sg) if req.want else (False, False)
+    if req.want and req.small:          # the request-sized form is the segment form
+        got_fr, got_sg = False, True
+    return req, sp_.choose_path(f, req, got_fr, got_sg, tiled)
+
+
+def test_score_plan_explicit_table():
+    """One row per situation the engine documents: (inputs) -> (path, kernel, list length, flags)."""
+    from rtrec_amd.score_plan import Path, TOPK_CANDIDATES as C, TOPK_DENSE as D, TOPK_SPARSE as S
+    T = [
+        # --- SPARSE, float32 W
+        (dict(), dict(), (Path.FAST, "feature_rows", 10, True)),                                  # bulk pass, feature-row W, tiled layout not built
+        (dict(), dict(tiled=True), (Path.FAST, "feature_rows", 10, False)),                        # ... tiled layout at hand: one launch, tie pass inside
+        (dict(), dict(has_fr=False, has_sg=True), (Path.FAST, "segments", 10, True)),              # general W: segments
+        (dict(n_rows=100), dict(), (Path.FAST, "segments", 10, True)),                             # request-sized batch: segment form even of a feature-row W
+        (dict(top_k=20), dict(), (Path.FAST, "segments", 20, True)),                               # top_k beyond the feature-row lists
+        (dict(top_k=100), dict(), (Path.TILED, "tiled", 100, False)),                              # beyond both fast kernels
+        (dict(top_k=20, seg_layout_on=False), dict(), (Path.TILED, "tiled", 20, False)),
+        (dict(feature_rows_on=False), dict(has_fr=True, has_sg=False), (Path.TILED, "tiled", 10, False)),
+        (dict(hip=False), dict(), (Path.TILED, "tiled", 10, False)),                               # the CPU stand-in backend
+        (dict(nonempty_shard=False), dict(), (Path.TILED, "tiled", 10, False)),                    # an empty column shard
+        (dict(lazy_tiled=False), dict(), (Path.FAST, "feature_rows", 10, False)),                  # laziness off: tiled layout built with W
+        (dict(full_range=False), dict(), (Path.FAST, "feature_rows", 10, True)),                   # SPARSE on a column shard is fine
+        # --- SPARSE, float64 W
+        (dict(acc_f64=True), dict(), (Path.FAST_F64, "feature_rows", 11, True)),                   # positive W and X: fast pass for k + 1, refine
+        (dict(acc_f64=True, f64_x_ok=False, f64_refine_mode=1), dict(), (Path.FAST_F64, "feature_rows", 11, True)),   # signed ratings: slack form
+        (dict(acc_f64=True, f64_w_ok=False, f64_refine_mode=2), dict(has_fr=False, has_sg=True), (Path.FAST_F64, "segments", 11, True)),
+        (dict(acc_f64=True, f64_w_ok=False, f64_refine_mode=0), dict(), (Path.TILED, "tiled", 10, False)),            # lossy float64 W
+        (dict(acc_f64=True, lazy_tiled=False), dict(), (Path.TILED, "tiled", 10, False)),
+        (dict(acc_f64=True, top_k=15), dict(), (Path.FAST_F64, "segments", 16, True)),             # k + 1 no longer fits the feature-row lists
+        (dict(acc_f64=True, top_k=63), dict(), (Path.TILED, "tiled", 63, False)),                  # k + 1 = 64 fits neither
+        # --- DENSE (string ids)
+        (dict(mode=D), dict(), (Path.FAST, "feature_rows", 10, True)),                             # all columns on this rank: fast pass + flagged rows
+        (dict(mode=D), dict(tiled=True), (Path.FAST, "feature_rows", 10, True)),                   # ... dense_fast always takes the lazy form
+        (dict(mode=D, full_range=False), dict(), (Path.FAST, "feature_rows", 10, True)),           # column shard: completed in place (dense_fill)
+        (dict(mode=D, full_range=False, dense_fill_ok=False), dict(), (Path.TILED, "tiled", 10, False)),
+        (dict(mode=D, full_range=False, dense_fill_on=False), dict(), (Path.TILED, "tiled", 10, False)),
+        (dict(mode=D, dense_fast_on=False), dict(), (Path.TILED, "tiled", 10, False)),
+        (dict(mode=D, acc_f64=True), dict(), (Path.FAST_F64, "feature_rows", 11, True)),
+        (dict(mode=D, acc_f64=True, f64_w_ok=False, f64_refine_mode=2), dict(), (Path.TILED, "tiled", 10, False)),   # signed W: DENSE keeps the tiled kernel
+        (dict(mode=D, acc_f64=True, full_range=False), dict(), (Path.TILED, "tiled", 10, False)),  # no dense_fill for a float64 W
+        # --- CANDIDATES (bulk form): always the tiled kernel
+        (dict(mode=C), dict(), (Path.TILED, "tiled", 10, False)),
+        (dict(mode=C, acc_f64=True), dict(), (Path.TILED, "tiled", 10, False)),
+    ]
+    for kw, lay, want in T:
+        req, plan = _plan(**lay, **kw)
+        assert (plan.path, plan.kernel, plan.k_fast, plan.lazy) == want, (kw, lay, plan)
+    # the dense_fill flag travels with the plan only where the fill kernel must run
+    assert _plan(mode=D, full_range=False)[1].fill and _plan(mode=D)[1].fill                     # (fill also completes short lists on a full range)
+    assert not _plan(mode=D, dense_fill_on=False)[1].fill and not _plan()[1].fill
+    assert _plan(acc_f64=True, f64_x_ok=False, f64_refine_mode=1)[1].f64_signed and not _plan(acc_f64=True)[1].f64_signed
+
+
+def test_score_plan_invariants_over_the_cross_product():
+    """Every combination of the inputs: the plan is internally consistent and never asks for something the layouts, the
+    backend or the kernels' list limits cannot deliver; data-dependent facts are only evaluated where the decision needs them."""
+    import itertools
+    from rtrec_amd.score_plan import Path, TOPK_DENSE as D, TOPK_SPARSE as S
+    n = 0
+    for (mode, hip, f64, top_k, n_rows, full, nonempty, dfast, dfill, lazy, fr_on, sg_on, sg_sup, fill_ok, w_ok, x_ok, rmode, has_fr, has_sg, tiled) in \
+            itertools.product((0, 1, 2), (True, False), (False, True), (10, 15, 16, 63, 64), (100, 100_000), (True, False), (True, False),
+                              (True, False), (True, False), (True, False), (True, False), (True, False), (True,), (True, False),
+                              (True, False), (True, False), (0, 1, 2), (True, False), (True, False), (True, False)):
+        if w_ok and rmode == 0:
+            continue                    # (a positive float32-valued W always has a refine mode)
+        calls = []
+        fact = lambda name, v: (lambda: (calls.append(name), v)[1])
+        f = _facts(mode=mode, hip=hip, acc_f64=f64, top_k=top_k, n_rows=n_rows, full_range=full, nonempty_shard=nonempty,
+                   dense_fast_on=dfast, dense_fill_on=dfill, lazy_tiled=lazy, feature_rows_on=fr_on, seg_layout_on=sg_on, seg_supported=sg_sup,
+                   dense_fill_ok=fact("fill", fill_ok), f64_w_ok=fact("w", w_ok), f64_x_ok=fact("x", x_ok), f64_refine_mode=fact("m", rmode))
+        from rtrec_amd import score_plan as sp_
+        req = sp_.plan_fast_layout(f)
+        got_fr, got_sg = (has_fr, has_sg) if req.want else (False, False)
+        plan = sp_.choose_path(f, req, got_fr, got_sg, tiled)
+        n += 1
+        ctx = (mode, hip, f64, top_k, n_rows, full, nonempty, dfast, dfill, lazy, fr_on, sg_on, fill_ok, w_ok, x_ok, rmode, has_fr, has_sg, tiled, plan)
+        assert not (plan.use_fr and plan.use_sg), ctx
+        assert plan.kernel == ("feature_rows" if plan.use_fr else "segments" if plan.use_sg else "tiled"), ctx
+        assert (plan.path is Path.TILED) == (plan.kernel == "tiled"), ctx
+        if plan.use_fr:
+            assert hip and fr_on and got_fr and plan.k_fast <= 15, ctx
+        if plan.use_sg:
+            assert hip and sg_on and got_sg and plan.k_fast <= 63, ctx
+        if not hip or not nonempty or mode == 2:
+            assert plan.path is Path.TILED and not req.want, ctx
+        if plan.path is Path.FAST_F64:
+            assert f64 and lazy and plan.k_fast == top_k + 1 and (mode == S or (mode == D and w_ok and x_ok)), ctx
+            assert plan.f64_signed == (not (w_ok and x_ok)), ctx
+        else:
+            assert plan.k_fast == top_k and not plan.f64_signed, ctx
+        if f64 and plan.path is Path.FAST:
+            assert False, ctx           # a float64 W never takes the float32 fast pass without the refine step
+        if plan.fill:
+            assert mode == D and plan.path is Path.FAST and plan.lazy and fill_ok and not f64 and top_k <= 63, ctx
+        if mode == D and plan.path is not Path.TILED:
+            assert dfast and lazy and (full or req.dense_fill), ctx
+        if plan.lazy and plan.path is Path.FAST:
+            assert lazy and (mode == D or not tiled), ctx
+        if not f64:
+            assert "w" not in calls and "x" not in calls and "m" not in calls, ctx      # float32 W: no float64 fact is ever computed
+        if mode != D:
+            assert "fill" not in calls, ctx
+    assert n > 100_000
