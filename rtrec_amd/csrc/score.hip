@@ -1064,7 +1064,18 @@ __host__ __device__ constexpr size_t fr_wave_scratch_words(int n_tiles, int regs
     return static_cast<size_t>(kFrUsers) * kFrUserWords / 2 + static_cast<size_t>(kFrUsers) * n_tiles * regs;
 }
 constexpr int kFrCandCap = 64;               // candidates a wave buffers per merge round (one per lane)
-__host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8; }
+#ifndef FR_MASKS_ON_DEMAND
+#define FR_MASKS_ON_DEMAND 0
+#endif
+// 0 (default): every user's dense interacted-column masks are built and parked, as in round 4.  1: masks rebuilt on demand
+// from the row's layout columns (WRITE_SIZE 364 -> ~57 MB per ML-20M pass) -- measured SLOWER, 1.29 against 1.22 ms per pass
+// (A/B on one box, tools/ab_c3_score.sh): the rebuild costs more instructions than the parking costs bandwidth, and the
+// columns kept in registers spill (33 VGPRs at 4 users per wave).  Kept for A/B runs.
+constexpr bool kFrOnDemand = FR_MASKS_ON_DEMAND != 0;
+constexpr int kFrHeadEntries = 128;          // entries of a user's row whose layout columns stay in registers
+constexpr int kFrTailMax = kFrUserWords;     // further entries whose layout columns are parked as a list (4 B each); longer rows: dense masks
+// per wave: the candidate buffer (scores, columns) and the interacted-column mask of ONE (user, tile), rebuilt on demand
+__host__ __device__ constexpr size_t fr_wave_extra_bytes() { return static_cast<size_t>(kFrCandCap) * 8 + 64; }
 constexpr int kFrStep = 2;                   // rows of W per sweep step
 constexpr int kFrSetupChunks = 4;            // 64-entry chunks of a long user row whose loads are issued together
 constexpr int kFrSetupChunksLong = 8;        // ... for rows of 1,152+ entries in the 2- and 4-user forms of the kernel
@@ -1335,15 +1346,23 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
             const int cl = c & (TC - 1);
             atomicOr(&Ml[(c / TC) * REGS + (cl & (REGS - 1))], 1ull << (cl / REGS));
         };
+        // The interacted-column masks are needed only where a tile survives the bound test AND holds a candidate -- a few
+        // (user, tile) pairs per user -- so they are no longer built and parked for every tile (round 4: 364 MB of stores per
+        // ML-20M pass for 11.6 MB of output).  A row of up to 128 entries keeps its layout columns in registers (cm0 / cm1);
+        // up to kFrTailMax further entries park theirs as a list (4 B each); the mask of one (user, tile) is rebuilt from those
+        // when the selection asks for it.  Only longer rows (a few percent of the users) still build dense masks here.
+        float xr[UW][XR];          // lane f: the user's rating of the item of row 64 * h + f of W (0: not owned)
         fr_static_for<UW>([&](auto Uc) {
             constexpr int u = decltype(Uc)::value;
             const int a0 = readlane_i(a0_l, u), n_a = readlane_i(na_l, u);
-            for (int w = lane; w < mwords; w += 64) Ml[w] = 0ull;
+            const bool dense_u = !kFrOnDemand || n_a > kFrHeadEntries + kFrTailMax;
+            uint32_t *tail_u = xs_wave + u * kFrUserWords;
+            if (dense_u) for (int w = lane; w < mwords; w += 64) Ml[w] = 0ull;
             fr_static_for<2>([&](auto H) { xl[H() * 64 + lane] = 0.0f; });
             if (fm0[u] >= 0) xl[fm0[u]] = xv0[u];                           // the items of one row are distinct
-            if (cm0[u] >= 0) mark(cm0[u]);
+            if (dense_u && cm0[u] >= 0) mark(cm0[u]);
             if (fm1[u] >= 0) xl[fm1[u]] = xv1[u];
-            if (cm1[u] >= 0) mark(cm1[u]);
+            if (dense_u && cm1[u] >= 0) mark(cm1[u]);
             // rows beyond 128 entries, four chunks per round: their entries, then what they map to, are requested together
             // (two round trips per round).  The 2- and 4-user forms (smaller passes: row shards, API batches -- their length is
             // their longest user's setup) first take a very long row eight chunks at a time (sixteen spill): a 78k-item user of the
@@ -1369,7 +1388,8 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
 #pragma unroll
                 for (int j = 0; j < CH; ++j) {
                     if (f[j] >= 0) xl[f[j]] = xv[j];
-                    if (c[j] >= 0) mark(c[j]);
+                    if (dense_u) { if (c[j] >= 0) mark(c[j]); }
+                    else if (b + 64 * j + lane < n_a) tail_u[b + 64 * j + lane - kFrHeadEntries] = static_cast<uint32_t>(c[j]);
                 }
             };
             int b = 128;
@@ -1378,20 +1398,13 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                     setup_round(std::integral_constant<int, kFrSetupChunksLong>{}, b);
             }
             for (; b < n_a; b += 64 * kFrSetupChunks) setup_round(std::integral_constant<int, kFrSetupChunks>{}, b);
-            uint32_t *xu = xs_wave + u * kFrUserWords;
-            fr_static_for<2>([&](auto H) { xu[H() * 64 + lane] = __float_as_uint(xl[H() * 64 + lane]); });
-            for (int w = lane; w < mwords; w += 64) ms_wave[static_cast<size_t>(u) * mwords + w] = Ml[w];
+            // the ratings by row of W go straight from the LDS image into registers (they used to take a round trip through
+            // the wave's global scratch)
+            fr_static_for<XR>([&](auto H) { xr[u][H()] = xl[H() * 64 + lane]; });
+            if (dense_u) for (int w = lane; w < mwords; w += 64) ms_wave[static_cast<size_t>(u) * mwords + w] = Ml[w];
         });
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_dcache_inv();                   // the masks are read back through the scalar cache
-        float xr[UW][XR];          // lane f: the user's rating of the item of row 64 * h + f of W (0: not owned)
-        fr_static_for<UW>([&](auto Uc) {
-            constexpr int u = decltype(Uc)::value;
-            const uint32_t *xu = xs_wave + u * kFrUserWords;
-            fr_static_for<XR>([&](auto H) {
-                xr[u][H()] = __uint_as_float(__hip_atomic_load(&xu[H() * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            });
-        });
+        __builtin_amdgcn_s_dcache_inv();                   // dense masks are read back through the scalar cache
         // running top-kk of every user, in registers: user u = lanes (u & 3) * 16 .. + kk - 1 of register u >> 2,
         // lane offset j = rank j (a DPP row is 16 lanes, so a list shifts with row_shr:1)
         float ls4[NL];
@@ -1551,10 +1564,43 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                     fr_static_for<REGS>([&](auto Rc) { best = acc[u][Rc()] > best ? acc[u][Rc()] : best; });
                     float thr = readlane_f(ls4[g], lb + kk - 1);      // the user's current kk-th best score
                     float tcut = thr;
-                    fr_const_u64 *mc = (fr_const_u64 *)(ms_wave + static_cast<size_t>(u) * mwords);
                     if (thr >= 0.0f) {
                         if (!__ballot(best > thr)) return;        // the common case after the first tiles: nothing enters
-                    } else if (thr == ninf) {
+                    }
+                    // the user's interacted columns in this tile, one 64-lane mask per register of the tile (see the setup)
+                    unsigned long long ex[REGS];
+                    fr_static_for<REGS>([&](auto Rc) { ex[Rc()] = 0ull; });
+                    if (a.filter) {
+                        const int n_a_u = readlane_i(na_l, u);
+                        if (!kFrOnDemand || n_a_u > kFrHeadEntries + kFrTailMax) {
+                            fr_const_u64 *mc = (fr_const_u64 *)(ms_wave + static_cast<size_t>(u) * mwords);
+                            fr_static_for<REGS>([&](auto Rc) { ex[Rc()] = mc[t * REGS + Rc()]; });
+                        } else {
+                            unsigned long long *mx = reinterpret_cast<unsigned long long *>(cp + kFrCandCap);
+                            if (lane < REGS) mx[lane] = 0ull;
+                            auto put = [&](int c) {
+                                if (c >= 0 && c / TC == t) {
+                                    const int cl = c & (TC - 1);
+                                    atomicOr(&mx[cl & (REGS - 1)], 1ull << (cl / REGS));
+                                }
+                            };
+                            put(cm0[u]);
+                            put(cm1[u]);
+                            const uint32_t *tail_u = xs_wave + u * kFrUserWords;
+                            for (int b = kFrHeadEntries; b < n_a_u; b += 64) {
+                                int c = -1;
+                                if (b + lane < n_a_u)
+                                    c = static_cast<int>(__hip_atomic_load(&tail_u[b + lane - kFrHeadEntries], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                                put(c);
+                            }
+                            fr_static_for<REGS>([&](auto Rc) {
+                                const unsigned long long v = mx[Rc()];       // LDS operations of one wave execute in order
+                                ex[Rc()] = (static_cast<unsigned long long>(readfirst_i(static_cast<int>(v >> 32))) << 32) |
+                                           static_cast<unsigned int>(readfirst_i(static_cast<int>(v & 0xffffffffull)));
+                            });
+                        }
+                    }
+                    if (thr == ninf) {
                         // The list is not full yet (first tile, or a user with few scored columns): everything
                         // non-zero would pass.  Take the tile's own kk-th best admissible score (a bound from the
                         // lane maxima) as the cut instead.
@@ -1562,9 +1608,8 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                         float bm = ninf;
                         fr_static_for<REGS>([&](auto Rc) {
                             constexpr int r = decltype(Rc)::value;
-                            const unsigned long long ex = a.filter ? mc[t * REGS + r] : 0ull;
                             const float v = acc[u][r];
-                            const float vm = (v != 0.0f && !((ex >> lane) & 1ull)) ? v : ninf;
+                            const float vm = (v != 0.0f && !((ex[r] >> lane) & 1ull)) ? v : ninf;
                             bm = vm > bm ? vm : bm;
                         });
                         // kk-th largest of the 64 lane maxima (the 16 quad maxima would do as a bound, but a loose one:
@@ -1606,7 +1651,7 @@ __global__ __launch_bounds__(kFrWaves * 64, 4) void score_frows_kernel(FrArgs a)
                         // only non-zero sums compete (scipy keeps `!= 0`)
                         unsigned long long m = __ballot(v > tcut && v != 0.0f);
                         if (!m) return;
-                        if (a.filter) m &= ~mc[t * REGS + r];
+                        m &= ~ex[r];
                         if (!m) return;
                         const int cnt = static_cast<int>(__builtin_popcountll(m));
                         if (nc + cnt > kFrCandCap) merge();      // the buffer holds one ballot's worth (64): make room first
