@@ -59,6 +59,9 @@ constexpr int kSgWaves = 4;          // waves per workgroup; they share nothing 
 #define SG_CAP 512
 #endif
 constexpr int kSgCap = SG_CAP;          // items of a user a wave keeps in LDS (layout columns, rows of W, ratings); longer users: heavy pass
+#ifndef SG_NT_USER_ROWS
+#define SG_NT_USER_ROWS 0
+#endif
 constexpr int kSgQueueChunk = 4;     // users per queue claim of a full-size pass (SegArgs::chunk)
 constexpr int kSgMaxKk = 64;         // top_k + 1 list entries: one per lane
 // A pass with fewer users than the chip has wave slots (~7k) leaves most of it idle, and its latency is its longest
@@ -466,8 +469,13 @@ __global__ __launch_bounds__(kSgWaves * 64, SG_OCC) void score_seg_kernel(SegArg
             int r = -1, lc = -1;
             float x = 0.0f;
             if (idx < n_a) {
+#if SG_NT_USER_ROWS       // the user-row stream is read once per pass: keep it from evicting W's records and tables out of L2
+                const int item = __builtin_nontemporal_load(&a.xb_col[a0 + idx]);
+                x = __builtin_nontemporal_load(&a.xb_val[a0 + idx]);
+#else
                 const int item = a.xb_col[a0 + idx];
                 x = a.xb_val[a0 + idx];
+#endif
                 if (item < a.n_items) { const int2 f = a.info[item]; r = f.x; lc = f.y; }      // items newer than W have neither
             }
             if (in_lds && idx < n_a) lcl[idx] = static_cast<IDX>(lc < 0 ? none : lc);
