@@ -1540,7 +1540,11 @@ __global__ __launch_bounds__(64, FIT_WAVES_PER_SIMD) void fit_columns_kernel(Fit
 constexpr int kFoldGroup = MW_FOLD_GROUP;   // chunks the consumer folds per loop iteration (power of two)
 constexpr int kMwWaves = 8;
 constexpr int kMwThreads = kMwWaves * 64;
-constexpr int kProducers = kMwWaves - 1;
+#ifndef MW_IDLE_WAVE4
+#define MW_IDLE_WAVE4 0
+#endif
+// MW_IDLE_WAVE4 (A/B): wave 4 shares SIMD 0 with the consumer (waves go to SIMD wave % 4); it then takes no part in the folds
+constexpr int kProducers = MW_IDLE_WAVE4 ? kMwWaves - 2 : kMwWaves - 1;
 constexpr int kProdDepth = 8;    // chunks a producer wave keeps in flight
 constexpr int kMwMaxTargets = 2048;  // calls with at most this many targets use the multi-wave kernel
 constexpr int kColWalkMinRows = 1024;  // targets with at least this many users take the column-walk X^T y
@@ -1724,7 +1728,7 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
                 }
             }
         };
-        int c0 = wave - 1;
+        int c0 = MW_IDLE_WAVE4 ? (wave < 4 ? wave - 1 : (wave == 4 ? n_chunks : wave - 2)) : wave - 1;
         if (c0 < n_chunks) load_idx(c0, rr, xx);
         for (; c0 < n_chunks; c0 += kStride) {
             float prod[kProdDepth];
