@@ -69,8 +69,9 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 def attach_profile(path, kernel_name, fingerprint, root=None):
     """A committed rocprofv3 summary (profiles/r*_<workload>_*.json) may ride on the bench line only when it describes (a) the
-    kernel the line names as dominant and (b) THE BUILD BEING TIMED: its "build".lib_sha256 equals the sha256 of the
-    librtrec_amd.so this process loaded (a summary of another round's kernels used to be attached by name
+    kernel the line names as dominant and (b) THE BUILD BEING TIMED: its "build" stamp names the librtrec_amd.so this process
+    loaded (equal sha256 of the library, or of the kernel sources + compiler flags it was built from -- a rebuild of the
+    same tree need not be byte-identical; rtrec_amd.build.same_build) (a summary of another round's kernels used to be attached by name
     alone).  Returns (summary or None, relative path of a summary that was refused as stale or None)."""
     root = root or ROOT
     if not path:
@@ -82,8 +83,8 @@ def attach_profile(path, kernel_name, fingerprint, root=None):
         return None, None
     if kernel_name is not None and j.get("kernel", "").split("<")[0] != kernel_name.split("<")[0]:
         return None, None                      # another kernel's counters: not this line's business
-    have = (j.get("build") or {}).get("lib_sha256")
-    if not have or have != (fingerprint or {}).get("lib_sha256"):
+    from rtrec_amd import build as _b
+    if not _b.same_build(j.get("build"), fingerprint):      # equal library bytes, or equal kernel sources + compiler flags
         return None, rel
     return dict(j, source=rel), None
 

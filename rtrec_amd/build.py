@@ -40,6 +40,26 @@ def _sha256(path: str) -> str:
     return h.hexdigest()
 
 
+def source_sha256() -> str:
+    """sha256 over the kernel sources the library is compiled from (csrc/*.hip, their headers, include/rtrec_amd.h) and the
+    compiler flags: the same for every rebuild of the same tree, whatever the binary's bytes."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for name in sorted(SOURCES) + sorted(HEADERS):
+        path = os.path.normpath(os.path.join(CSRC, name))
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def same_build(a: dict, b: dict) -> bool:
+    """Two fingerprints name the same kernels: equal library bytes, or equal sources + flags."""
+    a, b = a or {}, b or {}
+    return bool((a.get("lib_sha256") and a.get("lib_sha256") == b.get("lib_sha256"))
+                or (a.get("src_sha256") and a.get("src_sha256") == b.get("src_sha256")))
+
+
 def fingerprint() -> dict:
     """Identity of the kernel library a measurement was taken with: sha256 of librtrec_amd.so (what actually ran) plus the
     git commit it was built at (recorded at build time -- the GPU box has no .git).  Profile summaries carry it
@@ -54,7 +74,13 @@ def fingerprint() -> dict:
     sha = _sha256(lib) if os.path.exists(lib) else None
     if info.get("lib_sha256") != sha:           # an A/B library or a rebuild without the record: only the hash is known
         info = {"git_head": None, "git_dirty": None}
-    return {"lib_sha256": sha, "git_head": info.get("git_head"), "git_dirty": info.get("git_dirty")}
+    src = None
+    if not os.environ.get("RTREC_AMD_LIB"):         # (an A/B library was built from some other tree)
+        try:
+            src = source_sha256()
+        except OSError:
+            src = None
+    return {"lib_sha256": sha, "src_sha256": src, "git_head": info.get("git_head"), "git_dirty": info.get("git_dirty")}
 
 
 def _write_build_info() -> None:

@@ -1003,7 +1003,10 @@ def test_bench_attaches_a_profile_summary_only_for_the_build_it_times(tmp_path):
     # the running build's own fingerprint names the library file that is loaded
     from rtrec_amd import build
     f = build.fingerprint()
-    assert f["lib_sha256"] == build._sha256(build.LIB_PATH)
+    assert f["lib_sha256"] == build._sha256(build.LIB_PATH) and f["src_sha256"] == build.source_sha256()
+    # a rebuild of the same tree (other library bytes, same sources + flags) still matches; another tree does not
+    assert build.same_build({"lib_sha256": "x", "src_sha256": f["src_sha256"]}, f)
+    assert not build.same_build({"lib_sha256": "x", "src_sha256": "y"}, f) and not build.same_build({}, f) and not build.same_build(None, None)
 
 
 # ---- the scoring dispatch as pure functions (rtrec_amd/score_plan.py): explicit table + invariants over the cross product ----
