@@ -70,12 +70,14 @@ def fingerprint() -> dict:
         info = json.load(open(BUILD_INFO))
     except Exception:
         pass
-    lib = os.environ.get("RTREC_AMD_LIB") or LIB_PATH
+    from . import settings
+    ab_lib = settings.raw("RTREC_AMD_LIB")
+    lib = ab_lib or LIB_PATH
     sha = _sha256(lib) if os.path.exists(lib) else None
     if info.get("lib_sha256") != sha:           # an A/B library or a rebuild without the record: only the hash is known
         info = {"git_head": None, "git_dirty": None}
     src = None
-    if not os.environ.get("RTREC_AMD_LIB"):         # (an A/B library was built from some other tree)
+    if not ab_lib:                                   # (an A/B library was built from some other tree)
         try:
             src = source_sha256()
         except OSError:
