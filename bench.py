@@ -883,6 +883,15 @@ def main() -> None:
         for st_ in stale:
             log(f"[bench] {st_} was measured on another build of librtrec_amd.so: not attached")
 
+    # What the counters say physically: the share of the launch during which a SIMD's vector ALU is issuing.
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the 1,024 SIMDs (MI355X_MICROARCH.md); the kernel time is the one this
+    # run measured by events, the counters are those of the same build (attach_profile) -- so the figure mixes two runs of one build.
+    valu_issue_busy = None
+    if counters and (counters.get("per_launch") or {}).get("SQ_ACTIVE_INST_VALU"):
+        simd_cycles = kern_s * 2.4e9
+        valu_issue_busy = {"frac": counters["per_launch"]["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / simd_cycles,
+                           "how": "SQ_ACTIVE_INST_VALU (quad-cycles, all SIMDs) x 4 / 1024 SIMDs / (kernel_ms_avg x 2.4 GHz)",
+                           "wait_any_frac_of_wave_cycles": (counters.get("derived") or {}).get("wait_any_frac")}
     best = bounds[bound]
     line = {
         "metric": "users-scored/sec top-10 (SLIM recommend, int ids, filter_interacted) + fit interactions/sec in `fit`",
@@ -919,7 +928,7 @@ def main() -> None:
                      "traffic_measured_in_run": False, "traffic_stale": (stale or None), "build": fp,
                      "traffic_vs_compulsory": (traffic / compulsory_hbm if traffic else None),
                      "kernel_ms_avg": kern_ms, "launches": int(n_launch.value), "bounds": bounds,
-                     "algorithmic": algorithmic, "counters": counters, "score_path": score_path},
+                     "algorithmic": algorithmic, "counters": counters, "valu_issue_busy": valu_issue_busy, "score_path": score_path},
         "c4": c4_leg,
         "step_accounting": {"cold_step_ms": cold_step_ms, "row_order_ms": row_order_ms, "warm_ms_per_step": ms_per_step,
                             "note": "cold = the first pass after a new X / W: it builds the work order of the rows (an index of X for the "
