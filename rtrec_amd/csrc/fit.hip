@@ -50,6 +50,7 @@ struct FitArgs {
     rtrec_fit_cfg cfg;
     int *out_items; float *out_coef; int *out_count; int *out_niter; int cap;
     float *R;        // [slots][U]
+    float *stash;    // [slots][U]   latency mode: the add-back values of the column folded last (mw_fold -> mw_update_stashed)
     float *s;        // [slots][I]
     int *touched;    // [slots][I]
     float *cand_s;   // [slots][I]   K path: candidate scores; ALL path: ever_flag (as int)
@@ -1549,6 +1550,9 @@ constexpr int kProdDepth = 8;    // chunks a producer wave keeps in flight
 constexpr int kMwMaxTargets = 2048;  // calls with at most this many targets use the multi-wave kernel
 constexpr int kColWalkMinRows = 1024;  // targets with at least this many users take the column-walk X^T y
 constexpr int kRing = 128;       // ring slots of 64 products (>= kProducers * kProdDepth, power of 2)
+#ifndef MW_CHAIN_ALL_LANES
+#define MW_CHAIN_ALL_LANES 0
+#endif
 #ifndef MW_SPEC_GROUPS
 #define MW_SPEC_GROUPS 4
 #endif
@@ -1591,7 +1595,8 @@ __device__ __forceinline__ void lds_store_release(int *p, int v) {
 // running chunk number (identical in every wave).  Returns the sum in wave 0, 0 elsewhere.
 template <int MODE, bool SPEC>
 __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__ cval, const float *R, const MwLds &M,
-                         int b, int e, float w_old, int wave, int lane, int &seq, int spec_min, long long *wait_ticks = nullptr) {
+                         int b, int e, float w_old, int wave, int lane, int &seq, int spec_min, long long *wait_ticks = nullptr,
+                         float *stash = nullptr) {
     // padded to whole groups of kFoldGroup chunks: the extra products are +0.0 and never change the sum
     const int n_chunks = (((e - b + 63) >> 6) + kFoldGroup - 1) & ~(kFoldGroup - 1);
     float tmp = 0.0f;
@@ -1658,52 +1663,66 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
                 }
                 if (lane == 0) lds_store_release(M.done, seq + min(c + Cp, n_chunks));
             }
-        } else if (n_chunks > 0 && lane < 16) {
+        } else if (n_chunks > 0 && (MW_CHAIN_ALL_LANES || lane < 16)) {
+            // A group's four chunks are four consecutive ring slots (seq and every group start are multiples of four, the ring
+            // holds 128): one base address per group for the products and one for the flags.  Two groups per loop turn with the
+            // registers of A and B swapping roles (round 5: the sixteen v_mov of `A = B`, the per-chunk slot arithmetic, one loop
+            // branch and one `done` store per group were a quarter of the instructions between two chains -- every one of them
+            // sits ON the chain of a wave that issues in order).
             constexpr int Gp = kFoldGroup;
+            static_assert(Gp == 4 && (kRing & 3) == 0, "a group is four consecutive ring slots");
             const float4 *ring4 = reinterpret_cast<const float4 *>(M.ring);
-            auto slot_of = [&](int c) { return (seq + c) & (kRing - 1); };
+            const int l15 = lane & 15;
+            const int sq = __builtin_amdgcn_readfirstlane(seq);     // uniform: the slot arithmetic stays on the scalar unit
             float4 A[Gp], B[Gp];
             int f[Gp];
+            auto flags_bad = [&](int want) {
+                bool bad = false;
 #pragma unroll
-            for (int k = 0; k < Gp; ++k) {
-                while (lds_load_acquire(&M.ready[slot_of(k)]) != seq + k + 1) __builtin_amdgcn_s_sleep(1);
-                A[k] = ring4[slot_of(k) * 16 + lane];
-            }
+                for (int k = 0; k < Gp; ++k) bad |= (f[k] != want + k);
+                return bad;
+            };
+            auto read_flags = [&](int nb) {
 #pragma unroll
-            for (int k = 0; k < Gp; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            for (int c = 0; c < n_chunks; c += Gp) {
-                if (c + Gp < n_chunks) {
-#ifdef MW_TRACE_WAIT      // diagnostic build: ticks the chain consumer waits for its producers (tr[7] of the trace)
-                    bool waited = false;
-                    long long w0 = 0;
-#endif
-                    for (;;) {
-                        bool bad = false;
-#pragma unroll
-                        for (int k = 0; k < Gp; ++k) bad |= (f[k] != seq + c + Gp + k + 1);
-                        if (!bad) break;
-#ifdef MW_TRACE_WAIT
-                        if (wait_ticks && !waited) { waited = true; w0 = static_cast<long long>(wall_clock64()); }
-#endif
-                        __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-                        for (int k = 0; k < Gp; ++k)
-                            f[k] = __hip_atomic_load(&M.ready[slot_of(c + Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-#ifdef MW_TRACE_WAIT
-                    if (waited) *wait_ticks += static_cast<long long>(wall_clock64()) - w0;
-#endif
-                }
+                for (int k = 0; k < Gp; ++k) f[k] = __hip_atomic_load(&M.ready[nb + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            };
+            {
+                const int nb = sq & (kRing - 1);
+                read_flags(nb);
+                while (flags_bad(sq + 1)) { __builtin_amdgcn_s_sleep(1); read_flags(nb); }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
-                for (int k = 0; k < Gp; ++k) B[k] = ring4[slot_of(c + Gp + k) * 16 + lane];     // past the end: stale, unused
+                for (int k = 0; k < Gp; ++k) A[k] = ring4[(nb + k) * 16 + l15];
+                read_flags((sq + Gp) & (kRing - 1));
+            }
+            // folds the group held in X (chunks c .. c+3) after requesting the next group into Y and the flags of the one after.
+            // A taken branch costs a wave that runs alone an instruction refetch, so the expected path (the flags are ready, more
+            // groups follow) is laid out as the fall-through and the spin loop out of line.
+            auto step = [&](float4 (&X)[Gp], float4 (&Y)[Gp], int c) {
+                const int nb = (sq + c + Gp) & (kRing - 1);
+                if (__builtin_expect(c + Gp < n_chunks, 1)) {
+                    if (__builtin_expect(flags_bad(sq + c + Gp + 1), 0)) {
+#ifdef MW_TRACE_WAIT      // diagnostic build: ticks the chain consumer waits for its producers (tr[7] of the trace)
+                        const long long w0 = static_cast<long long>(wall_clock64());
+#endif
+                        do { __builtin_amdgcn_s_sleep(1); read_flags(nb); } while (flags_bad(sq + c + Gp + 1));
+#ifdef MW_TRACE_WAIT
+                        if (wait_ticks) *wait_ticks += static_cast<long long>(wall_clock64()) - w0;
+#endif
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const float4 *src = ring4 + nb * 16 + l15;
 #pragma unroll
-                for (int k = 0; k < Gp; ++k) f[k] = __hip_atomic_load(&M.ready[slot_of(c + 2 * Gp + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int k = 0; k < Gp; ++k) Y[k] = src[k * 16];                 // past the end: stale, unused
+                read_flags((sq + c + 2 * Gp) & (kRing - 1));
 #pragma unroll
-                for (int k = 0; k < Gp; ++k) tmp = chain64_dpp(tmp, A[k]);
-#pragma unroll
-                for (int k = 0; k < Gp; ++k) A[k] = B[k];
-                if (lane == 0) lds_store_release(M.done, seq + c + Gp);
+                for (int k = 0; k < Gp; ++k) tmp = chain64_dpp(tmp, X[k]);
+            };
+            for (int c = 0; c < n_chunks; c += 2 * Gp) {
+                step(A, B, c);
+                if (__builtin_expect(c + Gp < n_chunks, 1)) step(B, A, c + Gp);
+                if (lane == 0) lds_store_release(M.done, sq + min(c + 2 * Gp, n_chunks));
             }
         }
         tmp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tmp)));
@@ -1740,6 +1759,9 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
                 if (MODE == 0) {
                     float v = prod[u];
                     if (add_back) v = __fadd_rn(v, __fmul_rn(xx[u], w_old));
+                    // the residual update that follows this fold starts from exactly this value: kept (coalesced, fire and
+                    // forget) so that the update streams it instead of gathering R again (mw_update_stashed)
+                    if (stash && rr[u] >= 0) stash[(c0 + kProducers * u) * 64 + lane] = v;
                     prod[u] = (rr[u] >= 0) ? __fmul_rn(v, xx[u]) : 0.0f;
                 } else {
                     prod[u] = __fmul_rn(prod[u], prod[u]);
@@ -1796,6 +1818,53 @@ __device__ void mw_update(const int *__restrict__ crow, const float *__restrict_
 #pragma unroll
         for (int k = 0; k < kUpdDepth; ++k) { r[k] = rn[k]; x[k] = xn[k]; }
     }
+}
+
+// The same update after mw_fold<0> of the same column left v = R[r] (+ x*w_old) in stash[o - b]: R[r] <- v (- x*w_new).
+// Three coalesced streams and a scatter, no dependent gather: the update of a popular column is one memory round trip
+// per kUpdDepth * kMwThreads entries instead of two (round 5: 25 % of the heaviest target of a mini-batch was this pass).
+__device__ void mw_update_stashed(const int *__restrict__ crow, const float *__restrict__ cval, const float *__restrict__ stash,
+                                  float *R, int b, int e, float w_new, int tid) {
+    // Whole rounds (kUpdDepth * kMwThreads entries) are straight-line code: per-entry bounds tests put every load and store in
+    // a basic block of its own, and the compiler then waits for ALL outstanding memory operations -- the previous store
+    // included -- before each store (eight serial store round trips per round; measured 37 us per 52 k-entry update).
+    // The loads of round k+1 are issued BEFORE the scatter of round k: memory operations retire in order, so waiting for
+    // those loads leaves the stores in flight.
+    constexpr int kRound = kUpdDepth * kMwThreads;
+    const int full = (e - b) / kRound;
+    crow += b + tid; cval += b + tid; stash += tid;
+    int r[kUpdDepth], rn[kUpdDepth];
+    float x[kUpdDepth], xn[kUpdDepth], v[kUpdDepth], vn[kUpdDepth];
+    auto load = [&](int i, int (&rr)[kUpdDepth], float (&xx)[kUpdDepth], float (&vv)[kUpdDepth]) {
+#pragma unroll
+        for (int k = 0; k < kUpdDepth; ++k) {
+            const int oo = i * kRound + k * kMwThreads;
+            rr[k] = crow[oo]; xx[k] = cval[oo]; vv[k] = stash[oo];
+        }
+    };
+    auto scatter = [&](const int (&rr)[kUpdDepth], const float (&xx)[kUpdDepth], const float (&vv)[kUpdDepth]) {
+#pragma unroll
+        for (int k = 0; k < kUpdDepth; ++k) R[rr[k]] = (w_new != 0.0f) ? __fsub_rn(vv[k], __fmul_rn(xx[k], w_new)) : vv[k];
+    };
+    if (full > 0) {
+        load(0, r, x, v);
+        for (int i = 1; i < full; ++i) {
+            load(i, rn, xn, vn);
+            scatter(r, x, v);
+#pragma unroll
+            for (int k = 0; k < kUpdDepth; ++k) { r[k] = rn[k]; x[k] = xn[k]; v[k] = vn[k]; }
+        }
+        scatter(r, x, v);
+    }
+    const int rest = (e - b) - full * kRound - tid;     // entries of the last, partial round from this thread on
+#pragma unroll
+    for (int k = 0; k < kUpdDepth; ++k) {
+        const int oo = full * kRound + k * kMwThreads;
+        if (k * kMwThreads < rest) { r[k] = crow[oo]; x[k] = cval[oo]; v[k] = stash[oo]; }
+    }
+#pragma unroll
+    for (int k = 0; k < kUpdDepth; ++k)
+        if (k * kMwThreads < rest) R[r[k]] = (w_new != 0.0f) ? __fsub_rn(v[k], __fmul_rn(x[k], w_new)) : v[k];
 }
 
 // Screening pass (see screen_pass) by all threads of the workgroup; every thread returns the
@@ -2033,6 +2102,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
     const int U = a.U, I = a.I;
     const int j = a.targets[t];
     float *R = a.R + static_cast<size_t>(slot) * U;
+    float *stash = a.stash + static_cast<size_t>(slot) * U;
     float *s = a.s + static_cast<size_t>(slot) * I;
     int *touched = a.touched + static_cast<size_t>(slot) * I;
     float *cand_s = a.cand_s + static_cast<size_t>(slot) * I;
@@ -2108,6 +2178,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
             const int b = f_b[p], e = f_e[p];
             const float w_old = f_w[p];
             float w_new = 0.0f;
+            bool stashed = false;      // the fold of this draw left R[r] (+ x*w_old) of the column in `stash`
             if (!dirty) {
                 w_new = cd_update(f_s[p], alpha, beta, nrm, positive);     // identical in every wave
             } else {
@@ -2117,7 +2188,9 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                 if (!screened) {
                     const long long c0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
                     const long long k0 = a.trace ? static_cast<long long>(__builtin_amdgcn_s_memtime()) : 0;
-                    const float tmp = mw_fold<0, SPEC>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq, a.spec_min, a.trace ? &ph_wait : nullptr);
+                    const float tmp = mw_fold<0, SPEC>(a.crow, a.cval, R, M, b, e, w_old, wave, lane, seq, a.spec_min, a.trace ? &ph_wait : nullptr,
+                                                       w_old != 0.0f ? stash : nullptr);
+                    stashed = w_old != 0.0f;     // a zero coefficient mostly stays zero: nothing to update, nothing kept
                     if (a.trace) { ph_fold += static_cast<long long>(wall_clock64()) - c0; ph_cyc += static_cast<long long>(__builtin_amdgcn_s_memtime()) - k0; }
                     tr_folded += e - b;
                     upd ^= 1;
@@ -2137,8 +2210,12 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                     __syncthreads();
                 }
                 const long long c0 = a.trace ? static_cast<long long>(wall_clock64()) : 0;
-                mw_update(a.crow, a.cval, R, b, e, w_old, w_new, tid);
+                if (stashed) mw_update_stashed(a.crow, a.cval, stash, R, b, e, w_new, tid);
+                else mw_update(a.crow, a.cval, R, b, e, w_old, w_new, tid);
                 if (a.trace) { __syncthreads(); ph_upd += static_cast<long long>(wall_clock64()) - c0; }
+#ifdef MW_TRACE_UPD
+                ph_gap += e - b; ph_wait += 1;
+#endif
                 if (tid == 0) f_ever[p] = 1;
             }
             if (changed || touch_r) __syncthreads();
@@ -2231,7 +2308,9 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
                 stop = M.bc_i[2] != 0;
                 __syncthreads();
             }
+#ifndef MW_TRACE_UPD
             if (a.trace) ph_gap += static_cast<long long>(wall_clock64()) - g0;
+#endif
             if (stop) break;
         }
     }
@@ -2255,7 +2334,7 @@ __device__ void fit_one_mw(const FitArgs &a, int t, int slot, unsigned char *sme
         long long *tr = a.trace + static_cast<size_t>(t) * 8;
         tr[0] = tr0; tr[1] = tr1; tr[2] = static_cast<long long>(wall_clock64()); tr[3] = tr_folded;
         tr[4] = ph_fold; tr[5] = ph_upd; tr[6] = ph_gap;
-#ifdef MW_TRACE_WAIT
+#if defined(MW_TRACE_WAIT) || defined(MW_TRACE_UPD)   // MW_TRACE_UPD (diagnostic build): tr[6] entries updated, tr[7] updates
         tr[7] = ph_wait;
 #else
         tr[7] = SPEC && a.spec_min < 0x7fffffff ? ph_wait : ph_cyc;   // speculative fold: ticks the consumer waited for its producers
@@ -2384,12 +2463,13 @@ using namespace rtrec;
 
 namespace {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-struct FitWs { size_t R, s, touched, cand_s, cand_i, w_all, long_list, total; };
+struct FitWs { size_t R, stash, s, touched, cand_s, cand_i, w_all, long_list, total; };
 FitWs fit_ws_layout(int U, int I, int slots, int top_features) {
     FitWs w;
     size_t o = 0;
     const size_t sl = static_cast<size_t>(slots);
     w.R = o;       o = align_up(o + sl * U * 4, 256);
+    w.stash = o;   o = align_up(o + sl * U * 4, 256);
     w.s = o;       o = align_up(o + sl * I * 4, 256);
     w.touched = o; o = align_up(o + sl * I * 4, 256);
     w.cand_s = o;  o = align_up(o + sl * I * 4, 256);
@@ -2521,6 +2601,7 @@ static int fit_columns_impl(int32_t n_users, int32_t n_items,
     a.sqn = d_sqnorm; a.targets = d_targets; a.n_targets = n_targets; a.cfg = *cfg;
     a.out_items = d_out_items; a.out_coef = d_out_coef; a.out_count = d_out_count; a.out_niter = d_out_n_iter; a.cap = cap;
     a.R = reinterpret_cast<float *>(ws + L.R);
+    a.stash = reinterpret_cast<float *>(ws + L.stash);
     a.s = reinterpret_cast<float *>(ws + L.s);
     a.touched = reinterpret_cast<int *>(ws + L.touched);
     a.cand_s = reinterpret_cast<float *>(ws + L.cand_s);
