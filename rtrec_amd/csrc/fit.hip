@@ -1625,9 +1625,9 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
                 for (;;) {
                     bool bad = false;
 #pragma unroll
-                    for (int k = 0; k < Cp; ++k)
+                    for (int k = 0; k < Cp; k += 4)       // one flag per group of four chunks: tag = global group number + 1
                         if (c0 + k < n_chunks)
-                            bad |= (__hip_atomic_load(&M.ready[slot_of(c0 + k)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != seq + c0 + k + 1);
+                            bad |= (__hip_atomic_load(&M.ready[slot_of(c0 + k) >> 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ((seq + c0 + k) >> 2) + 1);
                     if (!bad) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
@@ -1675,54 +1675,49 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
             const int l15 = lane & 15;
             const int sq = __builtin_amdgcn_readfirstlane(seq);     // uniform: the slot arithmetic stays on the scalar unit
             float4 A[Gp], B[Gp];
-            int f[Gp];
-            auto flags_bad = [&](int want) {
-                bool bad = false;
-#pragma unroll
-                for (int k = 0; k < Gp; ++k) bad |= (f[k] != want + k);
-                return bad;
-            };
-            auto read_flags = [&](int nb) {
-#pragma unroll
-                for (int k = 0; k < Gp; ++k) f[k] = __hip_atomic_load(&M.ready[nb + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // one ready flag per GROUP (a producer wave owns whole groups): tag = global group number + 1
+            const int gq = sq >> 2;
+            int f;
+            auto read_flag = [&](int g) {
+                f = __hip_atomic_load(&M.ready[(gq + g) & (kRing / 4 - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             };
             {
                 const int nb = sq & (kRing - 1);
-                read_flags(nb);
-                while (flags_bad(sq + 1)) { __builtin_amdgcn_s_sleep(1); read_flags(nb); }
+                read_flag(0);
+                while (f != gq + 1) { __builtin_amdgcn_s_sleep(1); read_flag(0); }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
                 for (int k = 0; k < Gp; ++k) A[k] = ring4[(nb + k) * 16 + l15];
-                read_flags((sq + Gp) & (kRing - 1));
+                read_flag(1);
             }
-            // folds the group held in X (chunks c .. c+3) after requesting the next group into Y and the flags of the one after.
-            // A taken branch costs a wave that runs alone an instruction refetch, so the expected path (the flags are ready, more
+            // folds the group held in X (group g: chunks 4g .. 4g+3) after requesting group g+1 into Y and the flag of g+2.
+            // A taken branch costs a wave that runs alone an instruction refetch, so the expected path (the flag is set, more
             // groups follow) is laid out as the fall-through and the spin loop out of line.
-            auto step = [&](float4 (&X)[Gp], float4 (&Y)[Gp], int c) {
-                const int nb = (sq + c + Gp) & (kRing - 1);
-                if (__builtin_expect(c + Gp < n_chunks, 1)) {
-                    if (__builtin_expect(flags_bad(sq + c + Gp + 1), 0)) {
+            const int n_groups = n_chunks >> 2;
+            auto step = [&](float4 (&X)[Gp], float4 (&Y)[Gp], int g) {
+                if (__builtin_expect(g + 1 < n_groups, 1)) {
+                    if (__builtin_expect(f != gq + g + 2, 0)) {
 #ifdef MW_TRACE_WAIT      // diagnostic build: ticks the chain consumer waits for its producers (tr[7] of the trace)
                         const long long w0 = static_cast<long long>(wall_clock64());
 #endif
-                        do { __builtin_amdgcn_s_sleep(1); read_flags(nb); } while (flags_bad(sq + c + Gp + 1));
+                        do { __builtin_amdgcn_s_sleep(1); read_flag(g + 1); } while (f != gq + g + 2);
 #ifdef MW_TRACE_WAIT
                         if (wait_ticks) *wait_ticks += static_cast<long long>(wall_clock64()) - w0;
 #endif
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const float4 *src = ring4 + nb * 16 + l15;
+                const float4 *src = ring4 + ((sq + 4 * g + 4) & (kRing - 1)) * 16 + l15;
 #pragma unroll
                 for (int k = 0; k < Gp; ++k) Y[k] = src[k * 16];                 // past the end: stale, unused
-                read_flags((sq + c + 2 * Gp) & (kRing - 1));
+                read_flag(g + 2);
 #pragma unroll
                 for (int k = 0; k < Gp; ++k) tmp = chain64_dpp(tmp, X[k]);
             };
-            for (int c = 0; c < n_chunks; c += 2 * Gp) {
-                step(A, B, c);
-                if (__builtin_expect(c + Gp < n_chunks, 1)) step(B, A, c + Gp);
-                if (lane == 0) lds_store_release(M.done, sq + min(c + 2 * Gp, n_chunks));
+            for (int g = 0; g < n_groups; g += 2) {
+                step(A, B, g);
+                if (__builtin_expect(g + 1 < n_groups, 1)) step(B, A, g + 1);
+                if (lane == 0) lds_store_release(M.done, sq + 4 * min(g + 2, n_groups));
             }
         }
         tmp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tmp)));
@@ -1731,14 +1726,18 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
         // Producers are latency machines: a round is one index load and one dependent gather, so the
         // indices of round k+1 are requested before the gathers of round k are consumed (one memory
         // round trip per round instead of two) and a round carries kProdDepth chunks per wave.
+        // A wave owns whole groups of four chunks (two per round): the consumer then tests ONE ready flag per group.
+        static_assert(kProdDepth == 8 && kFoldGroup == 4, "a producer round is two groups of four chunks");
         const bool add_back = (w_old != 0.0f);
-        constexpr int kStride = kProducers * kProdDepth;
+        constexpr int kGroupStride = kProducers * (kProdDepth / 4);       // groups per round of all producers
+        const int n_groups = n_chunks >> 2;
+        auto chunk_of = [&](int g0, int u) { return 4 * (g0 + kProducers * (u >> 2)) + (u & 3); };   // < n_chunks iff its group < n_groups
         int rr[kProdDepth], rn[kProdDepth];
         float xx[kProdDepth], xn[kProdDepth];
-        auto load_idx = [&](int c0, int (&r)[kProdDepth], float (&x)[kProdDepth]) {
+        auto load_idx = [&](int g0, int (&r)[kProdDepth], float (&x)[kProdDepth]) {
 #pragma unroll
             for (int u = 0; u < kProdDepth; ++u) {
-                const int c = c0 + kProducers * u;
+                const int c = chunk_of(g0, u);
                 const int o = b + c * 64 + lane;
                 r[u] = -1; x[u] = 0.0f;
                 if (c < n_chunks && o < e) {
@@ -1747,13 +1746,13 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
                 }
             }
         };
-        int c0 = MW_IDLE_WAVE4 ? (wave < 4 ? wave - 1 : (wave == 4 ? n_chunks : wave - 2)) : wave - 1;
-        if (c0 < n_chunks) load_idx(c0, rr, xx);
-        for (; c0 < n_chunks; c0 += kStride) {
+        int g0 = MW_IDLE_WAVE4 ? (wave < 4 ? wave - 1 : (wave == 4 ? n_groups : wave - 2)) : wave - 1;
+        if (g0 < n_groups) load_idx(g0, rr, xx);
+        for (; g0 < n_groups; g0 += kGroupStride) {
             float prod[kProdDepth];
 #pragma unroll
             for (int u = 0; u < kProdDepth; ++u) prod[u] = (rr[u] >= 0) ? R[rr[u]] : 0.0f;     // gathers
-            if (c0 + kStride < n_chunks) load_idx(c0 + kStride, rn, xn);
+            if (g0 + kGroupStride < n_groups) load_idx(g0 + kGroupStride, rn, xn);
 #pragma unroll
             for (int u = 0; u < kProdDepth; ++u) {
                 if (MODE == 0) {
@@ -1761,20 +1760,21 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
                     if (add_back) v = __fadd_rn(v, __fmul_rn(xx[u], w_old));
                     // the residual update that follows this fold starts from exactly this value: kept (coalesced, fire and
                     // forget) so that the update streams it instead of gathering R again (mw_update_stashed)
-                    if (stash && rr[u] >= 0) stash[(c0 + kProducers * u) * 64 + lane] = v;
+                    if (stash && rr[u] >= 0) stash[chunk_of(g0, u) * 64 + lane] = v;
                     prod[u] = (rr[u] >= 0) ? __fmul_rn(v, xx[u]) : 0.0f;
                 } else {
                     prod[u] = __fmul_rn(prod[u], prod[u]);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < kProdDepth; ++u) {
-                const int c = c0 + kProducers * u;
+            for (int h = 0; h < kProdDepth / 4; ++h) {
+                const int c = chunk_of(g0, 4 * h);
                 if (c >= n_chunks) break;
-                const int G = seq + c, slot = G & (kRing - 1);
-                while (lds_load_acquire(M.done) <= G - kRing) __builtin_amdgcn_s_sleep(1);   // slot still in use
-                M.ring[slot * 64 + lane] = prod[u];
-                if (lane == 0) lds_store_release(&M.ready[slot], G + 1);
+                const int G = seq + c, slot = G & (kRing - 1);                            // the group's first chunk and ring slot
+                while (lds_load_acquire(M.done) <= G + 3 - kRing) __builtin_amdgcn_s_sleep(1);   // its slots are still in use
+#pragma unroll
+                for (int k = 0; k < 4; ++k) M.ring[(slot + k) * 64 + lane] = prod[4 * h + k];
+                if (lane == 0) lds_store_release(&M.ready[slot >> 2], (G >> 2) + 1);
             }
 #pragma unroll
             for (int u = 0; u < kProdDepth; ++u) { rr[u] = rn[u]; xx[u] = xn[u]; }
