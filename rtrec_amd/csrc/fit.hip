@@ -22,6 +22,7 @@
 // Scratch invariants between targets (set by rtrec_slim_fit_workspace_init): R == 0, s ==
 // kUntouched, w_all == 0, ever_flag == 0.
 #include "common.hip.h"
+#include <type_traits>
 #include "fold_spec.hip.h"
 #include "../../include/rtrec_amd.h"
 
@@ -1694,8 +1695,8 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
             // A taken branch costs a wave that runs alone an instruction refetch, so the expected path (the flag is set, more
             // groups follow) is laid out as the fall-through and the spin loop out of line.
             const int n_groups = n_chunks >> 2;
-            auto step = [&](float4 (&X)[Gp], float4 (&Y)[Gp], int g) {
-                if (__builtin_expect(g + 1 < n_groups, 1)) {
+            auto step = [&](auto sure, float4 (&X)[Gp], float4 (&Y)[Gp], int g) {      // sure: group g+1 exists, no test
+                if (decltype(sure)::value || g + 1 < n_groups) {
                     if (__builtin_expect(f != gq + g + 2, 0)) {
 #ifdef MW_TRACE_WAIT      // diagnostic build: ticks the chain consumer waits for its producers (tr[7] of the trace)
                         const long long w0 = static_cast<long long>(wall_clock64());
@@ -1714,11 +1715,15 @@ __device__ float mw_fold(const int *__restrict__ crow, const float *__restrict__
 #pragma unroll
                 for (int k = 0; k < Gp; ++k) tmp = chain64_dpp(tmp, X[k]);
             };
-            for (int g = 0; g < n_groups; g += 2) {
-                step(A, B, g);
-                if (__builtin_expect(g + 1 < n_groups, 1)) step(B, A, g + 1);
-                if (lane == 0) lds_store_release(M.done, sq + 4 * min(g + 2, n_groups));
+            int g = 0;
+            for (; g + 2 < n_groups; g += 2) {            // both groups of the turn have a successor: no tests on the chain
+                step(std::true_type{}, A, B, g);
+                step(std::true_type{}, B, A, g + 1);
+                if (lane == 0) lds_store_release(M.done, sq + 4 * (g + 2));
             }
+            step(std::false_type{}, A, B, g);             // the last one or two groups
+            if (g + 1 < n_groups) step(std::false_type{}, B, A, g + 1);
+            if (lane == 0) lds_store_release(M.done, sq + n_chunks);
         }
         tmp = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(tmp)));
         __builtin_amdgcn_s_setprio(0);
